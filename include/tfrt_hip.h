@@ -1,0 +1,265 @@
+/*
+ * tfrt_hip.h -- C ABI of libtfrt_hip.so, the MI355X (gfx950) implementation of the tfrt
+ * hot path: batched ray x boundary intersection, nearest-hit reduction, classification /
+ * stable compaction, Snell refraction / reflection, iterated over passes, plus the
+ * hand-derived reverse sweep.
+ *
+ * The upstream reference (ecpoppenheimer/TensorFlowRayTrace) is pure Python on TensorFlow
+ * eager ops: it has NO native/FFI boundary on this path.  Each entry point below therefore
+ * cites the Python seam it replaces (file:line in the reference); INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add at that seam.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensors); nothing is
+ *    allocated, freed or retained; no global state; re-entrant
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *    synchronises, so a caller may capture a call into a hipGraph
+ *  - ray sets are SoA: a "ray block" is 6 rows (3-D: xs,ys,zs,xe,ye,ze) or 4 rows
+ *    (2-D: xs,ys,xe,ye) of `stride` elements each; `state_dtype` selects the element type
+ *    of ray blocks (TFRT_F32 / TFRT_F64).  Geometry, indices of refraction and gradients
+ *    are always float64.
+ *  - return value: 0 on success, negative TFRT_E_* otherwise (see tfrt_strerror)
+ */
+#ifndef TFRT_HIP_H
+#define TFRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFRT_VERSION 100 /* 0.1.0 */
+
+#define TFRT_F32 0
+#define TFRT_F64 1
+
+/* boundary catagory, tfrt/engine.py:14-16 */
+#define TFRT_OPTICAL 0
+#define TFRT_STOP 1
+#define TFRT_TARGET 2
+
+/* ray classes produced by a pass (tfrt/engine.py:2027-2111) */
+#define TFRT_CLS_ACTIVE 0
+#define TFRT_CLS_FINISHED 1
+#define TFRT_CLS_STOPPED 2
+#define TFRT_CLS_DEAD 3
+
+/* flags (OpticalEngine constructor kwargs, tfrt/engine.py:1216-1230) */
+#define TFRT_COMPILE_ACTIVE 1u
+#define TFRT_COMPILE_FINISHED 2u
+#define TFRT_COMPILE_STOPPED 4u
+#define TFRT_COMPILE_DEAD 8u
+
+#define TFRT_E_BADARG (-1)
+#define TFRT_E_WORKSPACE (-2)
+#define TFRT_E_LAUNCH (-3)
+#define TFRT_E_UNSUPPORTED (-4)
+
+int tfrt_version(void);
+const char* tfrt_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Triangle boundaries: vertices -> per-face data.
+ * Replaces TriangleBoundaryBase.update_fields_from_vertices, tfrt/boundaries.py:890-923
+ * (gather faces, cross, normalize) and, in reverse, the tape's scatter through that gather
+ * with the per-corner stop_gradient mask (`vertex_update_map`, boundaries.py:900-913).
+ *
+ *   vertices    (V,3) f64 row-major
+ *   faces       (F,3) i32 vertex indices
+ *   face_verts  (F,9) f64 : xp,yp,zp,x1,y1,z1,x2,y2,z2 per face
+ *   norm        (F,3) f64 : normalize((P1-P0) x (P2-P1))
+ */
+int tfrt_build_faces_forward(const double* vertices, int64_t n_vertices, const int32_t* faces,
+                             int64_t n_faces, double* face_verts, double* norm, void* stream);
+
+/* grad_vertices (V,3) is ACCUMULATED into (caller zeroes).  grad_norm and update_mask may be
+ * NULL.  update_mask (F,3) u8: 0 = stop_gradient for that corner. */
+int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_norm,
+                              const double* face_verts, const int32_t* faces,
+                              const uint8_t* update_mask, int64_t n_faces, int64_t n_vertices,
+                              double* grad_vertices, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene description shared by the 3-D entry points (the merged boundary set of
+ * OpticalSystem3D._merge_boundaries, tfrt/engine.py:971-1018: optical, stop, target order).
+ */
+typedef struct tfrt_scene3d {
+  const double* face_verts; /* (M,9) f64 */
+  const int32_t* catagory;  /* (M) TFRT_OPTICAL / _STOP / _TARGET */
+  const int32_t* mat_in;    /* (M) material index opposite the norm, or NULL ("value" mode) */
+  const int32_t* mat_out;   /* (M) material index on the norm side, or NULL */
+  const double* n_in;       /* (M) per-face refractive index ("value" mode) or NULL */
+  const double* n_out;      /* (M) or NULL */
+  int64_t n_faces;          /* M */
+  /* n_table[m * n_table_stride + source_ray] = n_m(wavelength of that source ray); the
+   * host evaluates the material callables once per source ray (wavelength is inherited
+   * unchanged, tfrt/operation.py:238-239).  NULL in "value" mode. */
+  const double* n_table;
+  int64_t n_table_stride;
+  int32_t n_materials;
+  double intersect_epsilion; /* OpticalSystemBase kwargs, tfrt/engine.py:174-190 */
+  double size_epsilion;
+  double ray_start_epsilion;
+} tfrt_scene3d;
+
+/* One class of output rays (finished / active history / stopped / dead), compacted stably in
+ * source order pass after pass, exactly like the reference's per-pass boolean_mask + concat
+ * (tfrt/engine.py:2069-2111, 1379-1399). */
+typedef struct tfrt_ray_out {
+  void* rays;       /* 6 x capacity ray block (state dtype) or NULL if not compiled */
+  int32_t* ray_id;  /* (capacity) index of the source ray each output row descends from */
+  int32_t* face;    /* (capacity) merged face index hit (-1 for dead rays) */
+  int64_t capacity; /* row stride of `rays` */
+} tfrt_ray_out;
+
+/* Bytes of scratch+tape the trace needs.  The SAME buffer must be passed to forward and,
+ * untouched, to backward. */
+size_t tfrt_trace3d_workspace_bytes(int64_t n_rays, int64_t n_faces, int32_t max_passes,
+                                    int32_t state_dtype);
+
+/* Number of int32 in `counts`: per pass 8 ints {n_active,n_finished,n_stopped,n_dead,
+ * base_active,base_finished,base_stopped,base_dead}, then 8 trailing ints:
+ * {total_active,total_finished,total_stopped,total_dead,n_tests_lo,n_tests_hi,error,0}. */
+#define TFRT_COUNTS_PER_PASS 8
+#define TFRT_COUNTS_LEN(max_passes) (8 * ((max_passes) + 1))
+
+/* Whole trace, forward.  Replaces OpticalEngine.ray_trace -> single_pass ->
+ * process_projection_3D -> OpticalSystem3D.intersect/_intersection ->
+ * geometry.line_triangle_intersect, then StandardReaction.main -> geometry.snells_law_3D
+ * (tfrt/engine.py:2311-2330, 2193-2302, 1988-2191, 1020-1166; tfrt/geometry.py:191-320,
+ * 671-753; tfrt/operation.py:255-307).
+ *
+ *   src_rays   6 x src_stride ray block, n_rays valid columns
+ *   unfinished ray block (6 x n_rays) receiving the rays still active after the last pass
+ *              (what single_pass returns, engine.py:2302), + their source ids; may be NULL
+ *   counts     TFRT_COUNTS_LEN(max_passes) int32, written by the device
+ */
+int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                         const tfrt_scene3d* scene, double new_ray_length,
+                         double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                         uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
+                         tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
+                         int32_t* unfinished_id, int32_t* counts, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* Reverse sweep over the tape left in `workspace` by tfrt_trace3d_forward with the same
+ * arguments.  Replaces the ray-dependent part of tape.gradient in
+ * SGD_Optimizer.process_gradient, tfrt/optimizer.py:216-220.
+ *
+ *   grad_finished/active/stopped/dead : 6 x capacity f64 blocks (row stride = the matching
+ *              tfrt_ray_out.capacity of the forward call) or NULL
+ *   grad_face_verts (M,9) f64, ACCUMULATED into (caller zeroes)
+ *   grad_src_rays   6 x n_rays f64 or NULL
+ */
+int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                          const tfrt_scene3d* scene, double new_ray_length,
+                          double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                          const double* grad_finished, int64_t cap_finished,
+                          const double* grad_active, int64_t cap_active,
+                          const double* grad_stopped, int64_t cap_stopped,
+                          const double* grad_dead, int64_t cap_dead, double* grad_face_verts,
+                          double* grad_src_rays, const int32_t* counts, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Seam-level single kernels (same math, no pass loop).
+ */
+
+/* OpticalSystem3D._intersection, tfrt/engine.py:1103-1166: nearest valid triangle per ray.
+ * Outputs are (n_rays) arrays: x,y,z,ray_u,trig_u,trig_v f64; valid u8; gather_trig i32
+ * (0 where invalid, like tf.argmin over an all-sentinel column). */
+size_t tfrt_intersect3d_workspace_bytes(int64_t n_rays, int64_t n_faces);
+int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t state_dtype,
+                     const double* face_verts, int64_t n_faces, double intersect_epsilion,
+                     double size_epsilion, double ray_start_epsilion, double* x, double* y,
+                     double* z, uint8_t* valid, double* ray_u, double* trig_u, double* trig_v,
+                     int32_t* gather_trig, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* geometry.snells_law_3D, tfrt/geometry.py:671-753.  All arrays (n) f64; norm is (n,3).
+ * Writes the new ray (start = old end). */
+int tfrt_snell3d(int64_t n, const double* x_start, const double* y_start, const double* z_start,
+                 const double* x_end, const double* y_end, const double* z_end,
+                 const double* norm, const double* n_in, const double* n_out,
+                 double new_ray_length, double* out6 /* 6 x n */, void* stream);
+
+/* geometry.snells_law_2D, tfrt/geometry.py:565-653.  out4 = 4 x n (xs,ys,xe,ye). */
+int tfrt_snell2d(int64_t n, const double* x_start, const double* y_start, const double* x_end,
+                 const double* y_end, const double* norm, const double* n_in,
+                 const double* n_out, double new_ray_length, double* out4, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 2-D: segments + arcs (OpticalSystem2D, tfrt/engine.py:254-866).
+ */
+typedef struct tfrt_scene2d {
+  const double* seg;         /* (Ms,4) f64: x_start,y_start,x_end,y_end */
+  const int32_t* seg_cat;    /* (Ms) */
+  const int32_t* seg_mat_in; /* (Ms) or NULL */
+  const int32_t* seg_mat_out;
+  const double* seg_n_in;    /* (Ms) or NULL ("value" mode) */
+  const double* seg_n_out;
+  int64_t n_segments;
+  const double* arc;         /* (Ma,5) f64: x_center,y_center,angle_start,angle_end,radius */
+  const int32_t* arc_cat;
+  const int32_t* arc_mat_in;
+  const int32_t* arc_mat_out;
+  const double* arc_n_in;
+  const double* arc_n_out;
+  int64_t n_arcs;
+  const double* n_table;
+  int64_t n_table_stride;
+  int32_t n_materials;
+  double intersect_epsilion, size_epsilion, ray_start_epsilion;
+} tfrt_scene2d;
+
+/* OpticalSystem2D._segment_intersection, tfrt/engine.py:688-749 (rays: 4 x stride block). */
+int tfrt_segment_intersection(const void* rays, int64_t stride, int64_t n_rays,
+                              int32_t state_dtype, const double* seg, int64_t n_segments,
+                              double intersect_epsilion, double size_epsilion,
+                              double ray_start_epsilion, double* x, double* y, uint8_t* valid,
+                              double* ray_u, double* seg_u, int32_t* gather_segment,
+                              void* stream);
+
+/* OpticalSystem2D._arc_intersection, tfrt/engine.py:768-866. */
+int tfrt_arc_intersection(const void* rays, int64_t stride, int64_t n_rays, int32_t state_dtype,
+                          const double* arc, int64_t n_arcs, double intersect_epsilion,
+                          double size_epsilion, double ray_start_epsilion, double* x, double* y,
+                          uint8_t* valid, double* ray_u, double* arc_u, int32_t* gather_arc,
+                          void* stream);
+
+size_t tfrt_trace2d_workspace_bytes(int64_t n_rays, int64_t n_segments, int64_t n_arcs,
+                                    int32_t max_passes, int32_t state_dtype);
+
+/* OpticalEngine.ray_trace for dimension 2 (process_projection_2D, tfrt/engine.py:1544-1986,
+ * + snells_law_2D).  In a mixed segment+arc system every pass emits, per class, the
+ * segment-hit rays first and then the arc-hit rays (engine.py:1955-1981); the face index
+ * written is the merged segment index, or n_segments + merged arc index. */
+int tfrt_trace2d_forward(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                         const tfrt_scene2d* scene, double new_ray_length,
+                         double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                         uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
+                         tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
+                         int32_t* unfinished_id, int32_t* counts, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* Reverse sweep of tfrt_trace2d_forward (the tape part of tfrt/optimizer.py:216-220 for a
+ * 2-D system, e.g. dev/optimize_single_arc.py where the variable is an arc's centre/radius).
+ *   grad_seg (Ms,4) f64 and grad_arc (Ma,5) f64 are ACCUMULATED into (caller zeroes); the
+ *   angle_start/angle_end columns of grad_arc stay zero (they only feed comparisons).
+ *   grad_src_rays 4 x n_rays f64 or NULL. */
+int tfrt_trace2d_backward(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                          const tfrt_scene2d* scene, double new_ray_length,
+                          double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                          const double* grad_finished, int64_t cap_finished,
+                          const double* grad_active, int64_t cap_active,
+                          const double* grad_stopped, int64_t cap_stopped,
+                          const double* grad_dead, int64_t cap_dead, double* grad_seg,
+                          double* grad_arc, double* grad_src_rays, const int32_t* counts,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFRT_HIP_H */

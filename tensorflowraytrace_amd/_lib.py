@@ -1,0 +1,116 @@
+"""
+ctypes binding of libtfrt_hip.so (declared in include/tfrt_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or a tensor handed to a
+kernel wrapper is not on a HIP device, the call raises.  Build the library with
+``python -m tensorflowraytrace_amd._build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtfrt_hip.so")
+
+F32, F64 = 0, 1
+OPTICAL, STOP, TARGET = 0, 1, 2
+CLS_ACTIVE, CLS_FINISHED, CLS_STOPPED, CLS_DEAD = 0, 1, 2, 3
+COMPILE_ACTIVE, COMPILE_FINISHED, COMPILE_STOPPED, COMPILE_DEAD = 1, 2, 4, 8
+COUNTS_PER_PASS = 8
+
+c_i32, c_i64, c_f64, c_u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
+c_vp, c_sz = ctypes.c_void_p, ctypes.c_size_t
+
+
+class Scene3D(ctypes.Structure):
+    """struct tfrt_scene3d"""
+    _fields_ = [
+        ("face_verts", c_vp), ("catagory", c_vp), ("mat_in", c_vp), ("mat_out", c_vp),
+        ("n_in", c_vp), ("n_out", c_vp), ("n_faces", c_i64),
+        ("n_table", c_vp), ("n_table_stride", c_i64), ("n_materials", c_i32),
+        ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
+    ]
+
+
+class Scene2D(ctypes.Structure):
+    """struct tfrt_scene2d"""
+    _fields_ = [
+        ("seg", c_vp), ("seg_cat", c_vp), ("seg_mat_in", c_vp), ("seg_mat_out", c_vp),
+        ("seg_n_in", c_vp), ("seg_n_out", c_vp), ("n_segments", c_i64),
+        ("arc", c_vp), ("arc_cat", c_vp), ("arc_mat_in", c_vp), ("arc_mat_out", c_vp),
+        ("arc_n_in", c_vp), ("arc_n_out", c_vp), ("n_arcs", c_i64),
+        ("n_table", c_vp), ("n_table_stride", c_i64), ("n_materials", c_i32),
+        ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
+    ]
+
+
+class RayOut(ctypes.Structure):
+    """struct tfrt_ray_out"""
+    _fields_ = [("rays", c_vp), ("ray_id", c_vp), ("face", c_vp), ("capacity", c_i64)]
+
+
+_P = ctypes.POINTER
+
+# name -> (restype, argtypes); must list every symbol include/tfrt_hip.h declares
+SIGNATURES = {
+    "tfrt_version": (c_i32, []),
+    "tfrt_strerror": (ctypes.c_char_p, [c_i32]),
+    "tfrt_build_faces_forward": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "tfrt_build_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "tfrt_trace3d_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
+    "tfrt_trace3d_forward": (c_i32, [
+        c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32, c_u32,
+        _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_trace3d_backward": (c_i32, [
+        c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32,
+        c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_intersect3d_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "tfrt_intersect3d": (c_i32, [
+        c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,
+        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_snell3d": (c_i32, [c_i64] + [c_vp] * 9 + [c_f64, c_vp, c_vp]),
+    "tfrt_snell2d": (c_i32, [c_i64] + [c_vp] * 7 + [c_f64, c_vp, c_vp]),
+    "tfrt_segment_intersection": (c_i32, [
+        c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,
+        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tfrt_arc_intersection": (c_i32, [
+        c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,
+        c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tfrt_trace2d_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i32, c_i32]),
+    "tfrt_trace2d_forward": (c_i32, [
+        c_vp, c_i64, c_i64, _P(Scene2D), c_f64, c_f64, c_i32, c_i32, c_u32,
+        _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_trace2d_backward": (c_i32, [
+        c_vp, c_i64, c_i64, _P(Scene2D), c_f64, c_f64, c_i32, c_i32,
+        c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+        c_vp]),
+}
+
+_lib = None
+
+
+class TfrtError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TfrtError(
+                f"{LIB_PATH} not found: the tfrt HIP extension is not built.  Run "
+                "`python -m tensorflowraytrace_amd._build`.  There is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().tfrt_strerror(code).decode()
+        raise TfrtError(f"{what} failed: {msg} (code {code})")

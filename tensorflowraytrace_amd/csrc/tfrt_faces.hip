@@ -1,0 +1,182 @@
+// Triangle-boundary face construction (forward + reverse), the element-wise Snell seams and
+// the library bookkeeping entry points.
+//
+//   k_build_faces      tfrt/boundaries.py:890-923 update_fields_from_vertices
+//   k_build_faces_bwd  reverse of the same gather/cross/normalize incl. the per-corner
+//                      stop_gradient mask (vertex_update_map, boundaries.py:900-913)
+//   k_snell3d/2d       tfrt/geometry.py:671-753 / 565-653, one ray per lane
+#include "tfrt_common.h"
+
+namespace tfrt {
+
+__global__ __launch_bounds__(BLOCK) void k_build_faces(const double* __restrict__ vertices,
+                                                       int64_t V, const int32_t* __restrict__ faces,
+                                                       int64_t F, double* __restrict__ fverts,
+                                                       double* __restrict__ norm) {
+  const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (f >= F) return;
+  double P[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int64_t v = faces[3 * f + c];
+    if (v < 0 || v >= V) v = 0;  // host validates; keep the access in range regardless
+#pragma unroll
+    for (int k = 0; k < 3; ++k) P[3 * c + k] = vertices[3 * v + k];
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) fverts[9 * f + q] = P[q];
+  if (norm != nullptr) {
+    double N[3], C[3], clen;
+    face_normal(P, N, C, &clen);
+    norm[3 * f] = N[0];
+    norm[3 * f + 1] = N[1];
+    norm[3 * f + 2] = N[2];
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_build_faces_bwd(
+    const double* __restrict__ g_fverts, const double* __restrict__ g_norm,
+    const double* __restrict__ fverts, const int32_t* __restrict__ faces,
+    const uint8_t* __restrict__ mask, int64_t F, int64_t V, double* __restrict__ g_vertices) {
+  const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (f >= F) return;
+  double g[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g[q] = g_fverts ? g_fverts[9 * f + q] : 0.0;
+  if (g_norm != nullptr) {
+    // N = C/|C|, C = A x B, A = P1-P0, B = P2-P1
+    double P[9], N[3], C[3], clen;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) P[q] = fverts[9 * f + q];
+    face_normal(P, N, C, &clen);
+    const double gn[3] = {g_norm[3 * f], g_norm[3 * f + 1], g_norm[3 * f + 2]};
+    const double nn = dot3(N, gn);
+    double Cb[3];
+    for (int k = 0; k < 3; ++k) Cb[k] = (gn[k] - N[k] * nn) / clen;
+    const double A[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]};
+    const double B[3] = {P[6] - P[3], P[7] - P[4], P[8] - P[5]};
+    double Ab[3], Bb[3];
+    cross3(B, Cb, Ab);
+    cross3(Cb, A, Bb);
+    for (int k = 0; k < 3; ++k) {
+      g[k] -= Ab[k];
+      g[3 + k] += Ab[k] - Bb[k];
+      g[6 + k] += Bb[k];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (mask != nullptr && mask[3 * f + c] == 0) continue;
+    const int64_t v = faces[3 * f + c];
+    if (v < 0 || v >= V) continue;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double x = g[3 * c + k];
+      if (x != 0.0) unsafeAtomicAdd(g_vertices + 3 * v + k, x);
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_snell3d(int64_t n, const double* xs, const double* ys,
+                                                   const double* zs, const double* xe,
+                                                   const double* ye, const double* ze,
+                                                   const double* norm, const double* n_in,
+                                                   const double* n_out, double L, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double s[3] = {xs[i], ys[i], zs[i]}, h[3] = {xe[i], ye[i], ze[i]};
+  const double N[3] = {norm[3 * i], norm[3 * i + 1], norm[3 * i + 2]};
+  const Snell3 f = snell3d(s, h, N, n_in[i], n_out[i]);
+  for (int k = 0; k < 3; ++k) {
+    out[k * n + i] = h[k];
+    out[(3 + k) * n + i] = h[k] + L * f.w[k];
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_snell2d(int64_t n, const double* xs, const double* ys,
+                                                   const double* xe, const double* ye,
+                                                   const double* norm, const double* n_in,
+                                                   const double* n_out, double L, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double a = snell2d_angle(xs[i], ys[i], xe[i], ye[i], norm[i], n_in[i], n_out[i]);
+  out[i] = xe[i];
+  out[n + i] = ye[i];
+  out[2 * n + i] = xe[i] + L * cos(a);
+  out[3 * n + i] = ye[i] + L * sin(a);
+}
+
+}  // namespace tfrt
+
+using namespace tfrt;
+
+extern "C" {
+
+int tfrt_version(void) { return TFRT_VERSION; }
+
+const char* tfrt_strerror(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case TFRT_E_BADARG: return "bad argument (null pointer, negative size, stride < n, or too many faces)";
+    case TFRT_E_WORKSPACE: return "workspace too small (query tfrt_*_workspace_bytes)";
+    case TFRT_E_LAUNCH: return "HIP kernel launch failed";
+    case TFRT_E_UNSUPPORTED: return "unsupported state dtype or option";
+    default: return "unknown tfrt error";
+  }
+}
+
+int tfrt_build_faces_forward(const double* vertices, int64_t n_vertices, const int32_t* faces,
+                             int64_t n_faces, double* face_verts, double* norm, void* stream) {
+  if (n_faces < 0 || n_vertices < 0) return TFRT_E_BADARG;
+  if (n_faces == 0) return 0;
+  if (!vertices || !faces || !face_verts || n_vertices == 0) return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_build_faces, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), vertices, n_vertices, faces, n_faces,
+                     face_verts, norm);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_norm,
+                              const double* face_verts, const int32_t* faces,
+                              const uint8_t* update_mask, int64_t n_faces, int64_t n_vertices,
+                              double* grad_vertices, void* stream) {
+  if (n_faces < 0 || n_vertices < 0) return TFRT_E_BADARG;
+  if (n_faces == 0) return 0;
+  if (!faces || !grad_vertices || (!grad_face_verts && !grad_norm) ||
+      (grad_norm && !face_verts))
+    return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_build_faces_bwd, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
+                     faces, update_mask, n_faces, n_vertices, grad_vertices);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_snell3d(int64_t n, const double* x_start, const double* y_start, const double* z_start,
+                 const double* x_end, const double* y_end, const double* z_end,
+                 const double* norm, const double* n_in, const double* n_out,
+                 double new_ray_length, double* out6, void* stream) {
+  if (n < 0) return TFRT_E_BADARG;
+  if (n == 0) return 0;
+  if (!x_start || !y_start || !z_start || !x_end || !y_end || !z_end || !norm || !n_in ||
+      !n_out || !out6)
+    return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_snell3d, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), n, x_start, y_start, z_start, x_end, y_end,
+                     z_end, norm, n_in, n_out, new_ray_length, out6);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_snell2d(int64_t n, const double* x_start, const double* y_start, const double* x_end,
+                 const double* y_end, const double* norm, const double* n_in,
+                 const double* n_out, double new_ray_length, double* out4, void* stream) {
+  if (n < 0) return TFRT_E_BADARG;
+  if (n == 0) return 0;
+  if (!x_start || !y_start || !x_end || !y_end || !norm || !n_in || !n_out || !out4)
+    return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_snell2d, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), n, x_start, y_start, x_end, y_end, norm,
+                     n_in, n_out, new_ray_length, out4);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+}  // extern "C"

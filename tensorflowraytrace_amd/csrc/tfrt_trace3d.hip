@@ -1,0 +1,925 @@
+// tfrt 3-D hot path for MI355X (gfx950): ray x triangle intersection, nearest hit, stable
+// classification/compaction, Snell update, pass loop and reverse sweep.
+//
+// Structure of one pass (reference: tfrt/engine.py:2193-2302 single_pass):
+//
+//   k_intersect3d  grid (ray blocks, face chunks).  lane = R rays.  The chunk's faces stream
+//                  through an LDS tile as 16-byte bounding spheres; the hot loop is a
+//                  conservative float32 line-vs-sphere rejection test (10 VALU ops per
+//                  ray-face pair, Pluecker form |c x d^ - m|^2 <= r^2).  Pairs that survive
+//                  are queued per lane in LDS and then decided EXACTLY in float64 with the
+//                  reference's own Cramer sums and epsilons (trace_math.h exact_triangle),
+//                  so hit/miss and nearest-hit decisions are the float64 reference's
+//                  decisions; the float32 filter only ever removes pairs that cannot hit.
+//                  Running (ray_u, face) minimum lives in registers: no cross-lane reduce.
+//   k_classify3d   min over face chunks (first index wins ties, like tf.argmin), boundary
+//                  catagory -> ray class, per-block class histogram.
+//   k_scan3d       one block: exclusive scan of the histograms -> stable output slots,
+//                  per-pass counts, running totals, next pass's ray count (all on device:
+//                  the host never synchronises inside a trace).
+//   k_react3d      projects the ray end onto the hit, writes finished / stopped / dead /
+//                  active-history rows at their stable slots, refracts/reflects active rays
+//                  (float64 Snell) into the next pass's ray block, records the tape.
+//
+// Backward: k_backward3d walks the tape pass by pass in reverse, recomputes the per-ray
+// forward in float64 and applies the hand-derived adjoint (trace_math.h adjoint3d); face
+// gradients are accumulated with float64 hardware atomics.
+#include "tfrt_common.h"
+
+namespace tfrt {
+
+constexpr int TILE = 1024;  // spheres per LDS tile (16 KiB)
+constexpr int KC = 12;      // candidate slots per lane (12 KiB per block)
+
+// error bits written to counts[...error]
+constexpr int ERR_CAPACITY = 1;
+
+// ------------------------------------------------------------------------------ prep
+
+// c0 = mean of the face corner P0 over all faces: origin of the filter's coordinate frame
+// (keeps |c| small so the float32 rounding margin stays far below the sphere radii).
+__global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fverts, int M,
+                                                 double* __restrict__ c0) {
+  __shared__ double red[3][1024];
+  double a[3] = {0, 0, 0};
+  for (int j = threadIdx.x; j < M; j += 1024) {
+    a[0] += fverts[9 * (int64_t)j];
+    a[1] += fverts[9 * (int64_t)j + 1];
+    a[2] += fverts[9 * (int64_t)j + 2];
+  }
+  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = a[k];
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) c0[threadIdx.x] = (M > 0) ? red[threadIdx.x][0] / M : 0.0;
+}
+
+// Smallest enclosing sphere of each triangle, inflated so that the float32 filter is
+// conservative: r_eff = r (1 + 1e-5) + 64 u32 (|c| + r) + max(size_eps, 0) (|E1| + |E2|).
+__global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fverts, int M,
+                                                   const double* __restrict__ c0,
+                                                   double size_eps,
+                                                   float4* __restrict__ sphere) {
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= M) return;
+  const double* P = fverts + 9 * (int64_t)j;
+  const double A[3] = {P[0], P[1], P[2]}, B[3] = {P[3], P[4], P[5]}, C[3] = {P[6], P[7], P[8]};
+  double ab[3], ac[3], bc[3];
+  for (int k = 0; k < 3; ++k) {
+    ab[k] = B[k] - A[k];
+    ac[k] = C[k] - A[k];
+    bc[k] = C[k] - B[k];
+  }
+  double c[3], r2;
+  const double dA = dot3(ab, ac);           // angle at A obtuse/right if <= 0
+  const double dB = -dot3(ab, bc);          // (A-B).(C-B)
+  const double dC = dot3(ac, bc);           // (A-C).(B-C)
+  if (dA <= 0.0) {                          // longest edge BC
+    for (int k = 0; k < 3; ++k) c[k] = 0.5 * (B[k] + C[k]);
+    r2 = 0.25 * dot3(bc, bc);
+  } else if (dB <= 0.0) {                   // longest edge AC
+    for (int k = 0; k < 3; ++k) c[k] = 0.5 * (A[k] + C[k]);
+    r2 = 0.25 * dot3(ac, ac);
+  } else if (dC <= 0.0) {                   // longest edge AB
+    for (int k = 0; k < 3; ++k) c[k] = 0.5 * (A[k] + B[k]);
+    r2 = 0.25 * dot3(ab, ab);
+  } else {                                  // acute: circumcentre
+    double n[3], t1[3], t2[3];
+    cross3(ab, ac, n);
+    const double n2 = dot3(n, n);
+    cross3(n, ab, t1);   // (ab x ac) x ab
+    cross3(ac, n, t2);   // ac x (ab x ac)
+    const double ab2 = dot3(ab, ab), ac2 = dot3(ac, ac);
+    double off[3];
+    for (int k = 0; k < 3; ++k) off[k] = (ac2 * t1[k] + ab2 * t2[k]) / (2.0 * n2);
+    for (int k = 0; k < 3; ++k) c[k] = A[k] + off[k];
+    r2 = dot3(off, off);
+  }
+  double r = sqrt(r2);
+  // guard against a degenerate (zero-area) acute classification producing inf/nan
+  if (!(r2 == r2) || r2 > 1e300) {
+    for (int k = 0; k < 3; ++k) c[k] = (A[k] + B[k] + C[k]) / 3.0;
+    r = 0.0;
+    for (int v = 0; v < 3; ++v) {
+      double d2 = 0;
+      for (int k = 0; k < 3; ++k) d2 += (P[3 * v + k] - c[k]) * (P[3 * v + k] - c[k]);
+      r = fmax(r, sqrt(d2));
+    }
+  }
+  double cc[3] = {c[0] - c0[0], c[1] - c0[1], c[2] - c0[2]};
+  const double cn = sqrt(dot3(cc, cc));
+  const double u32 = 5.9604644775390625e-08;  // 2^-24
+  double reff = r * (1.0 + 1e-5) + 64.0 * u32 * (cn + r);
+  if (size_eps > 0.0) reff += size_eps * (sqrt(dot3(ab, ab)) + sqrt(dot3(ac, ac)));
+  float rf = static_cast<float>(reff * reff);
+  rf = nextafterf(rf, INFINITY);
+  rf = nextafterf(rf, INFINITY);
+  sphere[j] = make_float4((float)cc[0], (float)cc[1], (float)cc[2], rf);
+}
+
+// ------------------------------------------------------------------------- intersect
+
+template <typename T, int R>
+__global__ __launch_bounds__(BLOCK) void k_intersect3d(
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, const float4* __restrict__ sphere,
+    const double* __restrict__ fverts, const double* __restrict__ c0, int M, int chunk_faces,
+    double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
+    int32_t* __restrict__ part_i, int64_t part_stride) {
+  const int n = *n_ptr;
+  const int base = blockIdx.x * (BLOCK * R);
+  if (base >= n) return;  // block-uniform
+  const int tid = threadIdx.x;
+  const int f0 = blockIdx.y * chunk_faces;
+  const int f1 = min(M, f0 + chunk_faces);
+
+  __shared__ float4 tile[TILE];
+  __shared__ int32_t cand[KC * BLOCK];
+
+  // per-ray filter state: unit direction d^ and -moment, both float32, in the c0 frame
+  float dx[R], dy[R], dz[R], nmx[R], nmy[R], nmz[R];
+  double bt[R];
+  int32_t bi[R];
+  {
+    const double o0 = c0[0], o1 = c0[1], o2 = c0[2];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = base + r * BLOCK + tid;
+      bt[r] = INFINITY;
+      bi[r] = -1;
+      dx[r] = dy[r] = dz[r] = 0.f;
+      nmx[r] = nmy[r] = nmz[r] = INFINITY;  // never a candidate
+      if (i < n) {
+        double s[3], e[3];
+        load_ray3(rays, stride, i, s, e);
+        const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
+        const double l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (l2 > 0.0 && l2 < INFINITY) {
+          const double inv = 1.0 / sqrt(l2);
+          const double u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
+          const double sc[3] = {s[0] - o0, s[1] - o1, s[2] - o2};
+          dx[r] = (float)u[0];
+          dy[r] = (float)u[1];
+          dz[r] = (float)u[2];
+          // m = sc x u ; store -m.  w = c x u - m = (c - sc) x u
+          nmx[r] = -(float)(sc[1] * u[2] - sc[2] * u[1]);
+          nmy[r] = -(float)(sc[2] * u[0] - sc[0] * u[2]);
+          nmz[r] = -(float)(sc[0] * u[1] - sc[1] * u[0]);
+        }
+      }
+    }
+  }
+
+  int cnt = 0;
+  // exact float64 decision for every queued candidate of this lane
+  auto flush = [&]() {
+    for (int k = 0; k < cnt; ++k) {
+      const int v = cand[k * BLOCK + tid];
+      const int j = v >> 2;
+      const int r = v & 3;
+      const int i = base + r * BLOCK + tid;
+      if (last_tri != nullptr && last_tri[i] == j) continue;  // face the ray starts on
+      double s[3], e[3], P[9];
+      load_ray3(rays, stride, i, s, e);
+      const double* fp = fverts + 9 * (int64_t)j;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) P[q] = fp[q];
+      const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
+      if (h.valid) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+          if (rr == r && h.ray_u < bt[rr]) {  // strict <: lowest face index wins ties
+            bt[rr] = h.ray_u;
+            bi[rr] = j;
+          }
+        }
+      }
+    }
+    cnt = 0;
+  };
+
+  // One sphere against this lane's R rays: 9 FMA-class ops per ray, a min tree and ONE
+  // compare; the (rare) survivors are queued for the exact float64 stage.
+  auto test = [&](const float4 sp, const int face) {
+    float q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float wx = fmaf(sp.y, dz[r], fmaf(-sp.z, dy[r], nmx[r]));
+      const float wy = fmaf(sp.z, dx[r], fmaf(-sp.x, dz[r], nmy[r]));
+      const float wz = fmaf(sp.x, dy[r], fmaf(-sp.y, dx[r], nmz[r]));
+      q[r] = fmaf(wx, wx, fmaf(wy, wy, wz * wz));
+    }
+    float qmin = q[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) qmin = fminf(qmin, q[r]);
+    if (qmin <= sp.w) {  // rare
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (q[r] <= sp.w) {
+          cand[cnt * BLOCK + tid] = (face << 2) | r;
+          ++cnt;
+        }
+      }
+      if (cnt > KC - R) flush();
+    }
+  };
+
+  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 is never true
+  for (int t0 = f0; t0 < f1; t0 += TILE) {
+    const int nt = min(TILE, f1 - t0);
+    const int nt4 = (nt + 3) & ~3;
+    __syncthreads();  // previous tile fully consumed
+    for (int k = tid; k < nt4; k += BLOCK) tile[k] = (k < nt) ? sphere[t0 + k] : never;
+    __syncthreads();
+    for (int j = 0; j < nt4; j += 4) {
+      // same address in every lane: LDS broadcast reads, four in flight
+      const float4 s0 = tile[j], s1 = tile[j + 1], s2 = tile[j + 2], s3 = tile[j + 3];
+      test(s0, t0 + j);
+      test(s1, t0 + j + 1);
+      test(s2, t0 + j + 2);
+      test(s3, t0 + j + 3);
+    }
+  }
+  flush();
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = base + r * BLOCK + tid;
+    if (i < n) {
+      part_t[blockIdx.y * part_stride + i] = bt[r];
+      part_i[blockIdx.y * part_stride + i] = bi[r];
+    }
+  }
+}
+
+// -------------------------------------------------------------------------- classify
+
+__device__ __forceinline__ int cat_to_cls(int cat) {
+  return cat == CAT_OPTICAL ? CLS_ACTIVE : (cat == CAT_TARGET ? CLS_FINISHED : CLS_STOPPED);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_classify3d(
+    const int32_t* __restrict__ n_ptr, int chunks, const double* __restrict__ part_t,
+    const int32_t* __restrict__ part_i, int64_t part_stride,
+    const int32_t* __restrict__ catagory, int32_t* __restrict__ rec_tri,
+    double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls, int32_t* __restrict__ blockcnt) {
+  const int n = *n_ptr;
+  const int base = blockIdx.x * BLOCK;
+  if (base >= n) return;
+  const int i = base + threadIdx.x;
+  int cls = -1;
+  if (i < n) {
+    double bt = INFINITY;
+    int bi = -1;
+    for (int c = 0; c < chunks; ++c) {  // ascending faces, strict <: first index wins
+      const double t = part_t[c * part_stride + i];
+      if (t < bt) {
+        bt = t;
+        bi = part_i[c * part_stride + i];
+      }
+    }
+    cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
+    rec_tri[i] = bi;
+    rec_t[i] = bt;
+    rec_cls[i] = (uint8_t)cls;
+  }
+  __shared__ int wc[WAVES][4];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (lane_id() == 0) wc[wave][c] = __popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    int s = 0;
+    for (int w = 0; w < WAVES; ++w) s += wc[w][threadIdx.x];
+    blockcnt[blockIdx.x * 4 + threadIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------ scan
+
+// One block of 1024 threads: exclusive scan of the per-block class histograms.
+__global__ __launch_bounds__(1024) void k_scan3d(const int32_t* __restrict__ n_ptr,
+                                                 const int32_t* __restrict__ blockcnt,
+                                                 int32_t* __restrict__ blockoff,
+                                                 int32_t* __restrict__ pass_counts,
+                                                 int32_t* __restrict__ totals,
+                                                 int32_t* __restrict__ n_next,
+                                                 unsigned long long* __restrict__ n_tests,
+                                                 int M) {
+  const int n = *n_ptr;
+  const int nblk = (n + BLOCK - 1) / BLOCK;
+  const int per = (nblk + 1023) / 1024;
+  const int b0 = min(nblk, (int)threadIdx.x * per), b1 = min(nblk, b0 + per);
+  int loc[4] = {0, 0, 0, 0};
+  for (int b = b0; b < b1; ++b)
+    for (int c = 0; c < 4; ++c) loc[c] += blockcnt[b * 4 + c];
+
+  __shared__ int wsum[16][4];
+  __shared__ int wbase[16][4];
+  __shared__ int total[4];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  int pre[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int v = loc[c];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(v, d, 64);
+      if (lane >= d) v += o;
+    }
+    pre[c] = v - loc[c];  // exclusive within the wave
+    if (lane == 63) wsum[wave][c] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    int run = 0;
+    for (int w = 0; w < 16; ++w) {
+      wbase[w][threadIdx.x] = run;
+      run += wsum[w][threadIdx.x];
+    }
+    total[threadIdx.x] = run;
+  }
+  __syncthreads();
+  int run[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) run[c] = wbase[wave][c] + pre[c];
+  for (int b = b0; b < b1; ++b)
+    for (int c = 0; c < 4; ++c) {
+      blockoff[b * 4 + c] = run[c];
+      run[c] += blockcnt[b * 4 + c];
+    }
+  if (threadIdx.x < 4) {
+    const int c = threadIdx.x;
+    pass_counts[c] = total[c];
+    pass_counts[4 + c] = totals[c];
+    totals[c] += total[c];
+  }
+  if (threadIdx.x == 0) {
+    *n_next = total[CLS_ACTIVE];
+    *n_tests += (unsigned long long)n * (unsigned long long)M;
+  }
+}
+
+// ----------------------------------------------------------------------------- react
+
+__device__ __forceinline__ void face_indices(const tfrt_scene3d& sc, int tri, int rid,
+                                             double* n_in, double* n_out) {
+  if (sc.n_table != nullptr && sc.mat_in != nullptr) {
+    *n_in = sc.n_table[(int64_t)sc.mat_in[tri] * sc.n_table_stride + rid];
+    *n_out = sc.n_table[(int64_t)sc.mat_out[tri] * sc.n_table_stride + rid];
+  } else {
+    *n_in = sc.n_in[tri];
+    *n_out = sc.n_out[tri];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ bool emit(const tfrt_ray_out& o, int64_t slot, const double s[3],
+                                     const double e[3], int rid, int face) {
+  if (o.rays == nullptr) return true;
+  if (slot >= o.capacity) return false;
+  store_ray3(static_cast<T*>(o.rays), o.capacity, slot, s, e);
+  if (o.ray_id) o.ray_id[slot] = rid;
+  if (o.face) o.face[slot] = face;
+  return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_react3d(
+    const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
+    const double* __restrict__ rec_t, const uint8_t* __restrict__ rec_cls,
+    const int32_t* __restrict__ blockoff, const int32_t* __restrict__ pass_counts,
+    tfrt_scene3d sc, double L, double dead_len, uint32_t flags, T* __restrict__ rays_out,
+    int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_tri_out,
+    int32_t* __restrict__ rec_slot, tfrt_ray_out fin, tfrt_ray_out act, tfrt_ray_out stp,
+    tfrt_ray_out dead, int32_t* __restrict__ err) {
+  const int n = *n_ptr;
+  const int base = blockIdx.x * BLOCK;
+  if (base >= n) return;
+  const int i = base + threadIdx.x;
+  const int cls = (i < n) ? (int)rec_cls[i] : -1;
+
+  // stable rank of this ray inside its class within the block
+  __shared__ int wc[WAVES][4];
+  const int wave = threadIdx.x >> 6;
+  int rank = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const unsigned long long m = __ballot(cls == c);
+    if (cls == c) rank = rank_below(m);
+    if (lane_id() == 0) wc[wave][c] = __popcll(m);
+  }
+  __syncthreads();
+  if (i >= n) return;
+  for (int w = 0; w < wave; ++w) rank += wc[w][cls];
+  const int slot = blockoff[blockIdx.x * 4 + cls] + rank;  // within this pass
+  const int64_t gslot = (int64_t)pass_counts[4 + cls] + slot;  // within the whole trace
+
+  double s[3], e[3];
+  load_ray3(rays_in, stride_in, i, s, e);
+  const int rid = ray_id_in ? ray_id_in[i] : i;
+  const int tri = rec_tri[i];
+  bool ok = true;
+
+  if (cls == CLS_DEAD) {
+    if (flags & TFRT_COMPILE_DEAD) {
+      double e2[3] = {e[0], e[1], e[2]};
+      if (dead_len != 0.0)
+        for (int k = 0; k < 3; ++k) e2[k] = s[k] + dead_len * (e[k] - s[k]);
+      ok = emit<T>(dead, gslot, s, e2, rid, -1);
+    }
+    rec_slot[i] = (int32_t)gslot;
+  } else {
+    double h[3];
+    hit_point(s, e, rec_t[i], h);
+    if (cls == CLS_FINISHED) {
+      if (flags & TFRT_COMPILE_FINISHED) ok = emit<T>(fin, gslot, s, h, rid, tri);
+      rec_slot[i] = (int32_t)gslot;
+    } else if (cls == CLS_STOPPED) {
+      if (flags & TFRT_COMPILE_STOPPED) ok = emit<T>(stp, gslot, s, h, rid, tri);
+      rec_slot[i] = (int32_t)gslot;
+    } else {  // ACTIVE
+      if (flags & TFRT_COMPILE_ACTIVE) ok = emit<T>(act, gslot, s, h, rid, tri);
+      double P[9], N[3], C[3], clen, n_in, n_out;
+      const double* fp = sc.face_verts + 9 * (int64_t)tri;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) P[q] = fp[q];
+      face_normal(P, N, C, &clen);
+      face_indices(sc, tri, rid, &n_in, &n_out);
+      const Snell3 f = snell3d(s, h, N, n_in, n_out);
+      double e2[3];
+      for (int k = 0; k < 3; ++k) e2[k] = h[k] + L * f.w[k];
+      store_ray3(rays_out, stride_out, slot, h, e2);
+      ray_id_out[slot] = rid;
+      last_tri_out[slot] = tri;
+      rec_slot[i] = slot;
+    }
+  }
+  if (!ok) atomicOr(err, ERR_CAPACITY);
+}
+
+// -------------------------------------------------------------------------- backward
+
+__device__ __forceinline__ void add6(const double* g, int64_t cap, int64_t slot, double a[3],
+                                     double b[3]) {
+  if (g == nullptr) return;
+  for (int k = 0; k < 3; ++k) {
+    a[k] += g[k * cap + slot];
+    b[k] += g[(3 + k) * cap + slot];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_backward3d(
+    const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
+    const double* __restrict__ rec_t, const uint8_t* __restrict__ rec_cls,
+    const int32_t* __restrict__ rec_slot, const int32_t* __restrict__ pass_counts,
+    tfrt_scene3d sc, double L, double dead_len, const double* __restrict__ g_child,
+    int64_t child_stride, const double* __restrict__ g_fin, int64_t cap_fin,
+    const double* __restrict__ g_act, int64_t cap_act, const double* __restrict__ g_stp,
+    int64_t cap_stp, const double* __restrict__ g_dead, int64_t cap_dead,
+    double* __restrict__ g_out, int64_t out_stride, double* __restrict__ g_fverts) {
+  const int n = *n_ptr;
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int cls = rec_cls[i];
+  const int slot = rec_slot[i];
+  double s[3], e[3];
+  load_ray3(rays_in, stride_in, i, s, e);
+  double gs[3] = {0, 0, 0}, ge[3] = {0, 0, 0};
+
+  if (cls == CLS_DEAD) {
+    if (g_dead != nullptr) {
+      double a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+      add6(g_dead, cap_dead, slot, a, b);
+      const double dl = (dead_len != 0.0) ? dead_len : 1.0;
+      for (int k = 0; k < 3; ++k) {
+        gs[k] = a[k] + (1.0 - dl) * b[k];
+        ge[k] = dl * b[k];
+      }
+    }
+  } else {
+    double g_s[3] = {0, 0, 0}, g_h[3] = {0, 0, 0}, g_ce[3] = {0, 0, 0};
+    bool has_child = false;
+    if (cls == CLS_FINISHED) {
+      add6(g_fin, cap_fin, slot, g_s, g_h);
+    } else if (cls == CLS_STOPPED) {
+      add6(g_stp, cap_stp, slot, g_s, g_h);
+    } else {
+      add6(g_act, cap_act, (int64_t)pass_counts[4 + CLS_ACTIVE] + slot, g_s, g_h);
+      if (g_child != nullptr) {
+        has_child = true;
+        add6(g_child, child_stride, slot, g_h, g_ce);
+      }
+    }
+    bool nz = has_child;
+    for (int k = 0; k < 3; ++k) nz = nz || g_s[k] != 0.0 || g_h[k] != 0.0;
+    if (nz) {
+      const int tri = rec_tri[i];
+      const int rid = ray_id_in ? ray_id_in[i] : i;
+      double P[9], gP[9], n_in = 1.0, n_out = 1.0;
+      const double* fp = sc.face_verts + 9 * (int64_t)tri;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) P[q] = fp[q];
+      if (has_child) face_indices(sc, tri, rid, &n_in, &n_out);
+      adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP);
+      double* gp = g_fverts + 9 * (int64_t)tri;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        if (gP[q] == gP[q]) unsafeAtomicAdd(gp + q, gP[q]);  // drop NaN like optimizer.py:229
+      }
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    g_out[k * out_stride + i] = gs[k];
+    g_out[(3 + k) * out_stride + i] = ge[k];
+  }
+}
+
+// ------------------------------------------------------------------------------ misc
+
+__global__ void k_init(int32_t* nrays0, int n, int32_t* tail8) {
+  if (threadIdx.x == 0) *nrays0 = n;
+  if (threadIdx.x < 8) tail8[threadIdx.x] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_copy_rays(const T* __restrict__ in, int64_t sin,
+                                                     const int32_t* __restrict__ id_in,
+                                                     const int32_t* __restrict__ n_ptr,
+                                                     T* __restrict__ out, int64_t sout,
+                                                     int32_t* __restrict__ id_out) {
+  const int n = *n_ptr;
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  for (int k = 0; k < 6; ++k) out[k * sout + i] = in[k * sin + i];
+  if (id_out) id_out[i] = id_in ? id_in[i] : i;
+}
+
+// finalize for the seam-level tfrt_intersect3d
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_finalize_seam(
+    const T* __restrict__ rays, int64_t stride, int n, int chunks,
+    const double* __restrict__ part_t, const int32_t* __restrict__ part_i, int64_t part_stride,
+    const double* __restrict__ fverts, int M, double eps_int, double eps_size, double eps_start,
+    double* x, double* y, double* z, uint8_t* valid, double* ray_u, double* trig_u,
+    double* trig_v, int32_t* gather_trig) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  double bt = INFINITY;
+  int bi = -1;
+  for (int c = 0; c < chunks; ++c) {
+    const double t = part_t[c * part_stride + i];
+    if (t < bt) {
+      bt = t;
+      bi = part_i[c * part_stride + i];
+    }
+  }
+  const int tri = bi < 0 ? 0 : bi;  // tf.argmin over an all-sentinel column returns 0
+  double s[3], e[3], P[9], h[3] = {0, 0, 0};
+  TriHit th;
+  th.ray_u = th.trig_u = th.trig_v = 0.0;
+  th.valid = false;
+  if (M > 0) {
+    load_ray3(rays, stride, i, s, e);
+    for (int q = 0; q < 9; ++q) P[q] = fverts[9 * (int64_t)tri + q];
+    th = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
+    hit_point(s, e, th.ray_u, h);
+  }
+  x[i] = h[0];
+  y[i] = h[1];
+  z[i] = h[2];
+  valid[i] = bi >= 0;
+  ray_u[i] = bi >= 0 ? th.ray_u : INFINITY;
+  trig_u[i] = th.trig_u;
+  trig_v[i] = th.trig_v;
+  gather_trig[i] = tri;
+}
+
+// ------------------------------------------------------------------- host-side plan
+
+struct Plan3 {
+  int R, ray_blocks, chunks, chunk_faces, nblk;
+};
+
+static Plan3 make_plan(int64_t N, int64_t M) {
+  Plan3 p;
+  p.R = (N >= 32768) ? 4 : (N >= 8192 ? 2 : 1);
+  if (const char* env = getenv("TFRT_RAYS_PER_LANE")) {
+    const int r = atoi(env);
+    if (r == 1 || r == 2 || r == 4) p.R = r;
+  }
+  p.ray_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.R);
+  int target = 2048;  // ~8 workgroups per CU on 256 CUs
+  if (const char* env = getenv("TFRT_TARGET_BLOCKS")) target = atoi(env) > 0 ? atoi(env) : target;
+  int chunks = cdiv(target, p.ray_blocks);
+  const int max_chunks = cdiv(M > 0 ? M : 1, 256);
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  p.chunk_faces = cdiv(M > 0 ? M : 1, chunks);
+  p.chunks = cdiv(M > 0 ? M : 1, p.chunk_faces);
+  p.nblk = cdiv(N > 0 ? N : 1, BLOCK);
+  return p;
+}
+
+struct Layout3 {
+  size_t c0, sphere, nrays, blockcnt, blockoff, part_t, part_i;
+  size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, total;
+};
+
+static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& pl) {
+  Layout3 L;
+  const size_t esz = dtype == TFRT_F64 ? 8 : 4;
+  const size_t n = N > 0 ? N : 1, m = M > 0 ? M : 1;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes);
+    return at;
+  };
+  L.c0 = take(4 * sizeof(double));
+  L.sphere = take(m * sizeof(float4));
+  L.nrays = take((P + 2) * sizeof(int32_t));
+  L.blockcnt = take((size_t)pl.nblk * 4 * sizeof(int32_t));
+  L.blockoff = take((size_t)pl.nblk * 4 * sizeof(int32_t));
+  L.part_t = take((size_t)pl.chunks * n * sizeof(double));
+  L.part_i = take((size_t)pl.chunks * n * sizeof(int32_t));
+  L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
+  L.rayid = take((size_t)P * n * sizeof(int32_t));
+  L.lasttri = take((size_t)P * n * sizeof(int32_t));
+  L.rec_tri = take((size_t)P * n * sizeof(int32_t));
+  L.rec_slot = take((size_t)P * n * sizeof(int32_t));
+  L.rec_t = take((size_t)P * n * sizeof(double));
+  L.rec_cls = take((size_t)P * n);
+  L.gbuf = take((size_t)2 * 6 * n * sizeof(double));
+  L.total = o;
+  return L;
+}
+
+template <typename T>
+static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int64_t stride,
+                            const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
+                            const double* fverts, const double* c0, int M, double ei, double es,
+                            double er, double* part_t, int32_t* part_i, int64_t part_stride) {
+  dim3 grid(pl.ray_blocks, pl.chunks);
+#define TFRT_LAUNCH_R(RR)                                                                    \
+  hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
+                     last_tri, sphere, fverts, c0, M, pl.chunk_faces, ei, es, er, part_t,    \
+                     part_i, part_stride)
+  if (pl.R == 4) TFRT_LAUNCH_R(4);
+  else if (pl.R == 2) TFRT_LAUNCH_R(2);
+  else TFRT_LAUNCH_R(1);
+#undef TFRT_LAUNCH_R
+  return 0;
+}
+
+static bool scene_ok(const tfrt_scene3d* sc) {
+  if (!sc || sc->n_faces < 0) return false;
+  if (sc->n_faces > 0 && (!sc->face_verts || !sc->catagory)) return false;
+  if (sc->n_faces >= (1ll << 29)) return false;
+  const bool index_mode = sc->mat_in && sc->mat_out && sc->n_table;
+  const bool value_mode = sc->n_in && sc->n_out;
+  return sc->n_faces == 0 || index_mode || value_mode;
+}
+
+template <typename T>
+static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N,
+                             const tfrt_scene3d* sc, double L, double dead_len, int P,
+                             int dtype, uint32_t flags, tfrt_ray_out* fin, tfrt_ray_out* act,
+                             tfrt_ray_out* stp, tfrt_ray_out* dead, void* unfinished,
+                             int32_t* unfinished_id, int32_t* counts, void* workspace,
+                             size_t workspace_bytes, hipStream_t st) {
+  const int M = (int)sc->n_faces;
+  const Plan3 pl = make_plan(N, M);
+  const Layout3 lay = make_layout(N, M, P, dtype, pl);
+  if (workspace_bytes < lay.total) return TFRT_E_WORKSPACE;
+  char* ws = static_cast<char*>(workspace);
+  double* c0 = reinterpret_cast<double*>(ws + lay.c0);
+  float4* sphere = reinterpret_cast<float4*>(ws + lay.sphere);
+  int32_t* nrays = reinterpret_cast<int32_t*>(ws + lay.nrays);
+  int32_t* blockcnt = reinterpret_cast<int32_t*>(ws + lay.blockcnt);
+  int32_t* blockoff = reinterpret_cast<int32_t*>(ws + lay.blockoff);
+  double* part_t = reinterpret_cast<double*>(ws + lay.part_t);
+  int32_t* part_i = reinterpret_cast<int32_t*>(ws + lay.part_i);
+  T* rays_ws = reinterpret_cast<T*>(ws + lay.rays);
+  int32_t* rayid = reinterpret_cast<int32_t*>(ws + lay.rayid);
+  int32_t* lasttri = reinterpret_cast<int32_t*>(ws + lay.lasttri);
+  int32_t* rec_tri = reinterpret_cast<int32_t*>(ws + lay.rec_tri);
+  int32_t* rec_slot = reinterpret_cast<int32_t*>(ws + lay.rec_slot);
+  double* rec_t = reinterpret_cast<double*>(ws + lay.rec_t);
+  uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
+  int32_t* tail = counts + (size_t)P * TFRT_COUNTS_PER_PASS;
+  const size_t n = N > 0 ? N : 1;
+
+  hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail);
+  if (M > 0) {
+    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0);
+    hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M, c0,
+                       sc->size_epsilion, sphere);
+  }
+  const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};
+  for (int p = 0; p < P; ++p) {
+    const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
+    const int64_t sin = p == 0 ? src_stride : (int64_t)n;
+    const int32_t* idin = p == 0 ? nullptr : rayid + (size_t)(p - 1) * n;
+    const int32_t* ltin = p == 0 ? nullptr : lasttri + (size_t)(p - 1) * n;
+    T* rout = rays_ws + (size_t)p * 6 * n;
+    launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, M,
+                        sc->intersect_epsilion, sc->size_epsilion, sc->ray_start_epsilion,
+                        part_t, part_i, (int64_t)n);
+    hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, pl.chunks,
+                       part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
+                       rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt);
+    hipLaunchKernelGGL(k_scan3d, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt, blockoff,
+                       counts + (size_t)p * TFRT_COUNTS_PER_PASS, tail, nrays + p + 1,
+                       reinterpret_cast<unsigned long long*>(tail + 4), M);
+    hipLaunchKernelGGL((k_react3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
+                       idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
+                       rec_cls + (size_t)p * n, blockoff,
+                       counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, flags, rout,
+                       (int64_t)n, rayid + (size_t)p * n, lasttri + (size_t)p * n,
+                       rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
+                       stp ? *stp : none, dead ? *dead : none, tail + 6);
+  }
+  if (unfinished != nullptr && P > 0) {
+    hipLaunchKernelGGL((k_copy_rays<T>), dim3(pl.nblk), dim3(BLOCK), 0, st,
+                       rays_ws + (size_t)(P - 1) * 6 * n, (int64_t)n, rayid + (size_t)(P - 1) * n,
+                       nrays + P, static_cast<T*>(unfinished), (int64_t)N, unfinished_id);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+template <typename T>
+static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t N,
+                              const tfrt_scene3d* sc, double L, double dead_len, int P, int dtype,
+                              const double* g_fin, int64_t cap_fin, const double* g_act,
+                              int64_t cap_act, const double* g_stp, int64_t cap_stp,
+                              const double* g_dead, int64_t cap_dead, double* g_fverts,
+                              double* g_src, const int32_t* counts, void* workspace,
+                              size_t workspace_bytes, hipStream_t st) {
+  const int M = (int)sc->n_faces;
+  const Plan3 pl = make_plan(N, M);
+  const Layout3 lay = make_layout(N, M, P, dtype, pl);
+  if (workspace_bytes < lay.total) return TFRT_E_WORKSPACE;
+  char* ws = static_cast<char*>(workspace);
+  const int32_t* nrays = reinterpret_cast<int32_t*>(ws + lay.nrays);
+  const T* rays_ws = reinterpret_cast<T*>(ws + lay.rays);
+  const int32_t* rayid = reinterpret_cast<int32_t*>(ws + lay.rayid);
+  const int32_t* rec_tri = reinterpret_cast<int32_t*>(ws + lay.rec_tri);
+  const int32_t* rec_slot = reinterpret_cast<int32_t*>(ws + lay.rec_slot);
+  const double* rec_t = reinterpret_cast<double*>(ws + lay.rec_t);
+  const uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
+  double* gbuf = reinterpret_cast<double*>(ws + lay.gbuf);
+  const size_t n = N > 0 ? N : 1;
+  for (int p = P - 1; p >= 0; --p) {
+    const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
+    const int64_t sin = p == 0 ? src_stride : (int64_t)n;
+    const int32_t* idin = p == 0 ? nullptr : rayid + (size_t)(p - 1) * n;
+    const double* g_child = (p == P - 1) ? nullptr : gbuf + (size_t)((p + 1) & 1) * 6 * n;
+    double* g_out = (p == 0 && g_src != nullptr) ? g_src : gbuf + (size_t)(p & 1) * 6 * n;
+    const int64_t out_stride = (p == 0 && g_src != nullptr) ? N : (int64_t)n;
+    hipLaunchKernelGGL((k_backward3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
+                       idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
+                       rec_cls + (size_t)p * n, rec_slot + (size_t)p * n,
+                       counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
+                       (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
+                       cap_dead, g_out, out_stride, g_fverts);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+}  // namespace tfrt
+
+// ================================================================================ C ABI
+using namespace tfrt;
+
+extern "C" {
+
+size_t tfrt_trace3d_workspace_bytes(int64_t n_rays, int64_t n_faces, int32_t max_passes,
+                                    int32_t state_dtype) {
+  if (n_rays < 0 || n_faces < 0 || max_passes < 0) return 0;
+  const Plan3 pl = make_plan(n_rays, n_faces);
+  return make_layout(n_rays, n_faces, max_passes, state_dtype, pl).total;
+}
+
+int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                         const tfrt_scene3d* scene, double new_ray_length,
+                         double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                         uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
+                         tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
+                         int32_t* unfinished_id, int32_t* counts, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (!scene_ok(scene) || n_rays < 0 || n_rays >= (1ll << 31) - 4096 || max_passes < 0 ||
+      !counts || !workspace || (n_rays > 0 && !src_rays) || src_stride < n_rays)
+    return TFRT_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (state_dtype == TFRT_F32)
+    return trace3d_forward_t<float>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                    dead_ray_length, max_passes, state_dtype, flags, finished,
+                                    active, stopped, dead, unfinished, unfinished_id, counts,
+                                    workspace, workspace_bytes, st);
+  if (state_dtype == TFRT_F64)
+    return trace3d_forward_t<double>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                     dead_ray_length, max_passes, state_dtype, flags, finished,
+                                     active, stopped, dead, unfinished, unfinished_id, counts,
+                                     workspace, workspace_bytes, st);
+  return TFRT_E_UNSUPPORTED;
+}
+
+int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                          const tfrt_scene3d* scene, double new_ray_length,
+                          double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                          const double* grad_finished, int64_t cap_finished,
+                          const double* grad_active, int64_t cap_active,
+                          const double* grad_stopped, int64_t cap_stopped,
+                          const double* grad_dead, int64_t cap_dead, double* grad_face_verts,
+                          double* grad_src_rays, const int32_t* counts, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  if (!scene_ok(scene) || n_rays < 0 || max_passes < 0 || !counts || !workspace ||
+      !grad_face_verts)
+    return TFRT_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (state_dtype == TFRT_F32)
+    return trace3d_backward_t<float>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                     dead_ray_length, max_passes, state_dtype, grad_finished,
+                                     cap_finished, grad_active, cap_active, grad_stopped,
+                                     cap_stopped, grad_dead, cap_dead, grad_face_verts,
+                                     grad_src_rays, counts, workspace, workspace_bytes, st);
+  if (state_dtype == TFRT_F64)
+    return trace3d_backward_t<double>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                      dead_ray_length, max_passes, state_dtype, grad_finished,
+                                      cap_finished, grad_active, cap_active, grad_stopped,
+                                      cap_stopped, grad_dead, cap_dead, grad_face_verts,
+                                      grad_src_rays, counts, workspace, workspace_bytes, st);
+  return TFRT_E_UNSUPPORTED;
+}
+
+size_t tfrt_intersect3d_workspace_bytes(int64_t n_rays, int64_t n_faces) {
+  if (n_rays < 0 || n_faces < 0) return 0;
+  const Plan3 pl = make_plan(n_rays, n_faces);
+  const size_t n = n_rays > 0 ? n_rays : 1, m = n_faces > 0 ? n_faces : 1;
+  return align_up(4 * sizeof(double)) + align_up(m * sizeof(float4)) + align_up(64) +
+         align_up((size_t)pl.chunks * n * sizeof(double)) +
+         align_up((size_t)pl.chunks * n * sizeof(int32_t));
+}
+
+int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t state_dtype,
+                     const double* face_verts, int64_t n_faces, double intersect_epsilion,
+                     double size_epsilion, double ray_start_epsilion, double* x, double* y,
+                     double* z, uint8_t* valid, double* ray_u, double* trig_u, double* trig_v,
+                     int32_t* gather_trig, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+  if (n_rays < 0 || n_faces < 0 || n_faces >= (1ll << 29) || stride < n_rays || !workspace ||
+      (n_faces > 0 && !face_verts))
+    return TFRT_E_BADARG;
+  if (workspace_bytes < tfrt_intersect3d_workspace_bytes(n_rays, n_faces)) return TFRT_E_WORKSPACE;
+  if (n_rays == 0) return 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int M = (int)n_faces;
+  const Plan3 pl = make_plan(n_rays, n_faces);
+  const size_t n = n_rays, m = n_faces > 0 ? n_faces : 1;
+  char* ws = static_cast<char*>(workspace);
+  size_t o = 0;
+  double* c0 = reinterpret_cast<double*>(ws + o);
+  o += align_up(4 * sizeof(double));
+  float4* sphere = reinterpret_cast<float4*>(ws + o);
+  o += align_up(m * sizeof(float4));
+  int32_t* nptr = reinterpret_cast<int32_t*>(ws + o);
+  o += align_up(64);
+  double* part_t = reinterpret_cast<double*>(ws + o);
+  o += align_up((size_t)pl.chunks * n * sizeof(double));
+  int32_t* part_i = reinterpret_cast<int32_t*>(ws + o);
+  hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nptr, (int)n_rays, nptr + 8);
+  if (M > 0) {
+    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, face_verts, M, c0);
+    hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, face_verts, M, c0,
+                       size_epsilion, sphere);
+  }
+#define TFRT_SEAM(TT)                                                                          \
+  launch_intersect<TT>(pl, st, static_cast<const TT*>(rays), stride, nptr, nullptr, sphere,    \
+                       face_verts, c0, M, intersect_epsilion, size_epsilion,                   \
+                       ray_start_epsilion, part_t, part_i, (int64_t)n);                        \
+  hipLaunchKernelGGL((k_finalize_seam<TT>), dim3(pl.nblk), dim3(BLOCK), 0, st,                 \
+                     static_cast<const TT*>(rays), stride, (int)n_rays, pl.chunks, part_t,     \
+                     part_i, (int64_t)n, face_verts, M, intersect_epsilion, size_epsilion,     \
+                     ray_start_epsilion, x, y, z, valid, ray_u, trig_u, trig_v, gather_trig)
+  if (state_dtype == TFRT_F32) {
+    TFRT_SEAM(float);
+  } else if (state_dtype == TFRT_F64) {
+    TFRT_SEAM(double);
+  } else {
+    return TFRT_E_UNSUPPORTED;
+  }
+#undef TFRT_SEAM
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,308 @@
+"""
+torch-facing wrappers of the HIP entry points (tensors are only device-array containers).
+
+Everything here requires HIP tensors; CPU tensors raise ``TfrtError`` -- there is no CPU
+fallback of the hot path.
+
+* ``build_faces``            -> tfrt_build_faces_forward/backward  (autograd.Function)
+* ``trace3d`` / ``Trace3D``  -> tfrt_trace3d_forward/backward      (autograd.Function)
+* ``intersect3d``            -> tfrt_intersect3d                   (seam S1, engine.py:1103)
+* ``snell3d`` / ``snell2d``  -> tfrt_snell3d / tfrt_snell2d        (seam S3, geometry.py:671/565)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import TfrtError, RayOut, Scene3D, check
+
+_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise TfrtError(
+                "tfrt kernels need tensors on a HIP device (got a CPU tensor); the hot path has "
+                "no CPU fallback")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _c(t, dtype=None):
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------- build_faces
+
+class _BuildFaces(torch.autograd.Function):
+    """vertices (V,3) f64 -> face_verts (F,9) f64, norm (F,3) f64.
+
+    boundaries.py:890-923; ``update_mask`` (F,3) uint8 is the vertex_update_map
+    (0 = stop_gradient for that corner, boundaries.py:900-913)."""
+
+    @staticmethod
+    def forward(ctx, vertices, faces, update_mask):
+        _need_gpu(vertices, faces, update_mask)
+        vertices = _c(vertices, torch.float64)
+        F = faces.shape[0]
+        fv = torch.empty((F, 9), dtype=torch.float64, device=vertices.device)
+        norm = torch.empty((F, 3), dtype=torch.float64, device=vertices.device)
+        check(_lib.lib().tfrt_build_faces_forward(
+            _p(vertices), vertices.shape[0], _p(faces), F, _p(fv), _p(norm), _stream(vertices)),
+            "tfrt_build_faces_forward")
+        ctx.save_for_backward(fv, faces, update_mask)
+        ctx.n_vertices = vertices.shape[0]
+        return fv, norm
+
+    @staticmethod
+    def backward(ctx, g_fv, g_norm):
+        fv, faces, update_mask = ctx.saved_tensors
+        gv = torch.zeros((ctx.n_vertices, 3), dtype=torch.float64, device=fv.device)
+        g_fv = _c(g_fv, torch.float64)
+        g_norm = _c(g_norm, torch.float64)
+        if g_fv is None and g_norm is None:
+            return gv, None, None
+        check(_lib.lib().tfrt_build_faces_backward(
+            _p(g_fv), _p(g_norm), _p(fv), _p(faces), _p(update_mask), faces.shape[0],
+            ctx.n_vertices, _p(gv), _stream(fv)), "tfrt_build_faces_backward")
+        return gv, None, None
+
+
+def build_faces(vertices, faces, update_mask=None):
+    """faces: (F,3) int32 on the same device; update_mask: (F,3) uint8/bool or None."""
+    faces = _c(faces, torch.int32)
+    if update_mask is not None:
+        update_mask = _c(update_mask, torch.uint8)
+    return _BuildFaces.apply(vertices, faces, update_mask)
+
+
+# ----------------------------------------------------------------------------- trace3d
+
+class Scene3DArgs:
+    """Device tensors + scalars describing the merged 3-D boundary set (tfrt_scene3d)."""
+
+    def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
+                 n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
+                 ray_start_epsilion=1e-10):
+        self.face_verts = face_verts  # (M,9) f64, may require grad
+        self.catagory = _c(catagory, torch.int32)
+        self.mat_in = _c(mat_in, torch.int32)
+        self.mat_out = _c(mat_out, torch.int32)
+        self.n_in = _c(n_in, torch.float64)
+        self.n_out = _c(n_out, torch.float64)
+        self.n_table = _c(n_table, torch.float64)  # (n_materials, N)
+        self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
+
+    def struct(self, face_verts):
+        sc = Scene3D()
+        M = face_verts.shape[0]
+        sc.face_verts = face_verts.data_ptr() if M else None
+        sc.catagory = self.catagory.data_ptr() if M else None
+        for name in ("mat_in", "mat_out", "n_in", "n_out"):
+            t = getattr(self, name)
+            setattr(sc, name, t.data_ptr() if (t is not None and M) else None)
+        sc.n_faces = M
+        if self.n_table is not None and self.n_table.numel():
+            sc.n_table = self.n_table.data_ptr()
+            sc.n_table_stride = self.n_table.shape[1]
+            sc.n_materials = self.n_table.shape[0]
+        else:
+            sc.n_table, sc.n_table_stride, sc.n_materials = None, 0, 0
+        sc.intersect_epsilion, sc.size_epsilion, sc.ray_start_epsilion = self.eps
+        return sc
+
+
+class TraceTape:
+    """Everything the reverse sweep needs (kept alive by the autograd node)."""
+    pass
+
+
+def _ray_out(rays, ids, faces):
+    o = RayOut()
+    if rays is None:
+        o.rays, o.ray_id, o.face, o.capacity = None, None, None, 0
+    else:
+        o.rays, o.ray_id, o.face, o.capacity = rays.data_ptr(), ids.data_ptr(), faces.data_ptr(), rays.shape[1]
+    return o
+
+
+class _Trace3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, face_verts, scene, opts):
+        _need_gpu(src, face_verts)
+        dev = src.device
+        if src.dtype not in _DT:
+            raise TfrtError(f"ray state dtype must be float32 or float64, got {src.dtype}")
+        src = src.contiguous()
+        face_verts = _c(face_verts, torch.float64)
+        N = src.shape[1]
+        P = int(opts["max_passes"])
+        flags = int(opts["flags"])
+        dt = _DT[src.dtype]
+        L = _lib.lib()
+        wsb = L.tfrt_trace3d_workspace_bytes(N, face_verts.shape[0], P, dt)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        counts = torch.zeros(_lib.COUNTS_PER_PASS * (P + 1), dtype=torch.int32, device=dev)
+
+        def alloc(flag, cap):
+            if not (flags & flag):
+                return None, None, None
+            return (torch.empty((6, cap), dtype=src.dtype, device=dev),
+                    torch.empty(cap, dtype=torch.int32, device=dev),
+                    torch.empty(cap, dtype=torch.int32, device=dev))
+
+        capN = max(N, 1)
+        fin = alloc(_lib.COMPILE_FINISHED, capN)
+        act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
+        stp = alloc(_lib.COMPILE_STOPPED, capN)
+        dead = alloc(_lib.COMPILE_DEAD, capN)
+        unf = torch.empty((6, capN), dtype=src.dtype, device=dev)
+        unf_id = torch.empty(capN, dtype=torch.int32, device=dev)
+        sc = scene.struct(face_verts)
+        outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
+        check(L.tfrt_trace3d_forward(
+            _p(src), src.shape[1], N, ctypes.byref(sc), float(opts["new_ray_length"]),
+            float(opts["dead_ray_length"] or 0.0), P, dt, flags,
+            ctypes.byref(outs[0]), ctypes.byref(outs[1]), ctypes.byref(outs[2]),
+            ctypes.byref(outs[3]), _p(unf), _p(unf_id), _p(counts), _p(ws), wsb, _stream(src)),
+            "tfrt_trace3d_forward")
+        tape = TraceTape()
+        tape.src, tape.face_verts, tape.scene, tape.opts = src, face_verts, scene, dict(opts)
+        tape.ws, tape.wsb, tape.counts, tape.dt = ws, wsb, counts, dt
+        tape.caps = [o[0].shape[1] if o[0] is not None else 0 for o in (fin, act, stp, dead)]
+        ctx.tape = tape
+        aux = {
+            "counts": counts, "unfinished": unf, "unfinished_id": unf_id,
+            "finished_id": fin[1], "finished_face": fin[2],
+            "active_id": act[1], "active_face": act[2],
+            "stopped_id": stp[1], "stopped_face": stp[2],
+            "dead_id": dead[1], "dead_face": dead[2],
+        }
+        opts["_aux"] = aux
+        empty = torch.empty((6, 0), dtype=src.dtype, device=dev)
+        rays = [o[0] if o[0] is not None else empty for o in (fin, act, stp, dead)]
+        ctx.present = [o[0] is not None for o in (fin, act, stp, dead)]
+        return tuple(rays)
+
+    @staticmethod
+    def backward(ctx, g_fin, g_act, g_stp, g_dead):
+        t = ctx.tape
+        dev = t.src.device
+        M = t.face_verts.shape[0]
+        g_fv = torch.zeros((M, 9), dtype=torch.float64, device=dev)
+        need_src = ctx.needs_input_grad[0]
+        g_src = torch.zeros((6, t.src.shape[1]), dtype=torch.float64, device=dev) if need_src else None
+        gs = []
+        for g, present in zip((g_fin, g_act, g_stp, g_dead), ctx.present):
+            gs.append(_c(g, torch.float64) if (present and g is not None) else None)
+        sc = t.scene.struct(t.face_verts)
+        check(_lib.lib().tfrt_trace3d_backward(
+            _p(t.src), t.src.shape[1], t.src.shape[1], ctypes.byref(sc),
+            float(t.opts["new_ray_length"]), float(t.opts["dead_ray_length"] or 0.0),
+            int(t.opts["max_passes"]), t.dt,
+            _p(gs[0]), t.caps[0], _p(gs[1]), t.caps[1], _p(gs[2]), t.caps[2], _p(gs[3]), t.caps[3],
+            _p(g_fv), _p(g_src), _p(t.counts), _p(t.ws), t.wsb, _stream(t.src)),
+            "tfrt_trace3d_backward")
+        if g_src is not None:
+            g_src = g_src.to(t.src.dtype)
+        return g_src, g_fv, None, None
+
+
+def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
+            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED):
+    """Run the whole 3-D trace.  ``src`` is a (6,N) ray block (f32 or f64) on the GPU.
+
+    Returns a dict: for each class c in finished/active/stopped/dead (when compiled) the ray
+    block ``c`` (6, n_c) (differentiable w.r.t. ``face_verts`` and ``src``), ``c_id`` (source
+    ray index per row) and ``c_face`` (merged face hit); ``unfinished``/``unfinished_id``;
+    ``counts`` (host numpy, per pass) and ``n_tests``.  One host sync (to read the counts).
+    """
+    opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
+                dead_ray_length=dead_ray_length, flags=flags)
+    fin, act, stp, dead = _Trace3D.apply(src, face_verts, scene, opts)
+    aux = opts.pop("_aux")
+    counts = aux["counts"].cpu().numpy()  # the one sync of the trace
+    P = int(max_passes)
+    tail = counts[P * 8:]
+    if tail[6] != 0:
+        raise TfrtError("tfrt_trace3d_forward: output capacity exceeded (internal error)")
+    out = {
+        "counts": counts[:P * 8].reshape(P, 8).copy(),
+        "n_tests": int(np.uint32(tail[4])) | (int(np.uint32(tail[5])) << 32),
+    }
+    totals = {"active": int(tail[0]), "finished": int(tail[1]), "stopped": int(tail[2]),
+              "dead": int(tail[3])}
+    for name, rays in (("finished", fin), ("active", act), ("stopped", stp), ("dead", dead)):
+        if aux[name + "_id"] is None:
+            continue
+        n = totals[name]
+        out[name] = rays[:, :n]
+        out[name + "_id"] = aux[name + "_id"][:n]
+        out[name + "_face"] = aux[name + "_face"][:n]
+    n_unf = int(out["counts"][P - 1, 0]) if P > 0 else 0
+    out["unfinished"] = aux["unfinished"][:, :n_unf]
+    out["unfinished_id"] = aux["unfinished_id"][:n_unf]
+    return out
+
+
+# -------------------------------------------------------------------------------- seams
+
+def intersect3d(rays, face_verts, intersect_epsilion=1e-10, size_epsilion=1e-10,
+                ray_start_epsilion=1e-10):
+    """OpticalSystem3D._intersection (engine.py:1103-1166).  rays: (6,N) block."""
+    _need_gpu(rays, face_verts)
+    rays = rays.contiguous()
+    face_verts = _c(face_verts, torch.float64)
+    N, M = rays.shape[1], face_verts.shape[0]
+    dev = rays.device
+    L = _lib.lib()
+    wsb = L.tfrt_intersect3d_workspace_bytes(N, M)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    f = lambda: torch.empty(N, dtype=torch.float64, device=dev)
+    x, y, z, ray_u, trig_u, trig_v = f(), f(), f(), f(), f(), f()
+    valid = torch.empty(N, dtype=torch.uint8, device=dev)
+    gather = torch.empty(N, dtype=torch.int32, device=dev)
+    check(L.tfrt_intersect3d(
+        _p(rays), rays.shape[1], N, _DT[rays.dtype], _p(face_verts) if M else None, M,
+        float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion),
+        _p(x), _p(y), _p(z), _p(valid), _p(ray_u), _p(trig_u), _p(trig_v), _p(gather),
+        _p(ws), wsb, _stream(rays)), "tfrt_intersect3d")
+    return x, y, z, valid.bool(), ray_u, trig_u, trig_v, gather
+
+
+def snell3d(x_start, y_start, z_start, x_end, y_end, z_end, norm, n_in, n_out, new_ray_length):
+    """geometry.snells_law_3D (geometry.py:671-753) -> (6,n) f64 block of the new rays."""
+    args = [_c(a, torch.float64) for a in (x_start, y_start, z_start, x_end, y_end, z_end, norm)]
+    _need_gpu(*args)
+    n = args[0].shape[0]
+    n_in = _c(torch.as_tensor(n_in, dtype=torch.float64, device=args[0].device).expand(n), torch.float64)
+    n_out = _c(torch.as_tensor(n_out, dtype=torch.float64, device=args[0].device).expand(n), torch.float64)
+    out = torch.empty((6, n), dtype=torch.float64, device=args[0].device)
+    check(_lib.lib().tfrt_snell3d(n, *[_p(a) for a in args], _p(n_in), _p(n_out),
+                                  float(new_ray_length), _p(out), _stream(out)), "tfrt_snell3d")
+    return out
+
+
+def snell2d(x_start, y_start, x_end, y_end, norm, n_in, n_out, new_ray_length):
+    """geometry.snells_law_2D (geometry.py:565-653) -> (4,n) f64 block of the new rays."""
+    args = [_c(a, torch.float64) for a in (x_start, y_start, x_end, y_end, norm)]
+    _need_gpu(*args)
+    n = args[0].shape[0]
+    n_in = _c(torch.as_tensor(n_in, dtype=torch.float64, device=args[0].device).expand(n), torch.float64)
+    n_out = _c(torch.as_tensor(n_out, dtype=torch.float64, device=args[0].device).expand(n), torch.float64)
+    out = torch.empty((4, n), dtype=torch.float64, device=args[0].device)
+    check(_lib.lib().tfrt_snell2d(n, *[_p(a) for a in args], _p(n_in), _p(n_out),
+                                  float(new_ray_length), _p(out), _stream(out)), "tfrt_snell2d")
+    return out

@@ -1,0 +1,50 @@
+// CPU harness around tensorflowraytrace_amd/csrc/trace_math.h (TEST ONLY).
+// Built by tests/conftest.py with g++ into tests/host_math/_build/libhost_math.so so the
+// per-ray float64 math used by the HIP kernels can be checked against the oracle on a
+// machine with no GPU.  It is never loaded by the product package.
+#include <stdint.h>
+#include "trace_math.h"
+
+extern "C" {
+
+void hm_exact_triangle(int64_t n, const double* s, const double* e, const double* P,
+                       double eps_int, double eps_size, double eps_start,
+                       double* ray_u, double* trig_u, double* trig_v, uint8_t* valid,
+                       double* hit) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::TriHit h = tfrt::exact_triangle(s + 3 * i, e + 3 * i, P + 9 * i, eps_int, eps_size, eps_start);
+    ray_u[i] = h.ray_u; trig_u[i] = h.trig_u; trig_v[i] = h.trig_v; valid[i] = h.valid;
+    tfrt::hit_point(s + 3 * i, e + 3 * i, h.ray_u, hit + 3 * i);
+  }
+}
+
+void hm_snell3d(int64_t n, const double* s, const double* h, const double* P,
+                const double* n_in, const double* n_out, double L, double* e_new) {
+  for (int64_t i = 0; i < n; ++i) {
+    double N[3], C[3], clen;
+    tfrt::face_normal(P + 9 * i, N, C, &clen);
+    tfrt::Snell3 f = tfrt::snell3d(s + 3 * i, h + 3 * i, N, n_in[i], n_out[i]);
+    for (int k = 0; k < 3; ++k) e_new[3 * i + k] = h[3 * i + k] + L * f.w[k];
+  }
+}
+
+void hm_snell2d(int64_t n, const double* xs, const double* ys, const double* xe, const double* ye,
+                const double* norm, const double* n_in, const double* n_out, double L,
+                double* oxe, double* oye) {
+  for (int64_t i = 0; i < n; ++i) {
+    double a = tfrt::snell2d_angle(xs[i], ys[i], xe[i], ye[i], norm[i], n_in[i], n_out[i]);
+    oxe[i] = xe[i] + L * cos(a);
+    oye[i] = ye[i] + L * sin(a);
+  }
+}
+
+void hm_adjoint3d(int64_t n, const double* s, const double* e, const double* P,
+                  const double* ray_u, const uint8_t* has_child, const double* n_in,
+                  const double* n_out, double L, const double* g_s, const double* g_h,
+                  const double* g_ce, double* gs, double* ge, double* gP) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::adjoint3d(s + 3 * i, e + 3 * i, P + 9 * i, ray_u[i], has_child[i] != 0, n_in[i], n_out[i], L,
+                    g_s + 3 * i, g_h + 3 * i, g_ce + 3 * i, gs + 3 * i, ge + 3 * i, gP + 9 * i);
+  }
+}
+}

@@ -1,0 +1,130 @@
+"""
+GPU parity of the 3-D hot path (through the C ABI) against the float64 oracle.
+
+Tolerances (BASELINE.json north_star): 1e-5 relative on ray endpoints and gradients for
+float32 ray state; the float64-state path is held to 1e-9.
+"""
+import numpy as np
+import pytest
+import torch
+
+import scene_util
+import oracle_util
+from oracle import tracer
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
+
+
+def _gpu_scene(scene, dtype, p_f=None, p_b=None, masks=(None, None)):
+    from tensorflowraytrace_amd import ops
+    dev = torch.device("cuda:0")
+    tt = lambda a, dt=torch.float64: torch.tensor(np.asarray(a), dtype=dt, device=dev)
+    p_f = tt(scene["p_f"] if p_f is None else p_f).requires_grad_(True)
+    p_b = tt(scene["p_b"] if p_b is None else p_b).requires_grad_(True)
+    vec = tt(scene["vector"]).reshape(1, 3)
+    v_f = tt(scene["zero_f"]) + p_f.reshape(-1, 1) * vec
+    v_b = tt(scene["zero_b"]) + p_b.reshape(-1, 1) * vec
+    m = [None if x is None else tt(x, torch.uint8) for x in masks]
+    fv_f, _ = ops.build_faces(v_f, tt(scene["faces_f"], torch.int32), m[0])
+    fv_b, _ = ops.build_faces(v_b, tt(scene["faces_b"], torch.int32), m[1])
+    fv_t, _ = ops.build_faces(tt(scene["target_verts"]), tt(scene["target_faces"], torch.int32))
+    fv = torch.cat([fv_f, fv_b, fv_t])
+    nf, nb, nt = fv_f.shape[0], fv_b.shape[0], fv_t.shape[0]
+    cat = torch.cat([torch.zeros(nf + nb, dtype=torch.int32), torch.full((nt,), 2, dtype=torch.int32)]).to(dev)
+    mat_in = torch.cat([torch.ones(nf + nb, dtype=torch.int32), torch.zeros(nt, dtype=torch.int32)]).to(dev)
+    mat_out = torch.zeros(nf + nb + nt, dtype=torch.int32, device=dev)
+    wl = torch.tensor(scene["wavelength"], dtype=torch.float64)
+    n_table = torch.stack([tracer.MATERIALS["vacuum"](wl), tracer.MATERIALS["acrylic"](wl)]).to(dev)
+    sc = ops.Scene3DArgs(fv, cat, mat_in=mat_in, mat_out=mat_out, n_table=n_table)
+    src = tt(scene["rays"], dtype)
+    return src, fv, sc, (p_f, p_b)
+
+
+def _compare_sets(gpu, gpu_id, ref, tol, what):
+    ref_id = ref["ray_id"].numpy().astype(np.int64)
+    gid = gpu_id.cpu().numpy().astype(np.int64)
+    assert gid.shape == ref_id.shape, f"{what}: {gid.shape[0]} rays vs oracle {ref_id.shape[0]}"
+    mism = int((gid != ref_id).sum())
+    assert mism == 0, f"{what}: {mism} rays ordered/classified differently"
+    g = gpu.detach().cpu().double().numpy()
+    r = oracle_util.block(ref)
+    scale = max(1.0, np.abs(r).max()) if r.size else 1.0
+    err = np.abs(g - r).max() / scale if r.size else 0.0
+    assert err <= tol, f"{what}: max rel err {err:.3e} > {tol}"
+    return err
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+def test_forward_lens(dtype, tol):
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(3000, k_front=5, k_back=4)
+    src, fv, sc, _ = _gpu_scene(scene, dtype)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    out = ops.trace3d(src, fv, sc, max_passes=5, flags=flags)
+    system, _, _ = oracle_util.lens_oracle(scene)
+    ref = tracer.ray_trace(
+        system, oracle_util.source_dict(scene["rays"], scene["wavelength"],
+                                        np.float32 if dtype == torch.float32 else None),
+        max_iterations=5, inherit=("wavelength", "ray_id"),
+        flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    assert out["finished"].shape[1] > 2000
+    for cls in ("finished", "active", "dead"):
+        if not ref[cls]:
+            assert out[cls].shape[1] == 0
+            continue
+        _compare_sets(out[cls], out[cls + "_id"], ref[cls], tol, cls)
+    M = fv.shape[0]
+    assert out["n_tests"] == int(out["counts"][:, :4].sum(axis=1) @ np.ones(5)) * M
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-8), (torch.float32, 1e-5)])
+def test_backward_lens(dtype, tol):
+    from tensorflowraytrace_amd import ops
+    scene = scene_util.lens_scene(1500, k_front=4, k_back=3)
+    rng = np.random.default_rng(5)
+    mask_f = (rng.uniform(size=scene["faces_f"].shape) > 0.3)
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, masks=(mask_f.astype(np.uint8), None))
+    out = ops.trace3d(src, fv, sc, max_passes=4)
+    fin = out["finished"]
+    goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fin.device)[out["finished_id"].long()]
+    err = ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
+    err = err + 0.1 * (out["active"][3].double() ** 2).sum()  # gradient through the active history too
+    g_f, g_b = torch.autograd.grad(err, [p_f, p_b])
+
+    system, (q_f, q_b), _ = oracle_util.lens_oracle(scene, update_map_f=mask_f)
+    ref = tracer.ray_trace(
+        system, oracle_util.source_dict(scene["rays"], scene["wavelength"],
+                                        np.float32 if dtype == torch.float32 else None),
+        max_iterations=4, inherit=("wavelength", "ray_id"))
+    rf = ref["finished"]
+    rgoal = torch.tensor(scene["goal"], dtype=torch.float64)[rf["ray_id"].long()]
+    rerr = ((rf["y_end"] - rgoal[:, 0]) ** 2 + (rf["z_end"] - rgoal[:, 1]) ** 2).sum()
+    rerr = rerr + 0.1 * (ref["active"]["x_end"] ** 2).sum()
+    r_f, r_b = torch.autograd.grad(rerr, [q_f, q_b])
+    assert abs(err.item() - rerr.item()) <= tol * max(1.0, abs(rerr.item())) * 10
+    for g, r, name in ((g_f, r_f, "front"), (g_b, r_b, "back")):
+        g = g.cpu().numpy()
+        r = r.numpy()
+        rel = np.abs(g - r).max() / np.abs(r).max()
+        assert rel <= tol, f"{name} parameter gradient rel err {rel:.3e} > {tol}"
+
+
+def test_intersection_seam():
+    """S1: OpticalSystem3D._intersection (engine.py:1103-1166)."""
+    from tensorflowraytrace_amd import ops
+    scene = scene_util.lens_scene(2000, k_front=6, k_back=6, seed=3)
+    src, fv, sc, _ = _gpu_scene(scene, torch.float64)
+    x, y, z, valid, ray_u, trig_u, trig_v, gather = ops.intersect3d(src, fv)
+    system, _, _ = oracle_util.lens_oracle(scene)
+    m = system.merged
+    r = scene["rays"]
+    ref = tracer.intersection_3d(*[torch.tensor(r[i]) for i in range(6)],
+                                 m["xp"], m["yp"], m["zp"], m["x1"], m["y1"], m["z1"],
+                                 m["x2"], m["y2"], m["z2"], 1e-10, 1e-10, 1e-10)
+    rv = ref[3].numpy()
+    assert np.array_equal(valid.cpu().numpy(), rv)
+    assert np.array_equal(gather.cpu().numpy()[rv], ref[8].numpy()[rv])
+    for got, want in zip((x, y, z, ray_u, trig_u, trig_v), (ref[0], ref[1], ref[2], ref[4], ref[5], ref[6])):
+        np.testing.assert_allclose(got.cpu().numpy()[rv], want.detach().numpy()[rv], rtol=1e-12, atol=1e-12)
