@@ -102,6 +102,9 @@ typedef struct tfrt_scene3d {
   double intersect_epsilion; /* OpticalSystemBase kwargs, tfrt/engine.py:174-190 */
   double size_epsilion;
   double ray_start_epsilion;
+  /* (M) u8, backward only: 0 = this face's vertices are constants (e.g. a target plane),
+   * skip its gradient accumulation; NULL = accumulate for every face. */
+  const uint8_t* face_grad_mask;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in

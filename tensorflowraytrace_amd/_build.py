@@ -39,11 +39,13 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), drop_flags=(), lib_path=None, tag=""):
     sources = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "tfrt_hip.h"))
-    objdir = os.path.join(CSRC, "_obj")
+    objdir = os.path.join(CSRC, "_obj" + tag)
+    lib_out = lib_path or LIB
+    flags = [f for f in HIPCC_FLAGS if f not in drop_flags]
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     objs, procs = [], []
@@ -54,7 +56,7 @@ def build(force=False, verbose=False, extra_flags=()):
         if (not force and os.path.exists(op)
                 and os.path.getmtime(op) >= _newest([sp] + headers)):
             continue
-        cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-I", INCLUDE, "-I", CSRC, "-c", sp, "-o", op]
+        cmd = [hipcc, *flags, *extra_flags, "-I", INCLUDE, "-I", CSRC, "-c", sp, "-o", op]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -64,14 +66,14 @@ def build(force=False, verbose=False, extra_flags=()):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         if verbose and out:
             print(out.decode(errors="replace"))
-    if force or procs or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    if force or procs or not os.path.exists(lib_out) or os.path.getmtime(lib_out) < _newest(objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_out, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout.decode(errors='replace')}")
-    return LIB
+    return lib_out
 
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtfrt_hip.so")
+LIB_PATH = os.environ.get("TFRT_LIB_PATH") or os.path.join(HERE, "libtfrt_hip.so")
 
 F32, F64 = 0, 1
 OPTICAL, STOP, TARGET = 0, 1, 2
@@ -28,6 +28,7 @@ class Scene3D(ctypes.Structure):
         ("n_in", c_vp), ("n_out", c_vp), ("n_faces", c_i64),
         ("n_table", c_vp), ("n_table_stride", c_i64), ("n_materials", c_i32),
         ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
+        ("face_grad_mask", c_vp),
     ]
 
 

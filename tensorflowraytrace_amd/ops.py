@@ -95,7 +95,7 @@ class Scene3DArgs:
 
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
-                 ray_start_epsilion=1e-10):
+                 ray_start_epsilion=1e-10, face_grad_mask=None):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -103,6 +103,7 @@ class Scene3DArgs:
         self.n_in = _c(n_in, torch.float64)
         self.n_out = _c(n_out, torch.float64)
         self.n_table = _c(n_table, torch.float64)  # (n_materials, N)
+        self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -121,6 +122,8 @@ class Scene3DArgs:
         else:
             sc.n_table, sc.n_table_stride, sc.n_materials = None, 0, 0
         sc.intersect_epsilion, sc.size_epsilion, sc.ray_start_epsilion = self.eps
+        g = self.face_grad_mask
+        sc.face_grad_mask = g.data_ptr() if (g is not None and M) else None
         return sc
 
 

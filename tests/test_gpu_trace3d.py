@@ -37,7 +37,9 @@ def _gpu_scene(scene, dtype, p_f=None, p_b=None, masks=(None, None)):
     mat_out = torch.zeros(nf + nb + nt, dtype=torch.int32, device=dev)
     wl = torch.tensor(scene["wavelength"], dtype=torch.float64)
     n_table = torch.stack([tracer.MATERIALS["vacuum"](wl), tracer.MATERIALS["acrylic"](wl)]).to(dev)
-    sc = ops.Scene3DArgs(fv, cat, mat_in=mat_in, mat_out=mat_out, n_table=n_table)
+    gmask = (cat == 0).to(torch.uint8)  # the target plane is a constant
+    sc = ops.Scene3DArgs(fv, cat, mat_in=mat_in, mat_out=mat_out, n_table=n_table,
+                         face_grad_mask=gmask)
     src = tt(scene["rays"], dtype)
     return src, fv, sc, (p_f, p_b)
 
