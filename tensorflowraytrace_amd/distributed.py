@@ -1,0 +1,76 @@
+"""
+Ray-parallel multi-GPU support: one process per GPU, ``torch.distributed`` (backend "nccl" is
+RCCL on ROCm; "gloo" for CPU tests).
+
+The path shards by rays: every rank holds the full (small) boundary
+set and traces a contiguous block of the source rays; the only exchange per optimiser step is
+ONE all-reduce(sum) of a flat float64 buffer ``[grad(p_0), ..., grad(p_k), sum(error),
+n_error_terms]`` (tens of KB: latency-bound over xGMI, so a single fused buffer and a single
+collective).  Because the gradient of a vector error is the gradient of its sum
+(optimizer.py:219-220), summing shard gradients is exact; clip / accumulate / SGD / smooth /
+constraints then run identically on every rank, so parameters stay bit-identical without a
+broadcast.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank():
+    return dist.get_rank() if is_distributed() else 0
+
+
+def world_size():
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def init_from_env(backend=None):
+    """Initialise the process group from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, world_size, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rk = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rk)))
+    if world > 1 and not (dist.is_available() and dist.is_initialized()):
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rk, world_size=world)
+    return rk, world, local
+
+
+def shard_bounds(n, rk=None, world=None):
+    """Contiguous block [lo, hi) of n source rays owned by rank rk."""
+    rk = rank() if rk is None else rk
+    world = world_size() if world is None else world
+    base, rem = divmod(int(n), int(world))
+    lo = rk * base + min(rk, rem)
+    return lo, lo + base + (1 if rk < rem else 0)
+
+
+def all_reduce_step(grads, error_sum, error_count):
+    """Sum parameter gradients, the error sum and the number of error terms over ranks with a
+    single collective.  ``grads``: list of tensors (None allowed -> treated as zeros of the
+    matching parameter, supplied as (None, like) tuples).  Returns (grads, error_sum,
+    error_count) with the reduced values; a no-op for one process."""
+    if not is_distributed():
+        return grads, error_sum, error_count
+    flat = [g.reshape(-1).to(torch.float64) for g in grads]
+    dev = flat[0].device if flat else error_sum.device
+    tail = torch.stack([error_sum.to(torch.float64).reshape(()).to(dev),
+                        torch.as_tensor(float(error_count), dtype=torch.float64, device=dev)])
+    buf = torch.cat(flat + [tail])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    out, o = [], 0
+    for g in grads:
+        n = g.numel()
+        out.append(buf[o:o + n].reshape(g.shape).to(g.dtype))
+        o += n
+    return out, buf[o], float(buf[o + 1].item())

@@ -1,0 +1,804 @@
+"""
+Optical systems and the trace engine (tfrt/engine.py), host side.
+
+``OpticalSystem2D/3D`` collect sources and boundaries and merge them in the reference's order
+(optical, stop, target; engine.py:971-1018).  ``OpticalEngine.ray_trace`` hands the merged
+scene to ONE fused HIP trace (``ops.trace3d`` / ``ops.trace2d`` -> tfrt_trace*_forward): all
+passes run on the device without host round trips, and the ray sets the reference exposes
+(``finished_rays``, ``active_rays``, ``stopped_rays``, ``dead_rays``, ``all_rays``) are
+materialised lazily from the compacted outputs.  Geometric fields come straight from the
+kernels; every other field of an output ray (``wavelength`` and the user's inherited extra
+fields, engine.py:2242-2281) is a gather of the source's field by the source-ray index the
+kernels carry along -- exact for ``StandardReaction``, which emits one child per active ray.
+
+The result tensors are differentiable w.r.t. parametric boundary parameters and source ray
+coordinates: ``torch.autograd`` plays the role of ``tf.GradientTape`` and calls the
+hand-derived HIP reverse sweep.
+"""
+import math
+from abc import ABC, abstractmethod
+
+import torch
+
+from . import config, ops, _lib
+from . import distributed as tdist
+from . import operation as op
+from .boundaries import amalgamate as _amalgamate_plain
+from .update import RecursivelyUpdatable
+
+OPTICAL = 0
+STOP = 1
+TARGET = 2
+
+SEGMENT_GEO_SIG = {"x_start", "y_start", "x_end", "y_end"}
+ARC_GEO_SIG = {"x_center", "y_center", "angle_start", "angle_end", "radius"}
+SOURCE_3D_SIG = {"x_start", "y_start", "z_start", "x_end", "y_end", "z_end"}
+TRIANGLE_GEO_SIG = {"xp", "yp", "zp", "x1", "y1", "z1", "x2", "y2", "z2", "norm"}
+
+PI = math.pi
+_GEO3 = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
+_GEO2 = ("x_start", "y_start", "x_end", "y_end")
+_CLASSES = ("active", "finished", "stopped", "dead")
+
+
+class ReadOnlySet:
+    """Read-only view of a field dict (engine.py:27-46)."""
+
+    def __init__(self, fields):
+        self._fields = fields
+
+    def __getitem__(self, key):
+        try:
+            return self._fields[key]
+        except KeyError as e:
+            raise KeyError(f"key {key} not in the signature of this set.") from e
+
+    def __bool__(self):
+        return bool(self._fields)
+
+    def keys(self):
+        return self._fields.keys()
+
+    def items(self):
+        return self._fields.items()
+
+
+def amalgamate(stuff, signature=None):
+    """Join a list of field sets into one dict by concatenation (engine.py:50-76)."""
+    items = [s for s in stuff if bool(s)]
+    if len(items) == 1 and not signature:
+        return {f: items[0][f] for f in items[0].keys()}
+    return _amalgamate_plain(stuff, signature)
+
+
+def recursive_dict_key_print(dict_in, spacer=""):
+    """engine.py:80-99."""
+    if type(dict_in) is not dict:
+        return
+    for key, value in dict_in.items():
+        try:
+            print(spacer, f"{key} : {tuple(value.shape)}")
+        except AttributeError:
+            print(spacer, key)
+        recursive_dict_key_print(value, spacer + "    ")
+
+
+def annotation_helper(parent, field, value, valid_shape_field, dtype=torch.float64):
+    """Keep ``parent[field]`` populated after every update of ``parent``
+    (engine.py:103-142): ``value`` is broadcast to the shape of
+    ``parent[valid_shape_field]`` (or called with ``(shape, dtype)`` if callable)."""
+    if dtype in (int, "int64"):
+        dtype = torch.int64
+
+    if callable(value):
+        def f():
+            shape = parent[valid_shape_field].shape
+            parent[field] = value(shape, dtype)
+    else:
+        def f():
+            ref = parent[valid_shape_field]
+            parent[field] = torch.as_tensor(value, dtype=dtype, device=ref.device).expand(
+                ref.shape).clone()
+    parent.post_update_handles.append(f)
+
+
+# =================================================================================== systems
+
+class OpticalSystemBase(RecursivelyUpdatable, ABC):
+    """Holds sources and boundaries (engine.py:146-250).
+
+    ``intersect_epsilion`` / ``size_epsilion`` / ``ray_start_epsilion`` keep the reference's
+    meaning and defaults (1e-10) and are applied in the kernels' float64 decision stage.
+    """
+
+    _boundary_sets = ()
+
+    def __init__(self, manual_update_management=False, intersect_epsilion=1e-10,
+                 size_epsilion=1e-10, ray_start_epsilion=1e-10, **kwargs):
+        self._sources = []
+        self._read_only = {}
+        self.source_handles = []
+        self._amalgamated_sources = {}
+        self.manual_update_management = manual_update_management
+        self.materials = []
+        self.intersect_epsilion = intersect_epsilion
+        self.size_epsilion = size_epsilion
+        self.ray_start_epsilion = ray_start_epsilion
+        self.projection_results = {}
+        for name in self._boundary_sets:
+            setattr(self, "_" + name, [])
+            setattr(self, name + "_handles", [])
+            setattr(self, "_amalgamated_" + name, {})
+        self._scene_cache = None
+        super().__init__(**kwargs)
+
+    @property
+    @abstractmethod
+    def dimension(self):
+        raise NotImplementedError
+
+    def refresh_update_handles(self):
+        if not self.manual_update_management:
+            self.update_handles = self._generate_update_handles()
+
+    def _generate_update_handles(self):
+        handles = list(getattr(self, "source_handles", []))
+        for name in self._boundary_sets:
+            handles += getattr(self, name + "_handles", [])
+        return handles
+
+    def clear_read_only(self):
+        self._read_only = {}
+
+    def _ro(self, name, fields):
+        if name not in self._read_only:
+            self._read_only[name] = ReadOnlySet(fields)
+        return self._read_only[name]
+
+    @property
+    def sources(self):
+        return self._ro("sources", self._amalgamated_sources)
+
+    @sources.setter
+    def sources(self, new):
+        self.source_handles = []
+        for each in new:
+            assert each.dimension == self.dimension
+            self.source_handles.append(each.update)
+        self._sources = new
+        self.refresh_update_handles()
+
+    @property
+    def materials(self):
+        return self._materials
+
+    @materials.setter
+    def materials(self, val):
+        assert type(val) is list
+        self._materials = val
+
+    def _get_set(self, name):
+        return self._ro(name, getattr(self, "_amalgamated_" + name))
+
+    def _set_set(self, name, new):
+        handles = []
+        for each in new:
+            assert each.dimension == self.dimension
+            handles.append(each.update)
+        setattr(self, name + "_handles", handles)
+        setattr(self, "_" + name, new)
+        self._scene_cache = None
+        self.refresh_update_handles()
+
+    def _update(self):
+        if bool(self._sources):
+            self._amalgamated_sources = amalgamate(self._sources)
+        for name in self._boundary_sets:
+            lst = getattr(self, "_" + name)
+            if bool(lst):
+                setattr(self, "_amalgamated_" + name, _LazyAmalgam(lst))
+        self._merge_boundaries()
+        self.clear_read_only()
+
+    @abstractmethod
+    def _merge_boundaries(self):
+        raise NotImplementedError
+
+    # n(lambda) for every material x source ray, float64 (operation.py:261-272)
+    def material_table(self, wavelength):
+        mats = []
+        for m in self._materials:
+            f = m["n"] if isinstance(m, dict) else m
+            mats.append(f(wavelength.to(torch.float64)))
+        return torch.stack(mats).contiguous()
+
+
+class _LazyAmalgam:
+    """dict-like concatenation of a list of boundaries, field by field, on demand."""
+
+    def __init__(self, items):
+        self._items = [i for i in items if bool(i)]
+        self._cache = {}
+
+    def keys(self):
+        ks = None
+        for i in self._items:
+            k = set(i.keys())
+            ks = k if ks is None else (ks & k)
+        return ks or set()
+
+    def __bool__(self):
+        return bool(self._items)
+
+    def __contains__(self, key):
+        return key in self.keys()
+
+    def __getitem__(self, key):
+        if key not in self._cache:
+            parts = [i[key] for i in self._items]
+            self._cache[key] = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        return self._cache[key]
+
+    def __setitem__(self, key, value):
+        self._cache[key] = value
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def count(self, shape_field):
+        return sum(int(i[shape_field].shape[0]) for i in self._items)
+
+
+def _prop(name):
+    return property(lambda self: self._get_set(name), lambda self, new: self._set_set(name, new))
+
+
+class OpticalSystem3D(OpticalSystemBase):
+    """engine.py:871-1166."""
+
+    _boundary_sets = ("optical", "stop", "target")
+    optical = _prop("optical")
+    stops = _prop("stop")
+    targets = _prop("target")
+
+    @property
+    def dimension(self):
+        return 3
+
+    def _merge_boundaries(self):
+        """Label and merge optical, stop, target (engine.py:971-1018).  The merged geometry
+        is one (M,9) float64 tensor; catagory / material columns are cached int32."""
+        sets = [(getattr(self, "_" + n), c) for n, c in
+                (("optical", OPTICAL), ("stop", STOP), ("target", TARGET))]
+        parts, cats, grads = [], [], []
+        for lst, cat in sets:
+            for b in lst:
+                if not bool(b):
+                    continue
+                fv = b.face_verts
+                parts.append(fv)
+                cats.append((cat, fv.shape[0], b))
+                grads.append(fv.requires_grad)
+        self._optical_count = sum(n for c, n, _ in cats if c == OPTICAL)
+        self._stop_count = sum(n for c, n, _ in cats if c == STOP)
+        self._target_count = sum(n for c, n, _ in cats if c == TARGET)
+        if not parts:
+            self._merged = {}
+            self._merged_face_verts = None
+            return
+        self._merged_face_verts = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        self._merged = _MergedTriangles(self)
+        key = tuple((c, n, id(b)) + tuple(
+            (id(b[f]), b[f]._version) for f in ("mat_in", "mat_out", "n_in", "n_out") if f in b)
+            for c, n, b in cats) + (tuple(grads),)
+        if self._scene_cache is None or self._scene_cache[0] != key:
+            dev = self._merged_face_verts.device
+            catagory = torch.cat([torch.full((n,), c, dtype=torch.int32) for c, n, _ in cats]).to(dev)
+
+            def col(field, dtype):
+                if not any(c == OPTICAL and field in b for c, n, b in cats):
+                    return None
+                out = []
+                for c, n, b in cats:
+                    if c == OPTICAL and field in b:
+                        out.append(b[field].to(device=dev, dtype=dtype).reshape(-1))
+                    elif c == OPTICAL:
+                        raise KeyError(f"optical boundary lacks field {field}")
+                    else:
+                        out.append(torch.zeros(n, dtype=dtype, device=dev))
+                return torch.cat(out).contiguous()
+
+            gmask = torch.cat([torch.full((n,), 1 if g else 0, dtype=torch.uint8)
+                               for (c, n, _), g in zip(cats, grads)]).to(dev)
+            self._scene_cache = (key, dict(
+                catagory=catagory, mat_in=col("mat_in", torch.int32),
+                mat_out=col("mat_out", torch.int32), n_in=col("n_in", torch.float64),
+                n_out=col("n_out", torch.float64), face_grad_mask=gmask))
+
+    def scene_args(self, n_table, index_mode, ghost=False):
+        s = self._scene_cache[1]
+        kw = dict(intersect_epsilion=self.intersect_epsilion, size_epsilion=self.size_epsilion,
+                  ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"])
+        if ghost:
+            ones = torch.ones(s["catagory"].shape[0], dtype=torch.float64, device=s["catagory"].device)
+            return ops.Scene3DArgs(self._merged_face_verts, s["catagory"], n_in=ones, n_out=ones, **kw)
+        if index_mode:
+            if s["mat_in"] is None or s["mat_out"] is None:
+                raise RuntimeError("StandardReaction('index') needs mat_in / mat_out on every "
+                                   "optical boundary")
+            return ops.Scene3DArgs(self._merged_face_verts, s["catagory"], mat_in=s["mat_in"],
+                                   mat_out=s["mat_out"], n_table=n_table, **kw)
+        if s["n_in"] is None or s["n_out"] is None:
+            raise RuntimeError("StandardReaction('value') needs n_in / n_out on every optical "
+                               "boundary")
+        return ops.Scene3DArgs(self._merged_face_verts, s["catagory"], n_in=s["n_in"],
+                               n_out=s["n_out"], **kw)
+
+    def intersect(self, rays):
+        """Nearest triangle per ray (engine.py:1020-1078), via tfrt_intersect3d."""
+        result = {}
+        if self._merged_face_verts is not None:
+            block = torch.stack([rays[f] for f in _GEO3]).to(config.get_ray_dtype())
+            (result["x"], result["y"], result["z"], result["valid"], result["ray_u"],
+             result["trig_u"], result["trig_v"], result["gather_trig"]) = ops.intersect3d(
+                block, self._merged_face_verts.detach(), self.intersect_epsilion,
+                self.size_epsilion, self.ray_start_epsilion)
+            result["gather_ray"] = torch.arange(block.shape[1], device=block.device)
+            result["gather_trig"] = result["gather_trig"].long()
+            result["norm"] = self._merged["norm"][result["gather_trig"]]
+        return result
+
+    @staticmethod
+    def _intersection(rx1, ry1, rz1, rx2, ry2, rz2, xp, yp, zp, x1, y1, z1, x2, y2, z2,
+                      intersect_epsilion, size_epsilion, ray_start_epsilion):
+        """Same signature and returns as engine.py:1103-1166."""
+        rays = torch.stack([rx1, ry1, rz1, rx2, ry2, rz2])
+        fv = torch.stack([xp, yp, zp, x1, y1, z1, x2, y2, z2], dim=1)
+        x, y, z, valid, ray_u, trig_u, trig_v, gather = ops.intersect3d(
+            rays, fv, intersect_epsilion, size_epsilion, ray_start_epsilion)
+        gather_ray = torch.arange(rays.shape[1], device=rays.device)
+        return x, y, z, valid, ray_u, trig_u, trig_v, gather_ray, gather.long()
+
+
+class _MergedTriangles:
+    """The reference's ``system._merged`` dict (TRIANGLE_GEO_SIG + catagory), as views."""
+
+    _cols = {"xp": 0, "yp": 1, "zp": 2, "x1": 3, "y1": 4, "z1": 5, "x2": 6, "y2": 7, "z2": 8}
+
+    def __init__(self, system):
+        self._s = system
+
+    def __bool__(self):
+        return self._s._merged_face_verts is not None
+
+    def keys(self):
+        return set(self._cols) | {"norm", "catagory"}
+
+    def __getitem__(self, key):
+        s = self._s
+        if key in self._cols:
+            return s._merged_face_verts[:, self._cols[key]]
+        if key == "catagory":
+            return s._scene_cache[1]["catagory"].long()
+        if key == "norm":
+            lists = s._optical + s._stop + s._target
+            return torch.cat([b["norm"] for b in lists if bool(b)], 0)
+        raise KeyError(key)
+
+
+class OpticalSystem2D(OpticalSystemBase):
+    """engine.py:254-866: separate segment and arc sets per catagory."""
+
+    _boundary_sets = ("optical_segments", "optical_arcs", "stop_segments", "stop_arcs",
+                      "target_segments", "target_arcs")
+    optical_segments = _prop("optical_segments")
+    optical_arcs = _prop("optical_arcs")
+    stop_segments = _prop("stop_segments")
+    stop_arcs = _prop("stop_arcs")
+    target_segments = _prop("target_segments")
+    target_arcs = _prop("target_arcs")
+
+    @property
+    def dimension(self):
+        return 2
+
+    def _merge_kind(self, kind, geo):
+        sets = [(getattr(self, f"_amalgamated_{c}_{kind}"), cat) for c, cat in
+                (("optical", OPTICAL), ("stop", STOP), ("target", TARGET))]
+        geos, cats, extra = [], [], {f: [] for f in ("mat_in", "mat_out", "n_in", "n_out")}
+        for s, cat in sets:
+            if not bool(s):
+                continue
+            g = torch.stack([s[f].to(torch.float64) for f in geo], dim=1)
+            n = g.shape[0]
+            geos.append(g)
+            cats.append(torch.full((n,), cat, dtype=torch.int32, device=g.device))
+            for f in extra:
+                if cat == OPTICAL and f in s:
+                    extra[f].append(s[f].reshape(-1))
+                else:
+                    extra[f].append(None if cat == OPTICAL else torch.zeros(n, device=g.device))
+        if not geos:
+            return None
+        out = {"geo": torch.cat(geos, 0).contiguous(), "cat": torch.cat(cats).contiguous()}
+        for f, parts in extra.items():
+            if any(p is None for p in parts) or not parts:
+                out[f] = None
+            else:
+                dt = torch.int32 if f.startswith("mat") else torch.float64
+                out[f] = torch.cat([p.to(dt) for p in parts]).contiguous()
+        return out
+
+    def _merge_boundaries(self):
+        self._merged_segments = self._merge_kind("segments", _GEO2)
+        self._merged_arcs = self._merge_kind(
+            "arcs", ("x_center", "y_center", "angle_start", "angle_end", "radius"))
+
+    def scene_args(self, n_table, index_mode, ghost=False):
+        return ops.Scene2DArgs(self._merged_segments, self._merged_arcs, n_table, index_mode,
+                               ghost, self.intersect_epsilion, self.size_epsilion,
+                               self.ray_start_epsilion)
+
+    @staticmethod
+    def _segment_intersection(rx1, ry1, rx2, ry2, sx1, sy1, sx2, sy2, intersect_epsilion,
+                              size_epsilion, ray_start_epsilion):
+        """engine.py:688-749."""
+        rays = torch.stack([rx1, ry1, rx2, ry2])
+        seg = torch.stack([sx1, sy1, sx2, sy2], dim=1)
+        x, y, valid, ray_u, seg_u, gather = ops.segment_intersection(
+            rays, seg, intersect_epsilion, size_epsilion, ray_start_epsilion)
+        return x, y, valid, ray_u, seg_u, torch.arange(rays.shape[1], device=rays.device), gather.long()
+
+    @staticmethod
+    def _arc_intersection(rx1, ry1, rx2, ry2, xc, yc, a1, a2, r, intersect_epsilion,
+                          size_epsilion, ray_start_epsilion):
+        """engine.py:768-866."""
+        rays = torch.stack([rx1, ry1, rx2, ry2])
+        arc = torch.stack([xc, yc, a1, a2, r], dim=1)
+        x, y, valid, ray_u, arc_u, gather = ops.arc_intersection(
+            rays, arc, intersect_epsilion, size_epsilion, ray_start_epsilion)
+        return x, y, valid, ray_u, arc_u, torch.arange(rays.shape[1], device=rays.device), gather.long()
+
+
+# ==================================================================================== engine
+
+class OpticalEngine:
+    """Builds and runs the trace (engine.py:1170-2330).
+
+    Constructor arguments keep the reference's names and defaults.  ``ray_dtype`` (extra)
+    selects the ray-state precision inside the kernels (default: ``config.get_ray_dtype()``,
+    float32); decisions and Snell math are float64 either way.
+    """
+
+    def __init__(self, dimension, operations, optical_system=None,
+                 compile_technical_intersections=False, compile_stopped_rays=False,
+                 compile_dead_rays=False, compile_finished_rays=True, compile_active_rays=True,
+                 dead_ray_length=None, compile_geometry_specific_result=False,
+                 new_ray_length=1.0, simple_ray_inheritance={"wavelength"}, ray_dtype=None,
+                 ray_shard="auto"):
+        if dimension not in (2, 3):
+            raise ValueError(f"RayEngine: dimension must be 2 or 3, but was given {dimension}.")
+        self._dimension = dimension
+        self._check_exclusions(operations)
+        self._operations = operations
+        self._optical_system = optical_system
+        self.compile_technical_intersections = compile_technical_intersections
+        self.compile_stopped_rays = compile_stopped_rays
+        self.compile_dead_rays = compile_dead_rays
+        self.compile_finished_rays = compile_finished_rays
+        self.compile_active_rays = compile_active_rays
+        self.dead_ray_length = dead_ray_length
+        self.compile_geometry_specific_result = compile_geometry_specific_result
+        self.new_ray_length = new_ray_length
+        self.ray_dtype = ray_dtype
+        # (rank, world_size): trace only this rank's contiguous block of the source rays;
+        # "auto" = follow torch.distributed when a process group is up; None = all rays.
+        self.ray_shard = ray_shard
+        self.clear_ray_history()
+        self.last_projection_result = {}
+        self.last_trace = None
+
+        self.input_signature = set()
+        self.output_signature = set()
+        self.optical_signature = set()
+        self.stop_signature = set()
+        self.target_signature = set()
+        self.material_signature = set()
+        self.simple_ray_inheritance = set(simple_ray_inheritance)
+        for o in operations:
+            self.input_signature |= o.input_signature
+            self.output_signature |= o.output_signature
+            self.optical_signature |= o.optical_signature
+            self.stop_signature |= o.stop_signature
+            self.target_signature |= o.target_signature
+            self.material_signature |= o.material_signature
+            self.simple_ray_inheritance |= o.simple_ray_inheritance
+
+    # ------------------------------------------------------------------ configuration
+    def add_inheritable_field(self, fields):
+        if type(fields) is str:
+            fields = {fields}
+        self.simple_ray_inheritance = self.simple_ray_inheritance | set(fields)
+
+    def _check_exclusions(self, operations):
+        exclusions, used = set(), set()
+        for o in operations:
+            used.add(o.__class__)
+            exclusions |= o.exclusions
+        if used & exclusions:
+            raise RuntimeError(f"RayEngine: discovered exclusive operations: {used & exclusions}")
+        self.operations = operations
+
+    def _reaction(self):
+        """(index_mode, ghost) of the fused reaction declared by the operations."""
+        for o in self._operations:
+            if getattr(o, "ghost", False) and o.active:
+                return False, True
+            if isinstance(o, op.StandardReaction) and o.active:
+                return o.refractive_index_type == "index", False
+        raise RuntimeError(
+            "OpticalEngine: no active reaction operation (StandardReaction / GhostThrough); "
+            "the fused HIP trace implements those reactions only")
+
+    def update(self):
+        if self._optical_system is not None:
+            self._optical_system.update()
+
+    def annotate(self, op_list=None):
+        if bool(self.optical_system):
+            for o in (self._operations if op_list is None else op_list):
+                o.annotate(self)
+        else:
+            print("No optical system found, so annotating nothing.")
+
+    dimension = property(lambda self: self._dimension)
+
+    @property
+    def new_ray_length(self):
+        return self._new_ray_length
+
+    @new_ray_length.setter
+    def new_ray_length(self, val):
+        self._new_ray_length = float(val)
+
+    @property
+    def optical_system(self):
+        return self._optical_system
+
+    @optical_system.setter
+    def optical_system(self, val):
+        if val.dimension != self.dimension:
+            raise ValueError(
+                f"OpticalEngine: attempted to set an optical system with dimension "
+                f"{val.dimension}, but this engine is set to dimension {self.dimension}")
+        self._optical_system = val
+
+    # ------------------------------------------------------------------------ validation
+    def validate_system(self):
+        """Key-set checks of engine.py:1416-1522."""
+        system = self.optical_system
+        if not bool(system):
+            print("No optical system found, so validating nothing.")
+            return
+        for material in system.materials:
+            sig = set(material.keys()) if isinstance(material, dict) else {"n"}
+            if not (sig >= self.material_signature):
+                raise RuntimeError(
+                    f"Optical engine failed materials signature check.  System signature is "
+                    f"{sig} but needed {self.material_signature}")
+
+        def check(fields, required, what):
+            if bool(fields):
+                sig = set(fields.keys())
+                if not (sig >= required):
+                    raise RuntimeError(
+                        f"Optical engine failed {what} signature check.  System signature is "
+                        f"{sig}, but needed {required}.")
+
+        if self.dimension == 2:
+            check(system._amalgamated_sources, SEGMENT_GEO_SIG | self.input_signature, "sources")
+            for cat, sig in (("optical", self.optical_signature), ("stop", self.stop_signature),
+                             ("target", self.target_signature)):
+                check(getattr(system, f"_amalgamated_{cat}_segments"), SEGMENT_GEO_SIG | sig,
+                      f"{cat} segments")
+                check(getattr(system, f"_amalgamated_{cat}_arcs"), ARC_GEO_SIG | sig, f"{cat} arcs")
+        else:
+            check(system._amalgamated_sources, SOURCE_3D_SIG | self.input_signature, "sources")
+            check(system._amalgamated_optical, TRIANGLE_GEO_SIG | self.optical_signature, "optical")
+            check(system._amalgamated_stop, TRIANGLE_GEO_SIG | self.stop_signature, "stop")
+            check(system._amalgamated_target, TRIANGLE_GEO_SIG | self.target_signature, "target")
+
+    def validate_output(self):
+        if self.dimension == 2:
+            required = SEGMENT_GEO_SIG | self.output_signature
+            for rays in (self.active_rays, self.finished_rays, self.stopped_rays, self.dead_rays):
+                if bool(rays) and not (set(rays.keys()) >= required):
+                    raise RuntimeError(
+                        f"Optical engine failed output signature check.  System signature is "
+                        f"{set(rays.keys())}, but needed {required}.")
+
+    # ------------------------------------------------------------------------- history
+    def clear_ray_history(self):
+        self._history = {c: [] for c in _CLASSES}
+        self._unfinished_rays = {}
+
+    def _set(self, cls):
+        return ReadOnlySet(amalgamate(self._history[cls]))
+
+    active_rays = property(lambda self: self._set("active"))
+    finished_rays = property(lambda self: self._set("finished"))
+    dead_rays = property(lambda self: self._set("dead"))
+    stopped_rays = property(lambda self: self._set("stopped"))
+    unfinished_rays = property(lambda self: self._unfinished_rays)
+
+    @property
+    def all_rays(self):
+        h = self._history
+        return ReadOnlySet(amalgamate(h["active"] + h["finished"] + h["dead"] + h["stopped"]))
+
+    # --------------------------------------------------------------------------- trace
+    def _flags(self):
+        f = 0
+        if self.compile_active_rays:
+            f |= _lib.COMPILE_ACTIVE
+        if self.compile_finished_rays:
+            f |= _lib.COMPILE_FINISHED
+        if self.compile_stopped_rays:
+            f |= _lib.COMPILE_STOPPED
+        if self.compile_dead_rays:
+            f |= _lib.COMPILE_DEAD
+        return f
+
+    def _run(self, rays, max_passes, flags):
+        """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
+        system = self.optical_system
+        geo = _GEO3 if self.dimension == 3 else _GEO2
+        dt = self.ray_dtype or config.get_ray_dtype()
+        block = torch.stack([rays[f] for f in geo]).to(dt)
+        index_mode, ghost = self._reaction()
+        n_table = None
+        if index_mode:
+            n_table = system.material_table(rays["wavelength"].detach())
+        scene = system.scene_args(n_table, index_mode, ghost)
+        if self.dimension == 3:
+            fv = system._merged_face_verts
+            if fv is None:
+                fv = torch.zeros((0, 9), dtype=torch.float64, device=block.device)
+            out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
+                              self.dead_ray_length, flags)
+        else:
+            out = ops.trace2d(block, scene, max_passes, self.new_ray_length,
+                              self.dead_ray_length, flags)
+        return out
+
+    def _fields_from(self, out, cls, src, only_first_pass):
+        """Field dict of one output class: geometry from the kernels, everything else gathered
+        from the source set by source-ray index (simple inheritance, engine.py:2242-2281)."""
+        geo = _GEO3 if self.dimension == 3 else _GEO2
+        rays = out[cls]
+        ids = out[cls + "_id"].long()
+        fields = {g: rays[i] for i, g in enumerate(geo)}
+        carry = set(src.keys()) - set(geo)
+        if not only_first_pass:
+            carry &= self.simple_ray_inheritance
+        for f in carry:
+            fields[f] = src[f][ids]
+        return fields
+
+    def ray_trace(self, max_iterations=25):
+        """Trace the optical system (engine.py:2311-2330): all passes in one fused launch
+        sequence on the device."""
+        if not bool(self.optical_system):
+            return
+        self.clear_ray_history()
+        src = self.optical_system._amalgamated_sources
+        if not src:
+            return
+        shard = self.ray_shard
+        if shard == "auto":
+            shard = (tdist.rank(), tdist.world_size()) if tdist.is_distributed() else None
+        if shard is not None:
+            n = src["x_start"].shape[0]
+            lo, hi = tdist.shard_bounds(n, *shard)
+            src = {f: v[lo:hi] for f, v in src.items()}
+        out = self._run(src, int(max_iterations), self._flags())
+        self.last_trace = out
+        counts = out["counts"]
+        for k, cls in enumerate(_CLASSES):
+            if cls not in out or out[cls].shape[1] == 0:
+                continue
+            later = bool(counts[1:, k].sum() > 0) if counts.shape[0] > 1 else False
+            self._history[cls] = [self._fields_from(out, cls, src, not later)]
+        geo = _GEO3 if self.dimension == 3 else _GEO2
+        if out["unfinished"].shape[1]:
+            ids = out["unfinished_id"].long()
+            unf = {g: out["unfinished"][i] for i, g in enumerate(geo)}
+            for f in self.simple_ray_inheritance & set(src.keys()):
+                unf[f] = src[f][ids]
+            self._unfinished_rays = unf
+
+    def process_projection(self, input_rays):
+        """One projection (engine.py:1544-2191): returns the reference's result dict and, like
+        the reference, moves ``input_rays``' end points onto the boundaries they hit."""
+        return self._single(input_rays)[0]
+
+    def _single(self, input_rays):
+        system = self.optical_system
+        flags = self._flags() | _lib.COMPILE_ACTIVE
+        out = self._run(input_rays, 1, flags)
+        geo = _GEO3 if self.dimension == 3 else _GEO2
+        result = {"rays": {}}
+        for cls, on in (("active", True), ("finished", self.compile_finished_rays),
+                        ("stopped", self.compile_stopped_rays), ("dead", self.compile_dead_rays)):
+            if not on or cls not in out:
+                continue
+            fields = self._fields_from(out, cls, input_rays, True)
+            result["rays"][cls] = fields
+            if cls != "active" or self.compile_active_rays:
+                self._history[cls].append(fields)
+        # boundary data gathered to the reacting rays (engine.py:2113-2133)
+        if self.dimension == 3:
+            face = out["active_face"].long()
+            optical = {f: v[face] for f, v in system._amalgamated_optical.items()
+                       if f not in TRIANGLE_GEO_SIG} if bool(system._amalgamated_optical) else {}
+            for f in TRIANGLE_GEO_SIG:
+                if bool(system._merged):
+                    optical[f] = system._merged[f][face]
+            result["optical"] = optical
+            if self.compile_technical_intersections:
+                for cls, key, name, off in (
+                        ("stopped", "stop", "_amalgamated_stop", system._optical_count),
+                        ("finished", "target", "_amalgamated_target",
+                         system._optical_count + system._stop_count)):
+                    if cls in result["rays"] and bool(getattr(system, name)):
+                        face = out[cls + "_face"].long()
+                        d = {f: v[face - off] for f, v in getattr(system, name).items()}
+                        d["norm"] = system._merged["norm"][face]
+                        result[key] = d
+        else:
+            result["optical"] = ops.gather_optical_2d(system, out)
+        # update the caller's ray dict with the projected end points
+        n = input_rays[geo[0]].shape[0]
+        half = len(geo) // 2
+        for cls in ("active", "finished", "stopped"):
+            if cls in out and out[cls].shape[1]:
+                ids = out[cls + "_id"].long()
+                for i in range(half, len(geo)):
+                    col = input_rays[geo[i]].clone()
+                    col[ids] = out[cls][i].to(col.dtype)
+                    input_rays[geo[i]] = col
+        new = {}
+        if out["unfinished"].shape[1]:
+            ids = out["unfinished_id"].long()
+            new = {g: out["unfinished"][i] for i, g in enumerate(geo)}
+            for f in self.simple_ray_inheritance:
+                if f in input_rays:
+                    new[f] = input_rays[f][ids]
+        assert n == input_rays[geo[0]].shape[0]
+        return result, new
+
+    def single_pass(self, input_rays):
+        """One pass (engine.py:2193-2302): project, react, inherit.  Returns the new ray set
+        (``{}`` when no ray reacted)."""
+        if not bool(self.optical_system):
+            return {}
+        result, new = self._single(input_rays)
+        for cls in list(result["rays"].keys()):
+            if result["rays"][cls]["x_start"].shape[0] == 0:
+                result["rays"].pop(cls)
+        self.last_projection_result = result
+        for o in self._operations:
+            o.preprocess(self, result)
+        new_ray_dict = {}
+        if new:
+            valid = torch.ones(new["x_start"].shape[0], dtype=torch.bool, device=new["x_start"].device)
+            reaction = next(o for o in self._operations if getattr(o, "fused", False))
+            new_ray_dict[reaction] = {"active": {"rays": new, "valid": valid}}
+        for o in self._operations:
+            o.postprocess(self, result, new_ray_dict)
+        out_list = []
+        for entry in new_ray_dict.values():
+            for geo_entry in entry.values():
+                v = geo_entry["valid"]
+                out_list.append({k: f[v] for k, f in geo_entry["rays"].items()})
+        return amalgamate(out_list)

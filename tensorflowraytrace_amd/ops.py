@@ -309,3 +309,239 @@ def snell2d(x_start, y_start, x_end, y_end, norm, n_in, n_out, new_ray_length):
     check(_lib.lib().tfrt_snell2d(n, *[_p(a) for a in args], _p(n_in), _p(n_out),
                                   float(new_ray_length), _p(out), _stream(out)), "tfrt_snell2d")
     return out
+
+
+# ================================================================================= 2-D
+
+from ._lib import Scene2D  # noqa: E402
+
+
+class Scene2DArgs:
+    """Device tensors describing the merged 2-D boundary sets (tfrt_scene2d).  ``segments`` /
+    ``arcs`` are the dicts built by ``OpticalSystem2D._merge_kind`` (``geo`` (M,4|5) f64,
+    ``cat`` int32, optional ``mat_in/mat_out/n_in/n_out``) or None."""
+
+    def __init__(self, segments, arcs, n_table, index_mode, ghost, intersect_epsilion=1e-10,
+                 size_epsilion=1e-10, ray_start_epsilion=1e-10):
+        self.segments, self.arcs = segments, arcs
+        self.n_table = _c(n_table, torch.float64)
+        self.index_mode, self.ghost = index_mode, ghost
+        self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
+        self._keep = []
+
+    def struct(self, seg_geo, arc_geo):
+        sc = Scene2D()
+        self._keep = []
+
+        def fill(prefix, info, geo, count_field):
+            n = 0 if geo is None else geo.shape[0]
+            setattr(sc, count_field, n)
+            names = {"seg": ("seg", "seg_cat", "seg_mat_in", "seg_mat_out", "seg_n_in", "seg_n_out"),
+                     "arc": ("arc", "arc_cat", "arc_mat_in", "arc_mat_out", "arc_n_in", "arc_n_out")}[prefix]
+            for nm in names:
+                setattr(sc, nm, None)
+            if n == 0:
+                return
+            setattr(sc, names[0], geo.data_ptr())
+            setattr(sc, names[1], info["cat"].data_ptr())
+            if self.ghost:
+                ones = torch.ones(n, dtype=torch.float64, device=geo.device)
+                self._keep.append(ones)
+                setattr(sc, names[4], ones.data_ptr())
+                setattr(sc, names[5], ones.data_ptr())
+            elif self.index_mode:
+                if info["mat_in"] is None or info["mat_out"] is None:
+                    raise TfrtError("StandardReaction('index') needs mat_in / mat_out on every "
+                                    "optical boundary")
+                setattr(sc, names[2], info["mat_in"].data_ptr())
+                setattr(sc, names[3], info["mat_out"].data_ptr())
+            else:
+                if info["n_in"] is None or info["n_out"] is None:
+                    raise TfrtError("StandardReaction('value') needs n_in / n_out on every optical "
+                                    "boundary")
+                setattr(sc, names[4], info["n_in"].data_ptr())
+                setattr(sc, names[5], info["n_out"].data_ptr())
+
+        fill("seg", self.segments, seg_geo, "n_segments")
+        fill("arc", self.arcs, arc_geo, "n_arcs")
+        if self.n_table is not None and self.n_table.numel() and self.index_mode and not self.ghost:
+            sc.n_table = self.n_table.data_ptr()
+            sc.n_table_stride = self.n_table.shape[1]
+            sc.n_materials = self.n_table.shape[0]
+        else:
+            sc.n_table, sc.n_table_stride, sc.n_materials = None, 0, 0
+        sc.intersect_epsilion, sc.size_epsilion, sc.ray_start_epsilion = self.eps
+        return sc
+
+
+class _Trace2D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, seg_geo, arc_geo, scene, opts):
+        _need_gpu(src, seg_geo, arc_geo)
+        dev = src.device
+        if src.dtype not in _DT:
+            raise TfrtError(f"ray state dtype must be float32 or float64, got {src.dtype}")
+        src = src.contiguous()
+        seg_geo = _c(seg_geo, torch.float64)
+        arc_geo = _c(arc_geo, torch.float64)
+        N = src.shape[1]
+        P = int(opts["max_passes"])
+        flags = int(opts["flags"])
+        dt = _DT[src.dtype]
+        L = _lib.lib()
+        Ms = 0 if seg_geo is None else seg_geo.shape[0]
+        Ma = 0 if arc_geo is None else arc_geo.shape[0]
+        wsb = L.tfrt_trace2d_workspace_bytes(N, Ms, Ma, P, dt)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        counts = torch.zeros(_lib.COUNTS_PER_PASS * (P + 1), dtype=torch.int32, device=dev)
+
+        def alloc(flag, cap):
+            if not (flags & flag):
+                return None, None, None
+            return (torch.empty((4, cap), dtype=src.dtype, device=dev),
+                    torch.empty(cap, dtype=torch.int32, device=dev),
+                    torch.empty(cap, dtype=torch.int32, device=dev))
+
+        capN = max(N, 1)
+        fin = alloc(_lib.COMPILE_FINISHED, capN)
+        act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
+        stp = alloc(_lib.COMPILE_STOPPED, capN)
+        dead = alloc(_lib.COMPILE_DEAD, capN)
+        unf = torch.empty((4, capN), dtype=src.dtype, device=dev)
+        unf_id = torch.empty(capN, dtype=torch.int32, device=dev)
+        sc = scene.struct(seg_geo, arc_geo)
+        outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
+        check(L.tfrt_trace2d_forward(
+            _p(src), src.shape[1], N, ctypes.byref(sc), float(opts["new_ray_length"]),
+            float(opts["dead_ray_length"] or 0.0), P, dt, flags,
+            ctypes.byref(outs[0]), ctypes.byref(outs[1]), ctypes.byref(outs[2]),
+            ctypes.byref(outs[3]), _p(unf), _p(unf_id), _p(counts), _p(ws), wsb, _stream(src)),
+            "tfrt_trace2d_forward")
+        tape = TraceTape()
+        tape.src, tape.seg, tape.arc, tape.scene, tape.opts = src, seg_geo, arc_geo, scene, dict(opts)
+        tape.ws, tape.wsb, tape.counts, tape.dt = ws, wsb, counts, dt
+        tape.caps = [o[0].shape[1] if o[0] is not None else 0 for o in (fin, act, stp, dead)]
+        ctx.tape = tape
+        opts["_aux"] = {
+            "counts": counts, "unfinished": unf, "unfinished_id": unf_id,
+            "finished_id": fin[1], "finished_face": fin[2], "active_id": act[1],
+            "active_face": act[2], "stopped_id": stp[1], "stopped_face": stp[2],
+            "dead_id": dead[1], "dead_face": dead[2],
+        }
+        empty = torch.empty((4, 0), dtype=src.dtype, device=dev)
+        ctx.present = [o[0] is not None for o in (fin, act, stp, dead)]
+        return tuple(o[0] if o[0] is not None else empty for o in (fin, act, stp, dead))
+
+    @staticmethod
+    def backward(ctx, g_fin, g_act, g_stp, g_dead):
+        t = ctx.tape
+        dev = t.src.device
+        g_seg = None if t.seg is None else torch.zeros_like(t.seg)
+        g_arc = None if t.arc is None else torch.zeros_like(t.arc)
+        need_src = ctx.needs_input_grad[0]
+        g_src = torch.zeros((4, t.src.shape[1]), dtype=torch.float64, device=dev) if need_src else None
+        gs = []
+        for g, present in zip((g_fin, g_act, g_stp, g_dead), ctx.present):
+            gs.append(_c(g, torch.float64) if (present and g is not None) else None)
+        sc = t.scene.struct(t.seg, t.arc)
+        check(_lib.lib().tfrt_trace2d_backward(
+            _p(t.src), t.src.shape[1], t.src.shape[1], ctypes.byref(sc),
+            float(t.opts["new_ray_length"]), float(t.opts["dead_ray_length"] or 0.0),
+            int(t.opts["max_passes"]), t.dt,
+            _p(gs[0]), t.caps[0], _p(gs[1]), t.caps[1], _p(gs[2]), t.caps[2], _p(gs[3]), t.caps[3],
+            _p(g_seg), _p(g_arc), _p(g_src), _p(t.counts), _p(t.ws), t.wsb, _stream(t.src)),
+            "tfrt_trace2d_backward")
+        if g_src is not None:
+            g_src = g_src.to(t.src.dtype)
+        return g_src, g_seg, g_arc, None, None
+
+
+def trace2d(src, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
+            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED):
+    """Whole 2-D trace; same result dict as ``trace3d`` with (4, n) ray blocks.  The ``*_face``
+    arrays index the merged segments first and then ``n_segments + merged arc index``."""
+    opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
+                dead_ray_length=dead_ray_length, flags=flags)
+    seg_geo = None if scene.segments is None else scene.segments["geo"]
+    arc_geo = None if scene.arcs is None else scene.arcs["geo"]
+    fin, act, stp, dead = _Trace2D.apply(src, seg_geo, arc_geo, scene, opts)
+    aux = opts.pop("_aux")
+    counts = aux["counts"].cpu().numpy()
+    P = int(max_passes)
+    tail = counts[P * 8:]
+    if tail[6] != 0:
+        raise TfrtError("tfrt_trace2d_forward: output capacity exceeded (internal error)")
+    out = {"counts": counts[:P * 8].reshape(P, 8).copy(),
+           "n_tests": int(np.uint32(tail[4])) | (int(np.uint32(tail[5])) << 32),
+           "n_segments": 0 if seg_geo is None else seg_geo.shape[0]}
+    totals = {"active": int(tail[0]), "finished": int(tail[1]), "stopped": int(tail[2]),
+              "dead": int(tail[3])}
+    for name, rays in (("finished", fin), ("active", act), ("stopped", stp), ("dead", dead)):
+        if aux[name + "_id"] is None:
+            continue
+        n = totals[name]
+        out[name] = rays[:, :n]
+        out[name + "_id"] = aux[name + "_id"][:n]
+        out[name + "_face"] = aux[name + "_face"][:n]
+    n_unf = int(out["counts"][P - 1, 0]) if P > 0 else 0
+    out["unfinished"] = aux["unfinished"][:, :n_unf]
+    out["unfinished_id"] = aux["unfinished_id"][:n_unf]
+    return out
+
+
+def _seam2d(fn_name, rays, prim, eps):
+    _need_gpu(rays, prim)
+    rays = rays.contiguous()
+    prim = _c(prim, torch.float64)
+    N, M = rays.shape[1], prim.shape[0]
+    dev = rays.device
+    f = lambda: torch.empty(N, dtype=torch.float64, device=dev)
+    x, y, ray_u, prim_u = f(), f(), f(), f()
+    valid = torch.empty(N, dtype=torch.uint8, device=dev)
+    gather = torch.empty(N, dtype=torch.int32, device=dev)
+    check(getattr(_lib.lib(), fn_name)(
+        _p(rays), rays.shape[1], N, _DT[rays.dtype], _p(prim) if M else None, M,
+        float(eps[0]), float(eps[1]), float(eps[2]), _p(x), _p(y), _p(valid), _p(ray_u),
+        _p(prim_u), _p(gather), _stream(rays)), fn_name)
+    return x, y, valid.bool(), ray_u, prim_u, gather
+
+
+def segment_intersection(rays, seg, intersect_epsilion=1e-10, size_epsilion=1e-10,
+                         ray_start_epsilion=1e-10):
+    """OpticalSystem2D._segment_intersection (engine.py:688-749); rays (4,N), seg (M,4)."""
+    return _seam2d("tfrt_segment_intersection", rays, seg,
+                   (intersect_epsilion, size_epsilion, ray_start_epsilion))
+
+
+def arc_intersection(rays, arc, intersect_epsilion=1e-10, size_epsilion=1e-10,
+                     ray_start_epsilion=1e-10):
+    """OpticalSystem2D._arc_intersection (engine.py:768-866); rays (4,N), arc (M,5)."""
+    return _seam2d("tfrt_arc_intersection", rays, arc,
+                   (intersect_epsilion, size_epsilion, ray_start_epsilion))
+
+
+def gather_optical_2d(system, out):
+    """Boundary data of the reacting rays of a 2-D pass, in the order of ``out['active']``
+    (segment-hit rays then arc-hit rays), correctly paired (the reference's mixed-system
+    concat pairs them wrongly, engine.py:1958-1965)."""
+    face = out["active_face"].long()
+    ns = out["n_segments"]
+    result = {}
+    seg_set = system._amalgamated_optical_segments
+    arc_set = system._amalgamated_optical_arcs
+    is_arc = face >= ns
+    geo = {"x_start", "y_start", "x_end", "y_end", "x_center", "y_center", "angle_start",
+           "angle_end", "radius"}
+    keys = None
+    for s in (seg_set, arc_set):
+        if bool(s):
+            k = set(s.keys()) - geo
+            keys = k if keys is None else (keys & k)
+    for f in (keys or ()):
+        parts = []
+        if bool(seg_set):
+            parts.append(seg_set[f][face[~is_arc]])
+        if bool(arc_set):
+            parts.append(arc_set[f][face[is_arc] - ns])
+        result[f] = torch.cat(parts) if len(parts) > 1 else parts[0]
+    return result

@@ -1,0 +1,226 @@
+"""
+Gradient-descent driver (tfrt/optimizer.py:8-442) on torch autograd + the HIP reverse sweep.
+
+One step = ``system.update()`` (constraints, parameters -> vertices -> faces) ->
+``engine.ray_trace(trace_depth)`` -> user ``error_function(engine, ...)`` -> gradient ->
+[all-reduce over ray shards] -> non-finite -> 0, scale, clip, accumulator matmul
+(optimizer.py:223-257) -> SGD apply (optimizer.py:316) -> smoothing (optimizer.py:261-282).
+
+Effective update rule of the reference: it builds ``tf.optimizers.SGD(nesterov=True)`` with
+the Keras defaults (learning rate 0.01, momentum 0.0) and later only *assigns* ``momentum``
+(optimizer.py:103,128-132); in Keras OptimizerV2 the momentum branch is chosen at
+construction, so the step is plain ``p -= 0.01 * processed_grad``.  That is the default here
+(``sgd_learning_rate=0.01``, ``apply_momentum=False``); ``apply_momentum=True`` enables the
+Nesterov rule the constructor presumably intended.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import distributed as tdist
+
+
+class SGD_Optimizer:
+    def __init__(self, engine, parameters, error_function, trace_depth, momentum=0.0,
+                 learning_rate=1.0, individual_lr=None, grad_clip="default", clip_mode="common",
+                 clip_scale=10.0, sgd_learning_rate=0.01, apply_momentum=False):
+        self.engine = engine
+        if type(parameters) is list or type(parameters) is tuple:
+            self.parameters = parameters
+        else:
+            raise ValueError("SGD_Optimizer: parameters must be a list of tf.variable")
+        self.error_function = error_function
+        self.trace_depth = trace_depth
+        self.sgd_learning_rate = sgd_learning_rate
+        self.apply_momentum = apply_momentum
+        self._velocity = [None] * len(self.parameters)
+        self.momentum = momentum
+        self.learning_rate = learning_rate
+        self.individual_lr = individual_lr
+        self.clip_scale = clip_scale
+        self.grad_clip = self.clip_scale * learning_rate if grad_clip == "default" else grad_clip
+        self.clip_mode = clip_mode
+        self.suppress_warnings = False
+        self.iterations = 0
+        self.last_error_terms = 0
+
+    @property
+    def momentum(self):
+        return self._momentum
+
+    @momentum.setter
+    def momentum(self, val):
+        if 0.0 <= val <= 1.0:
+            self._momentum = val
+        else:
+            raise ValueError("SGD_Optimizer: Momentum must be between 0 and 1.")
+
+    @property
+    def individual_lr(self):
+        return self._individual_lr
+
+    @individual_lr.setter
+    def individual_lr(self, val):
+        if val is None:
+            self._individual_lr = [1.0] * len(self.parameters)
+            return
+        try:
+            if len(val) != len(self.parameters):
+                raise ValueError(
+                    "SGD_Optimizer: individual_lr must have as many elements as there are "
+                    "parameters.")
+        except TypeError as e:
+            raise TypeError(
+                "SGD_Optimizer: individual_lr must have as many elements as there are "
+                "parameters.") from e
+        self._individual_lr = val
+
+    def convert_to_plist(self, data):
+        p_count = len(self.parameters)
+        if type(data) is list or type(data) is tuple:
+            if len(data) == p_count:
+                return data
+            raise ValueError("SGD_Optimizer: plist arguments must have one element per parameter.")
+        return [data] * p_count
+
+    def convert_to_lrlist(self, lr, steps):
+        try:
+            return np.linspace(lr[0], lr[1], steps)
+        except TypeError:
+            return [lr] * steps
+
+    # ------------------------------------------------------------------------ gradient
+    def raw_gradient(self, *args, **kwargs):
+        """update -> trace -> error -> gradient, summed over ray shards.  Returns
+        (grads, error_sum, n_error_terms)."""
+        self.engine.clear_ray_history()
+        self.engine.optical_system.update()
+        self.engine.ray_trace(self.trace_depth)
+        error = self.error_function(self.engine, *args, **kwargs)
+        error_sum = error.sum()
+        n_terms = error.numel()
+        if error_sum.requires_grad:
+            grads = torch.autograd.grad(error_sum, self.parameters, allow_unused=True)
+        else:
+            grads = [None] * len(self.parameters)
+        fixed = []
+        for g, p in zip(grads, self.parameters):
+            if g is None:
+                if not self.suppress_warnings:
+                    print(
+                        "Warning: SGD_Optimizer.process_gradient encountered a possible issue:  "
+                        "The gradient was likely None, which can mean that the error does not "
+                        "depend on it.  The gradient will be set to zero and future instances "
+                        "of this message will be suppressed.")
+                    self.suppress_warnings = True
+                g = torch.zeros_like(p)
+            fixed.append(g)
+        fixed, error_sum, n_terms = tdist.all_reduce_step(fixed, error_sum.detach(), n_terms)
+        return fixed, error_sum, n_terms
+
+    def process_gradient(self, accumulators, *args, lr_scale=1.0, **kwargs):
+        """optimizer.py:187-258.  Returns (processed grads, mean error)."""
+        grads, error_sum, n_terms = self.raw_gradient(*args, **kwargs)
+        self.last_error_terms = n_terms
+        processed = []
+        for i, grad in enumerate(grads):
+            grad = torch.where(torch.isfinite(grad), grad, torch.zeros_like(grad))
+            grad = grad * (lr_scale * self.individual_lr[i] * self.learning_rate)
+            if self.clip_mode == "common":
+                grad = torch.clamp(grad, -self.grad_clip, self.grad_clip)
+            else:
+                clp = self.individual_lr[i] * self.clip_scale * self.learning_rate * lr_scale
+                grad = torch.clamp(grad, -clp, clp)
+            if accumulators[i] is not None:
+                shape = grad.shape
+                acc = accumulators[i]
+                if not isinstance(acc, torch.Tensor) or acc.device != grad.device:
+                    acc = torch.as_tensor(np.asarray(acc), dtype=grad.dtype, device=grad.device) \
+                        if not isinstance(acc, torch.Tensor) else acc.to(grad.device)
+                    accumulators[i] = acc
+                if acc.is_sparse or acc.layout == torch.sparse_csr:
+                    grad = (acc @ grad.reshape(-1, 1)).reshape(shape)
+                else:
+                    grad = torch.matmul(acc.to(grad.dtype), grad.reshape(-1, 1)).reshape(shape)
+            processed.append(grad)
+        mean = error_sum / max(n_terms, 1)
+        return processed, mean
+
+    @staticmethod
+    def smooth(parameters, smoother):
+        """optimizer.py:261-282: ``parameters <- smoother @ parameters`` in place."""
+        if smoother is not None:
+            with torch.no_grad():
+                s = smoother if isinstance(smoother, torch.Tensor) else torch.as_tensor(
+                    np.asarray(smoother))
+                s = s.to(device=parameters.device, dtype=parameters.dtype)
+                parameters.copy_((s @ parameters.reshape(-1, 1)).reshape(parameters.shape))
+
+    def apply_gradients(self, grads):
+        with torch.no_grad():
+            for i, (g, p) in enumerate(zip(grads, self.parameters)):
+                lr = self.sgd_learning_rate
+                if self.apply_momentum and self._momentum > 0.0:
+                    v = self._velocity[i]
+                    if v is None:
+                        v = torch.zeros_like(p)
+                    v = self._momentum * v - lr * g
+                    self._velocity[i] = v
+                    p.add_(self._momentum * v - lr * g)  # Nesterov form used by Keras
+                else:
+                    p.add_(g, alpha=-lr)
+
+    def single_step(self, accumulators, *args, lr_scale=1.0, momentum=0.0, verbose=False,
+                    **kwargs):
+        """optimizer.py:284-320."""
+        self.momentum = momentum
+        accumulators = self.convert_to_plist(accumulators)
+        grads, error = self.process_gradient(accumulators, *args, lr_scale=lr_scale, **kwargs)
+        self.apply_gradients(grads)
+        self.iterations += 1
+        err = float(error)
+        if verbose:
+            print(f"step {self.iterations} error: {err}")
+        return err
+
+    def training_routine(self, routine, post_step=None, report_frequency=1, show_time=True):
+        """optimizer.py:322-442: list of phase dicts, each updating the running phase."""
+        phase = {"steps": 10, "learning_rate": 1.0, "momentum": 0.0, "accumulators": None,
+                 "smoothers": None, "erf_args": [], "erf_kwargs": {}, "individual_lr": None}
+        self.iterations = 0
+        phase_count = len(routine)
+        total_iterations = 0
+        steps = phase["steps"]
+        start_time = time.time()
+        for new_phase in routine:
+            steps = new_phase.get("steps", steps)
+            total_iterations += steps
+        current_phase = 0
+        is_rank0 = tdist.rank() == 0
+        for new_phase in routine:
+            current_phase += 1
+            phase_iterations = 0
+            phase.update(new_phase)
+            phase["accumulators"] = self.convert_to_plist(phase["accumulators"])
+            phase["smoothers"] = self.convert_to_plist(phase["smoothers"])
+            lrs = self.convert_to_lrlist(phase["learning_rate"], phase["steps"])
+            self.individual_lr = phase["individual_lr"]
+            for i in range(phase["steps"]):
+                error = self.single_step(phase["accumulators"], *phase["erf_args"],
+                                         lr_scale=lrs[i], momentum=phase["momentum"],
+                                         verbose=False, **phase["erf_kwargs"])
+                for p, s in zip(self.parameters, phase["smoothers"]):
+                    self.smooth(p, s)
+                phase_iterations += 1
+                if report_frequency != 0 and is_rank0 and self.iterations % report_frequency == 0:
+                    print(f"Phase {current_phase}/{phase_count}, "
+                          f"step {phase_iterations}/{phase['steps']}, "
+                          f"total {self.iterations}/{total_iterations}-"
+                          f"{100 * self.iterations / total_iterations:.1f}%.  Error: {error}.")
+                if post_step:
+                    post_step()
+        total_time = time.time() - start_time
+        if show_time and is_rank0:
+            print(f"Completed training routine.  Took {total_time} seconds.")
+            print(f"Steps took an average of {total_time / max(total_iterations, 1)} seconds per step.")

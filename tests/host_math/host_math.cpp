@@ -4,6 +4,7 @@
 // machine with no GPU.  It is never loaded by the product package.
 #include <stdint.h>
 #include "trace_math.h"
+#include "trace_math2d.h"
 
 extern "C" {
 
@@ -45,6 +46,36 @@ void hm_adjoint3d(int64_t n, const double* s, const double* e, const double* P,
   for (int64_t i = 0; i < n; ++i) {
     tfrt::adjoint3d(s + 3 * i, e + 3 * i, P + 9 * i, ray_u[i], has_child[i] != 0, n_in[i], n_out[i], L,
                     g_s + 3 * i, g_h + 3 * i, g_ce + 3 * i, gs + 3 * i, ge + 3 * i, gP + 9 * i);
+  }
+}
+
+void hm_exact_segment(int64_t n, const double* s, const double* e, const double* seg,
+                      double eps_int, double eps_size, double eps_start, double* ray_u,
+                      double* seg_u, double* xy, uint8_t* valid) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::Hit2 h = tfrt::exact_segment(s + 2 * i, e + 2 * i, seg + 4 * i, eps_int, eps_size, eps_start);
+    ray_u[i] = h.ray_u; seg_u[i] = h.prim_u; xy[2 * i] = h.x; xy[2 * i + 1] = h.y; valid[i] = h.valid;
+  }
+}
+
+void hm_exact_arc(int64_t n, const double* s, const double* e, const double* arc,
+                  double eps_int, double eps_start, double* ray_u, double* arc_u, double* xy,
+                  uint8_t* valid, double* norm) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::Hit2 h = tfrt::exact_arc(s + 2 * i, e + 2 * i, arc + 5 * i, eps_int, eps_start);
+    ray_u[i] = h.ray_u; arc_u[i] = h.prim_u; xy[2 * i] = h.x; xy[2 * i + 1] = h.y; valid[i] = h.valid;
+    norm[i] = tfrt::arc_norm(arc[5 * i + 4], h.prim_u);
+  }
+}
+
+void hm_adjoint2d(int64_t n, const double* s, const double* e, const double* prim, int prim_stride,
+                  int is_arc, const double* u, const uint8_t* has_child, const double* n_in,
+                  const double* n_out, double L, const double* g_s, const double* g_h,
+                  const double* g_ce, double* gs, double* ge, double* gprim) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::adjoint2d(s + 2 * i, e + 2 * i, prim + prim_stride * i, is_arc != 0, u[i], has_child[i] != 0,
+                    n_in[i], n_out[i], L, g_s + 2 * i, g_h + 2 * i, g_ce + 2 * i, gs + 2 * i,
+                    ge + 2 * i, gprim + 5 * i);
   }
 }
 }

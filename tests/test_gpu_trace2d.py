@@ -1,0 +1,226 @@
+"""GPU parity of the 2-D hot path (segments + arcs) against the float64 oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_util
+from oracle import tracer
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+DEV = "cuda:0"
+
+
+def _scene(rng, n_rays, with_seg=True, with_arc=True):
+    """Random mixed scene: refracting arcs, a mirror polyline, a stop and a target wall."""
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sets = {}
+    if with_arc:
+        k = 6
+        xc = np.linspace(-2.5, 2.5, k) + rng.normal(size=k) * 0.1
+        sets["optical_arcs"] = dict(
+            x_center=t(xc), y_center=t(rng.normal(size=k) * 0.2 + 3.0),
+            angle_start=t(np.full(k, -PI + 0.3)), angle_end=t(np.full(k, -0.3)),
+            radius=t(rng.uniform(0.8, 1.4, k) * rng.choice([-1, 1], k)),
+            mat_in=torch.ones(k, dtype=torch.int64), mat_out=torch.zeros(k, dtype=torch.int64))
+        sets["target_arcs"] = dict(
+            x_center=t([0.0]), y_center=t([0.0]), angle_start=t([0.2]), angle_end=t([PI - 0.2]),
+            radius=t([9.0]))
+    if with_seg:
+        xs = np.linspace(-4, 4, 9)
+        ys = 5.0 + 0.3 * np.sin(xs)
+        sets["optical_segments"] = dict(
+            x_start=t(xs[:-1]), y_start=t(ys[:-1]), x_end=t(xs[1:]), y_end=t(ys[1:]),
+            mat_in=torch.full((8,), 2, dtype=torch.int64), mat_out=torch.zeros(8, dtype=torch.int64))
+        sets["stop_segments"] = dict(x_start=t([-6.0]), y_start=t([-1.0]), x_end=t([-6.0]), y_end=t([8.0]))
+        sets["target_segments"] = dict(x_start=t([6.0]), y_start=t([-1.0]), x_end=t([6.0]), y_end=t([8.0]))
+    ang = rng.uniform(0.25 * PI, 0.75 * PI, n_rays)
+    x0 = rng.uniform(-3, 3, n_rays)
+    rays = np.stack([x0, np.zeros(n_rays), x0 + np.cos(ang), np.sin(ang)])
+    wl = rng.uniform(450, 650, n_rays)
+    return sets, rays, wl
+
+
+def _gpu_scene(sets, wl, requires_grad=False):
+    from tensorflowraytrace_amd import ops
+
+    def merge(kind, geo):
+        geos, cats, mi, mo = [], [], [], []
+        for cname, cat in (("optical", 0), ("stop", 1), ("target", 2)):
+            s = sets.get(f"{cname}_{kind}")
+            if not s:
+                continue
+            g = torch.stack([s[f] for f in geo], dim=1)
+            n = g.shape[0]
+            geos.append(g)
+            cats.append(torch.full((n,), cat, dtype=torch.int32))
+            mi.append(s["mat_in"].int() if "mat_in" in s else torch.zeros(n, dtype=torch.int32))
+            mo.append(s["mat_out"].int() if "mat_out" in s else torch.zeros(n, dtype=torch.int32))
+        if not geos:
+            return None
+        g = torch.cat(geos).to(DEV)
+        if requires_grad:
+            g.requires_grad_(True)
+        return dict(geo=g, cat=torch.cat(cats).to(DEV), mat_in=torch.cat(mi).to(DEV),
+                    mat_out=torch.cat(mo).to(DEV), n_in=None, n_out=None)
+
+    seg = merge("segments", ("x_start", "y_start", "x_end", "y_end"))
+    arc = merge("arcs", ("x_center", "y_center", "angle_start", "angle_end", "radius"))
+    w = torch.tensor(wl, dtype=torch.float64)
+    n_table = torch.stack([tracer.MATERIALS["vacuum"](w), tracer.MATERIALS["acrylic"](w),
+                           tracer.MATERIALS["reflective"](w)]).to(DEV)
+    return ops.Scene2DArgs(seg, arc, n_table, True, False), seg, arc
+
+
+def _oracle_system(sets):
+    return tracer.System(2, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"],
+                                       tracer.MATERIALS["reflective"]], **sets)
+
+
+def _src2(rays, wl, f32):
+    r = rays.astype(np.float32).astype(np.float64) if f32 else rays
+    d = {n: torch.tensor(r[i]) for i, n in enumerate(("x_start", "y_start", "x_end", "y_end"))}
+    d["wavelength"] = torch.tensor(wl)
+    d["ray_id"] = torch.arange(rays.shape[1], dtype=torch.float64)
+    return d
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("kinds", ["both", "arc", "seg"])
+def test_forward_2d(dtype, tol, kinds):
+    from tensorflowraytrace_amd import ops, _lib
+    rng = np.random.default_rng(11)
+    sets, rays, wl = _scene(rng, 4000, with_seg=kinds != "arc", with_arc=kinds != "seg")
+    scene, _, _ = _gpu_scene(sets, wl)
+    src = torch.tensor(rays, dtype=dtype, device=DEV)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    out = ops.trace2d(src, scene, max_passes=6, flags=flags)
+    ref = tracer.ray_trace(_oracle_system(sets), _src2(rays, wl, dtype == torch.float32),
+                           max_iterations=6, inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    seen = 0
+    for cls in ("finished", "active", "stopped", "dead"):
+        r = ref[cls]
+        n_ref = r["x_start"].shape[0] if r else 0
+        assert out[cls].shape[1] == n_ref, f"{cls}: {out[cls].shape[1]} vs oracle {n_ref}"
+        if n_ref == 0:
+            continue
+        seen += 1
+        assert np.array_equal(out[cls + "_id"].cpu().numpy(), r["ray_id"].numpy().astype(np.int32)), cls
+        g = out[cls].detach().cpu().double().numpy()
+        rr = oracle_util.block(r, dim=2)
+        err = np.abs(g - rr).max() / max(1.0, np.abs(rr).max())
+        assert err <= tol, f"{cls}: rel err {err:.2e}"
+    assert seen >= 2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-7), (torch.float32, 1e-5)])
+def test_backward_2d(dtype, tol):
+    from tensorflowraytrace_amd import ops
+    rng = np.random.default_rng(5)
+    sets, rays, wl = _scene(rng, 3000)
+    scene, seg, arc = _gpu_scene(sets, wl, requires_grad=True)
+    src = torch.tensor(rays, dtype=dtype, device=DEV)
+    out = ops.trace2d(src, scene, max_passes=4)
+    loss = (out["finished"][2].double() ** 2).sum() + 0.3 * (out["active"][3].double()).sum()
+    g_seg, g_arc = torch.autograd.grad(loss, [seg["geo"], arc["geo"]])
+
+    osets = {k: {f: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v)
+                 for f, v in s.items()} for k, s in sets.items()}
+    ref = tracer.ray_trace(_oracle_system(osets), _src2(rays, wl, dtype == torch.float32),
+                           max_iterations=4, inherit=("wavelength", "ray_id"))
+    rloss = (ref["finished"]["x_end"] ** 2).sum() + 0.3 * ref["active"]["y_end"].sum()
+    leaves = []
+    for kind, geo in (("segments", ("x_start", "y_start", "x_end", "y_end")),
+                      ("arcs", ("x_center", "y_center", "radius"))):
+        for cname in ("optical", "stop", "target"):
+            s = osets.get(f"{cname}_{kind}")
+            if s:
+                leaves += [s[f] for f in geo]
+    grads = torch.autograd.grad(rloss, leaves, allow_unused=True)
+    grads = [torch.zeros_like(l) if g is None else g for g, l in zip(grads, leaves)]
+    # reassemble in merged order (optical, stop, target)
+    it = iter(grads)
+    segs = [torch.stack([next(it) for _ in range(4)], 1) for c in ("optical", "stop", "target")
+            if osets.get(f"{c}_segments")]
+    arcs = [torch.stack([next(it) for _ in range(3)], 1) for c in ("optical", "stop", "target")
+            if osets.get(f"{c}_arcs")]
+    r_seg = torch.cat(segs)
+    r_arc = torch.cat(arcs)
+    assert abs(loss.item() - rloss.item()) <= 10 * tol * abs(rloss.item())
+    rel = (g_seg.cpu() - r_seg).abs().max() / r_seg.abs().max()
+    assert rel <= tol, f"segment gradient rel err {rel:.2e}"
+    ga = g_arc.cpu()[:, [0, 1, 4]]
+    rel = (ga - r_arc).abs().max() / r_arc.abs().max()
+    assert rel <= tol, f"arc gradient rel err {rel:.2e}"
+    assert float(g_arc[:, 2:4].abs().max()) == 0.0
+
+
+def test_seams_2d():
+    from tensorflowraytrace_amd import ops
+    rng = np.random.default_rng(2)
+    sets, rays, wl = _scene(rng, 3000)
+    r = [torch.tensor(rays[i]) for i in range(4)]
+    src = torch.tensor(rays, dtype=torch.float64, device=DEV)
+    s = sets["optical_segments"]
+    seg = torch.stack([s[f] for f in ("x_start", "y_start", "x_end", "y_end")], 1).to(DEV)
+    got = ops.segment_intersection(src, seg)
+    ref = tracer.segment_intersection(*r, s["x_start"], s["y_start"], s["x_end"], s["y_end"],
+                                      1e-10, 1e-10, 1e-10)
+    v = ref[2].numpy()
+    assert np.array_equal(got[2].cpu().numpy(), v)
+    assert np.array_equal(got[5].cpu().numpy()[v], ref[6].numpy()[v])
+    for a, b in ((0, 0), (1, 1), (3, 3), (4, 4)):
+        np.testing.assert_allclose(got[a].cpu().numpy()[v], ref[b].numpy()[v], rtol=1e-13, atol=1e-13)
+    a = sets["optical_arcs"]
+    arc = torch.stack([a[f] for f in ("x_center", "y_center", "angle_start", "angle_end", "radius")], 1).to(DEV)
+    got = ops.arc_intersection(src, arc)
+    ref = tracer.arc_intersection(*r, a["x_center"], a["y_center"], a["angle_start"],
+                                  a["angle_end"], a["radius"], 1e-10, 1e-10, 1e-10)
+    v = ref[2].numpy()
+    assert v.sum() > 100
+    assert np.array_equal(got[2].cpu().numpy(), v)
+    assert np.array_equal(got[5].cpu().numpy()[v], ref[6].numpy()[v])
+    for i in (0, 1, 3, 4):
+        np.testing.assert_allclose(got[i].cpu().numpy()[v], ref[i].numpy()[v], rtol=1e-12, atol=1e-12)
+
+
+def test_config1_single_pass_api():
+    """BASELINE config 1 (dev/single_pass.py): 2-D beam, one acrylic arc, one pass."""
+    import tfrt.boundaries as boundaries
+    import tfrt.distributions as distributions
+    import tfrt.engine as eng
+    import tfrt.materials as materials
+    import tfrt.operation as op
+    import tfrt.sources as sources
+
+    arc = boundaries.ManualArcBoundary()
+    arc["x_center"] = np.array([5.0])
+    arc["y_center"] = np.array([0.0])
+    arc["angle_start"] = np.array([3 * PI / 4])
+    arc["angle_end"] = np.array([5 * PI / 4])
+    arc["radius"] = np.array([5.0])
+    eng.annotation_helper(arc, "mat_in", 1, "x_center", dtype=torch.int64)
+    eng.annotation_helper(arc, "mat_out", 0, "x_center", dtype=torch.int64)
+    beam = distributions.StaticUniformBeam(-1.5, 1.5, 10)
+    angles = distributions.StaticUniformAngularDistribution(0, 0, 1)
+    source = sources.AngularSource(2, (-1.0, 0.0), 0.0, angles, beam, [680.0])
+    system = eng.OpticalSystem2D()
+    system.optical_arcs = [arc]
+    system.sources = [source]
+    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
+    engine = eng.OpticalEngine(2, [op.StandardReaction()], compile_dead_rays=True,
+                               dead_ray_length=10, ray_dtype=torch.float64)
+    engine.optical_system = system
+    system.update()
+    engine.validate_system()
+    new = engine.single_pass(dict(system._amalgamated_sources))
+    res = engine.last_projection_result
+    x_hit = np.sort(res["rays"]["active"]["x_end"].cpu().numpy())
+    want = np.sort(np.array([0.2303, 0.1380, 0.0699, 0.0251, 0.0028] * 2))
+    np.testing.assert_allclose(x_hit, want, atol=5e-5)  # SURVEY.md section 8c known answer
+    ang = torch.atan2(new["y_end"] - new["y_start"], new["x_end"] - new["x_start"]).cpu().numpy()
+    np.testing.assert_allclose(np.sort(np.abs(ang)),
+                               np.sort([0.10188, 0.07819, 0.05531, 0.03297, 0.01096] * 2), atol=2e-5)
