@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the tfrt hot path on MI355X.
+
+Workload (BASELINE.json configs[3], SURVEY.md section 8d "cfg4"): 1,000,000 aperture-source
+rays x a two-surface parametric acrylic lens (front hex mesh H(41) = 10,086 faces, back
+H(9) = 486 faces) + a 2-triangle target = 10,574 merged faces; one step = one
+``SGD_Optimizer.single_step`` with ``trace_depth=3``: constraints + parameters->faces,
+3-pass trace, error function, hand-derived backward, gradient processing and SGD update.
+Synthetic, deterministic inputs (golden-spiral source points).
+
+Metric: ray-surface intersection tests/s (fwd+bwd), tests = sum over passes of
+N_active(pass) x M_merged (counted by the kernels).  With N GPUs the same 1M rays are sharded
+contiguously over the ranks (strong scaling) and the per-step parameter gradients are summed
+with one RCCL all-reduce.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--no-cpu-baseline]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak (6290 measured copy)
+FLOPS_PER_TEST = 45        # SURVEY.md section 8d algorithmic cost model (Moeller-Trumbore)
+BYTES_PER_RAY_FWD = 64     # 32 B read + 32 B written per active ray per pass
+BYTES_PER_FACE = 48
+
+
+def build_scene(n_rays, k_front, k_back, ray_dtype):
+    import tensorflowraytrace_amd as tfa
+    import tfrt.boundaries as boundaries
+    import tfrt.distributions as distributions
+    import tfrt.drawing as drawing
+    import tfrt.engine as engine
+    import tfrt.materials as materials
+    import tfrt.mesh_tools as mt
+    import tfrt.operation as operation
+    import tfrt.sources as sources
+
+    start_points = distributions.StaticUniformCircle(n_rays, 0.2)
+    distributions.BasePointTransformation(start_points, translation=(-10, 0, 0))
+    end_points = distributions.StaticUniformCircle(n_rays, 0.98)
+    distributions.BasePointTransformation(end_points)
+    source = sources.AperatureSource(
+        3, start_points, end_points, [drawing.YELLOW], dense=False,
+        extra_fields={"object_coords": ("start_point", start_points, "points")})
+
+    def surface(k, flip, sign):
+        zp = mt.hexagonal_mesh(1.0, k)
+        zp.rotate_y(90)
+        zp.rotate_x(90)
+        r2 = zp.points[:, 1] ** 2 + zp.points[:, 2] ** 2
+        return boundaries.ParametricTriangleBoundary(
+            zp, boundaries.FromVectorVG((1, 0, 0)), flip_norm=flip,
+            initial_parameters=sign * (0.1 + 0.15 * (1 - r2)),
+            material_dict={"mat_in": 1, "mat_out": 0})
+
+    front = surface(k_front, True, -1.0)
+    back = surface(k_back, False, +1.0)
+    target = boundaries.ManualTriangleBoundary(
+        mesh=mt.plane(center=(10, 0, 0), direction=(1, 0, 0), i_size=100, j_size=100))
+    target.frozen = True
+    system = engine.OpticalSystem3D()
+    system.optical = [front, back]
+    system.targets = [target]
+    system.sources = [source]
+    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
+    system.update()
+    eng = engine.OpticalEngine(
+        3, [operation.StandardReaction()], compile_active_rays=False,
+        simple_ray_inheritance={"wavelength", "object_coords"}, ray_dtype=ray_dtype)
+    eng.optical_system = system
+    eng.validate_system()
+    return eng, system, [front.parameters, back.parameters]
+
+
+def error_function(engine):
+    """Image-forming error of dev/hexalens.py:154-168 (inner goal, magnification 1)."""
+    fin = engine.finished_rays
+    out = torch.stack([fin["y_end"], fin["z_end"]], dim=1).double()
+    goal = -fin["object_coords"][:, 1:]
+    return (out - goal) ** 2
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The reference algorithm restated (oracle: dense (M,N) float64 torch ops, forward +
+    autograd) on the host cores, on a bounded sample of the same scene."""
+    import scene_util
+    import oracle_util
+    from oracle import tracer
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))  # a one-GPU box's CPU share is 16 cores
+    torch.set_num_threads(cores)
+    n = 256
+    scene = scene_util.lens_scene(n, k_front=41, k_back=9)
+    t0 = time.time()
+    tests = 0
+    reps = 0
+    while True:
+        system, (p_f, p_b), _ = oracle_util.lens_oracle(scene)
+        ref = tracer.ray_trace(system, oracle_util.source_dict(scene["rays"], scene["wavelength"]),
+                               max_iterations=3, inherit=("wavelength", "ray_id"), chunk=256)
+        fin = ref["finished"]
+        goal = torch.tensor(scene["goal"], dtype=torch.float64)[fin["ray_id"].long()]
+        err = ((fin["y_end"] - goal[:, 0]) ** 2 + (fin["z_end"] - goal[:, 1]) ** 2).sum()
+        torch.autograd.grad(err, [p_f, p_b])
+        m = system.merged["xp"].shape[0]
+        n_act = n + sum(int(h["x_start"].shape[0]) for h in [ref["active"]] if h)
+        tests += n_act * m
+        reps += 1
+        if time.time() - t0 > seconds_budget:
+            break
+    dt = time.time() - t0
+    return {
+        "value": tests / dt, "unit": "tests/s", "cores": cores, "kind": "port",
+        "sample": f"{reps} x (fwd + autograd) of the oracle (torch-CPU float64, dense (M,N) "
+                  f"temporaries, 256-ray chunks) on {n} rays x 10574 faces, 3 passes; "
+                  f"{dt:.1f} s wall",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=1_000_000, help="global ray count")
+    ap.add_argument("--k-front", type=int, default=41)
+    ap.add_argument("--k-back", type=int, default=9)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the tfrt hot path has no CPU fallback")
+
+    import tensorflowraytrace_amd as tfa
+    from tensorflowraytrace_amd import _lib, distributed as tdist
+    import tfrt.optimizer as optimizer
+
+    rank, world, local = tdist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local if world > 1 else 0)
+    tfa.set_device(f"cuda:{torch.cuda.current_device()}")
+    ray_dtype = torch.float32 if args.dtype == "f32" else torch.float64
+
+    eng, system, params = build_scene(args.rays, args.k_front, args.k_back, ray_dtype)
+    opt = optimizer.SGD_Optimizer(eng, params, error_function, trace_depth=3,
+                                  learning_rate=1e-6, grad_clip=1e-3)
+    opt.suppress_warnings = True
+    M = int(system._merged_face_verts.shape[0])
+    lib = _lib.lib()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        opt.single_step(None)
+    barrier()
+    lib.tfrt_profile_enable(1)
+    tests_local = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        opt.single_step(None)
+        tests_local += eng.last_trace["n_tests"]
+    barrier()
+    dt = time.perf_counter() - t0
+    import ctypes
+    buf = (ctypes.c_float * 4096)()
+    nrec = lib.tfrt_profile_read(buf, 4096)
+    lib.tfrt_profile_enable(0)
+    kernel_ms = [buf[i] for i in range(max(nrec, 0))]
+
+    stats = torch.tensor([dt, float(tests_local)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = stats[:1].clone()
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        tsum = stats[1:].clone()
+        torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+        dt, tests_total = float(tmax.item()), float(tsum.item())
+    else:
+        tests_total = float(tests_local)
+
+    if rank != 0:
+        return
+
+    counts = eng.last_trace["counts"]
+    n_active = [int(c[:4].sum()) for c in counts]          # rays entering each pass (rank 0)
+    launches = len(kernel_ms)
+    avg_ms = float(np.mean(kernel_ms)) if launches else float("nan")
+    tests_per_launch = float(np.mean([n * M for n in n_active])) if n_active else 0.0
+    alg_flops = tests_per_launch * FLOPS_PER_TEST
+    alg_bytes = float(np.mean(n_active)) * BYTES_PER_RAY_FWD + M * BYTES_PER_FACE
+    achieved_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if launches else float("nan")
+    roofline = {
+        "kernel": "tfrt::k_intersect3d",
+        "bound": "valu",
+        "achieved": achieved_tf, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved_tf / PEAK_VALU_TFLOPS,
+        "avg_launch_ms": avg_ms, "launches_timed": launches,
+        "tests_per_launch": tests_per_launch,
+        "model": "SURVEY.md 8d: 45 flop/test (Moeller-Trumbore); the kernel executes a "
+                 "10-VALU-op sphere filter per test + exact float64 on survivors, so the "
+                 "algorithmic rate can exceed the VALU peak",
+        "executed_valu_ops_per_test": 9.75,
+        "hbm_achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan"),
+        "hbm_frac": (alg_bytes / (avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBPS if launches else float("nan"),
+        "traffic": None,
+    }
+    line = {
+        "metric": "ray-surface intersection tests/sec (fwd+bwd)",
+        "value": tests_total / dt,
+        "unit": "tests/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": args.dtype + " ray state, f32 filter + f64 decisions",
+        "data": "synthetic",
+        "config": {
+            "workload": "cfg4: 1M-ray aperture source x 2-surface parametric hex lens "
+                        "(10086+486 faces) + 2-face target, SGD_Optimizer.single_step, "
+                        "trace_depth 3",
+            "global_rays": args.rays, "faces": M, "trace_depth": 3,
+            "parallelism": f"rays sharded over {args.gpus} GPU(s), 1 RCCL all-reduce/step",
+        },
+        "roofline": roofline,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

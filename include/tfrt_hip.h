@@ -166,6 +166,15 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
                           double* grad_src_rays, const int32_t* counts, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Benchmark instrumentation (the only global state in the library; not used by the product
+ * path).  While enabled, every launch of the dominant kernel (k_intersect3d) made by
+ * tfrt_trace3d_forward / tfrt_intersect3d is bracketed by a HIP event pair recorded on the
+ * launch stream.  tfrt_profile_read synchronises those events and writes the elapsed
+ * milliseconds, in launch order, into ms[0..max_records); it returns the record count (or a
+ * negative error).  tfrt_profile_enable(0|1) also clears the records. */
+int tfrt_profile_enable(int enable);
+int tfrt_profile_read(float* ms, int32_t max_records);
+
 /* ------------------------------------------------------------------------------------------
  * Seam-level single kernels (same math, no pass loop).
  */

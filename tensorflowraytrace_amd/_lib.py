@@ -55,6 +55,8 @@ _P = ctypes.POINTER
 SIGNATURES = {
     "tfrt_version": (c_i32, []),
     "tfrt_strerror": (ctypes.c_char_p, [c_i32]),
+    "tfrt_profile_enable": (c_i32, [c_i32]),
+    "tfrt_profile_read": (c_i32, [c_vp, c_i32]),
     "tfrt_build_faces_forward": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tfrt_build_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "tfrt_trace3d_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),

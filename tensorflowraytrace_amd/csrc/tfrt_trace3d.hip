@@ -24,6 +24,8 @@
 // Backward: k_backward3d walks the tape pass by pass in reverse, recomputes the per-ray
 // forward in float64 and applies the hand-derived adjoint (trace_math.h adjoint3d); face
 // gradients are accumulated with float64 hardware atomics.
+#include <vector>
+
 #include "tfrt_common.h"
 
 namespace tfrt {
@@ -670,12 +672,29 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   return L;
 }
 
+// ---- optional per-launch timing of k_intersect3d (benchmark use only; see tfrt_profile_*)
+struct ProfRec {
+  hipEvent_t a, b;
+  int64_t n_rays_cap;
+  int32_t n_faces;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
 template <typename T>
 static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int64_t stride,
                             const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
                             const double* fverts, const double* c0, int M, double ei, double es,
                             double er, double* part_t, int32_t* part_i, int64_t part_stride) {
   dim3 grid(pl.ray_blocks, pl.chunks);
+  ProfRec rec;
+  if (g_prof_on) {
+    (void)hipEventCreate(&rec.a);
+    (void)hipEventCreate(&rec.b);
+    rec.n_rays_cap = (int64_t)pl.ray_blocks * BLOCK * pl.R;
+    rec.n_faces = M;
+    (void)hipEventRecord(rec.a, st);
+  }
 #define TFRT_LAUNCH_R(RR)                                                                    \
   hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                      last_tri, sphere, fverts, c0, M, pl.chunk_faces, ei, es, er, part_t,    \
@@ -684,6 +703,10 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
   else if (pl.R == 2) TFRT_LAUNCH_R(2);
   else TFRT_LAUNCH_R(1);
 #undef TFRT_LAUNCH_R
+  if (g_prof_on) {
+    (void)hipEventRecord(rec.b, st);
+    g_prof.push_back(rec);
+  }
   return 0;
 }
 
@@ -926,6 +949,28 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
   }
 #undef TFRT_SEAM
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_profile_enable(int enable) {
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  g_prof_on = enable != 0;
+  return 0;
+}
+
+int tfrt_profile_read(float* ms, int32_t max_records) {
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (n >= max_records) break;
+    if (hipEventSynchronize(r.b) != hipSuccess) return TFRT_E_LAUNCH;
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    ms[n++] = t;
+  }
+  return n;
 }
 
 }  // extern "C"
