@@ -46,3 +46,14 @@ def host_math():
             "g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
             "-I", os.path.dirname(hdr), src, "-o", out])
     return ctypes.CDLL(out)
+
+
+@pytest.fixture
+def cpu_backend(monkeypatch):
+    """Oracle-backed stand-ins for ops.build_faces / ops.trace3d (tests/cpu_backend.py) so host
+    logic can run without a GPU.  Test infrastructure only."""
+    import cpu_backend as cb
+    cb.install(monkeypatch)
+    yield cb
+    import tensorflowraytrace_amd.config as config
+    config._device = None

@@ -1,0 +1,255 @@
+"""
+Host-side logic of the API mirror (no GPU): update plumbing, constraints, sources and
+distributions, mesh tools, engine field assembly / inheritance, optimizer gradient
+processing.  Where a HIP op would be needed the ``cpu_backend`` fixture swaps in the oracle.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+PI = math.pi
+
+
+def test_update_order_and_frozen():
+    from tensorflowraytrace_amd.update import RecursivelyUpdatable
+    log = []
+
+    class Thing(RecursivelyUpdatable):
+        def _update(self):
+            log.append("self")
+
+        def _generate_update_handles(self):
+            return [lambda: log.append("child")]
+
+    t = Thing()
+    t.post_update_handles.append(lambda: log.append("post"))
+    assert log == ["child", "self"]  # constructor updates once (update.py:50)
+    log.clear()
+    t.update()
+    assert log == ["child", "self", "post"]
+    t.frozen = True
+    log.clear()
+    t.update()
+    assert log == []
+    t.forced_update()
+    assert log == ["child", "self"]  # forced_update skips post handles, like the reference
+    t.frozen = False
+    t.recursively_update = False
+    log.clear()
+    t.update()
+    assert log == ["self", "post"]
+
+
+def test_variable_semantics():
+    from tensorflowraytrace_amd.variable import Variable
+    v = Variable([1.0, 2.0, 3.0], device="cpu")
+    assert v.dtype == torch.float64 and v.requires_grad and v.is_leaf
+    v.assign_add(1.0)
+    v.assign_sub([0.5, 0.5, 0.5])
+    np.testing.assert_allclose(v.numpy(), [1.5, 2.5, 3.5])
+    v.assign([0.0, 1.0, 2.0])
+    (v * v).sum().backward()
+    np.testing.assert_allclose(v.grad.numpy(), [0.0, 2.0, 4.0])
+
+
+def test_hexagonal_mesh_counts_and_orientation():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    for k in (1, 3, 9):
+        m = mt.hexagonal_mesh(1.0, k)
+        assert m.n_points == 3 * k * k + 3 * k + 1 and m.n_faces == 6 * k * k
+        tri = m.points[m.triangles()]
+        area2 = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])[:, 2]
+        assert np.all(area2 > 0)                       # counter-clockwise
+        np.testing.assert_allclose(area2, area2[0])    # equilateral, equal area
+        assert len({tuple(sorted(f)) for f in m.triangles()}) == m.n_faces
+    m = mt.hexagonal_mesh(2.0, 2)
+    np.testing.assert_allclose(m.points[0], 0)          # centre first, then ring by ring
+    np.testing.assert_allclose(np.linalg.norm(m.points[1:7], axis=1), 1.0)
+    np.testing.assert_allclose(m.points[7], [2.0, 0, 0], atol=1e-15)
+    m.rotate_y(90).rotate_x(90)
+    assert np.abs(m.points[:, 0]).max() < 1e-15         # now in the y-z plane
+
+
+def test_stl_round_trip(tmp_path):
+    import tensorflowraytrace_amd.mesh_tools as mt
+    m = mt.hexagonal_mesh(1.0, 2)
+    f = tmp_path / "m.stl"
+    m.save(str(f))
+    r = mt.read(str(f))
+    assert r.n_faces == m.n_faces and r.n_points == m.n_points
+    a = np.sort(m.points[m.triangles()].reshape(m.n_faces, -1), axis=0)
+    b = np.sort(r.points[r.triangles()].reshape(r.n_faces, -1), axis=0)
+    np.testing.assert_allclose(a, b)
+
+
+def test_distributions_and_sources_dense_undense(cpu_backend):
+    import tensorflowraytrace_amd.distributions as distributions
+    import tensorflowraytrace_amd.sources as sources
+    c = distributions.StaticUniformCircle(5, 2.0)
+    idx = np.arange(5) + 0.5
+    np.testing.assert_allclose(c.points[:, 0].numpy(),
+                               2.0 * np.sqrt(idx / 5) * np.cos(PI * (1 + 5 ** 0.5) * idx))
+    beam = distributions.StaticUniformBeam(-1.5, 1.5, 10)
+    np.testing.assert_allclose(beam.points[:, 0].numpy(), 0, atol=1e-15)
+    np.testing.assert_allclose(beam.points[:, 1].numpy(), np.linspace(-1.5, 1.5, 10))
+    angles = distributions.StaticUniformAngularDistribution(-0.1, 0.1, 3)
+    src = sources.AngularSource(2, (-1.0, 0.0), 0.0, angles, beam, [680.0, 450.0])
+    n = 3 * 10 * 2
+    assert all(src[f].shape == (n,) for f in ("x_start", "y_start", "x_end", "y_end", "wavelength"))
+    np.testing.assert_allclose(src["x_start"].numpy(), -1.0)
+    # dense = every combination exactly once
+    combos = {(round(float(a), 6), round(float(b), 6), float(w)) for a, b, w in zip(
+        torch.atan2(src["y_end"] - src["y_start"], src["x_end"] - src["x_start"]), src["y_start"],
+        src["wavelength"])}
+    assert len(combos) == n
+    # undense aperture source with an extra field lifted to 3-D by BasePointTransformation
+    a = distributions.StaticUniformCircle(7, 0.2)
+    distributions.BasePointTransformation(a, translation=(-10, 0, 0))
+    b = distributions.StaticUniformCircle(7, 0.9)
+    distributions.BasePointTransformation(b)
+    ap = sources.AperatureSource(3, a, b, [575.0], dense=False,
+                                 extra_fields={"object_coords": ("start_point", a, "points")})
+    assert ap["x_start"].shape == (7,) and ap["object_coords"].shape == (7, 3)
+    np.testing.assert_allclose(ap["x_start"].numpy(), -10.0)
+    np.testing.assert_allclose(ap["z_end"].numpy(), b.points[:, 2].numpy())
+    with pytest.raises(ValueError):
+        sources.AperatureSource(3, a, distributions.StaticUniformCircle(5, 1.0), [575.0], dense=False)
+
+
+def test_quaternion_helpers():
+    import tensorflowraytrace_amd.distributions as d
+    q = d.get_rotation_quaternion_from_u_to_v((1.0, 0, 0), (0, 1.0, 0))
+    v = d.rotate_vector_by_quaternion(q, torch.tensor([[1.0, 0, 0], [0, 0, 1.0]], dtype=torch.float64))
+    np.testing.assert_allclose(v.numpy(), [[0, 1, 0], [0, 0, 1]], atol=1e-15)
+    q = d.quaternion_from_euler((PI / 2, 0, 0))
+    v = d.rotate_vector_by_quaternion(q, torch.tensor([[0, 1.0, 0]], dtype=torch.float64))
+    np.testing.assert_allclose(v.numpy(), [[0, 0, 1]], atol=1e-15)
+
+
+def _lens_api(n_rays=300, k=2):
+    import tfrt.boundaries as boundaries
+    import tfrt.distributions as distributions
+    import tfrt.engine as engine
+    import tfrt.materials as materials
+    import tfrt.mesh_tools as mt
+    import tfrt.operation as operation
+    import tfrt.sources as sources
+    a = distributions.StaticUniformCircle(n_rays, 0.2)
+    distributions.BasePointTransformation(a, translation=(-10, 0, 0))
+    b = distributions.StaticUniformCircle(n_rays, 0.8)
+    distributions.BasePointTransformation(b)
+    source = sources.AperatureSource(3, a, b, [575.0], dense=False,
+                                     extra_fields={"object_coords": ("start_point", a, "points")})
+    zp = mt.hexagonal_mesh(1.0, k)
+    zp.rotate_y(90)
+    zp.rotate_x(90)
+    r2 = zp.points[:, 1] ** 2 + zp.points[:, 2] ** 2
+    lens = boundaries.ParametricMultiTriangleBoundary(
+        zp, boundaries.FromVectorVG((1, 0, 0)),
+        [boundaries.ThicknessConstraint(0.0, "min"), boundaries.ThicknessConstraint(0.2, "min")],
+        [True, False], initial_parameters=[-0.15 * (1 - r2), 0.15 * (1 - r2)],
+        material_list=[{"mat_in": 1, "mat_out": 0}] * 2)
+    target = boundaries.ManualTriangleBoundary(
+        mesh=mt.plane(center=(10, 0, 0), direction=(1, 0, 0), i_size=100, j_size=100))
+    system = engine.OpticalSystem3D()
+    system.optical = lens.surfaces
+    system.targets = [target]
+    system.sources = [source]
+    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
+    system.update()
+    eng = engine.OpticalEngine(3, [operation.StandardReaction()],
+                               simple_ray_inheritance={"wavelength", "object_coords"},
+                               ray_dtype=torch.float64)
+    eng.optical_system = system
+    eng.validate_system()
+    return eng, system, lens, target
+
+
+def test_boundaries_constraints_and_merge(cpu_backend):
+    eng, system, lens, target = _lens_api()
+    p0, p1 = lens.parameters
+    assert abs(float(p0.min())) < 1e-14                    # ThicknessConstraint(0, 'min') vs zero
+    assert abs(float((p1 - p0).min()) - 0.2) < 1e-14       # 0.2 'min' vs previous surface
+    s0, s1 = lens.surfaces
+    assert float(s0["norm"][:, 0].max()) < 0 < float(s1["norm"][:, 0].min())  # flip_norm
+    assert system._optical_count == 48 and system._target_count == 2
+    m = system._merged
+    assert m["xp"].shape == (50,) and m["norm"].shape == (50, 3)
+    assert m["catagory"].tolist() == [0] * 48 + [2] * 2      # optical, stop, target order
+    assert set(lens.keys()) >= {"xp", "norm", "mat_in"} and lens["xp"].shape == (48,)
+    np.testing.assert_allclose(s0["xp"].detach().numpy(),
+                               s0.face_verts[:, 0].detach().numpy())
+    with pytest.raises(RuntimeError):
+        s0.update_from_mesh()
+
+
+def test_engine_outputs_and_inheritance(cpu_backend):
+    from oracle import tracer
+    eng, system, lens, target = _lens_api()
+    eng.ray_trace(4)
+    fin = eng.finished_rays
+    n = fin["x_start"].shape[0]
+    assert n > 200
+    assert set(fin.keys()) == {"x_start", "y_start", "z_start", "x_end", "y_end", "z_end",
+                               "wavelength", "object_coords"}
+    assert fin["object_coords"].shape == (n, 3)
+    np.testing.assert_allclose(fin["x_end"].detach().numpy(), 10.0, atol=1e-12)
+    # inherited field really belongs to the ray's source ancestor: finished ray starts on the
+    # back surface, which the source ray through object_coords also reaches
+    act = eng.active_rays
+    assert act["x_start"].shape[0] >= 2 * n - 5
+    assert bool(eng.all_rays)
+    eng.clear_ray_history()
+    assert not bool(eng.finished_rays)
+    # single_pass keeps the reference's result structure
+    new = eng.single_pass(dict(system._amalgamated_sources))
+    res = eng.last_projection_result
+    assert "active" in res["rays"] and "optical" in res
+    assert new["x_start"].shape == res["rays"]["active"]["x_end"].shape
+
+
+def test_optimizer_gradient_processing(cpu_backend):
+    import tfrt.optimizer as optimizer
+    eng, system, lens, target = _lens_api(200)
+
+    def erf(engine):
+        fin = engine.finished_rays
+        out = torch.stack([fin["y_end"], fin["z_end"]], 1)
+        return (out + fin["object_coords"][:, 1:]) ** 2
+
+    opt = optimizer.SGD_Optimizer(eng, lens.parameters, erf, 3, learning_rate=2.0,
+                                  individual_lr=[1.0, 0.5], grad_clip=1e-3)
+    raw, err_sum, n_terms = opt.raw_gradient()
+    assert n_terms > 0 and float(err_sum) > 0
+    acc = [torch.eye(raw[0].numel(), dtype=torch.float64) * 2.0, None]
+    proc, mean = opt.process_gradient(acc, lr_scale=0.5)
+    want0 = torch.clamp(raw[0] * (0.5 * 1.0 * 2.0), -1e-3, 1e-3) * 2.0
+    want1 = torch.clamp(raw[1] * (0.5 * 0.5 * 2.0), -1e-3, 1e-3)
+    np.testing.assert_allclose(proc[0].numpy(), want0.numpy(), rtol=1e-12, atol=1e-18)
+    np.testing.assert_allclose(proc[1].numpy(), want1.numpy(), rtol=1e-12, atol=1e-18)
+    assert abs(float(mean) - float(err_sum) / n_terms) < 1e-15
+    before = [p.detach().clone() for p in lens.parameters]
+    e = opt.single_step(None, lr_scale=1.0)
+    assert np.isfinite(e) and opt.iterations == 1
+    delta = lens.parameters[1].detach() - before[1]
+    assert float(delta.abs().max()) <= 0.01 * 1e-3 + 1e-15   # Keras SGD lr 0.01 x clipped grad
+    sm = torch.full((raw[0].numel(), raw[0].numel()), 1.0 / raw[0].numel(), dtype=torch.float64)
+    opt.smooth(lens.parameters[0], sm)
+    assert float(lens.parameters[0].detach().std()) < 1e-15
+    with pytest.raises(ValueError):
+        opt.momentum = 1.5
+    with pytest.raises(ValueError):
+        optimizer.SGD_Optimizer(eng, lens.parameters[0], erf, 3)
+
+
+def test_shard_bounds_cover_exactly():
+    from tensorflowraytrace_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 1000, 1_000_003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
