@@ -79,7 +79,7 @@ def scene2d():
     src["ray_id"] = torch.arange(n, dtype=torch.float64)
     ref = tracer.ray_trace(system, src, max_iterations=5, inherit=("wavelength", "ray_id"),
                            flags=dict(compile_dead_rays=True))
-    loss = (ref["finished"]["y_end"] ** 2).sum()
+    loss = (ref["finished"]["y_end"] ** 2).sum() + 0.3 * ref["active"]["y_end"].sum()
     leaves = [oa["x_center"], oa["y_center"], oa["radius"]] + [os_[k] for k in ("x_start", "y_start", "x_end", "y_end")]
     grads = torch.autograd.grad(loss, leaves)
     out = dict(rays=rays, wavelength=wl, loss=float(loss))

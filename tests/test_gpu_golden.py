@@ -85,7 +85,7 @@ def test_scene2d_golden():
         assert np.array_equal(out[cls + "_id"].cpu().numpy(), g[cls + "_id"])
         if g[cls].size:
             np.testing.assert_allclose(out[cls].detach().cpu().numpy(), g[cls], rtol=0, atol=1e-9)
-    loss = (out["finished"][3] ** 2).sum()
+    loss = (out["finished"][3] ** 2).sum() + 0.3 * out["active"][3].sum()
     gs, ga = torch.autograd.grad(loss, [seg_geo, arc_geo])
     assert abs(loss.item() - float(g["loss"])) < 1e-9 * float(g["loss"])
     np.testing.assert_allclose(gs.cpu().numpy()[:6], g["grad_seg"], rtol=0,
