@@ -30,8 +30,17 @@
 
 namespace tfrt {
 
-constexpr int TILE = 1024;  // spheres per LDS tile (16 KiB)
-constexpr int KC = 24;      // candidate slots per lane (24 KiB per block)
+#ifndef TFRT_TILE
+#define TFRT_TILE 1024
+#endif
+#ifndef TFRT_KC
+#define TFRT_KC 24
+#endif
+#ifndef TFRT_MIN_WAVES
+#define TFRT_MIN_WAVES 1
+#endif
+constexpr int TILE = TFRT_TILE;  // spheres per LDS tile (16 KiB)
+constexpr int KC = TFRT_KC;    // candidate slots per lane (24 KiB per block)
 
 // error bits written to counts[...error]
 constexpr int ERR_CAPACITY = 1;
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
 // ------------------------------------------------------------------------- intersect
 
 template <typename T, int R>
-__global__ __launch_bounds__(BLOCK) void k_intersect3d(
+__global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ sphere,
     const double* __restrict__ fverts, const double* __restrict__ c0, int M, int chunk_faces,
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect3d(
   const int f0 = blockIdx.y * chunk_faces;
   const int f1 = min(M, f0 + chunk_faces);
 
-  __shared__ float4 tile[TILE];
+  __shared__ float4 tile[TILE + 8];
   __shared__ int32_t cand[KC * BLOCK];
 
   // per-ray filter state: unit direction d^ and -moment, both float32, in the c0 frame
@@ -179,6 +188,11 @@ __global__ __launch_bounds__(BLOCK) void k_intersect3d(
   int cnt = 0;
   // exact float64 decision for every queued candidate of this lane
   auto flush = [&]() {
+#ifdef TFRT_ABLATE_FLUSH
+    if (cnt > 1000000) bt[0] = 0.0;  // timing experiment only: drop the float64 stage
+    cnt = 0;
+    return;
+#endif
     for (int k = 0; k < cnt; ++k) {
       const int v = cand[k * BLOCK + tid];
       const int j = v >> 2;
@@ -229,6 +243,44 @@ __global__ __launch_bounds__(BLOCK) void k_intersect3d(
     }
   };
 
+#if defined(TFRT_VARIANT_SGPR)
+  // spheres through the scalar cache: wave-uniform address -> s_load_dwordx4, operands in SGPRs
+  {
+    const int nfull = (f1 - f0) & ~3;
+    int j = f0;
+    for (; j < f0 + nfull; j += 4) {
+      const float4 s0 = sphere[j], s1 = sphere[j + 1], s2 = sphere[j + 2], s3 = sphere[j + 3];
+      test(s0, j);
+      test(s1, j + 1);
+      test(s2, j + 2);
+      test(s3, j + 3);
+      if (__any(cnt > KC - 4 * R)) flush();
+    }
+    for (; j < f1; ++j) {
+      test(sphere[j], j);
+      if (__any(cnt > KC - 4 * R)) flush();
+    }
+  }
+#elif defined(TFRT_VARIANT_PREFETCH)
+  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 is never true
+  for (int t0 = f0; t0 < f1; t0 += TILE) {
+    const int nt = min(TILE, f1 - t0);
+    const int nt4 = (nt + 3) & ~3;
+    __syncthreads();
+    for (int k = tid; k < nt4 + 4; k += BLOCK) tile[k] = (k < nt) ? sphere[t0 + k] : never;
+    __syncthreads();
+    float4 a0 = tile[0], a1 = tile[1], a2 = tile[2], a3 = tile[3];
+    for (int j = 0; j < nt4; j += 4) {
+      const float4 b0 = tile[j + 4], b1 = tile[j + 5], b2 = tile[j + 6], b3 = tile[j + 7];
+      test(a0, t0 + j);
+      test(a1, t0 + j + 1);
+      test(a2, t0 + j + 2);
+      test(a3, t0 + j + 3);
+      a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+      if (__any(cnt > KC - 4 * R)) flush();
+    }
+  }
+#else
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 is never true
   for (int t0 = f0; t0 < f1; t0 += TILE) {
     const int nt = min(TILE, f1 - t0);
@@ -249,6 +301,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect3d(
       if (__any(cnt > KC - 4 * R)) flush();
     }
   }
+#endif
   flush();
 
 #pragma unroll

@@ -374,6 +374,17 @@ class CircleBase(ThetaMod, RecursivelyUpdatable):
 
 class StaticUniformCircle(CircleBase):
     def _update(self):
+        # deterministic: recompute only when a parameter changed (update() is called every
+        # optimiser step by system.update(); the result would be identical)
+        key = (self.sample_count, self.radius, self.theta_start, self.theta_end,
+               str(config.get_device()))
+        if getattr(self, "_memo_key", None) == key:
+            self._points = self._memo_points
+            return
+        self._compute()
+        self._memo_key, self._memo_points = key, self._points
+
+    def _compute(self):
         idx = torch.arange(self.sample_count, dtype=torch.float64, device=config.get_device()) + .5
         self._r = torch.sqrt(idx / self.sample_count)
         self._theta = self._theta_mod(PI * (1 + 5 ** 0.5) * idx)
@@ -449,6 +460,16 @@ class BasePointTransformation:
 
     def _apply_transformation(self):
         pts = self._base._points
+        key = (id(pts), pts._version, id(self._scale), id(self._rotation), id(self._translation))
+        if getattr(self, "_memo_key", None) == key:
+            self._base._points = self._memo_out
+            return
+        self._memo_in = pts  # keep the input alive so id() stays unique
+        out = self._transform(pts)
+        self._memo_key, self._memo_out = key, out
+        self._base._points = out
+
+    def _transform(self, pts):
         if pts.shape[1] == 2:
             pts = torch.cat([torch.zeros_like(pts[:, :1]), pts], dim=1)
         if self._scale is not None:
@@ -457,7 +478,7 @@ class BasePointTransformation:
             pts = rotate_vector_by_quaternion(self._rotation.to(pts.device), pts)
         if self._translation is not None:
             pts = pts + self._translation.to(pts.device)
-        self._base._points = pts
+        return pts
 
     rotation = property(lambda self: self._rotation)
     translation = property(lambda self: self._translation)

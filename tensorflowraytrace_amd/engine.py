@@ -63,10 +63,50 @@ class ReadOnlySet:
         return self._fields.items()
 
 
+class LazyFields:
+    """dict-like ray set whose non-geometric fields (inherited from the source rays by
+    source-ray index) are gathered on first access."""
+
+    def __init__(self, ready, lazy):
+        self._ready = dict(ready)
+        self._lazy = dict(lazy)  # name -> zero-argument callable
+
+    def keys(self):
+        return list(self._ready.keys()) + [k for k in self._lazy if k not in self._ready]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def __contains__(self, key):
+        return key in self._ready or key in self._lazy
+
+    def __bool__(self):
+        return bool(self._ready) or bool(self._lazy)
+
+    def __getitem__(self, key):
+        if key not in self._ready:
+            self._ready[key] = self._lazy[key]()
+        return self._ready[key]
+
+    def __setitem__(self, key, value):
+        self._ready[key] = value
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 def amalgamate(stuff, signature=None):
     """Join a list of field sets into one dict by concatenation (engine.py:50-76)."""
     items = [s for s in stuff if bool(s)]
     if len(items) == 1 and not signature:
+        if isinstance(items[0], LazyFields):
+            return items[0]
         return {f: items[0][f] for f in items[0].keys()}
     return _amalgamate_plain(stuff, signature)
 
@@ -494,6 +534,12 @@ class OpticalEngine:
         # (rank, world_size): trace only this rank's contiguous block of the source rays;
         # "auto" = follow torch.distributed when a process group is up; None = all rays.
         self.ray_shard = ray_shard
+        # When True, ray_trace() does not wait for the per-class ray counts: it cuts the output
+        # sets with the counts of the previous trace of the same shape and leaves the check to
+        # verify_trace() (SGD_Optimizer does this; a wrong guess only costs a re-evaluation of
+        # the error function).  Off by default: ray_trace() then returns exact sets.
+        self.speculative_counts = False
+        self._predicted = None
         self.clear_ray_history()
         self.last_projection_result = {}
         self.last_trace = None
@@ -649,26 +695,36 @@ class OpticalEngine:
             f |= _lib.COMPILE_DEAD
         return f
 
-    def _run(self, rays, max_passes, flags):
+    def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
         system = self.optical_system
         geo = _GEO3 if self.dimension == 3 else _GEO2
         dt = self.ray_dtype or config.get_ray_dtype()
-        block = torch.stack([rays[f] for f in geo]).to(dt)
         index_mode, ghost = self._reaction()
-        n_table = None
+        # the ray block and the n(lambda) table depend only on the input tensors: reuse them
+        # while the caller hands in the very same tensors (static sources between steps)
+        key = tuple((id(rays[f]), rays[f]._version) for f in geo) + (dt,)
         if index_mode:
-            n_table = system.material_table(rays["wavelength"].detach())
+            wl = rays["wavelength"]
+            key += (id(wl), wl._version, tuple(id(m) for m in system.materials))
+        cache = getattr(self, "_input_cache", None)
+        if (cache is not None and cache[0] == key
+                and not any(rays[f].requires_grad for f in geo)):
+            block, n_table = cache[1], cache[2]
+        else:
+            block = torch.stack([rays[f] for f in geo]).to(dt)
+            n_table = system.material_table(rays["wavelength"].detach()) if index_mode else None
+            self._input_cache = (key, block, n_table, [rays[f] for f in geo])
         scene = system.scene_args(n_table, index_mode, ghost)
         if self.dimension == 3:
             fv = system._merged_face_verts
             if fv is None:
                 fv = torch.zeros((0, 9), dtype=torch.float64, device=block.device)
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
-                              self.dead_ray_length, flags)
+                              self.dead_ray_length, flags, predicted_counts=predicted)
         else:
             out = ops.trace2d(block, scene, max_passes, self.new_ray_length,
-                              self.dead_ray_length, flags)
+                              self.dead_ray_length, flags, predicted_counts=predicted)
         return out
 
     def _fields_from(self, out, cls, src, only_first_pass):
@@ -681,9 +737,7 @@ class OpticalEngine:
         carry = set(src.keys()) - set(geo)
         if not only_first_pass:
             carry &= self.simple_ray_inheritance
-        for f in carry:
-            fields[f] = src[f][ids]
-        return fields
+        return LazyFields(fields, {f: (lambda f=f: src[f][ids]) for f in carry})
 
     def ray_trace(self, max_iterations=25):
         """Trace the optical system (engine.py:2311-2330): all passes in one fused launch
@@ -701,7 +755,35 @@ class OpticalEngine:
             n = src["x_start"].shape[0]
             lo, hi = tdist.shard_bounds(n, *shard)
             src = {f: v[lo:hi] for f, v in src.items()}
-        out = self._run(src, int(max_iterations), self._flags())
+        predicted = None
+        sig = (src["x_start"].shape[0], int(max_iterations), self._flags())
+        if self.speculative_counts and self._predicted is not None and self._predicted[0] == sig:
+            predicted = self._predicted[1]
+        out = self._run(src, int(max_iterations), self._flags(), predicted)
+        self._trace_sig, self._trace_src = sig, src
+        self._publish(out)
+        if "pending" not in out:
+            self._predicted = (sig, out["raw_counts"])
+
+    def verify_trace(self):
+        """Resolve a speculative ray_trace(): returns True if the predicted counts were right;
+        otherwise the ray sets have been rebuilt with the true counts (and the caller must
+        re-evaluate whatever it derived from them)."""
+        out = self.last_trace
+        if out is None or "pending" not in out:
+            return True
+        ok, actual, fixed = out["pending"].resolve()
+        self._predicted = (self._trace_sig, actual)
+        if ok:
+            out.pop("pending")
+            return True
+        self.clear_ray_history()
+        fixed["raw_counts"] = actual
+        self._publish(fixed)
+        return False
+
+    def _publish(self, out):
+        src = self._trace_src
         self.last_trace = out
         counts = out["counts"]
         for k, cls in enumerate(_CLASSES):

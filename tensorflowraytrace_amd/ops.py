@@ -159,20 +159,22 @@ class _Trace3D(torch.autograd.Function):
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
         counts = torch.zeros(_lib.COUNTS_PER_PASS * (P + 1), dtype=torch.int32, device=dev)
 
+        new = torch.zeros if opts.get("zero_init") else torch.empty
+
         def alloc(flag, cap):
             if not (flags & flag):
                 return None, None, None
-            return (torch.empty((6, cap), dtype=src.dtype, device=dev),
-                    torch.empty(cap, dtype=torch.int32, device=dev),
-                    torch.empty(cap, dtype=torch.int32, device=dev))
+            return (new((6, cap), dtype=src.dtype, device=dev),
+                    new(cap, dtype=torch.int32, device=dev),
+                    new(cap, dtype=torch.int32, device=dev))
 
         capN = max(N, 1)
         fin = alloc(_lib.COMPILE_FINISHED, capN)
         act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
         stp = alloc(_lib.COMPILE_STOPPED, capN)
         dead = alloc(_lib.COMPILE_DEAD, capN)
-        unf = torch.empty((6, capN), dtype=src.dtype, device=dev)
-        unf_id = torch.empty(capN, dtype=torch.int32, device=dev)
+        unf = new((6, capN), dtype=src.dtype, device=dev)
+        unf_id = new(capN, dtype=torch.int32, device=dev)
         sc = scene.struct(face_verts)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace3d_forward(
@@ -223,34 +225,21 @@ class _Trace3D(torch.autograd.Function):
         return g_src, g_fv, None, None
 
 
-def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
-            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED):
-    """Run the whole 3-D trace.  ``src`` is a (6,N) ray block (f32 or f64) on the GPU.
-
-    Returns a dict: for each class c in finished/active/stopped/dead (when compiled) the ray
-    block ``c`` (6, n_c) (differentiable w.r.t. ``face_verts`` and ``src``), ``c_id`` (source
-    ray index per row) and ``c_face`` (merged face hit); ``unfinished``/``unfinished_id``;
-    ``counts`` (host numpy, per pass) and ``n_tests``.  One host sync (to read the counts).
-    """
-    opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
-                dead_ray_length=dead_ray_length, flags=flags)
-    fin, act, stp, dead = _Trace3D.apply(src, face_verts, scene, opts)
-    aux = opts.pop("_aux")
-    counts = aux["counts"].cpu().numpy()  # the one sync of the trace
-    P = int(max_passes)
+def _slice_outputs(full, aux, counts, P, ncols_prefix=None):
+    """Cut the full-capacity class outputs down to the per-class totals in ``counts``."""
     tail = counts[P * 8:]
     if tail[6] != 0:
-        raise TfrtError("tfrt_trace3d_forward: output capacity exceeded (internal error)")
+        raise TfrtError("trace forward: output capacity exceeded (internal error)")
     out = {
         "counts": counts[:P * 8].reshape(P, 8).copy(),
         "n_tests": int(np.uint32(tail[4])) | (int(np.uint32(tail[5])) << 32),
     }
     totals = {"active": int(tail[0]), "finished": int(tail[1]), "stopped": int(tail[2]),
               "dead": int(tail[3])}
-    for name, rays in (("finished", fin), ("active", act), ("stopped", stp), ("dead", dead)):
+    for name, rays in full.items():
         if aux[name + "_id"] is None:
             continue
-        n = totals[name]
+        n = min(totals[name], rays.shape[1])
         out[name] = rays[:, :n]
         out[name + "_id"] = aux[name + "_id"][:n]
         out[name + "_face"] = aux[name + "_face"][:n]
@@ -258,6 +247,61 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     out["unfinished"] = aux["unfinished"][:, :n_unf]
     out["unfinished_id"] = aux["unfinished_id"][:n_unf]
     return out
+
+
+class PendingCounts:
+    """Counts of a trace whose device->host copy is still in flight (speculative slicing)."""
+
+    def __init__(self, host, event, full, aux, P, predicted):
+        self.host, self.event, self.full, self.aux, self.P = host, event, full, aux, P
+        self.predicted = predicted
+
+    def resolve(self):
+        """Wait for the copy.  Returns (prediction_was_right, outputs sliced by the true counts)."""
+        self.event.synchronize()
+        actual = self.host.numpy().copy()
+        ok = self.predicted is not None and np.array_equal(actual, self.predicted)
+        return ok, actual, _slice_outputs(self.full, self.aux, actual, self.P)
+
+
+def _finish_trace(full, aux, P, predicted_counts):
+    """Bring the per-class counts to the host.  Without a prediction this is the trace's one
+    host sync; with a prediction (the previous step's counts) the copy is left in flight, the
+    outputs are cut with the predicted sizes and ``out["pending"].resolve()`` verifies later."""
+    dev_counts = aux["counts"]
+    host = torch.empty(dev_counts.shape, dtype=dev_counts.dtype, pin_memory=True)
+    host.copy_(dev_counts, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev_counts.device))
+    pending = PendingCounts(host, ev, full, aux, P, predicted_counts)
+    if predicted_counts is None:
+        _, actual, out = pending.resolve()
+        out["raw_counts"] = actual
+        return out
+    out = _slice_outputs(full, aux, predicted_counts, P)
+    out["raw_counts"] = predicted_counts
+    out["pending"] = pending
+    return out
+
+
+def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
+            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED, predicted_counts=None):
+    """Run the whole 3-D trace.  ``src`` is a (6,N) ray block (f32 or f64) on the GPU.
+
+    Returns a dict: for each class c in finished/active/stopped/dead (when compiled) the ray
+    block ``c`` (6, n_c) (differentiable w.r.t. ``face_verts`` and ``src``), ``c_id`` (source
+    ray index per row) and ``c_face`` (merged face hit); ``unfinished``/``unfinished_id``;
+    ``counts`` (host numpy, per pass) and ``n_tests``.  One host sync (to read the counts),
+    unless ``predicted_counts`` (the ``raw_counts`` of an earlier, identical-shape trace) is
+    given: then nothing blocks and ``out["pending"].resolve()`` checks the prediction.
+    """
+    opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
+                dead_ray_length=dead_ray_length, flags=flags,
+                zero_init=predicted_counts is not None)
+    fin, act, stp, dead = _Trace3D.apply(src, face_verts, scene, opts)
+    aux = opts.pop("_aux")
+    full = {"finished": fin, "active": act, "stopped": stp, "dead": dead}
+    return _finish_trace(full, aux, int(max_passes), predicted_counts)
 
 
 # -------------------------------------------------------------------------------- seams
@@ -395,20 +439,22 @@ class _Trace2D(torch.autograd.Function):
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
         counts = torch.zeros(_lib.COUNTS_PER_PASS * (P + 1), dtype=torch.int32, device=dev)
 
+        new = torch.zeros if opts.get("zero_init") else torch.empty
+
         def alloc(flag, cap):
             if not (flags & flag):
                 return None, None, None
-            return (torch.empty((4, cap), dtype=src.dtype, device=dev),
-                    torch.empty(cap, dtype=torch.int32, device=dev),
-                    torch.empty(cap, dtype=torch.int32, device=dev))
+            return (new((4, cap), dtype=src.dtype, device=dev),
+                    new(cap, dtype=torch.int32, device=dev),
+                    new(cap, dtype=torch.int32, device=dev))
 
         capN = max(N, 1)
         fin = alloc(_lib.COMPILE_FINISHED, capN)
         act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
         stp = alloc(_lib.COMPILE_STOPPED, capN)
         dead = alloc(_lib.COMPILE_DEAD, capN)
-        unf = torch.empty((4, capN), dtype=src.dtype, device=dev)
-        unf_id = torch.empty(capN, dtype=torch.int32, device=dev)
+        unf = new((4, capN), dtype=src.dtype, device=dev)
+        unf_id = new(capN, dtype=torch.int32, device=dev)
         sc = scene.struct(seg_geo, arc_geo)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace2d_forward(
@@ -457,35 +503,19 @@ class _Trace2D(torch.autograd.Function):
 
 
 def trace2d(src, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
-            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED):
+            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED, predicted_counts=None):
     """Whole 2-D trace; same result dict as ``trace3d`` with (4, n) ray blocks.  The ``*_face``
     arrays index the merged segments first and then ``n_segments + merged arc index``."""
     opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
-                dead_ray_length=dead_ray_length, flags=flags)
+                dead_ray_length=dead_ray_length, flags=flags,
+                zero_init=predicted_counts is not None)
     seg_geo = None if scene.segments is None else scene.segments["geo"]
     arc_geo = None if scene.arcs is None else scene.arcs["geo"]
     fin, act, stp, dead = _Trace2D.apply(src, seg_geo, arc_geo, scene, opts)
     aux = opts.pop("_aux")
-    counts = aux["counts"].cpu().numpy()
-    P = int(max_passes)
-    tail = counts[P * 8:]
-    if tail[6] != 0:
-        raise TfrtError("tfrt_trace2d_forward: output capacity exceeded (internal error)")
-    out = {"counts": counts[:P * 8].reshape(P, 8).copy(),
-           "n_tests": int(np.uint32(tail[4])) | (int(np.uint32(tail[5])) << 32),
-           "n_segments": 0 if seg_geo is None else seg_geo.shape[0]}
-    totals = {"active": int(tail[0]), "finished": int(tail[1]), "stopped": int(tail[2]),
-              "dead": int(tail[3])}
-    for name, rays in (("finished", fin), ("active", act), ("stopped", stp), ("dead", dead)):
-        if aux[name + "_id"] is None:
-            continue
-        n = totals[name]
-        out[name] = rays[:, :n]
-        out[name + "_id"] = aux[name + "_id"][:n]
-        out[name + "_face"] = aux[name + "_face"][:n]
-    n_unf = int(out["counts"][P - 1, 0]) if P > 0 else 0
-    out["unfinished"] = aux["unfinished"][:, :n_unf]
-    out["unfinished_id"] = aux["unfinished_id"][:n_unf]
+    full = {"finished": fin, "active": act, "stopped": stp, "dead": dead}
+    out = _finish_trace(full, aux, int(max_passes), predicted_counts)
+    out["n_segments"] = 0 if seg_geo is None else seg_geo.shape[0]
     return out
 
 

@@ -24,7 +24,7 @@ from . import distributed as tdist
 class SGD_Optimizer:
     def __init__(self, engine, parameters, error_function, trace_depth, momentum=0.0,
                  learning_rate=1.0, individual_lr=None, grad_clip="default", clip_mode="common",
-                 clip_scale=10.0, sgd_learning_rate=0.01, apply_momentum=False):
+                 clip_scale=10.0, sgd_learning_rate=0.01, apply_momentum=False, speculative=True):
         self.engine = engine
         if type(parameters) is list or type(parameters) is tuple:
             self.parameters = parameters
@@ -34,6 +34,12 @@ class SGD_Optimizer:
         self.trace_depth = trace_depth
         self.sgd_learning_rate = sgd_learning_rate
         self.apply_momentum = apply_momentum
+        # overlap host and device: do not block on the per-class ray counts of the trace, guess
+        # them from the previous step and verify after the gradient has been enqueued
+        self.speculative = speculative
+        self.speculation_misses = 0
+        self._miss_rate = 0.0
+        self._last_counts = None
         self._velocity = [None] * len(self.parameters)
         self.momentum = momentum
         self.learning_rate = learning_rate
@@ -96,14 +102,42 @@ class SGD_Optimizer:
         (grads, error_sum, n_error_terms)."""
         self.engine.clear_ray_history()
         self.engine.optical_system.update()
+        # speculate only while guesses are mostly right (with many rays some ray changes class
+        # almost every step; a blocking count read is then cheaper than re-evaluating)
+        speculate = self.speculative and self._miss_rate < 0.4
+        if hasattr(self.engine, "speculative_counts"):
+            self.engine.speculative_counts = speculate
         self.engine.ray_trace(self.trace_depth)
-        error = self.error_function(self.engine, *args, **kwargs)
-        error_sum = error.sum()
-        n_terms = error.numel()
-        if error_sum.requires_grad:
-            grads = torch.autograd.grad(error_sum, self.parameters, allow_unused=True)
-        else:
-            grads = [None] * len(self.parameters)
+
+        def evaluate(retain=False):
+            error = self.error_function(self.engine, *args, **kwargs)
+            error_sum = error.sum()
+            if error_sum.requires_grad:
+                g = torch.autograd.grad(error_sum, self.parameters, allow_unused=True,
+                                        retain_graph=retain)
+            else:
+                g = [None] * len(self.parameters)
+            return g, error_sum, error.numel()
+
+        spec = speculate and hasattr(self.engine, "verify_trace") and \
+            "pending" in (self.engine.last_trace or {})
+        grads, error_sum, n_terms = evaluate(retain=spec)
+        if spec:
+            ok = self.engine.verify_trace()
+            self._miss_rate = 0.8 * self._miss_rate + (0.0 if ok else 0.2)
+            if not ok:  # ray counts changed since the last step
+                self.speculation_misses += 1
+                grads, error_sum, n_terms = evaluate()
+        elif self.speculative:
+            # not speculating: compare the counts with the previous step's to keep the estimate
+            prev, cur = self._last_counts, (self.engine.last_trace or {}).get("raw_counts")
+            if prev is not None and cur is not None and prev.shape == cur.shape:
+                same = bool((prev == cur).all())
+                self._miss_rate = 0.8 * self._miss_rate + (0.0 if same else 0.2)
+        if self.speculative and self.engine.last_trace is not None:
+            self._last_counts = self.engine.last_trace.get("raw_counts")
+        if hasattr(self.engine, "speculative_counts"):
+            self.engine.speculative_counts = False
         fixed = []
         for g, p in zip(grads, self.parameters):
             if g is None:

@@ -151,8 +151,22 @@ class SourceBase(RecursivelyUpdatable, ABC):
     def _update(self):
         if self._needs_resize or self.always_resize:
             self._resize()
-        self._internal_update(self.make_vars(self._internal_vars()))
+        ivars = self._internal_vars()
+        # memoize: identical input tensors (same objects, same versions) -> identical fields
+        key = tuple((n, d, id(v), getattr(v, "_version", None)) for n, (d, v) in ivars.items())
+        key += tuple((f, id(self._resolve_extra(it)[1])) for f, it in self._extra_fields.items())
+        key += (self.dense, self._dimension_key())
+        if getattr(self, "_memo_key", None) == key:
+            return
+        self._memo_inputs = [v for _, (_, v) in ivars.items()]  # keep ids unique
+        self._internal_update(self.make_vars(ivars))
         self.publish_extra_fields()
+        self._memo_key = key
+
+    def _dimension_key(self):
+        return (getattr(self, "_dimension", None), getattr(self, "ray_length", None),
+                getattr(self, "start_on_center", None), getattr(self, "start_on_base", None),
+                id(getattr(self, "_center", None)), id(getattr(self, "_central_angle", None)))
 
     def snapshot(self, do_update=True):
         if do_update:

@@ -21,7 +21,7 @@ def build_faces(vertices, faces, update_mask=None):
 
 
 def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
-            flags=3):
+            flags=3, predicted_counts=None):
     n = src.shape[1]
     fv = face_verts.double()
     fields = {c: fv[:, i] for i, c in enumerate(_COLS)}
@@ -72,7 +72,7 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
         for k, cls in ((1, "finished"), (2, "stopped"), (3, "dead")):
             if len(history[cls]) > before[cls]:
                 counts[p, k] = history[cls][-1]["x_start"].shape[0]
-    out = {"counts": counts, "n_tests": n_tests}
+    out = {"counts": counts, "n_tests": n_tests, "raw_counts": counts.reshape(-1)}
     for cls, flag in (("finished", 2), ("active", 1), ("stopped", 4), ("dead", 8)):
         if not (flags & flag):
             continue
