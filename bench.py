@@ -221,9 +221,9 @@ def main():
         "avg_launch_ms": avg_ms, "launches_timed": launches,
         "tests_per_launch": tests_per_launch,
         "model": "SURVEY.md 8d: 45 flop/test (Moeller-Trumbore); the kernel executes a "
-                 "10-VALU-op sphere filter per test + exact float64 on survivors, so the "
+                 "8.75-VALU-op line-vs-sphere filter per test + exact float64 on survivors, so the "
                  "algorithmic rate can exceed the VALU peak",
-        "executed_valu_ops_per_test": 9.75,
+        "executed_valu_ops_per_test": 8.75,
         "hbm_achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan"),
         "hbm_frac": (alg_bytes / (avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBPS if launches else float("nan"),
         "traffic": None,

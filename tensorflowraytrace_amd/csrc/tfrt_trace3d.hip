@@ -31,7 +31,7 @@
 namespace tfrt {
 
 #ifndef TFRT_TILE
-#define TFRT_TILE 1024
+#define TFRT_TILE 512
 #endif
 #ifndef TFRT_KC
 #define TFRT_KC 24
@@ -39,7 +39,7 @@ namespace tfrt {
 #ifndef TFRT_MIN_WAVES
 #define TFRT_MIN_WAVES 1
 #endif
-constexpr int TILE = TFRT_TILE;  // spheres per LDS tile (16 KiB)
+constexpr int TILE = TFRT_TILE;  // spheres per LDS tile (8 KiB; measured best on MI355X)
 constexpr int KC = TFRT_KC;    // candidate slots per lane (24 KiB per block)
 
 // error bits written to counts[...error]
@@ -131,15 +131,56 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
   sphere[j] = make_float4((float)cc[0], (float)cc[1], (float)cc[2], rf);
 }
 
+// ---------------------------------------------------------------------- ray filter state
+
+// Per ray and pass, once: the float32 filter state (an orthonormal pair (a, b) spanning the
+// plane perpendicular to the ray and the offsets -s.a, -s.b, in the c0 frame), 8 floats per
+// ray stored SoA.  Computing it here instead of in every (ray block, face chunk) workgroup of
+// k_intersect3d keeps the float64 sqrt/divide work off the hot kernel when faces are chunked.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, int64_t stride,
+                                                   const int32_t* __restrict__ n_ptr,
+                                                   const double* __restrict__ c0,
+                                                   float* __restrict__ prep, int64_t pstride) {
+  const int n = *n_ptr;
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, INFINITY, INFINITY};  // never a candidate
+  double s[3], e[3];
+  load_ray3(rays, stride, i, s, e);
+  const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
+  const double l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  if (l2 > 0.0 && l2 < INFINITY) {
+    const double inv = 1.0 / sqrt(l2);
+    const double u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
+    const double sc[3] = {s[0] - c0[0], s[1] - c0[1], s[2] - c0[2]};
+    // a = normalize(u x e_k) with e_k the axis least aligned with u; b = u x a
+    const double f0 = fabs(u[0]), f1 = fabs(u[1]), f2 = fabs(u[2]);
+    const bool k0 = (f0 <= f1 && f0 <= f2), k1 = !k0 && (f1 <= f2);
+    const double ek[3] = {k0 ? 1.0 : 0.0, k1 ? 1.0 : 0.0, (!k0 && !k1) ? 1.0 : 0.0};
+    double a[3], b[3];
+    cross3(u, ek, a);
+    const double ia = 1.0 / sqrt(dot3(a, a));
+    a[0] *= ia; a[1] *= ia; a[2] *= ia;
+    cross3(u, a, b);
+    o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)a[2];
+    o[3] = (float)b[0]; o[4] = (float)b[1]; o[5] = (float)b[2];
+    o[6] = -(float)dot3(sc, a);
+    o[7] = -(float)dot3(sc, b);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) prep[k * pstride + i] = o[k];
+}
+
 // ------------------------------------------------------------------------- intersect
 
 template <typename T, int R>
 __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ sphere,
-    const double* __restrict__ fverts, const double* __restrict__ c0, int M, int chunk_faces,
-    double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
-    int32_t* __restrict__ part_i, int64_t part_stride) {
+    const double* __restrict__ fverts, const float* __restrict__ prep, int64_t pstride, int M,
+    int chunk_faces, double eps_int, double eps_size, double eps_start,
+    double* __restrict__ part_t, int32_t* __restrict__ part_i, int64_t part_stride) {
   const int n = *n_ptr;
   const int base = blockIdx.x * (BLOCK * R);
   if (base >= n) return;  // block-uniform
@@ -150,37 +191,28 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
   __shared__ float4 tile[TILE + 8];
   __shared__ int32_t cand[KC * BLOCK];
 
-  // per-ray filter state: unit direction d^ and -moment, both float32, in the c0 frame
-  float dx[R], dy[R], dz[R], nmx[R], nmy[R], nmz[R];
+  // per-ray filter state (float32, c0 frame): an orthonormal pair (a, b) spanning the plane
+  // perpendicular to the ray, and the ray's offsets -s.a, -s.b in it.  The squared distance
+  // from a sphere centre c to the ray's line is (c.a - s.a)^2 + (c.b - s.b)^2: 8 VALU ops.
+  float ax[R], ay[R], az[R], bx[R], by[R], bz[R], nsa[R], nsb[R];
   double bt[R];
   int32_t bi[R];
-  {
-    const double o0 = c0[0], o1 = c0[1], o2 = c0[2];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = base + r * BLOCK + tid;
-      bt[r] = INFINITY;
-      bi[r] = -1;
-      dx[r] = dy[r] = dz[r] = 0.f;
-      nmx[r] = nmy[r] = nmz[r] = INFINITY;  // never a candidate
-      if (i < n) {
-        double s[3], e[3];
-        load_ray3(rays, stride, i, s, e);
-        const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
-        const double l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-        if (l2 > 0.0 && l2 < INFINITY) {
-          const double inv = 1.0 / sqrt(l2);
-          const double u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
-          const double sc[3] = {s[0] - o0, s[1] - o1, s[2] - o2};
-          dx[r] = (float)u[0];
-          dy[r] = (float)u[1];
-          dz[r] = (float)u[2];
-          // m = sc x u ; store -m.  w = c x u - m = (c - sc) x u
-          nmx[r] = -(float)(sc[1] * u[2] - sc[2] * u[1]);
-          nmy[r] = -(float)(sc[2] * u[0] - sc[0] * u[2]);
-          nmz[r] = -(float)(sc[0] * u[1] - sc[1] * u[0]);
-        }
-      }
+  for (int r = 0; r < R; ++r) {
+    const int i = base + r * BLOCK + tid;
+    bt[r] = INFINITY;
+    bi[r] = -1;
+    ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
+    nsa[r] = nsb[r] = INFINITY;  // never a candidate
+    if (i < n) {
+      ax[r] = prep[i];
+      ay[r] = prep[pstride + i];
+      az[r] = prep[2 * pstride + i];
+      bx[r] = prep[3 * pstride + i];
+      by[r] = prep[4 * pstride + i];
+      bz[r] = prep[5 * pstride + i];
+      nsa[r] = prep[6 * pstride + i];
+      nsb[r] = prep[7 * pstride + i];
     }
   }
 
@@ -218,16 +250,15 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
     cnt = 0;
   };
 
-  // One sphere against this lane's R rays: 9 FMA-class ops per ray, a min tree and ONE
+  // One sphere against this lane's R rays: 8 FMA-class ops per ray, a min tree and ONE
   // compare; the (rare) survivors are queued for the exact float64 stage.
   auto test = [&](const float4 sp, const int face) {
     float q[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const float wx = fmaf(sp.y, dz[r], fmaf(-sp.z, dy[r], nmx[r]));
-      const float wy = fmaf(sp.z, dx[r], fmaf(-sp.x, dz[r], nmy[r]));
-      const float wz = fmaf(sp.x, dy[r], fmaf(-sp.y, dx[r], nmz[r]));
-      q[r] = fmaf(wx, wx, fmaf(wy, wy, wz * wz));
+      const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+      const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+      q[r] = fmaf(pa, pa, pb * pb);
     }
     float qmin = q[0];
 #pragma unroll
@@ -692,7 +723,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 }
 
 struct Layout3 {
-  size_t c0, sphere, nrays, blockcnt, blockoff, part_t, part_i;
+  size_t c0, sphere, nrays, blockcnt, blockoff, part_t, part_i, prep;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, total;
 };
 
@@ -713,6 +744,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.blockoff = take((size_t)pl.nblk * 4 * sizeof(int32_t));
   L.part_t = take((size_t)pl.chunks * n * sizeof(double));
   L.part_i = take((size_t)pl.chunks * n * sizeof(int32_t));
+  L.prep = take((size_t)8 * n * sizeof(float));
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -737,8 +769,11 @@ static std::vector<ProfRec> g_prof;
 template <typename T>
 static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int64_t stride,
                             const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
-                            const double* fverts, const double* c0, int M, double ei, double es,
-                            double er, double* part_t, int32_t* part_i, int64_t part_stride) {
+                            const double* fverts, const double* c0, float* prep, int64_t pstride,
+                            int M, double ei, double es, double er, double* part_t,
+                            int32_t* part_i, int64_t part_stride) {
+  hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
+                     prep, pstride);
   dim3 grid(pl.ray_blocks, pl.chunks);
   ProfRec rec;
   if (g_prof_on) {
@@ -750,8 +785,8 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
   }
 #define TFRT_LAUNCH_R(RR)                                                                    \
   hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
-                     last_tri, sphere, fverts, c0, M, pl.chunk_faces, ei, es, er, part_t,    \
-                     part_i, part_stride)
+                     last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
+                     part_t, part_i, part_stride)
   if (pl.R == 4) TFRT_LAUNCH_R(4);
   else if (pl.R == 2) TFRT_LAUNCH_R(2);
   else TFRT_LAUNCH_R(1);
@@ -791,6 +826,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* blockoff = reinterpret_cast<int32_t*>(ws + lay.blockoff);
   double* part_t = reinterpret_cast<double*>(ws + lay.part_t);
   int32_t* part_i = reinterpret_cast<int32_t*>(ws + lay.part_i);
+  float* prep = reinterpret_cast<float*>(ws + lay.prep);
   T* rays_ws = reinterpret_cast<T*>(ws + lay.rays);
   int32_t* rayid = reinterpret_cast<int32_t*>(ws + lay.rayid);
   int32_t* lasttri = reinterpret_cast<int32_t*>(ws + lay.lasttri);
@@ -814,8 +850,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     const int32_t* idin = p == 0 ? nullptr : rayid + (size_t)(p - 1) * n;
     const int32_t* ltin = p == 0 ? nullptr : lasttri + (size_t)(p - 1) * n;
     T* rout = rays_ws + (size_t)p * 6 * n;
-    launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, M,
-                        sc->intersect_epsilion, sc->size_epsilion, sc->ray_start_epsilion,
+    launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, prep,
+                        (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion, sc->ray_start_epsilion,
                         part_t, part_i, (int64_t)n);
     hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, pl.chunks,
                        part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
@@ -950,7 +986,7 @@ size_t tfrt_intersect3d_workspace_bytes(int64_t n_rays, int64_t n_faces) {
   const size_t n = n_rays > 0 ? n_rays : 1, m = n_faces > 0 ? n_faces : 1;
   return align_up(4 * sizeof(double)) + align_up(m * sizeof(float4)) + align_up(64) +
          align_up((size_t)pl.chunks * n * sizeof(double)) +
-         align_up((size_t)pl.chunks * n * sizeof(int32_t));
+         align_up((size_t)pl.chunks * n * sizeof(int32_t)) + align_up((size_t)8 * n * sizeof(float));
 }
 
 int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t state_dtype,
@@ -979,6 +1015,8 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
   double* part_t = reinterpret_cast<double*>(ws + o);
   o += align_up((size_t)pl.chunks * n * sizeof(double));
   int32_t* part_i = reinterpret_cast<int32_t*>(ws + o);
+  o += align_up((size_t)pl.chunks * n * sizeof(int32_t));
+  float* prep = reinterpret_cast<float*>(ws + o);
   hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nptr, (int)n_rays, nptr + 8);
   if (M > 0) {
     hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, face_verts, M, c0);
@@ -987,7 +1025,7 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
   }
 #define TFRT_SEAM(TT)                                                                          \
   launch_intersect<TT>(pl, st, static_cast<const TT*>(rays), stride, nptr, nullptr, sphere,    \
-                       face_verts, c0, M, intersect_epsilion, size_epsilion,                   \
+                       face_verts, c0, prep, (int64_t)n, M, intersect_epsilion, size_epsilion, \
                        ray_start_epsilion, part_t, part_i, (int64_t)n);                        \
   hipLaunchKernelGGL((k_finalize_seam<TT>), dim3(pl.nblk), dim3(BLOCK), 0, st,                 \
                      static_cast<const TT*>(rays), stride, (int)n_rays, pl.chunks, part_t,     \
