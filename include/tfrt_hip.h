@@ -16,7 +16,7 @@
  *    synchronises, so a caller may capture a call into a hipGraph
  *  - ray sets are SoA: a "ray block" is 6 rows (3-D: xs,ys,zs,xe,ye,ze) or 4 rows
  *    (2-D: xs,ys,xe,ye) of `stride` elements each; `state_dtype` selects the element type
- *    of ray blocks (TFRT_F32 / TFRT_F64).  Geometry, indices of refraction and gradients
+ *    of ray blocks (TFRT_F32 / TFRT_F64 / TFRT_F16).  Geometry, indices of refraction and gradients
  *    are always float64.
  *  - return value: 0 on success, negative TFRT_E_* otherwise (see tfrt_strerror)
  */
@@ -34,6 +34,7 @@ extern "C" {
 
 #define TFRT_F32 0
 #define TFRT_F64 1
+#define TFRT_F16 2 /* storage-only experiment (BASELINE config 5): half ray state, math stays f32/f64 */
 
 /* boundary catagory, tfrt/engine.py:14-16 */
 #define TFRT_OPTICAL 0

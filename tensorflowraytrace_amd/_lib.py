@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFRT_LIB_PATH") or os.path.join(HERE, "libtfrt_hip.so")
 
-F32, F64 = 0, 1
+F32, F64, F16 = 0, 1, 2
 OPTICAL, STOP, TARGET = 0, 1, 2
 CLS_ACTIVE, CLS_FINISHED, CLS_STOPPED, CLS_DEAD = 0, 1, 2, 3
 COMPILE_ACTIVE, COMPILE_FINISHED, COMPILE_STOPPED, COMPILE_DEAD = 1, 2, 4, 8

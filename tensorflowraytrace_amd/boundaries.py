@@ -805,3 +805,111 @@ class ParametricMultiTriangleBoundary(TriangleBoundaryBase):
     @property
     def parameters(self):
         return [s.parameters for s in self._surfaces]
+
+
+class ParametricCylindricalGuide(TriangleBoundaryBase):
+    """Closed cylinder-like light guide whose radius varies along (and optionally around) its
+    axis (boundaries.py:1416-1717).
+
+    ``parameters`` has ``z_res`` entries (``rotationally_symmetric=True``: one radius offset per
+    ring) or ``z_res * theta_res`` entries (one per wall vertex); before every update the
+    constraint ``p -= min(p)`` pins the thinnest point to ``minimum_radius``
+    (boundaries.py:1613-1617).  Wall vertices move along ``FromAxisVG`` vectors; the optional
+    cap-centre vertices stay on the axis.
+
+    Difference from the reference: at HEAD the class drops the cap vertices from ``_vertices``
+    but keeps face indices that still count them (boundaries.py:1607-1611, 1703-1717), which
+    shifts every face by one vertex; here the vertex array keeps the cap vertices (fixed, zero
+    displacement vector) so faces index what the mesh generator intended.
+    """
+
+    def __init__(self, start, end, minimum_radius, theta_res=6, z_res=8, start_cap=True,
+                 end_cap=True, rotationally_symmetric=False, initial_parameters=0.0,
+                 initial_taper=None, auto_update_mesh=False, use_vertex_update_map=True,
+                 use_twist=False, **kwargs):
+        self._mesh = mt.cylindrical_mesh(start, end, radius=minimum_radius, theta_res=theta_res,
+                                         z_res=z_res, end_cap=end_cap, start_cap=start_cap,
+                                         use_twist=use_twist)
+        self._zero_points_mesh = self._mesh.copy()
+        self._zero_points = config.as_f64(self._mesh.points)
+        self._start_cap, self._end_cap = bool(start_cap), bool(end_cap)
+        self._theta_res, self._z_res = int(theta_res), int(z_res)
+        self._vertex_update_map = None
+        self._init_geometry()
+        self._vertices = self._zero_points
+        self._set_faces(self._mesh.triangles())
+        self._full_update_map, self._accumulator = mt.mesh_parametrization_tools(
+            self._mesh, mt.get_closest_point(self._mesh, start))
+        self.vector_generator = FromAxisVG(start, point=end)
+        self.auto_update_mesh = auto_update_mesh
+        self.reparametrize(self._zero_points)
+        self.use_vertex_update_map = use_vertex_update_map
+        self._rotationally_symmetric = bool(rotationally_symmetric)
+        size = self._z_res if self._rotationally_symmetric else self._z_res * self._theta_res
+        if initial_taper:
+            try:
+                t0, t1 = initial_taper[0], initial_taper[1]
+            except (IndexError, TypeError) as e:
+                raise ValueError(
+                    "ParametricCylindricalGuide: initial_taper must be None or a 2-tuple.") from e
+            init = torch.linspace(float(t0), float(t1), self._z_res, dtype=torch.float64,
+                                  device=config.get_device())
+            if not self._rotationally_symmetric:
+                init = init.repeat_interleave(self._theta_res)
+        else:
+            init = config.as_f64(initial_parameters).expand(size).clone()
+        self.parameters = Variable(init)
+        BoundaryBase.__init__(self, **kwargs)
+        if not self.auto_update_mesh:
+            self.update_mesh_from_vertices()
+
+    def _generate_update_handles(self):
+        return []
+
+    def _constraint(self):
+        with torch.no_grad():
+            self.parameters.sub_(self.parameters.min())
+
+    def _update(self):
+        self._constraint()
+        p = self.parameters
+        if self._rotationally_symmetric:
+            p = p.repeat_interleave(self._theta_res)
+        pads = []
+        if self._start_cap:
+            pads.append(torch.zeros(1, dtype=p.dtype, device=p.device))
+        pads.append(p)
+        if self._end_cap:
+            pads.append(torch.zeros(1, dtype=p.dtype, device=p.device))
+        p = torch.cat(pads) if len(pads) > 1 else p
+        self._vertices = self._zero_points + p.reshape(-1, 1) * self._vectors
+        if self.auto_update_mesh:
+            self.update_mesh_from_vertices()
+        self.update_fields_from_vertices()
+
+    def reparametrize(self, zero_points):
+        v = self.vector_generator.generate(self._zero_points)
+        self._vectors = torch.where(torch.isfinite(v), v, torch.zeros_like(v))  # caps: on axis
+
+    zero_points = property(lambda self: self._zero_points_mesh)
+    vectors = property(lambda self: self._vectors)
+    accumulator = property(lambda self: self._accumulator)
+    rotationally_symmetric = property(lambda self: self._rotationally_symmetric)
+
+    @property
+    def use_vertex_update_map(self):
+        return self._use_vertex_update_map
+
+    @use_vertex_update_map.setter
+    def use_vertex_update_map(self, val):
+        self._use_vertex_update_map = bool(val)
+        self.vertex_update_map = self._full_update_map if val else None
+
+    def update_vertices_from_mesh(self):
+        raise RuntimeError(
+            "ParametricCylindricalGuide: update_vertices_from_mesh is disabled for parametric "
+            "boundaries.")
+
+    def update_from_mesh(self):
+        raise RuntimeError(
+            "ParametricCylindricalGuide: update_from_mesh is disabled for parametric boundaries.")

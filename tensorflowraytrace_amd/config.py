@@ -28,8 +28,8 @@ def get_ray_dtype():
 
 def set_ray_dtype(dtype):
     global _ray_dtype
-    if dtype not in (torch.float32, torch.float64):
-        raise ValueError("ray dtype must be torch.float32 or torch.float64")
+    if dtype not in (torch.float32, torch.float64, torch.float16):
+        raise ValueError("ray dtype must be torch.float32, torch.float64 or torch.float16")
     _ray_dtype = dtype
 
 

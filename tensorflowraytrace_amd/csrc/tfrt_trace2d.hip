@@ -43,7 +43,8 @@ __device__ __forceinline__ int cat_cls(int cat) {
 
 // Nearest segment and nearest arc for ray (s, e); then engine.py:652-657 seg-vs-arc.
 // Returns merged primitive index (segments first) or -1.
-template <bool F32STATE>
+// STATE_ULP: unit roundoff of the ray-state storage type (0 for float64 state)
+template <int STATE_BITS>
 __device__ __forceinline__ int nearest2d(const double s[2], const double e[2],
                                          const double* __restrict__ seg, int Ms,
                                          const double* __restrict__ arc, int Ma, double ei,
@@ -75,12 +76,12 @@ __device__ __forceinline__ int nearest2d(const double s[2], const double e[2],
     if (active) {
       for (int j = 0; j < nt; ++j) {
         double er_j = er;
-        if (F32STATE && Ms + t0 + j == last_prim) {
-          // float32-rounded start sits up to ~1 ulp off the arc it left: do not let the
-          // near root (u ~ 0) count as a new hit
+        if (STATE_BITS < 53 && Ms + t0 + j == last_prim) {
+          // a rounded (float32 / float16) start sits up to ~1 ulp off the arc it left: do not
+          // let the near root (u ~ 0) count as a new hit
           const double dl = sqrt((e[0] - s[0]) * (e[0] - s[0]) + (e[1] - s[1]) * (e[1] - s[1]));
           const double mag = fabs(s[0]) + fabs(s[1]) + fabs(lds[5 * j + 4]);
-          er_j = fmax(er, 64.0 * 5.9604644775390625e-08 * mag / fmax(dl, 1e-300));
+          er_j = fmax(er, 64.0 * ldexp(1.0, -STATE_BITS) * mag / fmax(dl, 1e-300));
         }
         const Hit2 h = exact_arc(s, e, lds + 5 * j, ei, er_j);
         if (h.valid && h.ray_u < au) {
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect2d(
   const int lp = (active && last_prim) ? last_prim[i] : -1;
   const int Ms = (int)sc.n_segments, Ma = (int)sc.n_arcs;
   double u, aux;
-  const int prim = nearest2d<sizeof(T) == 4>(s, e, sc.seg, Ms, sc.arc, Ma, sc.intersect_epsilion,
+  const int prim = nearest2d<(sizeof(T) == 8 ? 53 : (sizeof(T) == 4 ? 24 : 11))>(s, e, sc.seg, Ms, sc.arc, Ma, sc.intersect_epsilion,
                                             sc.size_epsilion, sc.ray_start_epsilion, lp, lds,
                                             active, &u, &aux);
   int bin = -1;
@@ -484,7 +485,7 @@ struct Layout2 {
 
 static Layout2 make_layout2(int64_t N, int P, int dtype) {
   Layout2 L;
-  const size_t esz = dtype == TFRT_F64 ? 8 : 4;
+  const size_t esz = dtype == TFRT_F64 ? 8 : (dtype == TFRT_F16 ? 2 : 4);
   const size_t n = N > 0 ? N : 1;
   L.nblk = cdiv(n, BLOCK);
   size_t o = 0;
@@ -635,6 +636,10 @@ static int seam2d(const void* rays, int64_t stride, int64_t n_rays, int32_t dtyp
     hipLaunchKernelGGL((k_seam2d<double, ARC>), grid, dim3(BLOCK), 0, st,
                        static_cast<const double*>(rays), stride, (int)n_rays, prim, (int)M, ei, es,
                        er, x, y, valid, ray_u, prim_u, gather);
+  } else if (dtype == TFRT_F16) {
+    hipLaunchKernelGGL((k_seam2d<_Float16, ARC>), grid, dim3(BLOCK), 0, st,
+                       static_cast<const _Float16*>(rays), stride, (int)n_rays, prim, (int)M, ei,
+                       es, er, x, y, valid, ray_u, prim_u, gather);
   } else {
     return TFRT_E_UNSUPPORTED;
   }
@@ -695,6 +700,11 @@ int tfrt_trace2d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
                                      dead_ray_length, max_passes, state_dtype, flags, finished,
                                      active, stopped, dead, unfinished, unfinished_id, counts,
                                      workspace, workspace_bytes, st);
+  if (state_dtype == TFRT_F16)
+    return trace2d_forward_t<_Float16>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                     dead_ray_length, max_passes, state_dtype, flags, finished,
+                                     active, stopped, dead, unfinished, unfinished_id, counts,
+                                     workspace, workspace_bytes, st);
   return TFRT_E_UNSUPPORTED;
 }
 
@@ -718,6 +728,12 @@ int tfrt_trace2d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
                                      grad_src_rays, counts, workspace, workspace_bytes, st);
   if (state_dtype == TFRT_F64)
     return trace2d_backward_t<double>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                      dead_ray_length, max_passes, state_dtype, grad_finished,
+                                      cap_finished, grad_active, cap_active, grad_stopped,
+                                      cap_stopped, grad_dead, cap_dead, grad_seg, grad_arc,
+                                      grad_src_rays, counts, workspace, workspace_bytes, st);
+  if (state_dtype == TFRT_F16)
+    return trace2d_backward_t<_Float16>(src_rays, src_stride, n_rays, scene, new_ray_length,
                                       dead_ray_length, max_passes, state_dtype, grad_finished,
                                       cap_finished, grad_active, cap_active, grad_stopped,
                                       cap_stopped, grad_dead, cap_dead, grad_seg, grad_arc,

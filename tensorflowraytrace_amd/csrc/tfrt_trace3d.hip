@@ -729,7 +729,7 @@ struct Layout3 {
 
 static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& pl) {
   Layout3 L;
-  const size_t esz = dtype == TFRT_F64 ? 8 : 4;
+  const size_t esz = dtype == TFRT_F64 ? 8 : (dtype == TFRT_F16 ? 2 : 4);
   const size_t n = N > 0 ? N : 1, m = M > 0 ? M : 1;
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -949,6 +949,11 @@ int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
                                      dead_ray_length, max_passes, state_dtype, flags, finished,
                                      active, stopped, dead, unfinished, unfinished_id, counts,
                                      workspace, workspace_bytes, st);
+  if (state_dtype == TFRT_F16)
+    return trace3d_forward_t<_Float16>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                     dead_ray_length, max_passes, state_dtype, flags, finished,
+                                     active, stopped, dead, unfinished, unfinished_id, counts,
+                                     workspace, workspace_bytes, st);
   return TFRT_E_UNSUPPORTED;
 }
 
@@ -973,6 +978,12 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
                                      grad_src_rays, counts, workspace, workspace_bytes, st);
   if (state_dtype == TFRT_F64)
     return trace3d_backward_t<double>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                      dead_ray_length, max_passes, state_dtype, grad_finished,
+                                      cap_finished, grad_active, cap_active, grad_stopped,
+                                      cap_stopped, grad_dead, cap_dead, grad_face_verts,
+                                      grad_src_rays, counts, workspace, workspace_bytes, st);
+  if (state_dtype == TFRT_F16)
+    return trace3d_backward_t<_Float16>(src_rays, src_stride, n_rays, scene, new_ray_length,
                                       dead_ray_length, max_passes, state_dtype, grad_finished,
                                       cap_finished, grad_active, cap_active, grad_stopped,
                                       cap_stopped, grad_dead, cap_dead, grad_face_verts,
@@ -1035,6 +1046,8 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
     TFRT_SEAM(float);
   } else if (state_dtype == TFRT_F64) {
     TFRT_SEAM(double);
+  } else if (state_dtype == TFRT_F16) {
+    TFRT_SEAM(_Float16);
   } else {
     return TFRT_E_UNSUPPORTED;
   }

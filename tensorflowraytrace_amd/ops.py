@@ -17,7 +17,7 @@ import torch
 from . import _lib
 from ._lib import TfrtError, RayOut, Scene3D, check
 
-_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64, torch.float16: _lib.F16}
 
 
 def _need_gpu(*tensors):
@@ -147,7 +147,7 @@ class _Trace3D(torch.autograd.Function):
         _need_gpu(src, face_verts)
         dev = src.device
         if src.dtype not in _DT:
-            raise TfrtError(f"ray state dtype must be float32 or float64, got {src.dtype}")
+            raise TfrtError(f"ray state dtype must be float32, float64 or float16, got {src.dtype}")
         src = src.contiguous()
         face_verts = _c(face_verts, torch.float64)
         N = src.shape[1]
@@ -424,7 +424,7 @@ class _Trace2D(torch.autograd.Function):
         _need_gpu(src, seg_geo, arc_geo)
         dev = src.device
         if src.dtype not in _DT:
-            raise TfrtError(f"ray state dtype must be float32 or float64, got {src.dtype}")
+            raise TfrtError(f"ray state dtype must be float32, float64 or float16, got {src.dtype}")
         src = src.contiguous()
         seg_geo = _c(seg_geo, torch.float64)
         arc_geo = _c(arc_geo, torch.float64)

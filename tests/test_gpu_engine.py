@@ -166,3 +166,73 @@ def test_single_pass_result_structure():
     # new rays start where the projected active rays end
     np.testing.assert_allclose(new["x_start"].detach().cpu().numpy(),
                                res["rays"]["active"]["x_end"].detach().cpu().numpy(), atol=1e-12)
+
+
+def test_cylindrical_guide_total_internal_reflection():
+    """Light guide (dev/light_guide.py style, 3-D): rays launched inside an acrylic cylinder
+    bounce by TIR off the wall until they reach the end cap; compare with the oracle."""
+    import tfrt.boundaries as boundaries
+    import tfrt.engine as engine
+    import tfrt.materials as materials
+    import tfrt.operation as operation
+    import tfrt.sources as sources
+    import tfrt.mesh_tools as mt
+
+    guide = boundaries.ParametricCylindricalGuide(
+        (0, 0, 0), (0, 0, 6), 0.5, theta_res=16, z_res=7, initial_taper=(0.0, 0.15),
+        material_dict={"mat_in": 1, "mat_out": 0})
+    target = boundaries.ManualTriangleBoundary(
+        mesh=mt.plane(center=(0, 0, 5.9), direction=(0, 0, 1), i_size=3, j_size=3))
+    rng = np.random.default_rng(3)
+    n = 800
+    src = sources.ManualSource(3)
+    ang = rng.uniform(0, 2 * math.pi, n)
+    tilt = rng.uniform(0.05, 0.35, n)
+    r0 = rng.uniform(0, 0.3, (n, 2))
+    src["x_start"], src["y_start"], src["z_start"] = r0[:, 0], r0[:, 1], np.full(n, 0.2)
+    src["x_end"] = r0[:, 0] + np.sin(tilt) * np.cos(ang)
+    src["y_end"] = r0[:, 1] + np.sin(tilt) * np.sin(ang)
+    src["z_end"] = 0.2 + np.cos(tilt)
+    src["wavelength"] = np.full(n, 550.0)
+    system = engine.OpticalSystem3D()
+    system.optical = [guide]
+    system.targets = [target]
+    system.sources = [src]
+    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
+    system.update()
+    eng = engine.OpticalEngine(3, [operation.StandardReaction()], ray_dtype=torch.float64)
+    eng.optical_system = system
+    eng.ray_trace(12)
+    fin = eng.finished_rays
+    assert fin["x_start"].shape[0] > 0.9 * n                      # guided to the end
+    assert eng.last_trace["counts"][:, 1].nonzero()[0].size >= 2  # after different bounce counts
+
+    verts = guide.vertices.detach().cpu()
+    opt = tracer.faces_from_vertices(verts, guide.faces[:, 1:])
+    nf = opt["xp"].shape[0]
+    opt["mat_in"] = torch.ones(nf, dtype=torch.int64)
+    opt["mat_out"] = torch.zeros(nf, dtype=torch.int64)
+    tgt = tracer.faces_from_vertices(target.vertices.detach().cpu(), target.faces[:, 1:])
+    osys = tracer.System(3, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"]],
+                         optical=opt, target=tgt)
+    osrc = {k: v.detach().cpu().double() for k, v in system._amalgamated_sources.items()}
+    ref = tracer.ray_trace(osys, osrc, max_iterations=12)
+    for f in ("x_start", "z_start", "x_end", "y_end", "z_end"):
+        np.testing.assert_allclose(fin[f].detach().cpu().numpy(), ref["finished"][f].numpy(), atol=1e-9)
+
+
+def test_ghost_through_goes_straight():
+    import tfrt.operation as operation
+    eng, system, lens, target, source = _build_lens(500, k=2)
+    import tfrt.engine as engine
+    ghost = engine.OpticalEngine(3, [operation.GhostThrough()], ray_dtype=torch.float64)
+    ghost.optical_system = system
+    ghost.ray_trace(4)
+    fin = ghost.finished_rays
+    src = system._amalgamated_sources
+    # straight lines from the source through the lens to the target plane x = 10
+    d = torch.stack([src[a + "_end"] - src[a + "_start"] for a in "xyz"], 1)
+    t = (10.0 - src["x_start"]) / d[:, 0]
+    want_y = src["y_start"] + t * d[:, 1]
+    ids = ghost.last_trace["finished_id"].long()
+    np.testing.assert_allclose(fin["y_end"].detach().cpu().numpy(), want_y[ids].cpu().numpy(), atol=1e-9)

@@ -253,3 +253,64 @@ def test_shard_bounds_cover_exactly():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_mesh_tools_parametrisation_and_smoothing():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    h = mt.hexagonal_mesh(1.0, 3)
+    top = mt.get_closest_point(h, (0, 0, 0))
+    assert top == 0
+    vmap, acc = mt.mesh_parametrization_tools(h, top)
+    assert vmap.shape == (h.n_faces, 3) and vmap.dtype == bool and vmap.any(axis=1).all()
+    tri = h.triangles()
+    r = np.linalg.norm(h.points, axis=1)
+    # a face never moves its innermost vertex (the sweep front that reached it)
+    for f in range(h.n_faces):
+        inner = tri[f][np.argmin(r[tri[f]])]
+        assert not vmap[f][list(tri[f]).index(inner)] or np.isclose(r[tri[f]], r[inner]).all()
+    n = h.n_points
+    assert acc.shape == (n, n) and np.allclose(np.diag(acc), 1.0)
+    assert acc[0].sum() == 1.0                     # the top parent has no ancestors
+    assert np.all(acc[:, 0] == 1.0)                # and is everybody's ancestor
+    outer = np.argmax(r)
+    assert acc[outer].sum() > 3                    # ancestors chain back to the centre
+    sm = mt.mesh_smoothing_tool(h, [4, 2, 1])
+    assert np.allclose(sm.sum(axis=1), 1.0) and np.isclose(sm[0, 0], 4 / 7)
+    assert np.isclose(sm[0, 1], 2 / 7 / 6)         # six first neighbours share 2/7
+    sub = mt.mesh_smoothing_tool(h, [1, 1], active_vertices=range(7))
+    assert sub.shape == (7, 7)
+    c = mt.circular_mesh(1.0, 0.2)
+    t = c.points[c.triangles()]
+    area = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])[:, 2]
+    assert (area > 0).all() and abs(area.sum() / 2 - math.pi) < 0.05
+    w = mt.circular_mesh(1.0, 0.2, starting_radius=0.5, theta_start=0, theta_end=math.pi / 2)
+    t = w.points[w.triangles()]
+    area = np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0])[:, 2]
+    assert (area > 0).all() and abs(area.sum() / 2 - math.pi / 4 * 0.75) < 0.02
+    cyl = mt.cylindrical_mesh((0, 0, 0), (0, 0, 2), 0.5, theta_res=8, z_res=5)
+    assert cyl.n_points == 8 * 5 + 2 and cyl.n_faces == 8 * 2 + 8 * 2 * 4
+    edges = {}
+    for f in cyl.triangles():
+        for a, b in ((f[0], f[1]), (f[1], f[2]), (f[2], f[0])):
+            edges[(a, b)] = edges.get((a, b), 0) + 1
+    assert all(v == 1 for v in edges.values()) and all((b, a) in edges for a, b in edges)  # closed, oriented
+
+
+def test_cylindrical_guide(cpu_backend):
+    import tensorflowraytrace_amd.boundaries as boundaries
+    g = boundaries.ParametricCylindricalGuide((0, 0, 0), (0, 0, 4), 0.5, theta_res=6, z_res=5,
+                                              initial_taper=(0.0, 0.4),
+                                              material_dict={"mat_in": 1, "mat_out": 0})
+    assert g.parameters.shape == (30,) and abs(float(g.parameters.min())) < 1e-15
+    v = g.vertices.detach().numpy()
+    rad = np.hypot(v[1:-1, 0], v[1:-1, 1]).reshape(5, 6)
+    np.testing.assert_allclose(rad, 0.5 + np.linspace(0, 0.4, 5)[:, None] * np.ones((1, 6)), atol=1e-12)
+    np.testing.assert_allclose(v[0], [0, 0, 0]); np.testing.assert_allclose(v[-1], [0, 0, 4])
+    assert g["xp"].shape == (g.faces.shape[0],) and g["mat_in"].shape == g["xp"].shape
+    assert g.accumulator.shape == (32, 32)
+    sym = boundaries.ParametricCylindricalGuide((0, 0, 0), (0, 0, 4), 0.5, theta_res=6, z_res=5,
+                                                rotationally_symmetric=True, initial_parameters=0.1)
+    assert sym.parameters.shape == (5,)
+    loss = (sym["xp"] ** 2).sum()
+    gp, = torch.autograd.grad(loss, [sym.parameters])
+    assert gp.shape == (5,) and float(gp.abs().sum()) > 0
