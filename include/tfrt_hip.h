@@ -106,6 +106,11 @@ typedef struct tfrt_scene3d {
   /* (M) u8, backward only: 0 = this face's vertices are constants (e.g. a target plane),
    * skip its gradient accumulation; NULL = accumulate for every face. */
   const uint8_t* face_grad_mask;
+  /* (M) i32, optional: a permutation of the face indices that puts spatially close faces next
+   * to each other (e.g. Morton order of the centroids).  When given (and M >= 64) the trace
+   * visits faces in clusters of 16 consecutive entries behind a bounding-sphere test and rays
+   * in a sorted, coherent order; results are identical to the all-pairs path (NULL). */
+  const int32_t* cluster_order;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in

@@ -5,7 +5,8 @@ import torch
 import bench
 import tfrt.optimizer as optimizer
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000
-eng, system, params = bench.build_scene(N, 41, 9, torch.float32)
+ACC = len(sys.argv) > 2 and sys.argv[2] == 'acc'
+eng, system, params = bench.build_scene(N, 41, 9, torch.float32, accelerate=ACC)
 opt = optimizer.SGD_Optimizer(eng, params, bench.error_function, trace_depth=3, learning_rate=1e-6, grad_clip=1e-3)
 opt.suppress_warnings = True
 for _ in range(3): opt.single_step(None)

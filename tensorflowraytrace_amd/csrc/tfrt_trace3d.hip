@@ -65,18 +65,38 @@ __global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fver
       for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x < 3) c0[threadIdx.x] = (M > 0) ? red[threadIdx.x][0] / M : 0.0;
+  __shared__ double ctr[3];
+  if (threadIdx.x < 3) {
+    ctr[threadIdx.x] = (M > 0) ? red[threadIdx.x][0] / M : 0.0;
+    c0[threadIdx.x] = ctr[threadIdx.x];
+  }
+  __syncthreads();
+  // c0[3] = length scale for the ray sort keys of the clustered path: twice the RMS distance
+  // of the faces from c0 (robust against a few huge faces such as a distant target plane;
+  // rays passing farther out simply clamp to the border cell)
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < M; j += 1024) {
+    double d2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const double d = fverts[9 * (int64_t)j + k] - ctr[k];
+      d2 += d * d;
+    }
+    acc += d2;
+  }
+  red[0][threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[0][threadIdx.x] += red[0][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) c0[3] = 2.0 * sqrt(red[0][0] / (M > 0 ? M : 1));
 }
 
-// Smallest enclosing sphere of each triangle, inflated so that the float32 filter is
+// Smallest enclosing sphere of a triangle, inflated so that the float32 filter is
 // conservative: r_eff = r (1 + 1e-5) + 64 u32 (|c| + r) + max(size_eps, 0) (|E1| + |E2|).
-__global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fverts, int M,
-                                                   const double* __restrict__ c0,
-                                                   double size_eps,
-                                                   float4* __restrict__ sphere) {
-  const int j = blockIdx.x * BLOCK + threadIdx.x;
-  if (j >= M) return;
-  const double* P = fverts + 9 * (int64_t)j;
+// cc = centre relative to c0 (float64), reff = inflated radius.
+__device__ __forceinline__ void face_sphere(const double* __restrict__ P, const double* c0,
+                                            double size_eps, double cc[3], double* reff_out) {
   const double A[3] = {P[0], P[1], P[2]}, B[3] = {P[3], P[4], P[5]}, C[3] = {P[6], P[7], P[8]};
   double ab[3], ac[3], bc[3];
   for (int k = 0; k < 3; ++k) {
@@ -120,15 +140,77 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
       r = fmax(r, sqrt(d2));
     }
   }
-  double cc[3] = {c[0] - c0[0], c[1] - c0[1], c[2] - c0[2]};
+  for (int k = 0; k < 3; ++k) cc[k] = c[k] - c0[k];
   const double cn = sqrt(dot3(cc, cc));
   const double u32 = 5.9604644775390625e-08;  // 2^-24
   double reff = r * (1.0 + 1e-5) + 64.0 * u32 * (cn + r);
   if (size_eps > 0.0) reff += size_eps * (sqrt(dot3(ab, ab)) + sqrt(dot3(ac, ac)));
+  *reff_out = reff;
+}
+
+__device__ __forceinline__ float4 pack_sphere(const double cc[3], double reff) {
   float rf = static_cast<float>(reff * reff);
   rf = nextafterf(rf, INFINITY);
   rf = nextafterf(rf, INFINITY);
-  sphere[j] = make_float4((float)cc[0], (float)cc[1], (float)cc[2], rf);
+  return make_float4((float)cc[0], (float)cc[1], (float)cc[2], rf);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fverts, int M,
+                                                   const double* __restrict__ c0,
+                                                   double size_eps,
+                                                   float4* __restrict__ sphere) {
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= M) return;
+  double cc[3], reff;
+  face_sphere(fverts + 9 * (int64_t)j, c0, size_eps, cc, &reff);
+  sphere[j] = pack_sphere(cc, reff);
+}
+
+// Clustered path: faces are visited in `order` (spatially coherent groups of CLUSTER faces).
+// One thread per cluster writes its members' spheres (cluster order, padded with never-hit
+// entries), the member -> face map and the cluster's own bounding sphere.
+constexpr int CLUSTER = 16;
+
+__global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
+    const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
+    const double* __restrict__ c0, double size_eps, int n_clusters,
+    float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= n_clusters) return;
+  double ctr[CLUSTER][3], rad[CLUSTER];
+  double mean[3] = {0, 0, 0};
+  int cnt = 0;
+  for (int g = 0; g < CLUSTER; ++g) {
+    const int k = c * CLUSTER + g;
+    int f = (k < M) ? order[k] : -1;
+    if (f < 0 || f >= M) f = -1;
+    cface[k] = f;
+    if (f >= 0) {
+      face_sphere(fverts + 9 * (int64_t)f, c0, size_eps, ctr[g], &rad[g]);
+      csphere[k] = pack_sphere(ctr[g], rad[g]);
+      for (int q = 0; q < 3; ++q) mean[q] += ctr[g][q];
+      ++cnt;
+    } else {
+      rad[g] = -1.0;
+      csphere[k] = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 never holds
+    }
+  }
+  double R = -1.0;
+  if (cnt > 0) {
+    for (int q = 0; q < 3; ++q) mean[q] /= cnt;
+    R = 0.0;
+    for (int g = 0; g < CLUSTER; ++g) {
+      if (rad[g] < 0.0) continue;
+      double d2 = 0;
+      for (int q = 0; q < 3; ++q) d2 += (ctr[g][q] - mean[q]) * (ctr[g][q] - mean[q]);
+      R = fmax(R, sqrt(d2) + rad[g]);
+    }
+    const double cn = sqrt(dot3(mean, mean));
+    R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
+    clsphere[c] = pack_sphere(mean, R);
+  } else {
+    clsphere[c] = make_float4(0.f, 0.f, 0.f, -1.f);
+  }
 }
 
 // ---------------------------------------------------------------------- ray filter state
@@ -141,10 +223,19 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, int64_t stride,
                                                    const int32_t* __restrict__ n_ptr,
                                                    const double* __restrict__ c0,
-                                                   float* __restrict__ prep, int64_t pstride) {
+                                                   float* __restrict__ prep, int64_t pstride,
+                                                   uint32_t* __restrict__ keys,
+                                                   int32_t* __restrict__ vals, int n_cap) {
   const int n = *n_ptr;
   const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n) {
+    if (keys != nullptr && i < n_cap) {  // unused slots sort to the end
+      keys[i] = 0xFFFFFFFFu;
+      vals[i] = i;
+    }
+    return;
+  }
+  uint32_t key = 0x3FFFFFFFu;
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, INFINITY, INFINITY};  // never a candidate
   double s[3], e[3];
   load_ray3(rays, stride, i, s, e);
@@ -167,9 +258,30 @@ __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, i
     o[3] = (float)b[0]; o[4] = (float)b[1]; o[5] = (float)b[2];
     o[6] = -(float)dot3(sc, a);
     o[7] = -(float)dot3(sc, b);
+    if (keys != nullptr) {
+      // sort key: Morton code of the foot of the perpendicular from the mesh centre to the
+      // ray's line -- rays whose lines pass close to each other near the mesh sort together
+      const double su = dot3(sc, u);
+      const double inv_r = 1.0 / fmax(c0[3], 1e-300);
+      key = 0;
+      for (int k = 0; k < 3; ++k) {
+        double q = ((sc[k] - su * u[k]) * inv_r * 0.5 + 0.5) * 1023.0;
+        q = fmin(fmax(q, 0.0), 1023.0);
+        uint32_t v = (uint32_t)q;
+        v = (v | (v << 16)) & 0x030000FFu;
+        v = (v | (v << 8)) & 0x0300F00Fu;
+        v = (v | (v << 4)) & 0x030C30C3u;
+        v = (v | (v << 2)) & 0x09249249u;
+        key |= v << k;
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) prep[k * pstride + i] = o[k];
+  if (keys != nullptr) {
+    keys[i] = key;
+    vals[i] = i;
+  }
 }
 
 // ------------------------------------------------------------------------- intersect
@@ -341,6 +453,155 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
     if (i < n) {
       part_t[blockIdx.y * part_stride + i] = bt[r];
       part_i[blockIdx.y * part_stride + i] = bi[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ clustered intersect
+
+// Same decisions as k_intersect3d, fewer filter evaluations: rays are visited in the order of
+// `rperm` (sorted by a Morton key of their line, so the R*256 rays of a workgroup form a narrow
+// bundle) and faces in spatial clusters of CLUSTER.  A cluster's bounding sphere is tested
+// first; only when some lane of the wave touches it are its member spheres tested.  Every
+// ray-face pair the all-pairs kernel would hand to the float64 stage still reaches it (both
+// sphere levels are conservative), so results are identical; ties on ray_u are broken by the
+// lower face index explicitly because faces are no longer visited in index order.
+template <typename T, int R>
+__global__ __launch_bounds__(BLOCK) void k_intersect_cull(
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, const int32_t* __restrict__ rperm,
+    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
+    const int32_t* __restrict__ cface, const double* __restrict__ fverts,
+    const float* __restrict__ prep, int64_t pstride, int n_clusters, double eps_int,
+    double eps_size, double eps_start, double* __restrict__ out_t, int32_t* __restrict__ out_i) {
+  const int n = *n_ptr;
+  const int base = blockIdx.x * (BLOCK * R);
+  if (base >= n) return;
+  const int tid = threadIdx.x;
+
+  __shared__ float4 tile[TILE + 8];
+  __shared__ int32_t cand[KC * BLOCK];
+
+  float ax[R], ay[R], az[R], bx[R], by[R], bz[R], nsa[R], nsb[R];
+  double bt[R];
+  int32_t bi[R], slot[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int q = base + r * BLOCK + tid;
+    bt[r] = INFINITY;
+    bi[r] = -1;
+    slot[r] = -1;
+    ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
+    nsa[r] = nsb[r] = INFINITY;
+    if (q < n) {
+      const int i = rperm[q];
+      slot[r] = i;
+      ax[r] = prep[i];
+      ay[r] = prep[pstride + i];
+      az[r] = prep[2 * pstride + i];
+      bx[r] = prep[3 * pstride + i];
+      by[r] = prep[4 * pstride + i];
+      bz[r] = prep[5 * pstride + i];
+      nsa[r] = prep[6 * pstride + i];
+      nsb[r] = prep[7 * pstride + i];
+    }
+  }
+
+  int cnt = 0;
+  auto flush = [&]() {
+    for (int k = 0; k < cnt; ++k) {
+      const int v = cand[k * BLOCK + tid];
+      const int j = cface[v >> 2];
+      const int r = v & 3;
+      int i = -1;
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr)
+        if (rr == r) i = slot[rr];
+      if (j < 0 || i < 0) continue;
+      if (last_tri != nullptr && last_tri[i] == j) continue;
+      double s[3], e[3], P[9];
+      load_ray3(rays, stride, i, s, e);
+      const double* fp = fverts + 9 * (int64_t)j;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) P[q] = fp[q];
+      const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
+      if (h.valid) {
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+          if (rr == r && (h.ray_u < bt[rr] || (h.ray_u == bt[rr] && j < bi[rr]))) {
+            bt[rr] = h.ray_u;
+            bi[rr] = j;
+          }
+        }
+      }
+    }
+    cnt = 0;
+  };
+
+  auto dist2 = [&](const float4 sp, float q[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+      const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+      q[r] = fmaf(pa, pa, pb * pb);
+    }
+    float qmin = q[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) qmin = fminf(qmin, q[r]);
+    return qmin;
+  };
+
+  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
+  for (int t0 = 0; t0 < n_clusters; t0 += TILE) {
+    const int nt = min(TILE, n_clusters - t0);
+    const int nt4 = (nt + 3) & ~3;
+    __syncthreads();
+    for (int k = tid; k < nt4; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
+    __syncthreads();
+    for (int j = 0; j < nt4; j += 4) {
+      float4 cs[4] = {tile[j], tile[j + 1], tile[j + 2], tile[j + 3]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float q[R];
+        const float qmin = dist2(cs[c], q);
+        if (__any(qmin <= cs[c].w)) {  // wave-uniform: some ray of this wave touches the cluster
+          const int k0 = (t0 + j + c) * CLUSTER;
+          // one coalesced load brings the cluster's 16 member spheres into lanes 0..15;
+          // each member is then broadcast to the wave with readlane (SGPR operands)
+          const float4 mine = csphere[k0 + (lane_id() & (CLUSTER - 1))];
+          for (int g = 0; g < CLUSTER; g += 4) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+              float4 sp;
+              sp.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), g + gg));
+              sp.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), g + gg));
+              sp.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), g + gg));
+              sp.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.w), g + gg));
+              float qq[R];
+              const float m = dist2(sp, qq);
+              if (m <= sp.w) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                  if (qq[r] <= sp.w) {
+                    cand[cnt * BLOCK + tid] = ((k0 + g + gg) << 2) | r;
+                    ++cnt;
+                  }
+                }
+              }
+            }
+            if (__any(cnt > KC - 4 * R)) flush();
+          }
+        }
+      }
+    }
+  }
+  flush();
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (slot[r] >= 0) {
+      out_t[slot[r]] = bt[r];
+      out_i[slot[r]] = bi[r];
     }
   }
 }
@@ -567,6 +828,17 @@ __device__ __forceinline__ void add6(const double* g, int64_t cap, int64_t slot,
 }
 
 template <typename T>
+__device__ __forceinline__ int backward_ray(
+    int i, const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ ray_id_in,
+    const int32_t* __restrict__ rec_tri, const double* __restrict__ rec_t,
+    const uint8_t* __restrict__ rec_cls, const int32_t* __restrict__ rec_slot,
+    const int32_t* __restrict__ pass_counts, const tfrt_scene3d& sc, double L, double dead_len,
+    const double* __restrict__ g_child, int64_t child_stride, const double* __restrict__ g_fin,
+    int64_t cap_fin, const double* __restrict__ g_act, int64_t cap_act,
+    const double* __restrict__ g_stp, int64_t cap_stp, const double* __restrict__ g_dead,
+    int64_t cap_dead, double* __restrict__ g_out, int64_t out_stride, double gP[9]);
+
+template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_backward3d(
     const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
@@ -576,10 +848,68 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     int64_t child_stride, const double* __restrict__ g_fin, int64_t cap_fin,
     const double* __restrict__ g_act, int64_t cap_act, const double* __restrict__ g_stp,
     int64_t cap_stp, const double* __restrict__ g_dead, int64_t cap_dead,
-    double* __restrict__ g_out, int64_t out_stride, double* __restrict__ g_fverts) {
+    double* __restrict__ g_out, int64_t out_stride, double* __restrict__ g_fverts,
+    const int32_t* __restrict__ rperm) {
   const int n = *n_ptr;
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const int q0 = blockIdx.x * BLOCK + threadIdx.x;
+  if (rperm != nullptr) {
+    // sorted (coherent) order: neighbouring lanes mostly hit the same few faces, so face
+    // gradients are summed across the wave before touching memory
+    const bool live = q0 < n;
+    const int i = live ? rperm[q0] : 0;
+    double gP[9];
+    int tri = -1;
+    if (live)
+      tri = backward_ray<T>(i, rays_in, stride_in, ray_id_in, rec_tri, rec_t, rec_cls, rec_slot,
+                            pass_counts, sc, L, dead_len, g_child, child_stride, g_fin, cap_fin,
+                            g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead, g_out, out_stride, gP);
+    unsigned long long todo = __ballot(tri >= 0);
+    int guard = 0;
+    while (todo != 0ull && guard++ < 64) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k = __shfl(tri, leader, 64);
+      const bool mine = tri == k;
+      const unsigned long long grp = __ballot(mine);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        double v = (mine && gP[c] == gP[c]) ? gP[c] : 0.0;  // drop NaN like optimizer.py:229
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((int)lane_id() == leader && v != 0.0) unsafeAtomicAdd(g_fverts + 9 * (int64_t)k + c, v);
+      }
+      todo &= ~grp;
+    }
+    return;
+  }
+  const int i = q0;
   if (i >= n) return;
+  double gP[9];
+  const int tri = backward_ray<T>(i, rays_in, stride_in, ray_id_in, rec_tri, rec_t, rec_cls,
+                                  rec_slot, pass_counts, sc, L, dead_len, g_child, child_stride,
+                                  g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead,
+                                  g_out, out_stride, gP);
+  if (tri >= 0) {
+    double* gp = g_fverts + 9 * (int64_t)tri;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      if (gP[c] == gP[c]) unsafeAtomicAdd(gp + c, gP[c]);  // drop NaN like optimizer.py:229
+    }
+  }
+}
+
+// Reverse of one ray slot of one pass.  Writes the gradient w.r.t. the slot's input ray to
+// g_out and returns the face whose gradient gP must be accumulated (-1: none).
+template <typename T>
+__device__ __forceinline__ int backward_ray(
+    int i, const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ ray_id_in,
+    const int32_t* __restrict__ rec_tri, const double* __restrict__ rec_t,
+    const uint8_t* __restrict__ rec_cls, const int32_t* __restrict__ rec_slot,
+    const int32_t* __restrict__ pass_counts, const tfrt_scene3d& sc, double L, double dead_len,
+    const double* __restrict__ g_child, int64_t child_stride, const double* __restrict__ g_fin,
+    int64_t cap_fin, const double* __restrict__ g_act, int64_t cap_act,
+    const double* __restrict__ g_stp, int64_t cap_stp, const double* __restrict__ g_dead,
+    int64_t cap_dead, double* __restrict__ g_out, int64_t out_stride, double gP[9]) {
+  int face_out = -1;
   const int cls = rec_cls[i];
   const int slot = rec_slot[i];
   double s[3], e[3];
@@ -615,25 +945,20 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     if (nz) {
       const int tri = rec_tri[i];
       const int rid = ray_id_in ? ray_id_in[i] : i;
-      double P[9], gP[9], n_in = 1.0, n_out = 1.0;
+      double P[9], n_in = 1.0, n_out = 1.0;
       const double* fp = sc.face_verts + 9 * (int64_t)tri;
 #pragma unroll
       for (int q = 0; q < 9; ++q) P[q] = fp[q];
       if (has_child) face_indices(sc, tri, rid, &n_in, &n_out);
       adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP);
-      if (sc.face_grad_mask == nullptr || sc.face_grad_mask[tri] != 0) {
-        double* gp = g_fverts + 9 * (int64_t)tri;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          if (gP[q] == gP[q]) unsafeAtomicAdd(gp + q, gP[q]);  // drop NaN like optimizer.py:229
-        }
-      }
+      if (sc.face_grad_mask == nullptr || sc.face_grad_mask[tri] != 0) face_out = tri;
     }
   }
   for (int k = 0; k < 3; ++k) {
     g_out[k * out_stride + i] = gs[k];
     g_out[(3 + k) * out_stride + i] = ge[k];
   }
+  return face_out;
 }
 
 // ------------------------------------------------------------------------------ misc
@@ -698,8 +1023,27 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_seam(
 
 // ------------------------------------------------------------------- host-side plan
 
+size_t sort_pairs_temp_bytes(size_t n);
+int sort_pairs_u32_i32(void* tmp, size_t bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                       const int32_t* vals_in, int32_t* vals_out, size_t n, hipStream_t st);
+
 struct Plan3 {
   int R, ray_blocks, chunks, chunk_faces, nblk;
+};
+
+// device buffers of the clustered path for one pass (order == nullptr: all-pairs filter)
+struct Accel3 {
+  const int32_t* order;
+  int n_clusters;
+  float4* csphere;
+  int32_t* cface;
+  float4* clsphere;
+  uint32_t* keys_in;
+  uint32_t* keys_out;
+  int32_t* vals_in;
+  int32_t* rperm;  // sorted slot order of this pass (kept: the reverse sweep reuses it)
+  void* sort_tmp;
+  size_t sort_bytes;
 };
 
 static Plan3 make_plan(int64_t N, int64_t M) {
@@ -724,6 +1068,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, part_t, part_i, prep;
+  size_t csphere, cface, clsphere, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, total;
 };
 
@@ -745,6 +1090,16 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.part_t = take((size_t)pl.chunks * n * sizeof(double));
   L.part_i = take((size_t)pl.chunks * n * sizeof(int32_t));
   L.prep = take((size_t)8 * n * sizeof(float));
+  const size_t ncl = (m + CLUSTER - 1) / CLUSTER;
+  L.csphere = take(ncl * CLUSTER * sizeof(float4));
+  L.cface = take(ncl * CLUSTER * sizeof(int32_t));
+  L.clsphere = take(ncl * sizeof(float4));
+  L.keys_in = take(n * sizeof(uint32_t));
+  L.keys_out = take(n * sizeof(uint32_t));
+  L.vals_in = take(n * sizeof(int32_t));
+  L.rperm = take((size_t)(P > 0 ? P : 1) * n * sizeof(int32_t));
+  L.sort_bytes = sort_pairs_temp_bytes(n);
+  L.sort_tmp = take(L.sort_bytes);
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -771,10 +1126,19 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                             const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
                             const double* fverts, const double* c0, float* prep, int64_t pstride,
                             int M, double ei, double es, double er, double* part_t,
-                            int32_t* part_i, int64_t part_stride) {
+                            int32_t* part_i, int64_t part_stride, const Accel3* ac, int n_cap) {
+  const bool clustered = ac != nullptr && ac->order != nullptr;
   hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
-                     prep, pstride);
-  dim3 grid(pl.ray_blocks, pl.chunks);
+                     prep, pstride, clustered ? ac->keys_in : nullptr,
+                     clustered ? ac->vals_in : nullptr, n_cap);
+  if (clustered) {
+    if (sort_pairs_u32_i32(ac->sort_tmp, ac->sort_bytes, ac->keys_in, ac->keys_out, ac->vals_in,
+                           ac->rperm, (size_t)n_cap, st) != 0)
+      return TFRT_E_LAUNCH;
+  }
+  const int Rc = 1;  // rays per lane in the clustered kernel
+  dim3 grid(clustered ? cdiv(n_cap > 0 ? n_cap : 1, BLOCK * Rc) : pl.ray_blocks,
+            clustered ? 1 : pl.chunks);
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a);
@@ -783,13 +1147,18 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     rec.n_faces = M;
     (void)hipEventRecord(rec.a, st);
   }
-#define TFRT_LAUNCH_R(RR)                                                                    \
-  hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
-                     last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
-                     part_t, part_i, part_stride)
-  if (pl.R == 4) TFRT_LAUNCH_R(4);
-  else if (pl.R == 2) TFRT_LAUNCH_R(2);
-  else TFRT_LAUNCH_R(1);
+#define TFRT_LAUNCH_R(RR)                                                                      \
+  if (clustered)                                                                               \
+    hipLaunchKernelGGL((k_intersect_cull<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,      \
+                       n_ptr, last_tri, ac->rperm, ac->clsphere, ac->csphere, ac->cface,       \
+                       fverts, prep, pstride, ac->n_clusters, ei, es, er, part_t, part_i);     \
+  else                                                                                         \
+    hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
+                       last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
+                       part_t, part_i, part_stride)
+  if (clustered || pl.R == 1) { TFRT_LAUNCH_R(1); }
+  else if (pl.R == 4) { TFRT_LAUNCH_R(4); }
+  else { TFRT_LAUNCH_R(2); }
 #undef TFRT_LAUNCH_R
   if (g_prof_on) {
     (void)hipEventRecord(rec.b, st);
@@ -838,11 +1207,29 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   const size_t n = N > 0 ? N : 1;
 
   hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail);
+  Accel3 ac;
+  ac.order = (M >= 4 * CLUSTER) ? sc->cluster_order : nullptr;
+  ac.n_clusters = cdiv(M > 0 ? M : 1, CLUSTER);
+  ac.csphere = reinterpret_cast<float4*>(ws + lay.csphere);
+  ac.cface = reinterpret_cast<int32_t*>(ws + lay.cface);
+  ac.clsphere = reinterpret_cast<float4*>(ws + lay.clsphere);
+  ac.keys_in = reinterpret_cast<uint32_t*>(ws + lay.keys_in);
+  ac.keys_out = reinterpret_cast<uint32_t*>(ws + lay.keys_out);
+  ac.vals_in = reinterpret_cast<int32_t*>(ws + lay.vals_in);
+  ac.sort_tmp = ws + lay.sort_tmp;
+  ac.sort_bytes = lay.sort_bytes;
+  int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
   if (M > 0) {
     hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0);
-    hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M, c0,
-                       sc->size_epsilion, sphere);
+    if (ac.order != nullptr)
+      hipLaunchKernelGGL(k_cluster_spheres, dim3(cdiv(ac.n_clusters, BLOCK)), dim3(BLOCK), 0, st,
+                         sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
+                         ac.csphere, ac.cface, ac.clsphere);
+    else
+      hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,
+                         c0, sc->size_epsilion, sphere);
   }
+  const int chunks_used = ac.order != nullptr ? 1 : pl.chunks;
   const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};
   for (int p = 0; p < P; ++p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
@@ -850,10 +1237,12 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     const int32_t* idin = p == 0 ? nullptr : rayid + (size_t)(p - 1) * n;
     const int32_t* ltin = p == 0 ? nullptr : lasttri + (size_t)(p - 1) * n;
     T* rout = rays_ws + (size_t)p * 6 * n;
-    launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, prep,
-                        (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion, sc->ray_start_epsilion,
-                        part_t, part_i, (int64_t)n);
-    hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, pl.chunks,
+    ac.rperm = rperm_all + (size_t)p * n;
+    if (launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, prep,
+                            (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion,
+                            sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac, (int)N) != 0)
+      return TFRT_E_LAUNCH;
+    hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, chunks_used,
                        part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
                        rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt);
     hipLaunchKernelGGL(k_scan3d, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt, blockoff,
@@ -896,6 +1285,8 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   const double* rec_t = reinterpret_cast<double*>(ws + lay.rec_t);
   const uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
   double* gbuf = reinterpret_cast<double*>(ws + lay.gbuf);
+  const int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
+  const bool clustered = sc->cluster_order != nullptr && M >= 4 * CLUSTER;
   const size_t n = N > 0 ? N : 1;
   for (int p = P - 1; p >= 0; --p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
@@ -909,7 +1300,8 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                        rec_cls + (size_t)p * n, rec_slot + (size_t)p * n,
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
-                       cap_dead, g_out, out_stride, g_fverts);
+                       cap_dead, g_out, out_stride, g_fverts,
+                       clustered ? rperm_all + (size_t)p * n : nullptr);
   }
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
@@ -1037,7 +1429,7 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
 #define TFRT_SEAM(TT)                                                                          \
   launch_intersect<TT>(pl, st, static_cast<const TT*>(rays), stride, nptr, nullptr, sphere,    \
                        face_verts, c0, prep, (int64_t)n, M, intersect_epsilion, size_epsilion, \
-                       ray_start_epsilion, part_t, part_i, (int64_t)n);                        \
+                       ray_start_epsilion, part_t, part_i, (int64_t)n, nullptr, (int)n_rays);  \
   hipLaunchKernelGGL((k_finalize_seam<TT>), dim3(pl.nblk), dim3(BLOCK), 0, st,                 \
                      static_cast<const TT*>(rays), stride, (int)n_rays, pl.chunks, part_t,     \
                      part_i, (int64_t)n, face_verts, M, intersect_epsilion, size_epsilion,     \

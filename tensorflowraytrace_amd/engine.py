@@ -355,10 +355,19 @@ class OpticalSystem3D(OpticalSystemBase):
                 mat_out=col("mat_out", torch.int32), n_in=col("n_in", torch.float64),
                 n_out=col("n_out", torch.float64), face_grad_mask=gmask))
 
-    def scene_args(self, n_table, index_mode, ghost=False):
+    def scene_args(self, n_table, index_mode, ghost=False, cluster=False):
         s = self._scene_cache[1]
+        order = None
+        if cluster:
+            # spatial face order for the clustered trace; computed once per scene topology
+            # (faces move a little every step, the clusters' bounding spheres are recomputed
+            # from the current vertices inside every trace, so a stale order is still exact)
+            if s.get("cluster_order") is None:
+                s["cluster_order"] = ops.morton_order(self._merged_face_verts)
+            order = s["cluster_order"]
         kw = dict(intersect_epsilion=self.intersect_epsilion, size_epsilion=self.size_epsilion,
-                  ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"])
+                  ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"],
+                  cluster_order=order)
         if ghost:
             ones = torch.ones(s["catagory"].shape[0], dtype=torch.float64, device=s["catagory"].device)
             return ops.Scene3DArgs(self._merged_face_verts, s["catagory"], n_in=ones, n_out=ones, **kw)
@@ -474,7 +483,7 @@ class OpticalSystem2D(OpticalSystemBase):
         self._merged_arcs = self._merge_kind(
             "arcs", ("x_center", "y_center", "angle_start", "angle_end", "radius"))
 
-    def scene_args(self, n_table, index_mode, ghost=False):
+    def scene_args(self, n_table, index_mode, ghost=False, cluster=False):
         return ops.Scene2DArgs(self._merged_segments, self._merged_arcs, n_table, index_mode,
                                ghost, self.intersect_epsilion, self.size_epsilion,
                                self.ray_start_epsilion)
@@ -515,7 +524,7 @@ class OpticalEngine:
                  compile_dead_rays=False, compile_finished_rays=True, compile_active_rays=True,
                  dead_ray_length=None, compile_geometry_specific_result=False,
                  new_ray_length=1.0, simple_ray_inheritance={"wavelength"}, ray_dtype=None,
-                 ray_shard="auto"):
+                 ray_shard="auto", accelerate=False):
         if dimension not in (2, 3):
             raise ValueError(f"RayEngine: dimension must be 2 or 3, but was given {dimension}.")
         self._dimension = dimension
@@ -534,6 +543,10 @@ class OpticalEngine:
         # (rank, world_size): trace only this rank's contiguous block of the source rays;
         # "auto" = follow torch.distributed when a process group is up; None = all rays.
         self.ray_shard = ray_shard
+        # True: 3-D traces sort the rays and visit faces in spatial clusters behind a
+        # bounding-sphere test (identical results, far fewer filter evaluations).  False
+        # (default): every ray-face pair goes through the float32 filter.
+        self.accelerate = accelerate
         # When True, ray_trace() does not wait for the per-class ray counts: it cuts the output
         # sets with the counts of the previous trace of the same shape and leaves the check to
         # verify_trace() (SGD_Optimizer does this; a wrong guess only costs a re-evaluation of
@@ -715,7 +728,7 @@ class OpticalEngine:
             block = torch.stack([rays[f] for f in geo]).to(dt)
             n_table = system.material_table(rays["wavelength"].detach()) if index_mode else None
             self._input_cache = (key, block, n_table, [rays[f] for f in geo])
-        scene = system.scene_args(n_table, index_mode, ghost)
+        scene = system.scene_args(n_table, index_mode, ghost, cluster=bool(self.accelerate))
         if self.dimension == 3:
             fv = system._merged_face_verts
             if fv is None:

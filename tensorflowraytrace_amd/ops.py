@@ -95,7 +95,7 @@ class Scene3DArgs:
 
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
-                 ray_start_epsilion=1e-10, face_grad_mask=None):
+                 ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -104,6 +104,7 @@ class Scene3DArgs:
         self.n_out = _c(n_out, torch.float64)
         self.n_table = _c(n_table, torch.float64)  # (n_materials, N)
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
+        self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: clustered path
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -124,6 +125,10 @@ class Scene3DArgs:
         sc.intersect_epsilion, sc.size_epsilion, sc.ray_start_epsilion = self.eps
         g = self.face_grad_mask
         sc.face_grad_mask = g.data_ptr() if (g is not None and M) else None
+        co = self.cluster_order
+        if co is not None and co.numel() != M:
+            raise TfrtError("cluster_order must be a permutation of the M face indices")
+        sc.cluster_order = co.data_ptr() if (co is not None and M) else None
         return sc
 
 
@@ -327,6 +332,25 @@ def intersect3d(rays, face_verts, intersect_epsilion=1e-10, size_epsilion=1e-10,
         _p(x), _p(y), _p(z), _p(valid), _p(ray_u), _p(trig_u), _p(trig_v), _p(gather),
         _p(ws), wsb, _stream(rays)), "tfrt_intersect3d")
     return x, y, z, valid.bool(), ray_u, trig_u, trig_v, gather
+
+
+def morton_order(face_verts):
+    """Permutation of the faces by the Morton code of their centroids (30-bit, 10 bits per
+    axis): spatially close faces become neighbours.  Pass it as ``cluster_order``."""
+    fv = face_verts.detach()
+    c = (fv[:, 0:3] + fv[:, 3:6] + fv[:, 6:9]) / 3.0
+    lo, hi = c.min(dim=0).values, c.max(dim=0).values
+    q = ((c - lo) / torch.clamp(hi - lo, min=1e-300) * 1023.0).clamp(0, 1023).to(torch.int64)
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    return torch.argsort(key, stable=True).to(torch.int32)
 
 
 def snell3d(x_start, y_start, z_start, x_end, y_end, z_end, norm, n_in, n_out, new_ray_length):

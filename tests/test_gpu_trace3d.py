@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 NAMES = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
 
 
-def _gpu_scene(scene, dtype, p_f=None, p_b=None, masks=(None, None)):
+def _gpu_scene(scene, dtype, p_f=None, p_b=None, masks=(None, None), cluster=False):
     from tensorflowraytrace_amd import ops
     dev = torch.device("cuda:0")
     tt = lambda a, dt=torch.float64: torch.tensor(np.asarray(a), dtype=dt, device=dev)
@@ -39,7 +39,8 @@ def _gpu_scene(scene, dtype, p_f=None, p_b=None, masks=(None, None)):
     n_table = torch.stack([tracer.MATERIALS["vacuum"](wl), tracer.MATERIALS["acrylic"](wl)]).to(dev)
     gmask = (cat == 0).to(torch.uint8)  # the target plane is a constant
     sc = ops.Scene3DArgs(fv, cat, mat_in=mat_in, mat_out=mat_out, n_table=n_table,
-                         face_grad_mask=gmask)
+                         face_grad_mask=gmask,
+                         cluster_order=ops.morton_order(fv) if cluster else None)
     src = tt(scene["rays"], dtype)
     return src, fv, sc, (p_f, p_b)
 
@@ -195,3 +196,38 @@ def test_empty_and_degenerate_inputs():
     # a single ray / a single face
     out = ops.trace3d(src[:, :1].contiguous(), fv, sc, max_passes=3, flags=flags)
     assert out["finished"].shape[1] + out["dead"].shape[1] + out["unfinished"].shape[1] == 1
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-5)])
+def test_clustered_path_matches_oracle_and_all_pairs(dtype, tol):
+    """cluster_order given: rays sorted, faces visited in clusters -- identical results."""
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(5000, k_front=8, k_back=6)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster=True)
+    assert fv.shape[0] >= 64
+    out = ops.trace3d(src, fv, sc, max_passes=5, flags=flags)
+    src2, fv2, sc2, (q_f, q_b) = _gpu_scene(scene, dtype, cluster=False)
+    ref = ops.trace3d(src2, fv2, sc2, max_passes=5, flags=flags)
+    assert np.array_equal(out["counts"], ref["counts"]) and out["n_tests"] == ref["n_tests"]
+    for cls in ("finished", "active", "dead"):
+        assert torch.equal(out[cls + "_id"], ref[cls + "_id"])
+        assert torch.equal(out[cls + "_face"], ref[cls + "_face"])
+        assert torch.equal(out[cls], ref[cls])          # bit-identical ray blocks
+    # against the oracle
+    system, _, _ = oracle_util.lens_oracle(scene)
+    oref = tracer.ray_trace(
+        system, oracle_util.source_dict(scene["rays"], scene["wavelength"],
+                                        np.float32 if dtype == torch.float32 else None),
+        max_iterations=5, inherit=("wavelength", "ray_id"), flags=dict(compile_dead_rays=True))
+    _compare_sets(out["finished"], out["finished_id"], oref["finished"], tol, "finished")
+    # gradients: same up to the order of the float64 sums
+    def grads(o, params):
+        fin = o["finished"]
+        goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fin.device)[o["finished_id"].long()]
+        err = ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
+        return torch.autograd.grad(err, params)
+    ga, gb = grads(out, [p_f, p_b]), grads(ref, [q_f, q_b])
+    for a, b in zip(ga, gb):
+        rel = float((a - b).abs().max() / b.abs().max())
+        assert rel < 1e-11, rel
