@@ -18,9 +18,10 @@ size_t sort_pairs_temp_bytes(size_t n) {
 }
 
 int sort_pairs_u32_i32(void* tmp, size_t bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                       const int32_t* vals_in, int32_t* vals_out, size_t n, hipStream_t st) {
-  return (int)rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 32,
-                                        st);
+                       const int32_t* vals_in, int32_t* vals_out, size_t n, int end_bit,
+                       hipStream_t st) {
+  return (int)rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0,
+                                        (unsigned)end_bit, st);
 }
 
 }  // namespace tfrt
