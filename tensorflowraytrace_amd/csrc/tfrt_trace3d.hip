@@ -1312,6 +1312,8 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // off when many rays pile onto each face: measured 10.6 -> 3.6 ms at 4M rays x 974 faces,
   // but a small loss at 1M rays x 10574 faces, where plain scattered atomics are cheaper.
   const bool sorted = M > 0 && N >= 65536 && N / M >= 512;
+  // the clustered forward left its Morton ray order in rperm: coherent enough to aggregate
+  const bool coherent = sc->cluster_order != nullptr && M >= 4 * CLUSTER;
   int key_bits = 1;
   while ((1ll << key_bits) < (long long)M + 2) ++key_bits;
   const size_t n = N > 0 ? N : 1;
@@ -1335,7 +1337,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
                        cap_dead, g_out, out_stride, g_fverts,
-                       sorted ? rperm_all + (size_t)p * n : nullptr);
+                       (sorted || coherent) ? rperm_all + (size_t)p * n : nullptr);
   }
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
