@@ -163,7 +163,7 @@ def main():
     rank, world, local = tdist.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local if world > 1 else 0)
+    torch.cuda.set_device((local % torch.cuda.device_count()) if world > 1 else 0)
     tfa.set_device(f"cuda:{torch.cuda.current_device()}")
     ray_dtype = torch.float32 if args.dtype == "f32" else torch.float64
 
@@ -234,6 +234,15 @@ def main():
         "hbm_frac": (alg_bytes / (avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBPS if launches else float("nan"),
         "traffic": None,
     }
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+    # of the same kernel on the same workload, committed under profiles/
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if (os.path.exists(tpath) and not args.accelerate and args.rays == 1_000_000
+            and args.gpus == 1 and args.k_front == 41):
+        tj = json.load(open(tpath))
+        roofline["traffic"] = (tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
+        roofline["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, uncorrected)"
+        roofline["traffic_source"] = "profiles/r01_traffic.json"
     line = {
         "metric": "ray-surface intersection tests/sec (fwd+bwd)",
         "value": tests_total / dt,

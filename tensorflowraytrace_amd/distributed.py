@@ -37,9 +37,12 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", str(rk)))
     if world > 1 and not (dist.is_available() and dist.is_initialized()):
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            backend = os.environ.get("TFRT_DIST_BACKEND") or (
+                "nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            # one rank per GPU; the modulo only matters for rehearsals with more ranks than GPUs
+            # (TFRT_DIST_BACKEND=gloo), RCCL itself needs distinct devices
+            torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rk, world_size=world)
