@@ -83,6 +83,28 @@ int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_
                               double* grad_vertices, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Optimiser step, parameter side (SGD_Optimizer.process_gradient / single_step,
+ * tfrt/optimizer.py:223-257 and :316).
+ *
+ * tfrt_sgd_process: per element, in the tensors' own dtype (TFRT_F32 / TFRT_F64)
+ *     g = isfinite(grad) ? grad : 0            (optimizer.py:226-229)
+ *     g = g * scale                            (:233, scale = lr_scale*individual_lr*learning_rate)
+ *     g = min(max(g, -clip), clip)             (:236-247, clip >= 0)
+ *     processed[i] = g                         (skipped when processed == NULL)
+ *     param[i]    -= sgd_learning_rate * g     (skipped when param == NULL; the Keras SGD
+ *                                               apply of optimizer.py:316, no momentum)
+ * `processed` may alias `grad`.
+ */
+int tfrt_sgd_process(const void* grad, void* processed, void* param, int64_t n, int32_t dtype,
+                     double scale, double clip, double sgd_learning_rate, void* stream);
+
+/* y = A x, A in CSR form (int64 indices, f64 values): the accumulator (optimizer.py:250-255)
+ * and smoother (optimizer.py:277-282) products for the sparse matrices the mesh tools
+ * produce (mesh_tools.py:221-421).  x and y must not alias. */
+int tfrt_csr_matvec(const int64_t* crow_indices, const int64_t* col_indices, const double* values,
+                    const double* x, double* y, int64_t n_rows, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Scene description shared by the 3-D entry points (the merged boundary set of
  * OpticalSystem3D._merge_boundaries, tfrt/engine.py:971-1018: optical, stop, target order).
  */

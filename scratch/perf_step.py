@@ -34,4 +34,4 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(5): opt.single_step(None)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=30, max_name_column_width=45))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))

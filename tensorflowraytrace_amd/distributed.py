@@ -62,7 +62,8 @@ def all_reduce_step(grads, error_sum, error_count):
     """Sum parameter gradients, the error sum and the number of error terms over ranks with a
     single collective.  ``grads``: list of tensors (None allowed -> treated as zeros of the
     matching parameter, supplied as (None, like) tuples).  Returns (grads, error_sum,
-    error_count) with the reduced values; a no-op for one process."""
+    error_count) with the reduced values (error_count: float, or a 0-dim device tensor when
+    the buffer lives on a GPU); a no-op for one process."""
     if not is_distributed():
         return grads, error_sum, error_count
     flat = [g.reshape(-1).to(torch.float64) for g in grads]
@@ -76,4 +77,7 @@ def all_reduce_step(grads, error_sum, error_count):
         n = g.numel()
         out.append(buf[o:o + n].reshape(g.shape).to(g.dtype))
         o += n
-    return out, buf[o], float(buf[o + 1].item())
+    # the reduced count stays a device scalar on a GPU: reading it here would block the host on
+    # the backward pass + collective once per step
+    count = buf[o + 1] if buf.is_cuda else float(buf[o + 1].item())
+    return out, buf[o], count

@@ -88,6 +88,61 @@ def build_faces(vertices, faces, update_mask=None):
     return _BuildFaces.apply(vertices, faces, update_mask)
 
 
+# ------------------------------------------------------------------- parameter update
+
+def sgd_process(grad, scale, clip, param=None, sgd_learning_rate=0.0):
+    """optimizer.py:223-247 (+ :316 when ``param`` is given) in one launch: returns
+    ``clip(where(isfinite(grad), grad, 0) * scale, -clip, clip)`` and, if ``param`` is given,
+    also applies ``param -= sgd_learning_rate * processed`` in place."""
+    _need_gpu(grad, param)
+    if grad.dtype not in (torch.float32, torch.float64):
+        raise TfrtError(f"sgd_process: float32/float64 gradients only, got {grad.dtype}")
+    grad = grad.contiguous()
+    out = torch.empty_like(grad)
+    if param is not None and (param.dtype != grad.dtype or param.shape != grad.shape
+                              or not param.is_contiguous()):
+        raise TfrtError("sgd_process: param must be contiguous with the gradient's shape and dtype")
+    check(_lib.lib().tfrt_sgd_process(
+        _p(grad), _p(out), _p(param), grad.numel(), _DT[grad.dtype], float(scale), float(clip),
+        float(sgd_learning_rate), _stream(grad)), "tfrt_sgd_process")
+    return out
+
+
+class CsrMatrix:
+    """A square accumulator / smoother matrix held in CSR form on the device
+    (optimizer.py:250-255, 277-282 multiply dense (P,P) matrices whose rows hold a few
+    non-zeros, mesh_tools.py:221-421)."""
+
+    def __init__(self, matrix, device):
+        if isinstance(matrix, torch.Tensor):
+            dense = matrix.detach().to_dense() if matrix.layout != torch.strided else matrix.detach()
+            dense = dense.to(device="cpu", dtype=torch.float64).numpy()
+        else:
+            dense = np.asarray(matrix, dtype=np.float64)
+        if dense.ndim != 2:
+            raise TfrtError("CsrMatrix: need a rank-2 matrix")
+        rows, cols = np.nonzero(dense)                      # row-major order = CSR order
+        crow = np.zeros(dense.shape[0] + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=dense.shape[0]), out=crow[1:])
+        self.shape = tuple(dense.shape)
+        self.nnz = int(rows.size)
+        self.crow = torch.as_tensor(crow).to(device)
+        self.col = torch.as_tensor(cols.astype(np.int64)).to(device)
+        self.val = torch.as_tensor(np.ascontiguousarray(dense[rows, cols])).to(device)
+
+    def matvec(self, x):
+        """A @ x for a (P,) or (P,1) float64 vector on the matrix's device."""
+        _need_gpu(x)
+        shape = x.shape
+        v = _c(x.reshape(-1), torch.float64)
+        if v.shape[0] != self.shape[1]:
+            raise TfrtError(f"CsrMatrix.matvec: matrix is {self.shape}, vector has {v.shape[0]}")
+        y = torch.empty(self.shape[0], dtype=torch.float64, device=v.device)
+        check(_lib.lib().tfrt_csr_matvec(_p(self.crow), _p(self.col), _p(self.val), _p(v), _p(y),
+                                         self.shape[0], _stream(v)), "tfrt_csr_matvec")
+        return y.reshape(shape).to(x.dtype) if self.shape[0] == self.shape[1] else y
+
+
 # ----------------------------------------------------------------------------- trace3d
 
 class Scene3DArgs:

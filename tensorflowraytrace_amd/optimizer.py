@@ -21,6 +21,94 @@ import torch
 from . import distributed as tdist
 
 
+class DeferredScalar:
+    """The step error as the reference returns it (``error.numpy()``, optimizer.py:320), except
+    that the device->host read happens when the value is first used (``float(e)``, printing,
+    comparing, arithmetic) instead of inside ``single_step``: a blocking read there would drain
+    the GPU queue once per step and leave the device idle while the host prepares the next
+    trace."""
+    __slots__ = ("_tensor", "_value")
+
+    def __init__(self, tensor):
+        self._tensor = tensor.detach()
+        self._value = None
+
+    def __float__(self):
+        if self._value is None:
+            self._value = float(self._tensor)
+            self._tensor = None
+        return self._value
+
+    def item(self):
+        return float(self)
+
+    def numpy(self):
+        return np.float64(float(self))
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(float(self), dtype=dtype)
+
+    def __repr__(self):
+        return repr(float(self))
+
+    __str__ = __repr__
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __bool__(self):
+        return bool(float(self))
+
+    def __hash__(self):
+        return hash(float(self))
+
+    def __eq__(self, other):
+        return float(self) == other
+
+    def __lt__(self, other):
+        return float(self) < other
+
+    def __le__(self, other):
+        return float(self) <= other
+
+    def __gt__(self, other):
+        return float(self) > other
+
+    def __ge__(self, other):
+        return float(self) >= other
+
+    def __neg__(self):
+        return -float(self)
+
+    def __abs__(self):
+        return abs(float(self))
+
+    def __add__(self, other):
+        return float(self) + other
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return float(self) - other
+
+    def __rsub__(self, other):
+        return other - float(self)
+
+    def __mul__(self, other):
+        return float(self) * other
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return float(self) / other
+
+    def __rtruediv__(self, other):
+        return other / float(self)
+
+    def __pow__(self, other):
+        return float(self) ** other
+
+
 class SGD_Optimizer:
     def __init__(self, engine, parameters, error_function, trace_depth, momentum=0.0,
                  learning_rate=1.0, individual_lr=None, grad_clip="default", clip_mode="common",
@@ -50,6 +138,7 @@ class SGD_Optimizer:
         self.suppress_warnings = False
         self.iterations = 0
         self.last_error_terms = 0
+        self._acc_cache = {}
 
     @property
     def momentum(self):
@@ -153,47 +242,95 @@ class SGD_Optimizer:
         fixed, error_sum, n_terms = tdist.all_reduce_step(fixed, error_sum.detach(), n_terms)
         return fixed, error_sum, n_terms
 
+    def _matrix_product(self, cache, key, matrix, vec):
+        """``matrix @ vec`` for an accumulator / smoother.  On a HIP device the matrix is
+        converted to CSR once (cached on the object it came from) and multiplied by the
+        tfrt_csr_matvec kernel; CPU tensors (host-logic tests) use a dense torch product."""
+        shape = vec.shape
+        if vec.is_cuda:
+            from . import ops
+            entry = cache.get(key)
+            if entry is None or entry[0] is not matrix:
+                entry = (matrix, ops.CsrMatrix(matrix, vec.device))
+                cache[key] = entry
+            return entry[1].matvec(vec)
+        m = matrix if isinstance(matrix, torch.Tensor) else torch.as_tensor(np.asarray(matrix))
+        m = m.to(device=vec.device)
+        if m.layout != torch.strided:
+            m = m.to_dense()
+        return torch.matmul(m.to(vec.dtype), vec.reshape(-1, 1)).reshape(shape)
+
     def process_gradient(self, accumulators, *args, lr_scale=1.0, **kwargs):
         """optimizer.py:187-258.  Returns (processed grads, mean error)."""
+        processed, mean, _ = self._process(accumulators, args, kwargs, lr_scale, apply=False)
+        return processed, mean
+
+    def _process(self, accumulators, args, kwargs, lr_scale, apply):
+        """Gradient processing; with ``apply`` the SGD update of every parameter that has no
+        accumulator is fused into the processing kernel (returns which ones were applied)."""
         grads, error_sum, n_terms = self.raw_gradient(*args, **kwargs)
         self.last_error_terms = n_terms
-        processed = []
+        processed, applied = [], []
+        plain_sgd = not (self.apply_momentum and self._momentum > 0.0)
         for i, grad in enumerate(grads):
-            grad = torch.where(torch.isfinite(grad), grad, torch.zeros_like(grad))
-            grad = grad * (lr_scale * self.individual_lr[i] * self.learning_rate)
+            scale = lr_scale * self.individual_lr[i] * self.learning_rate
             if self.clip_mode == "common":
-                grad = torch.clamp(grad, -self.grad_clip, self.grad_clip)
+                clp = self.grad_clip
             else:
                 clp = self.individual_lr[i] * self.clip_scale * self.learning_rate * lr_scale
+            if grad.is_cuda:
+                from . import ops
+                p = self.parameters[i]
+                fuse = (apply and plain_sgd and accumulators[i] is None and p.is_contiguous()
+                        and p.dtype == grad.dtype and p.shape == grad.shape)
+                with torch.no_grad():
+                    grad = ops.sgd_process(grad, scale, clp, param=p if fuse else None,
+                                           sgd_learning_rate=self.sgd_learning_rate)
+                applied.append(fuse)
+            else:  # host tensors (CPU logic tests): the same arithmetic as eager torch ops
+                grad = torch.where(torch.isfinite(grad), grad, torch.zeros_like(grad))
+                grad = grad * scale
                 grad = torch.clamp(grad, -clp, clp)
+                applied.append(False)
             if accumulators[i] is not None:
-                shape = grad.shape
-                acc = accumulators[i]
-                if not isinstance(acc, torch.Tensor) or acc.device != grad.device:
-                    acc = torch.as_tensor(np.asarray(acc), dtype=grad.dtype, device=grad.device) \
-                        if not isinstance(acc, torch.Tensor) else acc.to(grad.device)
-                    accumulators[i] = acc
-                if acc.is_sparse or acc.layout == torch.sparse_csr:
-                    grad = (acc @ grad.reshape(-1, 1)).reshape(shape)
-                else:
-                    grad = torch.matmul(acc.to(grad.dtype), grad.reshape(-1, 1)).reshape(shape)
+                grad = self._matrix_product(self._acc_cache, i, accumulators[i], grad)
             processed.append(grad)
-        mean = error_sum / max(n_terms, 1)
-        return processed, mean
+        if isinstance(n_terms, torch.Tensor):
+            mean = error_sum / torch.clamp(n_terms, min=1.0)
+        else:
+            mean = error_sum / max(n_terms, 1)
+        return processed, mean, applied
+
+    _smoother_cache = {}
 
     @staticmethod
     def smooth(parameters, smoother):
         """optimizer.py:261-282: ``parameters <- smoother @ parameters`` in place."""
         if smoother is not None:
             with torch.no_grad():
+                if parameters.is_cuda:
+                    from . import ops
+                    cache = SGD_Optimizer._smoother_cache
+                    entry = cache.get(id(smoother))
+                    if entry is None or entry[0] is not smoother:
+                        if len(cache) > 64:
+                            cache.clear()
+                        entry = (smoother, ops.CsrMatrix(smoother, parameters.device))
+                        cache[id(smoother)] = entry
+                    parameters.copy_(entry[1].matvec(parameters.detach()))
+                    return
                 s = smoother if isinstance(smoother, torch.Tensor) else torch.as_tensor(
                     np.asarray(smoother))
                 s = s.to(device=parameters.device, dtype=parameters.dtype)
+                if s.layout != torch.strided:
+                    s = s.to_dense()
                 parameters.copy_((s @ parameters.reshape(-1, 1)).reshape(parameters.shape))
 
-    def apply_gradients(self, grads):
+    def apply_gradients(self, grads, skip=None):
         with torch.no_grad():
             for i, (g, p) in enumerate(zip(grads, self.parameters)):
+                if skip is not None and skip[i]:
+                    continue  # already applied by the fused processing kernel
                 lr = self.sgd_learning_rate
                 if self.apply_momentum and self._momentum > 0.0:
                     v = self._velocity[i]
@@ -210,10 +347,11 @@ class SGD_Optimizer:
         """optimizer.py:284-320."""
         self.momentum = momentum
         accumulators = self.convert_to_plist(accumulators)
-        grads, error = self.process_gradient(accumulators, *args, lr_scale=lr_scale, **kwargs)
-        self.apply_gradients(grads)
+        grads, error, applied = self._process(accumulators, args, kwargs, lr_scale, apply=True)
+        self.apply_gradients(grads, skip=applied)
         self.iterations += 1
-        err = float(error)
+        err = DeferredScalar(error) if isinstance(error, torch.Tensor) and error.is_cuda \
+            else float(error)
         if verbose:
             print(f"step {self.iterations} error: {err}")
         return err
