@@ -150,6 +150,8 @@ def main():
                          "test): identical results, fewer filter evaluations; tests/s then counts "
                          "decided ray-face pairs, not executed filter tests")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clustered", action="store_true",
+                    help="skip the separately reported clustered-trace leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -267,6 +269,33 @@ def main():
         },
         "roofline": roofline,
     }
+    if world == 1 and not args.accelerate and not args.no_clustered:
+        # second, separately reported leg (never `value`): the same step through the clustered
+        # trace; identical results, fewer executed filter tests
+        del eng, system, params, opt
+        torch.cuda.empty_cache()
+        eng2, system2, params2 = build_scene(args.rays, args.k_front, args.k_back, ray_dtype,
+                                             accelerate=True)
+        opt2 = optimizer.SGD_Optimizer(eng2, params2, error_function, trace_depth=3,
+                                       learning_rate=1e-6, grad_clip=1e-3)
+        opt2.suppress_warnings = True
+        for _ in range(args.warmup):
+            opt2.single_step(None)
+        torch.cuda.synchronize()
+        pairs = 0
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            opt2.single_step(None)
+            pairs += eng2.last_trace["n_tests"]
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        line["clustered_trace"] = {
+            "ms_per_step": dt2 / args.steps * 1e3,
+            "ray_face_pairs_decided_per_s": pairs / dt2,
+            "note": "same step with OpticalEngine(accelerate=True): Morton-sorted rays, 16-face "
+                    "clusters behind a bounding-sphere test; bit-identical outputs; pairs = "
+                    "N_active x M as in `value`, most of them culled, not tested",
+        }
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(line))

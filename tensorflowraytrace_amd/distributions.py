@@ -1,7 +1,7 @@
 """
-Angle / base-point clouds that feed the sources (subset of tfrt/distributions.py: the
-distributions the hot-path configs use).  Host-side, O(N), runs once per ``update()``;
-torch ops on the configured device.
+Angle / base-point clouds that feed the sources (tfrt/distributions.py).  Host-side, O(N),
+runs once per ``update()``; torch ops on the configured device, numpy/scipy for the
+density-inversion helpers the reference also does in numpy.
 
 Random distributions draw from a module-level ``torch.Generator`` (``seed(n)``) so runs and
 ranks of a sharded job are reproducible.
@@ -171,6 +171,29 @@ class RandomUniformAngularDistribution(AngularDistributionBase):
         self.angle_limit_validation(-PI, PI)
         self._angles = _uniform(self.sample_count, float(self.min_angle), float(self.max_angle))
         self._ranks = self._update_ranks(self._angles, self.min_angle, self.max_angle)
+
+
+class StaticLambertianAngularDistribution(AngularDistributionBase):
+    """Cosine-weighted fan: the rank is sin(angle), spaced evenly between sin(min_angle) and
+    sin(max_angle) (distributions.py:394-470).  Limits must lie in [-pi/2, pi/2]."""
+
+    def update(self):
+        self.angle_limit_validation(-PI / 2.0, PI / 2.0)
+        self._ranks = torch.linspace(math.sin(float(self.min_angle)),
+                                     math.sin(float(self.max_angle)), int(self.sample_count),
+                                     dtype=torch.float64, device=config.get_device())
+        self._angles = torch.asin(self._ranks)
+
+
+class RandomLambertianAngularDistribution(AngularDistributionBase):
+    """As above with the ranks drawn uniformly (distributions.py:473-556); re-sampled at
+    every update."""
+
+    def update(self):
+        self.angle_limit_validation(-PI / 2.0, PI / 2.0)
+        self._ranks = _uniform(self.sample_count, math.sin(float(self.min_angle)),
+                               math.sin(float(self.max_angle)))
+        self._angles = torch.asin(self._ranks)
 
 
 # ------------------------------------------------------------------------- base points
@@ -424,7 +447,7 @@ class SphereBase(ThetaMod, RecursivelyUpdatable):
 
     @property
     def ranks(self):
-        return torch.stack([self._phi / self.angular_size, torch.remainder(self._theta, 2 * PI)], dim=1)
+        return torch.stack([self._phi, torch.remainder(self._theta, 2 * PI)], dim=1)
 
 
 class StaticUniformSphere(SphereBase):
@@ -444,6 +467,518 @@ class RandomUniformSphere(SphereBase):
         self._phi = torch.acos(c)
         self._theta = self._theta_mod(PI * (1 + 5 ** 0.5) * _uniform(self.sample_count))
         self._finish()
+
+
+class StaticLambertianSphere(SphereBase):
+    """Golden-spiral cap whose polar density follows Lambert's cosine law: cos^2(phi) is
+    spaced evenly from 1 to cos^2(angular_size) (distributions.py:1778-1811)."""
+
+    def _update(self):
+        dev = config.get_device()
+        idx = torch.arange(self.sample_count, dtype=torch.float64, device=dev) + .5
+        c2 = torch.linspace(1.0, math.cos(self.angular_size) ** 2, self.sample_count,
+                            dtype=torch.float64, device=dev)
+        self._phi = torch.acos(torch.sqrt(c2))
+        self._theta = self._theta_mod(PI * (1 + 5 ** 0.5) * idx)
+        self._finish()
+
+
+class RandomLambertianSphere(SphereBase):
+    """distributions.py:1814-1850."""
+
+    def _update(self):
+        c2 = _uniform(self.sample_count, math.cos(self.angular_size) ** 2, 1.0)
+        self._phi = torch.acos(torch.sqrt(c2))
+        self._theta = self._theta_mod(PI * (1 + 5 ** 0.5) * _uniform(self.sample_count))
+        self._finish()
+
+
+class SquareRankLambertianSphere(RecursivelyUpdatable):
+    """Lambertian direction cloud whose ranks fill the square [-1,1]^2 uniformly
+    (distributions.py:1853-2011): uniform square -> (via an ArbitraryDistribution of a disc of
+    radius sin(angular_cutoff)) uniform disc -> lifted onto the unit sphere, which makes the
+    polar density cosine-weighted."""
+
+    def __init__(self, sample_count, angular_cutoff=PI / 2.0, sampling_resolution=256, **kwargs):
+        self.sampling_resolution = sampling_resolution
+        self.angular_cutoff = angular_cutoff
+        self.sample_count = sample_count
+        RecursivelyUpdatable.__init__(self, **kwargs)
+
+    sample_count = property(lambda self: self._sample_count)
+    angular_cutoff = property(lambda self: self._angular_cutoff)
+    sampling_resolution = property(lambda self: self._sampling_resolution)
+    points = property(lambda self: self._points)
+    angles = property(lambda self: self._points)
+    ranks = property(lambda self: self._ranks)
+
+    @sample_count.setter
+    def sample_count(self, val):
+        if val < 0:
+            raise ValueError("SquareRankLambertianSphere: Sample count must be > 0.")
+        self._sample_count = int(val)
+
+    @sampling_resolution.setter
+    def sampling_resolution(self, val):
+        if val < 0:
+            raise ValueError("SquareRankLambertianSphere: Sample count must be > 0.")
+        self._sampling_resolution = int(val)
+
+    @angular_cutoff.setter
+    def angular_cutoff(self, val):
+        if val > PI / 2.0 or val < 0:
+            raise ValueError(
+                "SquareRankLambertianSphere: angular cutoff must be between zero and PI/2.")
+        self._angular_cutoff = float(val)
+        limit = math.sin(self._angular_cutoff)
+
+        def density(x, y):
+            return (np.sqrt(x * x + y * y) < limit).astype(np.float64) + 1e-10
+
+        res = self._sampling_resolution
+        self._circle_maker = ArbitraryDistribution(density, ((-1.0, 1.0, res), (-1.0, 1.0, res)))
+
+    def _update(self):
+        n = self._sample_count
+        ranks = np.stack([_uniform(n, -1.0, 1.0).cpu().numpy(),
+                          _uniform(n, -1.0, 1.0).cpu().numpy()], axis=1)
+        cx, cy = self._circle_maker(ranks[:, 0], ranks[:, 1])
+        cx, cy = _f64(cx), _f64(cy)
+        self._ranks = _f64(ranks)
+        theta = torch.atan2(cy, cx)
+        rad2 = cx * cx + cy * cy
+        phi = torch.atan2(torch.sqrt(rad2), torch.sqrt(torch.clamp(1.0 - rad2, min=0.0)))
+        self._phi = phi
+        self._points = torch.stack([torch.cos(phi), torch.sin(phi) * torch.cos(theta),
+                                    torch.sin(phi) * torch.sin(theta)], dim=1)
+
+    def _generate_update_handles(self):
+        return []
+
+
+# --------------------------------------------------------------- arbitrary densities (host)
+
+def _as_np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def _read_grey_image(filename):
+    """Grey levels (ITU-R 601 luma, float) of an image file; the reference uses
+    ``imageio.imread(..., as_gray=True)`` (distributions.py:2191, 2930), which is not
+    installed here, Pillow is."""
+    try:
+        from PIL import Image
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("reading an image file needs Pillow (PIL)") from e
+    with Image.open(filename) as im:
+        return np.array(im.convert("F"), dtype=np.float64)
+
+
+def _cumulative_tables(density):
+    """Zero-started cumulative sums used by every density -> quantile mapping below
+    (distributions.py:2230-2236): cumulate along axis 0 for each column, and cumulate the
+    column totals along axis 1."""
+    padded = np.pad(density, ((1, 0), (1, 0)), mode="constant", constant_values=0)
+    per_column = np.cumsum(padded, axis=0)
+    totals = np.cumsum(per_column[-1])
+    return totals, per_column[:, 1:]
+
+
+class ArbitraryDistribution:
+    """Maps a uniform point cloud on a rectangle onto one that follows a 2-D density
+    (distributions.py:2123-2280): the density (callable sampled on a grid, 2-D array, or grey
+    image file) is cumulated, the cumulative curves are inverted by linear interpolation into
+    an x quantile function and one y quantile function per x cell.  Host-side numpy/scipy,
+    as in the reference."""
+
+    def __init__(self, density_function, evaluation_limits):
+        from scipy.interpolate import interp1d
+        if type(density_function) is str:
+            self._x_min, self._x_max = evaluation_limits[0]
+            self._y_min, self._y_max = evaluation_limits[1]
+            density = _read_grey_image(density_function)
+            self._x_count, self._y_count = density.shape
+        elif callable(density_function):
+            self._x_min, self._x_max, self._x_count = evaluation_limits[0]
+            self._y_min, self._y_max, self._y_count = evaluation_limits[1]
+            gx, gy = np.meshgrid(np.linspace(self._x_min, self._x_max, self._x_count),
+                                 np.linspace(self._y_min, self._y_max, self._y_count))
+            density = np.asarray(density_function(gx, gy), dtype=np.float64)
+        else:
+            density = np.array(_as_np(density_function), dtype=np.float64)
+            if density.ndim != 2:
+                raise ValueError("PointCloudSampler: density function must be 2D.")
+            self._x_min, self._x_max = evaluation_limits[0]
+            self._y_min, self._y_max = evaluation_limits[1]
+            self._x_count, self._y_count = density.shape
+        if np.any(density < 0):
+            raise ValueError("PointCloudSampler: density function must be non-negative on the "
+                             "whole evaluation grid.")
+        self.density_function = density
+        totals, per_column = _cumulative_tables(density)
+        totals = self._rescale(totals, self._x_min, self._x_max)
+        columns = [self._rescale(per_column[:, i], self._y_min, self._y_max)
+                   for i in range(self._x_count)]
+        knots_x = np.linspace(self._x_min, self._x_max, self._x_count + 1)
+        knots_y = np.linspace(self._y_min, self._y_max, self._y_count + 1)
+        self._x_quantile = interp1d(totals, knots_x)
+        self._y_quantiles = [interp1d(c, knots_y) for c in columns]
+
+    @staticmethod
+    def _rescale(n, n_min, n_max):
+        top = np.amax(n)
+        if top <= 0:
+            raise ValueError(
+                "PointCloudSampler: Discovered a slice where the density was zero, which causes "
+                "problems, because the quantile function would have to have infinite slope.  "
+                "Either restrict the evaluation range, or add a very small constant to the "
+                "density function.")
+        return n * (n_max - n_min) / top + n_min
+
+    def __call__(self, x, y):
+        x, y = np.asarray(_as_np(x), dtype=np.float64), np.asarray(_as_np(y), dtype=np.float64)
+        x_out = self._x_quantile(x)
+        cell = np.floor((x_out - self._x_min) * self._x_count
+                        / (self._x_max - self._x_min)).astype(int)
+        y_out = np.zeros_like(y)
+        for i in range(self._y_count):
+            pick = cell == i
+            if pick.any():
+                y_out[pick] = self._y_quantiles[i](y[pick])
+        return x_out, y_out
+
+
+def flatten_distribution(x, y, evaluation_limits):
+    """Inverse of ArbitraryDistribution for an empirical cloud: histogram (x, y), build the
+    cumulative curves and push the cloud through them so it becomes uniform on [0,1]^2
+    (distributions.py:2283-2369, including its transposed-histogram convention)."""
+    from scipy.interpolate import interp1d
+    x_min, x_max, x_res = evaluation_limits[0]
+    y_min, y_max, y_res = evaluation_limits[1]
+    x = np.clip(_as_np(x), x_min, x_max)
+    y = np.clip(_as_np(y), y_min, y_max)
+    hist, _, _ = np.histogram2d(x, y, bins=(x_res, y_res),
+                                range=((x_min, x_max), (y_min, y_max)))
+    totals, per_column = _cumulative_tables(hist.T)
+    totals = totals / np.amax(totals)
+    columns = [per_column[:, i] / np.amax(per_column[:, i]) for i in range(x_res)]
+    knots_x = np.linspace(x_min, x_max, x_res + 1)
+    knots_y = np.linspace(y_min, y_max, y_res + 1)
+    x_cdf = interp1d(knots_x, totals)
+    y_cdfs = [interp1d(knots_y, c) for c in columns]
+    x_out = x_cdf(x)
+    cell = np.floor((x_out - x_min) * x_res / (x_max - x_min)).astype(int)
+    y_out = np.zeros_like(y)
+    for i in range(y_res):
+        pick = cell == i
+        if pick.any():
+            y_out[pick] = y_cdfs[i](y[pick])
+    return x_out, y_out
+
+
+class CumulativeDensityFunction:
+    """Forward (uniform -> density) and inverse (density -> uniform) maps of a 2-D histogram
+    that can be accumulated over several batches (distributions.py:2372-2632).  ``cdf`` maps y
+    first, then x with the curve of the y cell it landed in."""
+
+    def __init__(self, eval_limits, density=None, direction="both"):
+        self.x_res = 10
+        self.y_res = 10
+        self._y_cdf = self._x_cdfs = self._y_icdf = self._x_icdfs = None
+        self.x_min, self.x_max = eval_limits[0]
+        self.y_min, self.y_max = eval_limits[1]
+        self._density = None
+        if density is not None:
+            self.compute(density, direction)
+
+    def accumulate_density(self, density):
+        d = np.array(_as_np(density), dtype=np.float32)
+        if self._density is None:
+            self._density = d
+            self.x_res, self.y_res = d.shape
+        else:
+            self._density += d
+
+    def clear_density(self):
+        self._density = None
+
+    def compute(self, density=None, direction="both", epsilon=1e-10):
+        from scipy.interpolate import interp1d
+        if density is not None:
+            self.clear_density()
+            self.accumulate_density(density)
+        if direction not in {"forward", "inverse", "both"}:
+            raise ValueError("CumulativeDensityFunction: direction must be one of {'forward', "
+                             "'backward', 'both'}")
+        if self._density is None:
+            raise RuntimeError("CumulativeDensityFunction: cannot call compute before "
+                               "accumulating data.")
+        y_sum, x_sums = _cumulative_tables(self._density + epsilon)
+        y_sum = y_sum / y_sum[-1]
+        x_sums = x_sums / x_sums[-1:]
+        knots_x = np.linspace(self.x_min, self.x_max, self.x_res + 1)
+        knots_y = np.linspace(self.y_min, self.y_max, self.y_res + 1)
+        if direction in {"forward", "both"}:
+            self._y_cdf = interp1d(y_sum, knots_y)
+            self._x_cdfs = [interp1d(x_sums[:, i], knots_x) for i in range(self.y_res)]
+        else:
+            self._y_cdf = self._x_cdfs = None
+        if direction in {"inverse", "both"}:
+            self._y_icdf = interp1d(knots_y, y_sum)
+            self._x_icdfs = [interp1d(knots_x, x_sums[:, i]) for i in range(self.y_res)]
+        else:
+            self._y_icdf = self._x_icdfs = None
+
+    def _apply(self, points, y_map, x_maps, cell_of):
+        pts = _as_np(points)
+        x, y = np.asarray(pts[:, 0], dtype=np.float64), np.asarray(pts[:, 1], dtype=np.float64)
+        y_out = y_map(y)
+        cell = np.floor(cell_of(y_out)).astype(int)
+        x_out = np.zeros_like(x)
+        for i in range(self.y_res):
+            pick = cell == i
+            if pick.any():
+                x_out[pick] = x_maps[i](x[pick])
+        return np.column_stack((x_out.astype(pts.dtype), y_out.astype(pts.dtype)))
+
+    def cdf(self, points):
+        if self._y_cdf is None:
+            raise RuntimeError("CumulativeDensityFunction: Must call compute() with the correct "
+                               "direction before evaluation.")
+        return self._apply(points, self._y_cdf, self._x_cdfs,
+                           lambda yo: (yo - self.y_min) * self.y_res / (self.y_max - self.y_min))
+
+    def icdf(self, points):
+        if self._y_icdf is None:
+            raise RuntimeError("CumulativeDensityFunction: Must call compute() with the correct "
+                               "direction before evaluation.")
+        return self._apply(points, self._y_icdf, self._x_icdfs, lambda yo: yo * (self.y_res - 1))
+
+    def __call__(self, points):
+        return self.cdf(points)
+
+
+class ArbitraryBasePoints(BasePointDistributionBase):
+    """Base points following an ArbitraryDistribution, with ranks from a second one evaluated
+    at the same uniform seeds (distributions.py:2635-2798); ``enforce_etendue`` rescales the
+    ranks so their mean distance from ``origin`` equals the points'."""
+
+    def __init__(self, base_point_distribution, sample_count, rank_distribution=None,
+                 auto_reroll=True, conserve_etendue=True, etendue_origin=(0, 0), **kwargs):
+        self.sample_count = sample_count
+        self.base_point_distribution = base_point_distribution
+        self.rank_distribution = rank_distribution
+        self.auto_reroll = auto_reroll
+        self.rank_scale_factor = 1
+        super().__init__(**kwargs)
+        if conserve_etendue:
+            self.enforce_etendue(etendue_origin)
+
+    sample_count = property(lambda self: self._sample_count)
+
+    @sample_count.setter
+    def sample_count(self, val):
+        if int(val) != val or val <= 0:
+            raise ValueError("AribitraryBasePoints: sample_count must be an integer > 0.")
+        self._sample_count = int(val)
+
+    def reroll(self):
+        d = self.base_point_distribution
+        self._base_x = _uniform(self._sample_count, d._x_min, d._x_max).cpu().numpy()
+        self._base_y = _uniform(self._sample_count, d._y_min, d._y_max).cpu().numpy()
+
+    def _update(self):
+        if self.auto_reroll or self._ranks is None:
+            self.reroll()
+        self._points = _f64(np.stack(self.base_point_distribution(self._base_x, self._base_y), 1))
+        if self.rank_distribution is not None:
+            self._ranks = self.rank_scale_factor * _f64(
+                np.stack(self.rank_distribution(self._base_x, self._base_y), 1))
+        else:
+            self._ranks = None
+
+    def enforce_etendue(self, origin=(0, 0)):
+        if self._ranks is not None:
+            o = _f64(origin)
+            base = torch.linalg.norm(self._points - o, dim=1).mean()
+            ranks = torch.linalg.norm(self._ranks - o, dim=1).mean()
+            self.rank_scale_factor = float(base / ranks)
+            self._ranks = self._ranks * self.rank_scale_factor
+
+
+def transform_map_old(fixed, mutable, origin=None, furthest_first=True):
+    """Greedy matching (distributions.py:2804-2857): visit the fixed points by distance from
+    ``origin`` (furthest first by default) and give each the closest still-unused mutable
+    point.  Returns ``mutable`` re-ordered to line up with ``fixed``."""
+    fixed, mutable = np.array(_as_np(fixed)), np.array(_as_np(mutable))
+    if fixed.shape != mutable.shape:
+        raise ValueError("transform_map: both inputs must have exactly the same shape.")
+    if origin is None:
+        origin = np.zeros(fixed.shape[1])
+    elif np.shape(origin)[0] != fixed.shape[1]:
+        raise ValueError("transform_map: origin must have the same dimension as fixed.")
+    order = np.argsort(np.linalg.norm(fixed - origin, axis=1))
+    if furthest_first:
+        order = order[::-1]
+    out = np.zeros_like(mutable)
+    used = np.zeros(mutable.shape[0], dtype=bool)
+    for f in order:
+        d = np.linalg.norm(fixed[f] - mutable, axis=1)
+        d[used] = 2 * np.amax(d)
+        pick = np.argmin(d)
+        used[pick] = True
+        out[f] = mutable[pick]
+    return out
+
+
+def transform_map(fixed, mutable):
+    """Minimum-total-distance matching (Hungarian method, scipy) of ``mutable`` onto
+    ``fixed`` (distributions.py:2860-2903)."""
+    from scipy.optimize import linear_sum_assignment
+    fixed, mutable = np.array(_as_np(fixed)), np.array(_as_np(mutable))
+    if fixed.shape != mutable.shape:
+        raise ValueError("transform_map: both inputs must have exactly the same shape.")
+    cost = np.linalg.norm(fixed[:, None, :] - mutable[None, :, :], axis=2)
+    rows, cols = linear_sum_assignment(cost)
+    return mutable[cols[rows]]
+
+
+class ImageBasePoints(BasePointDistributionBase):
+    """Random points whose count per pixel is the pixel's grey level index
+    (distributions.py:2906-3003).  ``filename`` may also be a 2-D array of grey values."""
+
+    def __init__(self, filename, x_size, y_size=None, **kwargs):
+        self.x_size = x_size
+        self.y_size = y_size or x_size
+        raw = _read_grey_image(filename) if isinstance(filename, str) else \
+            np.array(_as_np(filename), dtype=np.float64)
+        self._x_res, self._y_res = raw.shape
+        levels, inverse = np.unique(raw, return_inverse=True)
+        self._grey_levels = len(levels)
+        self._image = np.reshape(np.arange(self._grey_levels)[inverse.reshape(-1)],
+                                 (self._x_res, self._y_res))
+        super().__init__(**kwargs)
+
+    x_size = property(lambda self: self._x_size)
+    y_size = property(lambda self: self._y_size)
+    grey_levels = property(lambda self: self._grey_levels)
+    x_res = property(lambda self: self._x_res)
+    y_res = property(lambda self: self._y_res)
+
+    @x_size.setter
+    def x_size(self, val):
+        if float(val) <= 0:
+            raise ValueError("ImageBasePoints: x_size must be > 0.")
+        self._x_size = float(val)
+
+    @y_size.setter
+    def y_size(self, val):
+        if float(val) <= 0:
+            raise ValueError("ImageBasePoints: y_size must be > 0.")
+        self._y_size = float(val)
+
+    def _update(self):
+        counts = self._image.reshape(-1)
+        total = int(counts.sum())
+        x_edges = np.linspace(-self._x_size / 2, self._x_size / 2, self._x_res + 1)
+        y_edges = np.linspace(-self._y_size / 2, self._y_size / 2, self._y_res + 1)
+        # pixel (row-major) of every point, then a uniform offset inside that pixel
+        pix = np.repeat(np.arange(counts.size), counts)
+        ix, iy = pix // self._y_res, pix % self._y_res
+        u = _uniform(total).cpu().numpy()
+        v = _uniform(total).cpu().numpy()
+        px = x_edges[ix] + u * (x_edges[ix + 1] - x_edges[ix])
+        py = y_edges[iy] + v * (y_edges[iy + 1] - y_edges[iy])
+        self._points = _f64(np.stack([px, py], axis=1))
+
+    @BasePointDistributionBase.ranks.setter
+    def ranks(self, val):
+        self._ranks = val
+
+
+class PrecompiledBasePoints(RecursivelyUpdatable):
+    """Stored base points (and ranks), optionally re-sampled with replacement and jittered at
+    each update (distributions.py:3006-3195).  File format: pickle of
+    ``{"points": ndarray|None, "ranks": ndarray|None}`` (distributions.py:3080-3095)."""
+
+    def __init__(self, arg, sample_count=100, do_downsample=True, perturbation=None, **kwargs):
+        if type(arg) is str:
+            import pickle
+            with open(arg, "rb") as f:
+                data = pickle.load(f)
+            self._full_points, self._full_ranks = data["points"], data["ranks"]
+        else:
+            self._full_points = getattr(arg, "points", None)
+            self._full_ranks = getattr(arg, "ranks", None)
+        self._full_points = None if self._full_points is None else _f64(_as_np(self._full_points))
+        self._full_ranks = None if self._full_ranks is None else _f64(_as_np(self._full_ranks))
+        self._points = self._ranks = None
+        self.perturbation = perturbation
+        self.sample_count = sample_count
+        self.do_downsample = do_downsample
+        RecursivelyUpdatable.__init__(self, **kwargs)
+
+    def save(self, filename):
+        import pickle
+        out = {"points": None if self._full_points is None else self._full_points.cpu().numpy(),
+               "ranks": None if self._full_ranks is None else self._full_ranks.cpu().numpy()}
+        with open(filename, "wb") as f:
+            pickle.dump(out, f, pickle.HIGHEST_PROTOCOL)
+
+    def _update(self):
+        if self.do_downsample and self.sampling_domain_size > 0:
+            n = self.sampling_domain_size
+            idx = (_uniform(self.sample_count) * n).long().clamp_(max=n - 1)
+            if self._full_points is not None:
+                self._points = self._full_points[idx.to(self._full_points.device)]
+            if self._full_ranks is not None:
+                self._ranks = self._full_ranks[idx.to(self._full_ranks.device)]
+        else:
+            self._points, self._ranks = self._full_points, self._full_ranks
+        if self._perturbation is not None and self._points is not None:
+            global _generator
+            if _generator is None:
+                seed(1234)
+            noise = torch.randn(self._points.shape, dtype=torch.float64, generator=_generator)
+            self._points = self._points + noise.to(self._points.device) * self._perturbation
+
+    def clear(self):
+        self._full_points = self._full_ranks = self._points = self._ranks = None
+
+    def _generate_update_handles(self):
+        return []
+
+    @property
+    def sampling_domain_size(self):
+        return 0 if self._full_points is None else int(self._full_points.shape[0])
+
+    points = property(lambda self: self._points)
+    ranks = property(lambda self: self._ranks)
+    full_points = property(lambda self: self._full_points)
+    full_ranks = property(lambda self: self._full_ranks)
+    perturbation = property(lambda self: self._perturbation)
+
+    @points.setter
+    def points(self, val):
+        self._full_points = None if val is None else _f64(_as_np(val))
+
+    @ranks.setter
+    def ranks(self, val):
+        self._full_ranks = None if val is None else _f64(_as_np(val))
+
+    @perturbation.setter
+    def perturbation(self, val):
+        if val is not None:
+            if self._full_points is None:
+                raise ValueError("PrecompiledBasePoints: perturbation must be None, scalar, or "
+                                 "must have one entry per dimension of the points.")
+            try:
+                val = _f64(np.broadcast_to(np.asarray(val, dtype=np.float64),
+                                           (self._full_points.shape[1],)).copy())
+            except ValueError as e:
+                raise ValueError("PrecompiledBasePoints: perturbation must be None, scalar, or "
+                                 "must have one entry per dimension of the points.") from e
+        self._perturbation = val
 
 
 class BasePointTransformation:
