@@ -68,12 +68,22 @@ class PolyData:
     def triangulate(self):
         return self
 
-    def save(self, filename, **kwargs):
-        """ASCII STL (what boundary.save wrote through pyvista, boundaries.py:872-874)."""
+    def save(self, filename, binary=True, **kwargs):
+        """Write an STL file: binary little-endian by default (what ``boundary.save`` produced
+        through pyvista, boundaries.py:872-874), ASCII with ``binary=False``."""
         tri = self.points[self.triangles()]
         n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
         ln = np.linalg.norm(n, axis=1, keepdims=True)
         n = np.divide(n, ln, out=np.zeros_like(n), where=ln > 0)
+        if binary:
+            rec = np.zeros(tri.shape[0], dtype=_STL_RECORD)
+            rec["normal"] = n
+            rec["v"] = tri
+            with open(filename, "wb") as f:
+                f.write(b"tfrt binary STL".ljust(80, b" "))
+                f.write(np.uint32(tri.shape[0]).tobytes())
+                f.write(rec.tobytes())
+            return
         with open(filename, "w") as f:
             f.write("solid tfrt\n")
             for nn, t in zip(n, tri):
@@ -84,23 +94,42 @@ class PolyData:
             f.write("endsolid tfrt\n")
 
 
+# binary STL: 80-byte header, uint32 count, then 50-byte records (float32 normal, 3 float32
+# vertices, uint16 attribute)
+_STL_RECORD = np.dtype([("normal", "<f4", (3,)), ("v", "<f4", (3, 3)), ("attr", "<u2")])
+
+
+def _merge_vertices(tri):
+    """(F,3,3) corner coordinates -> PolyData with exactly equal corners merged, first
+    occurrence order (so a mesh written by ``PolyData.save`` reads back with its topology)."""
+    flat = tri.reshape(-1, 3)
+    uniq, first, inverse = np.unique(flat, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first)                    # np.unique sorts by value: undo that
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    idx = rank[inverse.reshape(-1)].reshape(-1, 3)
+    faces = np.concatenate([np.full((idx.shape[0], 1), 3, dtype=np.int64), idx], axis=1)
+    return PolyData(uniq[order].astype(np.float64), faces.reshape(-1))
+
+
 def read(filename):
-    """Read an ASCII STL written by ``PolyData.save`` (vertices are merged exactly)."""
-    verts, index, faces = [], {}, []
-    cur = []
-    with open(filename) as f:
-        for line in f:
-            parts = line.split()
-            if parts[:1] == ["vertex"]:
-                key = tuple(float(x) for x in parts[1:4])
-                if key not in index:
-                    index[key] = len(verts)
-                    verts.append(key)
-                cur.append(index[key])
-                if len(cur) == 3:
-                    faces.append([3] + cur)
-                    cur = []
-    return PolyData(np.array(verts).reshape(-1, 3), np.array(faces, dtype=np.int64).reshape(-1))
+    """Read an STL file, binary or ASCII (the reference reads meshes through ``pv.read``,
+    boundaries.py:859-861).  Binary is recognised by its size: 84 + 50 * n_facets bytes."""
+    with open(filename, "rb") as f:
+        blob = f.read()
+    if len(blob) >= 84:
+        count = int(np.frombuffer(blob[80:84], dtype="<u4")[0])
+        if len(blob) == 84 + 50 * count:
+            rec = np.frombuffer(blob[84:], dtype=_STL_RECORD, count=count)
+            return _merge_vertices(rec["v"].astype(np.float64))
+    corners = []
+    for line in blob.decode("ascii", errors="replace").splitlines():
+        parts = line.split()
+        if parts[:1] == ["vertex"]:
+            corners.append([float(x) for x in parts[1:4]])
+    if len(corners) % 3:
+        raise ValueError(f"{filename}: ASCII STL with a vertex count that is not a multiple of 3")
+    return _merge_vertices(np.array(corners, dtype=np.float64).reshape(-1, 3, 3))
 
 
 def get_closest_point(mesh, target):
@@ -142,6 +171,33 @@ def hexagonal_mesh(radius=1.0, step_count=10):
                     i1 = ring_index(r - 1, t * (r - 1) + m + 1)
                     faces.append((3, i0, o1, i1))
     return PolyData(np.array(points), np.array(faces, dtype=np.int64).reshape(-1))
+
+
+def sphere(radius=0.5, center=(0, 0, 0), theta_resolution=30, phi_resolution=30):
+    """Latitude/longitude triangulation of a sphere, poles on the z axis (the role of
+    ``pv.Sphere`` in dev/3d_trace.py:32): ``theta_resolution`` meridians,
+    ``phi_resolution`` latitude rings including the two poles.  Outward-facing triangles."""
+    nt, nphi = int(theta_resolution), int(phi_resolution)
+    if nt < 3 or nphi < 3:
+        raise ValueError("sphere: theta_resolution and phi_resolution must be >= 3")
+    theta = np.linspace(0.0, 2 * PI, nt, endpoint=False)
+    phi = np.linspace(0.0, PI, nphi)[1:-1]
+    ring = np.stack([np.outer(np.sin(phi), np.cos(theta)), np.outer(np.sin(phi), np.sin(theta)),
+                     np.outer(np.cos(phi), np.ones(nt))], axis=2).reshape(-1, 3)
+    pts = np.concatenate([[[0.0, 0.0, 1.0]], ring, [[0.0, 0.0, -1.0]]]) * radius
+    pts = pts + np.asarray(center, dtype=np.float64)
+    south = pts.shape[0] - 1
+    at = lambda r, t: 1 + r * nt + (t % nt)
+    faces = []
+    for t in range(nt):
+        faces.append((0, at(0, t), at(0, t + 1)))
+        for r in range(nphi - 3):
+            faces.append((at(r, t), at(r + 1, t), at(r + 1, t + 1)))
+            faces.append((at(r, t), at(r + 1, t + 1), at(r, t + 1)))
+        faces.append((south, at(nphi - 3, t + 1), at(nphi - 3, t)))
+    faces = np.array(faces, dtype=np.int64)
+    cells = np.concatenate([np.full((faces.shape[0], 1), 3, dtype=np.int64), faces], axis=1)
+    return PolyData(pts, cells.reshape(-1))
 
 
 def plane(center=(0, 0, 0), direction=(1, 0, 0), i_size=1.0, j_size=1.0):

@@ -41,3 +41,84 @@ def test_single_pass_example_structure():
     order = torch.argsort(wl[top])
     a = ang[top][order].abs().cpu().numpy()
     assert np.all(np.diff(a) < 0)
+
+
+def _fields(d, names):
+    return {n: d[n].detach().cpu().double() for n in names}
+
+
+def _cmp_sets(engine_set, oracle_set, names, atol):
+    n_engine = engine_set["x_start"].shape[0] if "x_start" in engine_set.keys() else 0
+    n_oracle = oracle_set["x_start"].shape[0] if oracle_set else 0
+    assert n_engine == n_oracle
+    if n_engine == 0:
+        return
+    for n in names:
+        np.testing.assert_allclose(engine_set[n].detach().cpu().double().numpy(),
+                                   oracle_set[n].numpy(), rtol=0, atol=atol, err_msg=n)
+
+
+# float32 ray state re-rounds the ray at each of the (up to 50) bounces and the dead rays are
+# then extended to length 10: the rounding compounds, so the float32 bound here is looser than
+# the 1e-5 of a 3-pass trace; classes, order and counts are still identical
+@pytest.mark.parametrize("ray_dtype,atol", [(torch.float64, 1e-9), (torch.float32, 5e-4)])
+def test_light_guide_example_matches_oracle_over_fifty_bounces(ray_dtype, atol):
+    """dev/light_guide.py counterpart: 2-D wedge, total internal reflection, 50 passes; every
+    class of the ray history equals the float64 restatement of the reference algorithm."""
+    import light_guide
+    from oracle import tracer
+    eng, system = light_guide.main(sample_count=200, max_iterations=50, random=False,
+                                   verbose=False, ray_dtype=ray_dtype)
+    seg = {n: torch.tensor([s[i] for s in light_guide.WEDGE], dtype=torch.float64)
+           for i, n in enumerate(("x_start", "y_start", "x_end", "y_end"))}
+    seg["mat_in"] = torch.ones(3, dtype=torch.int64)
+    seg["mat_out"] = torch.zeros(3, dtype=torch.int64)
+    osys = tracer.System(2, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"]],
+                         optical_segments=seg)
+    names = ("x_start", "y_start", "x_end", "y_end", "wavelength")
+    src = _fields(system._amalgamated_sources, names)
+    if ray_dtype == torch.float32:                      # the engine rounds the source rays too
+        src = {k: (v.float().double() if k != "wavelength" else v) for k, v in src.items()}
+    ref = tracer.ray_trace(osys, src, max_iterations=50, inherit=("wavelength",),
+                           flags={"compile_dead_rays": True, "dead_ray_length": 10})
+    assert eng.active_rays["x_start"].shape[0] > 1000          # many bounces inside the wedge
+    assert eng.dead_rays["x_start"].shape[0] >= 100             # and most rays leak out
+    _cmp_sets(eng.active_rays, ref["active"], names, atol)
+    _cmp_sets(eng.dead_rays, ref["dead"], names, atol)
+    n_unf = ref["unfinished"]["x_start"].shape[0] if ref["unfinished"] else 0
+    unf = eng.unfinished_rays
+    assert (unf["x_start"].shape[0] if "x_start" in unf.keys() else 0) == n_unf
+    # inside the guide the rays stay within the wedge outline
+    act = eng.active_rays
+    inside = act["y_end"].abs() <= 4 + 1e-9
+    assert bool(inside.all())
+
+
+def test_trace_3d_example_matches_oracle(tmp_path):
+    """dev/3d_trace.py counterpart: STL-loaded pyramid + ball + target, dense point source."""
+    import trace_3d
+    from oracle import tracer
+    eng, system, (s1, s2, s3), _ = trace_3d.build(stl_dir=str(tmp_path), ray_dtype=torch.float64)
+    eng.ray_trace(6)
+    assert os.path.getsize(tmp_path / "short_pyramid.stl") == 84 + 50 * 6   # binary STL, 6 facets
+
+    def faces_of(b, optical):
+        f = tracer.faces_from_vertices(b._vertices.detach().cpu(), b._faces[:, 1:])
+        if optical:
+            n = f["xp"].shape[0]
+            f["mat_in"] = torch.ones(n, dtype=torch.int64)
+            f["mat_out"] = torch.zeros(n, dtype=torch.int64)
+        return f
+
+    osys = tracer.System(3, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"]],
+                         optical=tracer.amalgamate([faces_of(s1, True), faces_of(s2, True)]),
+                         target=faces_of(s3, False))
+    names = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end", "wavelength")
+    src = _fields(system._amalgamated_sources, names)
+    assert src["x_start"].shape[0] == 25 * 6
+    ref = tracer.ray_trace(osys, src, max_iterations=6, inherit=("wavelength",),
+                           flags={"compile_dead_rays": True, "dead_ray_length": 10})
+    assert eng.finished_rays["x_start"].shape[0] > 0
+    _cmp_sets(eng.active_rays, ref["active"], names, 1e-9)
+    _cmp_sets(eng.finished_rays, ref["finished"], names, 1e-9)
+    _cmp_sets(eng.dead_rays, ref["dead"], names, 1e-9)

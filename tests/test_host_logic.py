@@ -314,3 +314,42 @@ def test_cylindrical_guide(cpu_backend):
     loss = (sym["xp"] ** 2).sum()
     gp, = torch.autograd.grad(loss, [sym.parameters])
     assert gp.shape == (5,) and float(gp.abs().sum()) > 0
+
+
+def test_stl_binary_and_ascii_round_trip(tmp_path):
+    """boundary.save / file_name= (boundaries.py:859-874 via pyvista): binary STL by default,
+    ASCII on request; topology survives the trip (vertices merged exactly)."""
+    import tfrt.mesh_tools as mt
+    mesh = mt.hexagonal_mesh(1.0, 3)
+    mesh.rotate_y(30)
+    for binary in (True, False):
+        path = str(tmp_path / f"mesh_{binary}.stl")
+        mesh.save(path, binary=binary)
+        back = mt.read(path)
+        assert (back.n_points, back.n_faces) == (mesh.n_points, mesh.n_faces)
+        tol = 1e-6 if binary else 0.0                     # binary STL stores float32
+        assert np.abs(back.points[back.triangles()] - mesh.points[mesh.triangles()]).max() <= tol
+    import os
+    assert os.path.getsize(str(tmp_path / "mesh_True.stl")) == 84 + 50 * mesh.n_faces
+    with open(str(tmp_path / "bad.stl"), "w") as f:
+        f.write("solid x\nvertex 0 0 0\nvertex 1 0 0\nendsolid x\n")
+    with pytest.raises(ValueError):
+        mt.read(str(tmp_path / "bad.stl"))
+
+
+def test_sphere_mesh_is_closed_and_outward():
+    import tfrt.mesh_tools as mt
+    from collections import Counter
+    m = mt.sphere(0.5, (1.0, -2.0, 0.25), theta_resolution=9, phi_resolution=7)
+    assert m.n_points == 2 + 9 * 5 and m.n_faces == 2 * 9 + 2 * 9 * 4
+    np.testing.assert_allclose(np.linalg.norm(m.points - [1.0, -2.0, 0.25], axis=1), 0.5, rtol=1e-12)
+    edges = Counter()
+    for a, b, c in m.triangles():
+        for e in ((a, b), (b, c), (c, a)):
+            edges[frozenset(e)] += 1
+    assert set(edges.values()) == {2}                     # watertight
+    tri = m.points[m.triangles()]
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert (np.sum(n * (tri.mean(1) - [1.0, -2.0, 0.25]), axis=1) > 0).all()
+    with pytest.raises(ValueError):
+        mt.sphere(1.0, theta_resolution=2)
