@@ -15,8 +15,10 @@ SGD_Optimizer.training_routine instead of a hand-written tf.GradientTape loop.  
 """
 import argparse
 import os
+import pickle
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -83,8 +85,41 @@ def build(ray_count=20000, lens_res_scale=0.12, source_distance=10.0, magnificat
                 accumulator=accumulator, smoother=smoother, zero_points=zero_points)
 
 
-def run(ray_count=20000, steps=30, lens_res_scale=0.12, verbose=True):
+def save_parameters(lens, filename, history=None):
+    """Parameter-history file of dev/hexalens.py:305-306, 338-347: a pickled list of
+    ``(first_surface_parameters, second_surface_parameters)`` numpy tuples, one per record."""
+    if history is None:
+        history = [tuple(p.detach().cpu().numpy() for p in lens.parameters)]
+    with open(filename, "wb") as f:
+        pickle.dump(history, f, pickle.HIGHEST_PROTOCOL)
+
+
+def load_parameters(lens, system, filename):
+    """dev/hexalens.py:327-336: restore both surfaces from the last record of a history file."""
+    with open(filename, "rb") as f:
+        history = pickle.load(f)
+    with torch.no_grad():
+        for p, saved in zip(lens.parameters, history[-1]):
+            p.copy_(torch.as_tensor(np.asarray(saved), dtype=p.dtype, device=p.device))
+    system.update()
+    return history
+
+
+def save_meshes(lens, directory):
+    """dev/hexalens.py:322-325: both lens surfaces as STL files."""
+    os.makedirs(directory, exist_ok=True)
+    for surface in lens.surfaces:       # the reference's drawers do this before every redraw
+        surface.update_mesh_from_vertices()
+    lens.surfaces[0].save(os.path.join(directory, "hexalens_first.stl"))
+    lens.surfaces[1].save(os.path.join(directory, "hexalens_second.stl"))
+
+
+def run(ray_count=20000, steps=30, lens_res_scale=0.12, verbose=True, history_file=None,
+        resume_from=None):
     s = build(ray_count, lens_res_scale)
+    parameter_history = []
+    if resume_from:
+        parameter_history = load_parameters(s["lens"], s["system"], resume_from)
     opt = optimizer.SGD_Optimizer(s["engine"], s["lens"].parameters, s["error_function"], 3,
                                   learning_rate=2e-5 * (20000 / ray_count), grad_clip=1.0)
     opt.suppress_warnings = True
@@ -92,6 +127,8 @@ def run(ray_count=20000, steps=30, lens_res_scale=0.12, verbose=True):
 
     def record():
         errors.append(opt.last_error)
+        if history_file and opt.iterations % 10 == 0:       # dev/hexalens.py:294-303
+            parameter_history.append(tuple(p.detach().cpu().numpy() for p in s["lens"].parameters))
 
     # wrap single_step to keep the per-step mean error
     orig = opt.single_step
@@ -109,6 +146,9 @@ def run(ray_count=20000, steps=30, lens_res_scale=0.12, verbose=True):
     ]
     opt.training_routine(routine, post_step=record, report_frequency=5 if verbose else 0,
                          show_time=verbose)
+    if history_file:
+        parameter_history.append(tuple(p.detach().cpu().numpy() for p in s["lens"].parameters))
+        save_parameters(s["lens"], history_file, parameter_history)
     return errors, s
 
 
@@ -117,6 +157,11 @@ if __name__ == "__main__":
     ap.add_argument("--rays", type=int, default=20000)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--edge", type=float, default=0.12)
+    ap.add_argument("--history", default=None, help="write the parameter history (pickle) here")
+    ap.add_argument("--resume", default=None, help="start from the last record of this history")
+    ap.add_argument("--stl-dir", default=None, help="write both optimised surfaces as STL here")
     a = ap.parse_args()
-    errs, _ = run(a.rays, a.steps, a.edge)
+    errs, state = run(a.rays, a.steps, a.edge, history_file=a.history, resume_from=a.resume)
+    if a.stl_dir:
+        save_meshes(state["lens"], a.stl_dir)
     print(f"mean squared image error: first {errs[0]:.6g} -> last {errs[-1]:.6g}")

@@ -26,6 +26,34 @@ def test_hexalens_optimisation_reduces_image_error():
     assert float(p0.max()) > 1e-4                      # and the surfaces actually moved
 
 
+def test_hexalens_history_file_round_trip(tmp_path):
+    """Parameter-history pickle (dev/hexalens.py:305-347) and STL export of the surfaces."""
+    import pickle
+    import hexalens
+    import tensorflowraytrace_amd.mesh_tools as mt
+    hist = str(tmp_path / "hexalens_parameters.dat")
+    errors, s = hexalens.run(ray_count=3000, steps=10, lens_res_scale=0.3, verbose=False,
+                             history_file=hist)
+    with open(hist, "rb") as f:
+        records = pickle.load(f)
+    assert isinstance(records, list) and len(records) == 2        # step 10 + final
+    assert all(isinstance(a, np.ndarray) for rec in records for a in rec)
+    final = [p.detach().cpu().numpy() for p in s["lens"].parameters]
+    for saved, live in zip(records[-1], final):
+        np.testing.assert_array_equal(saved, live)
+    fresh = hexalens.build(3000, 0.3)
+    hexalens.load_parameters(fresh["lens"], fresh["system"], hist)
+    s["system"].update()
+    for a, b in zip(fresh["lens"].parameters, s["lens"].parameters):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=1e-15)
+    hexalens.save_meshes(s["lens"], str(tmp_path / "stl"))
+    back = mt.read(str(tmp_path / "stl" / "hexalens_first.stl"))
+    surf = s["lens"].surfaces[0]
+    assert back.n_faces == surf._faces.shape[0]
+    want = surf._vertices.detach().cpu().numpy()[np.asarray(surf._faces)[:, 1:]]
+    assert np.abs(back.points[back.triangles()] - want).max() < 1e-6   # float32 on disk
+
+
 def test_single_pass_example_structure():
     import single_pass
     engine, new_rays = single_pass.main()
