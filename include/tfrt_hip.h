@@ -130,9 +130,13 @@ typedef struct tfrt_scene3d {
   const uint8_t* face_grad_mask;
   /* (M) i32, optional: a permutation of the face indices that puts spatially close faces next
    * to each other (e.g. Morton order of the centroids).  When given (and M >= 64) the trace
-   * visits faces in clusters of 16 consecutive entries behind a bounding-sphere test and rays
-   * in a sorted, coherent order; results are identical to the all-pairs path (NULL). */
+   * visits faces in clusters of 16 consecutive entries behind a bounding-sphere test (a
+   * two-level conservative filter); results are identical to the all-pairs path (NULL). */
   const int32_t* cluster_order;
+  /* With cluster_order: 0 = rays stay in their natural order, each ray queues the clusters its
+   * line touches (the default fast path); 1 = rays are additionally visited in a sorted,
+   * spatially coherent order and whole wavefronts skip untouched clusters. */
+  int32_t sort_rays;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in

@@ -284,6 +284,62 @@ __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, i
   }
 }
 
+// ------------------------------------------------------------------- float32 screen
+//
+// Second conservative screen between the bounding-sphere filter and the float64 decision: a
+// float32 Moeller-Trumbore evaluation with running error bounds.  Returns false only when
+// exact_triangle() is certain to report "no valid hit" -- or a hit that cannot displace the
+// current nearest one (ray_u certainly above `best`) -- so skipping the float64 test cannot
+// change any result.  A line that passes through a face's bounding sphere usually misses the
+// face itself (or hits it behind the ray's start): most sphere survivors end here, at ~50
+// float32 ops instead of the ~200 float64 ops (three divisions) of the exact sums.
+//
+// Error model: every quantity is a triple product of float32-rounded differences; its
+// absolute error is below K*2^-24 times the product of the factors' 1-norms (K = 16 covers
+// the ~9 roundings of the fma chains plus the three input roundings).
+__device__ __forceinline__ bool may_hit(const double s[3], const double e[3], const double P[9],
+                                        double eps_size, double eps_start, double best) {
+  const float dx = (float)(e[0] - s[0]), dy = (float)(e[1] - s[1]), dz = (float)(e[2] - s[2]);
+  const float ux = (float)(P[3] - P[0]), uy = (float)(P[4] - P[1]), uz = (float)(P[5] - P[2]);
+  const float vx = (float)(P[6] - P[0]), vy = (float)(P[7] - P[1]), vz = (float)(P[8] - P[2]);
+  const float tx = (float)(s[0] - P[0]), ty = (float)(s[1] - P[1]), tz = (float)(s[2] - P[2]);
+  // p = d x e2, q = t x e1
+  const float px = dy * vz - dz * vy, py = dz * vx - dx * vz, pz = dx * vy - dy * vx;
+  const float qx = ty * uz - tz * uy, qy = tz * ux - tx * uz, qz = tx * uy - ty * ux;
+  const float det = ux * px + uy * py + uz * pz;
+  const float bu = tx * px + ty * py + tz * pz;   // trig_u * det
+  const float bv = dx * qx + dy * qy + dz * qz;   // trig_v * det
+  const float bw = vx * qx + vy * qy + vz * qz;   // ray_u  * det
+  const float nd = fabsf(dx) + fabsf(dy) + fabsf(dz);
+  const float n1 = fabsf(ux) + fabsf(uy) + fabsf(uz);
+  const float n2 = fabsf(vx) + fabsf(vy) + fabsf(vz);
+  const float nt = fabsf(tx) + fabsf(ty) + fabsf(tz);
+  const float k = 16.0f * 5.9604644775390625e-08f;
+  const float e_det = k * nd * n1 * n2, e_u = k * nt * nd * n2, e_v = k * nd * nt * n1;
+  const float e_w = k * n2 * nt * n1;
+  const float ad = fabsf(det);
+  if (!(ad > e_det)) return true;  // too close to parallel to decide here (also NaN/inf)
+  const float sg = det > 0.f ? 1.f : -1.f;
+  const float lo = ad - e_det, hi = ad + e_det;
+  const float es = (float)eps_size, er = (float)eps_start;
+  const float su = sg * bu, sv = sg * bv, sw = sg * bw;
+  // trig_u < -eps_size, trig_v < -eps_size
+  const float thr = fminf(-es * lo, -es * hi) - 1e-30f;
+  if (su + e_u < thr) return false;
+  if (sv + e_v < thr) return false;
+  // trig_u + trig_v > 1 + eps_size
+  if (su + sv - e_u - e_v > fmaxf((1.f + es) * lo, (1.f + es) * hi) + 1e-30f) return false;
+  // ray_u < eps_start
+  if (sw + e_w < fminf(er * lo, er * hi) - 1e-30f) return false;
+  // ray_u > best: cannot displace the nearest hit found so far (ties still go to float64)
+  if (best < 3.0e38) {
+    float bf = (float)best;
+    bf = nextafterf(bf, INFINITY);
+    if (sw - e_w > fmaxf(bf * lo, bf * hi) + 1e-30f) return false;
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------- intersect
 
 template <typename T, int R>
@@ -348,6 +404,11 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
       const double* fp = fverts + 9 * (int64_t)j;
 #pragma unroll
       for (int q = 0; q < 9; ++q) P[q] = fp[q];
+      double best = bt[0];
+#pragma unroll
+      for (int rr = 1; rr < R; ++rr)
+        if (rr == r) best = bt[rr];
+      if (!may_hit(s, e, P, eps_size, eps_start, best)) continue;
       const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
       if (h.valid) {
 #pragma unroll
@@ -524,6 +585,11 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_cull(
       const double* fp = fverts + 9 * (int64_t)j;
 #pragma unroll
       for (int q = 0; q < 9; ++q) P[q] = fp[q];
+      double best = bt[0];
+#pragma unroll
+      for (int rr = 1; rr < R; ++rr)
+        if (rr == r) best = bt[rr];
+      if (!may_hit(s, e, P, eps_size, eps_start, best)) continue;
       const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
       if (h.valid) {
 #pragma unroll
@@ -606,6 +672,260 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_cull(
   }
 }
 
+// ---------------------------------------------------------------- grouped intersect
+//
+// Two-level filter in the rays' natural order (no sort).
+//   level 1 (per lane)  : each ray against the bounding spheres of the face clusters (CLUSTER
+//                         faces each: M/16 spheres, the loop that is M spheres long in
+//                         k_intersect3d); clusters a ray's line touches go to the lane's queue.
+//   level 2 (per wave)  : the wave drains its lanes' queues together -- 16 lanes take one
+//                         queued (ray, cluster) and test the cluster's 16 member spheres, one
+//                         each (the 256 B of member spheres are one coalesced read; per-lane
+//                         gathers of them cost 16 uncoalesced loads per candidate and were the
+//                         bottleneck); member hits become (ray, face) pairs.
+//   decision (per wave) : pairs are dealt one per lane: float32 screen, then the exact float64
+//                         test; the nearest hit per ray is kept in LDS with 64-bit atomic min
+//                         on an order-preserving key of ray_u, ties to the lower face index.
+// All filters are conservative, so the float64 stage sees every pair that can win and the
+// results equal those of k_intersect3d.
+__device__ __forceinline__ unsigned long long dkey(double x) {  // monotone double -> u64
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dkey_inv(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+// Ordering point between LDS accesses of ONE wave that communicate across lanes.  The LDS
+// executes a wave's instructions in issue order, so no wait is needed; this only keeps the
+// compiler from moving memory accesses across it.
+__device__ __forceinline__ void wave_fence() {
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(BLOCK) void k_intersect_group(
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, const float4* __restrict__ clsphere,
+    const float4* __restrict__ csphere, const int32_t* __restrict__ cface,
+    const double* __restrict__ fverts, const float* __restrict__ prep, int64_t pstride,
+    int n_clusters, int chunk_clusters, double eps_int, double eps_size, double eps_start,
+    double* __restrict__ part_t, int32_t* __restrict__ part_i, int64_t part_stride) {
+  constexpr int KQ = 4 * R + 8;   // queue slots per lane
+  constexpr int RW = 64 * R;      // rays per wave
+  constexpr int GT = 256;         // cluster spheres per LDS tile
+  const int n = *n_ptr;
+  const int base = blockIdx.x * (BLOCK * R);
+  if (base >= n) return;  // block-uniform
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int c_lo = blockIdx.y * chunk_clusters;
+  const int c_hi = min(n_clusters, c_lo + chunk_clusters);
+
+  __shared__ float4 tile[GT];
+  __shared__ int32_t cand[KQ * BLOCK];
+  __shared__ float prep_l[WAVES][8][RW];
+  __shared__ unsigned long long best_k[WAVES][RW];
+  __shared__ int32_t best_i[WAVES][RW];
+  __shared__ int32_t owners[WAVES][64];
+  __shared__ int32_t pair_slot[WAVES][128];
+  __shared__ int32_t pair_memb[WAVES][128];
+
+  float ax[R], ay[R], az[R], bx[R], by[R], bz[R], nsa[R], nsb[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = base + r * BLOCK + tid;
+    ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
+    nsa[r] = nsb[r] = INFINITY;  // never a candidate
+    if (i < n) {
+      ax[r] = prep[i];
+      ay[r] = prep[pstride + i];
+      az[r] = prep[2 * pstride + i];
+      bx[r] = prep[3 * pstride + i];
+      by[r] = prep[4 * pstride + i];
+      bz[r] = prep[5 * pstride + i];
+      nsa[r] = prep[6 * pstride + i];
+      nsb[r] = prep[7 * pstride + i];
+    }
+    const int slot = r * 64 + lane;
+    prep_l[wave][0][slot] = ax[r];
+    prep_l[wave][1][slot] = ay[r];
+    prep_l[wave][2][slot] = az[r];
+    prep_l[wave][3][slot] = bx[r];
+    prep_l[wave][4][slot] = by[r];
+    prep_l[wave][5][slot] = bz[r];
+    prep_l[wave][6][slot] = nsa[r];
+    prep_l[wave][7][slot] = nsb[r];
+    best_k[wave][slot] = dkey(INFINITY);
+    best_i[wave][slot] = -1;
+  }
+
+  int cnt = 0;
+
+  // One (ray, face) pair per lane: float32 screen, exact float64 test, LDS min per ray.
+  auto decide = [&](const int nb) {
+    bool have = false;
+    unsigned long long key = 0, old = 0;
+    int j = -1, slot = 0;
+    if (lane < nb) {
+      slot = pair_slot[wave][lane];
+      j = cface[pair_memb[wave][lane]];
+      const int i = base + (slot >> 6) * BLOCK + wave * 64 + (slot & 63);
+      old = best_k[wave][slot];
+      if (j >= 0 && (last_tri == nullptr || last_tri[i] != j)) {
+        double s[3], e[3], P[9];
+        load_ray3(rays, stride, i, s, e);
+        const double* fp = fverts + 9 * (int64_t)j;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) P[q] = fp[q];
+        if (may_hit(s, e, P, eps_size, eps_start, dkey_inv(old))) {
+          const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
+          if (h.valid) {
+            have = true;
+            key = dkey(h.ray_u);
+          }
+        }
+      }
+    }
+    wave_fence();
+    if (have) atomicMin(&best_k[wave][slot], key);
+    wave_fence();
+    bool win = false;
+    if (have) {
+      const unsigned long long now = best_k[wave][slot];
+      win = key == now;
+      if (win && now < old) best_i[wave][slot] = 0x7FFFFFFF;  // a nearer hit: restart the tie-break
+    }
+    wave_fence();
+    if (win) atomicMin(&best_i[wave][slot], j);
+    wave_fence();
+  };
+
+  // Drain every lane's queue with the whole wave.
+  auto flush = [&]() {
+#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 1
+    cnt = 0;  // timing experiment only: level 1 alone
+    return;
+#endif
+    int pn = 0;  // pairs waiting in pair_slot / pair_memb (wave-uniform)
+    for (int k = 0;; ++k) {
+      const unsigned long long rowmask = __ballot(cnt > k);
+      if (rowmask == 0ull) break;
+      const int n_row = __popcll(rowmask);
+      if (cnt > k) owners[wave][rank_below(rowmask)] = lane;
+      wave_fence();
+      // 16 queued candidates per step: each 16-lane group takes four, their member spheres
+      // are fetched first (four independent coalesced loads in flight), then tested
+      for (int j0 = 0; j0 < n_row; j0 += 16) {
+        float4 sp[4];
+        int slot[4], memb[4];
+        bool act[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = j0 + 4 * u + (lane >> 4);
+          act[u] = q < n_row;
+          const int own = owners[wave][act[u] ? q : 0];
+          const int v = cand[k * BLOCK + wave * 64 + own];
+          memb[u] = (v >> 2) * CLUSTER + (lane & (CLUSTER - 1));
+          slot[u] = (v & 3) * 64 + own;
+          sp[u] = make_float4(0.f, 0.f, 0.f, -1.f);
+          if (act[u]) sp[u] = csphere[memb[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int sl = slot[u];
+          const float pa = fmaf(sp[u].x, prep_l[wave][0][sl], fmaf(sp[u].y, prep_l[wave][1][sl],
+                                fmaf(sp[u].z, prep_l[wave][2][sl], prep_l[wave][6][sl])));
+          const float pb = fmaf(sp[u].x, prep_l[wave][3][sl], fmaf(sp[u].y, prep_l[wave][4][sl],
+                                fmaf(sp[u].z, prep_l[wave][5][sl], prep_l[wave][7][sl])));
+          const bool hit = act[u] && fmaf(pa, pa, pb * pb) <= sp[u].w;
+          const unsigned long long hm = __ballot(hit);
+#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 2
+          if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
+          continue;
+#endif
+          if (hit) {
+            const int pos = pn + rank_below(hm);
+            pair_slot[wave][pos] = sl;
+            pair_memb[wave][pos] = memb[u];
+          }
+          pn += __popcll(hm);
+          if (pn >= 64) {
+            wave_fence();
+            decide(64);
+            int ts = 0, tm = 0;
+            if (lane < pn - 64) {
+              ts = pair_slot[wave][64 + lane];
+              tm = pair_memb[wave][64 + lane];
+            }
+            wave_fence();
+            if (lane < pn - 64) {
+              pair_slot[wave][lane] = ts;
+              pair_memb[wave][lane] = tm;
+            }
+            pn -= 64;
+            wave_fence();
+          }
+        }
+      }
+    }
+    wave_fence();
+    if (pn > 0) decide(pn);
+    cnt = 0;
+  };
+
+  auto test = [&](const float4 sp, const int cluster) {
+    float q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+      const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+      q[r] = fmaf(pa, pa, pb * pb);
+    }
+    float qmin = q[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) qmin = fminf(qmin, q[r]);
+    if (qmin <= sp.w) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (q[r] <= sp.w) {
+          cand[cnt * BLOCK + tid] = (cluster << 2) | r;
+          ++cnt;
+        }
+      }
+    }
+  };
+
+  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
+  for (int t0 = c_lo; t0 < c_hi; t0 += GT) {
+    const int nt = min(GT, c_hi - t0);
+    const int nt4 = (nt + 3) & ~3;
+    __syncthreads();
+    for (int k = tid; k < nt4; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
+    __syncthreads();
+    for (int j = 0; j < nt4; j += 4) {
+      const float4 s0 = tile[j], s1 = tile[j + 1], s2 = tile[j + 2], s3 = tile[j + 3];
+      test(s0, t0 + j);
+      test(s1, t0 + j + 1);
+      test(s2, t0 + j + 2);
+      test(s3, t0 + j + 3);
+      if (__any(cnt > KQ - 4 * R)) flush();
+    }
+  }
+  flush();
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = base + r * BLOCK + tid;
+    if (i < n) {
+      const int slot = r * 64 + lane;
+      part_t[blockIdx.y * part_stride + i] = dkey_inv(best_k[wave][slot]);
+      part_i[blockIdx.y * part_stride + i] = best_i[wave][slot];
+    }
+  }
+}
+
 // -------------------------------------------------------------------------- classify
 
 __device__ __forceinline__ int cat_to_cls(int cat) {
@@ -625,11 +945,12 @@ __global__ __launch_bounds__(BLOCK) void k_classify3d(
   if (i < n) {
     double bt = INFINITY;
     int bi = -1;
-    for (int c = 0; c < chunks; ++c) {  // ascending faces, strict <: first index wins
+    for (int c = 0; c < chunks; ++c) {  // ties: the lowest face index wins (tf.argmin)
       const double t = part_t[c * part_stride + i];
-      if (t < bt) {
+      const int pi = part_i[c * part_stride + i];
+      if (t < bt || (t == bt && pi >= 0 && pi < bi)) {
         bt = t;
-        bi = part_i[c * part_stride + i];
+        bi = pi;
       }
     }
     cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
@@ -1048,11 +1369,14 @@ int sort_pairs_u32_i32(void* tmp, size_t bytes, const uint32_t* keys_in, uint32_
 
 struct Plan3 {
   int R, ray_blocks, chunks, chunk_faces, nblk;
+  // grouped (two-level) kernel: rays per lane, grid and clusters per chunk
+  int gR, g_blocks, g_chunks, g_chunk_clusters;
 };
 
 // device buffers of the clustered path for one pass (order == nullptr: all-pairs filter)
 struct Accel3 {
   const int32_t* order;
+  bool sort_rays;  // true: Morton-sorted rays + wave-level cluster test; false: grouped kernel
   int n_clusters;
   float4* csphere;
   int32_t* cface;
@@ -1082,6 +1406,23 @@ static Plan3 make_plan(int64_t N, int64_t M) {
   p.chunk_faces = cdiv(M > 0 ? M : 1, chunks);
   p.chunks = cdiv(M > 0 ? M : 1, p.chunk_faces);
   p.nblk = cdiv(N > 0 ? N : 1, BLOCK);
+  // grouped kernel: level 1 is 16x shorter, so favour more workgroups over rays per lane
+  const int n_clusters = cdiv(M > 0 ? M : 1, 16);
+  p.gR = (N >= (1 << 21)) ? 4 : (N >= (1 << 19) ? 2 : 1);
+  if (const char* env = getenv("TFRT_GROUP_RAYS_PER_LANE")) {
+    const int r = atoi(env);
+    if (r == 1 || r == 2 || r == 4) p.gR = r;
+  }
+  p.g_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.gR);
+  int gtarget = 2048;
+  if (const char* env = getenv("TFRT_GROUP_TARGET_BLOCKS")) gtarget = atoi(env) > 0 ? atoi(env) : gtarget;
+  int gch = cdiv(gtarget, p.g_blocks);
+  const int gmax = cdiv(n_clusters, 64);       // at least 64 clusters (1024 faces) per chunk
+  if (gch > gmax) gch = gmax;
+  if (gch > p.chunks) gch = p.chunks;           // part_t / part_i are sized for p.chunks
+  if (gch < 1) gch = 1;
+  p.g_chunk_clusters = cdiv(n_clusters, gch);
+  p.g_chunks = cdiv(n_clusters, p.g_chunk_clusters);
   return p;
 }
 
@@ -1146,7 +1487,9 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                             const double* fverts, const double* c0, float* prep, int64_t pstride,
                             int M, double ei, double es, double er, double* part_t,
                             int32_t* part_i, int64_t part_stride, const Accel3* ac, int n_cap) {
-  const bool clustered = ac != nullptr && ac->order != nullptr;
+  const bool accel = ac != nullptr && ac->order != nullptr;
+  const bool clustered = accel && ac->sort_rays;
+  const bool grouped = accel && !ac->sort_rays;
   hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
                      prep, pstride, clustered ? ac->keys_in : nullptr,
                      clustered ? ac->vals_in : nullptr, n_cap);
@@ -1156,8 +1499,9 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
       return TFRT_E_LAUNCH;
   }
   const int Rc = 1;  // rays per lane in the clustered kernel
-  dim3 grid(clustered ? cdiv(n_cap > 0 ? n_cap : 1, BLOCK * Rc) : pl.ray_blocks,
-            clustered ? 1 : pl.chunks);
+  dim3 grid(pl.ray_blocks, pl.chunks);
+  if (clustered) grid = dim3(cdiv(n_cap > 0 ? n_cap : 1, BLOCK * Rc), 1);
+  if (grouped) grid = dim3(pl.g_blocks, pl.g_chunks);
   ProfRec rec;
   if (g_prof_on) {
     (void)hipEventCreate(&rec.a);
@@ -1171,12 +1515,18 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     hipLaunchKernelGGL((k_intersect_cull<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,      \
                        n_ptr, last_tri, ac->rperm, ac->clsphere, ac->csphere, ac->cface,       \
                        fverts, prep, pstride, ac->n_clusters, ei, es, er, part_t, part_i);     \
+  else if (grouped)                                                                            \
+    hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
+                       n_ptr, last_tri, ac->clsphere, ac->csphere, ac->cface, fverts, prep,    \
+                       pstride, ac->n_clusters, pl.g_chunk_clusters, ei, es, er, part_t,       \
+                       part_i, part_stride);                                                   \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
                        part_t, part_i, part_stride)
-  if (clustered || pl.R == 1) { TFRT_LAUNCH_R(1); }
-  else if (pl.R == 4) { TFRT_LAUNCH_R(4); }
+  const int Ruse = clustered ? 1 : (grouped ? pl.gR : pl.R);
+  if (Ruse == 1) { TFRT_LAUNCH_R(1); }
+  else if (Ruse == 4) { TFRT_LAUNCH_R(4); }
   else { TFRT_LAUNCH_R(2); }
 #undef TFRT_LAUNCH_R
   if (g_prof_on) {
@@ -1228,6 +1578,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail);
   Accel3 ac;
   ac.order = (M >= 4 * CLUSTER) ? sc->cluster_order : nullptr;
+  ac.sort_rays = sc->sort_rays != 0;
   ac.n_clusters = cdiv(M > 0 ? M : 1, CLUSTER);
   ac.csphere = reinterpret_cast<float4*>(ws + lay.csphere);
   ac.cface = reinterpret_cast<int32_t*>(ws + lay.cface);
@@ -1248,7 +1599,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,
                          c0, sc->size_epsilion, sphere);
   }
-  const int chunks_used = ac.order != nullptr ? 1 : pl.chunks;
+  const int chunks_used = ac.order == nullptr ? pl.chunks : (ac.sort_rays ? 1 : pl.g_chunks);
   const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};
   for (int p = 0; p < P; ++p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
@@ -1313,7 +1664,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // but a small loss at 1M rays x 10574 faces, where plain scattered atomics are cheaper.
   const bool sorted = M > 0 && N >= 65536 && N / M >= 512;
   // the clustered forward left its Morton ray order in rperm: coherent enough to aggregate
-  const bool coherent = sc->cluster_order != nullptr && M >= 4 * CLUSTER;
+  const bool coherent = sc->cluster_order != nullptr && sc->sort_rays != 0 && M >= 4 * CLUSTER;
   int key_bits = 1;
   while ((1ll << key_bits) < (long long)M + 2) ++key_bits;
   const size_t n = N > 0 ? N : 1;

@@ -355,7 +355,7 @@ class OpticalSystem3D(OpticalSystemBase):
                 mat_out=col("mat_out", torch.int32), n_in=col("n_in", torch.float64),
                 n_out=col("n_out", torch.float64), face_grad_mask=gmask))
 
-    def scene_args(self, n_table, index_mode, ghost=False, cluster=False):
+    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False):
         s = self._scene_cache[1]
         order = None
         if cluster:
@@ -363,11 +363,11 @@ class OpticalSystem3D(OpticalSystemBase):
             # (faces move a little every step, the clusters' bounding spheres are recomputed
             # from the current vertices inside every trace, so a stale order is still exact)
             if s.get("cluster_order") is None:
-                s["cluster_order"] = ops.morton_order(self._merged_face_verts)
+                s["cluster_order"] = ops.cluster_order(self._merged_face_verts)
             order = s["cluster_order"]
         kw = dict(intersect_epsilion=self.intersect_epsilion, size_epsilion=self.size_epsilion,
                   ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"],
-                  cluster_order=order)
+                  cluster_order=order, sort_rays=bool(sort_rays and order is not None))
         if ghost:
             ones = torch.ones(s["catagory"].shape[0], dtype=torch.float64, device=s["catagory"].device)
             return ops.Scene3DArgs(self._merged_face_verts, s["catagory"], n_in=ones, n_out=ones, **kw)
@@ -483,7 +483,7 @@ class OpticalSystem2D(OpticalSystemBase):
         self._merged_arcs = self._merge_kind(
             "arcs", ("x_center", "y_center", "angle_start", "angle_end", "radius"))
 
-    def scene_args(self, n_table, index_mode, ghost=False, cluster=False):
+    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False):
         return ops.Scene2DArgs(self._merged_segments, self._merged_arcs, n_table, index_mode,
                                ghost, self.intersect_epsilion, self.size_epsilion,
                                self.ray_start_epsilion)
@@ -524,7 +524,7 @@ class OpticalEngine:
                  compile_dead_rays=False, compile_finished_rays=True, compile_active_rays=True,
                  dead_ray_length=None, compile_geometry_specific_result=False,
                  new_ray_length=1.0, simple_ray_inheritance={"wavelength"}, ray_dtype=None,
-                 ray_shard="auto", accelerate=False):
+                 ray_shard="auto", accelerate="auto"):
         if dimension not in (2, 3):
             raise ValueError(f"RayEngine: dimension must be 2 or 3, but was given {dimension}.")
         self._dimension = dimension
@@ -543,9 +543,15 @@ class OpticalEngine:
         # (rank, world_size): trace only this rank's contiguous block of the source rays;
         # "auto" = follow torch.distributed when a process group is up; None = all rays.
         self.ray_shard = ray_shard
-        # True: 3-D traces sort the rays and visit faces in spatial clusters behind a
-        # bounding-sphere test (identical results, far fewer filter evaluations).  False
-        # (default): every ray-face pair goes through the float32 filter.
+        # How a 3-D trace culls ray-face pairs before the exact float64 decision.  Every mode
+        # gives identical results (all filters are conservative):
+        #   False / "all-pairs": every pair goes through the float32 bounding-sphere filter;
+        #   "group": faces in spatial clusters of 16 behind a cluster bounding sphere, rays in
+        #            their natural order (two-level filter, ~16x fewer level-1 tests);
+        #   True / "sort": as "group" plus Morton-sorted rays, whole wavefronts skip clusters;
+        #   "auto" (default): "group" once the merged scene has >= 64 faces.
+        if accelerate not in (False, True, None, "all-pairs", "group", "sort", "auto"):
+            raise ValueError(f"OpticalEngine: unknown accelerate mode {accelerate!r}")
         self.accelerate = accelerate
         # When True, ray_trace() does not wait for the per-class ray counts: it cuts the output
         # sets with the counts of the previous trace of the same shape and leaves the check to
@@ -677,6 +683,18 @@ class OpticalEngine:
                         f"{set(rays.keys())}, but needed {required}.")
 
     # ------------------------------------------------------------------------- history
+    def _trace_mode(self, system=None):
+        a = self.accelerate
+        if a in (False, None, "all-pairs") or self._dimension != 3:
+            return "all-pairs"
+        if a in (True, "sort"):
+            return "sort"
+        if a == "group":
+            return "group"
+        fv = getattr(system if system is not None else self._optical_system,
+                     "_merged_face_verts", None)
+        return "group" if (fv is not None and fv.shape[0] >= 64) else "all-pairs"
+
     def clear_ray_history(self):
         self._history = {c: [] for c in _CLASSES}
         self._unfinished_rays = {}
@@ -728,7 +746,12 @@ class OpticalEngine:
             block = torch.stack([rays[f] for f in geo]).to(dt)
             n_table = system.material_table(rays["wavelength"].detach()) if index_mode else None
             self._input_cache = (key, block, n_table, [rays[f] for f in geo])
-        scene = system.scene_args(n_table, index_mode, ghost, cluster=bool(self.accelerate))
+        mode = self._trace_mode(system)
+        if self.dimension == 3:
+            scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
+                                      sort_rays=mode == "sort")
+        else:
+            scene = system.scene_args(n_table, index_mode, ghost)
         if self.dimension == 3:
             fv = system._merged_face_verts
             if fv is None:

@@ -150,7 +150,8 @@ class Scene3DArgs:
 
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
-                 ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None):
+                 ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None,
+                 sort_rays=False):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -159,7 +160,8 @@ class Scene3DArgs:
         self.n_out = _c(n_out, torch.float64)
         self.n_table = _c(n_table, torch.float64)  # (n_materials, N)
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
-        self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: clustered path
+        self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
+        self.sort_rays = bool(sort_rays)                       # + Morton-sorted rays
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -184,6 +186,7 @@ class Scene3DArgs:
         if co is not None and co.numel() != M:
             raise TfrtError("cluster_order must be a permutation of the M face indices")
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
+        sc.sort_rays = 1 if self.sort_rays else 0
         return sc
 
 
@@ -406,6 +409,33 @@ def morton_order(face_verts):
 
     key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
     return torch.argsort(key, stable=True).to(torch.int32)
+
+
+def cluster_order(face_verts, leaf=16):
+    """Permutation of the faces that makes every run of ``leaf`` consecutive entries a compact
+    patch: recursive median split of the face centroids along the longest axis of their
+    bounding box (left part a multiple of ``leaf``) down to parts of <= ``leaf`` faces.  Pass it
+    as ``cluster_order``.  Unlike a Morton order there are no space-filling-curve jumps inside
+    a run, so the clusters' bounding spheres stay small (measured on the cfg4 lens: 10 cluster
+    hits per ray instead of 17).  Host-side numpy, once per mesh topology (2 s for 1e6 faces)."""
+    fv = face_verts.detach().to("cpu", torch.float64).numpy()
+    cent = (fv[:, 0:3] + fv[:, 3:6] + fv[:, 6:9]) / 3.0
+    n = cent.shape[0]
+    out = np.empty(n, dtype=np.int64)
+    stack = [(np.arange(n), 0)]
+    while stack:
+        idx, at = stack.pop()
+        m = idx.size
+        if m <= leaf:
+            out[at:at + m] = idx
+            continue
+        c = cent[idx]
+        axis = int(np.argmax(c.max(0) - c.min(0)))
+        n_left = leaf * (((m + leaf - 1) // leaf) // 2)
+        part = np.argpartition(c[:, axis], n_left - 1)
+        stack.append((idx[part[n_left:]], at + n_left))
+        stack.append((idx[part[:n_left]], at))
+    return torch.as_tensor(out, dtype=torch.int32, device=face_verts.device)
 
 
 def snell3d(x_start, y_start, z_start, x_end, y_end, z_end, norm, n_in, n_out, new_ray_length):

@@ -38,9 +38,13 @@ def _gpu_scene(scene, dtype, p_f=None, p_b=None, masks=(None, None), cluster=Fal
     wl = torch.tensor(scene["wavelength"], dtype=torch.float64)
     n_table = torch.stack([tracer.MATERIALS["vacuum"](wl), tracer.MATERIALS["acrylic"](wl)]).to(dev)
     gmask = (cat == 0).to(torch.uint8)  # the target plane is a constant
+    # cluster: False = all-pairs filter; True / "group" = two-level filter (k-d clusters);
+    # "group-morton" = same with a Morton face order; "sort" = clusters + sorted rays
+    order = None
+    if cluster:
+        order = ops.morton_order(fv) if cluster == "group-morton" else ops.cluster_order(fv)
     sc = ops.Scene3DArgs(fv, cat, mat_in=mat_in, mat_out=mat_out, n_table=n_table,
-                         face_grad_mask=gmask,
-                         cluster_order=ops.morton_order(fv) if cluster else None)
+                         face_grad_mask=gmask, cluster_order=order, sort_rays=cluster == "sort")
     src = tt(scene["rays"], dtype)
     return src, fv, sc, (p_f, p_b)
 
@@ -198,13 +202,15 @@ def test_empty_and_degenerate_inputs():
     assert out["finished"].shape[1] + out["dead"].shape[1] + out["unfinished"].shape[1] == 1
 
 
+@pytest.mark.parametrize("mode", ["group", "group-morton", "sort"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-5)])
-def test_clustered_path_matches_oracle_and_all_pairs(dtype, tol):
-    """cluster_order given: rays sorted, faces visited in clusters -- identical results."""
+def test_clustered_path_matches_oracle_and_all_pairs(dtype, tol, mode):
+    """cluster_order given (two-level filter, with or without sorted rays): results identical
+    to the all-pairs filter, bit for bit."""
     from tensorflowraytrace_amd import ops, _lib
     scene = scene_util.lens_scene(5000, k_front=8, k_back=6)
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD
-    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster=True)
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster=mode)
     assert fv.shape[0] >= 64
     out = ops.trace3d(src, fv, sc, max_passes=5, flags=flags)
     src2, fv2, sc2, (q_f, q_b) = _gpu_scene(scene, dtype, cluster=False)
@@ -231,3 +237,30 @@ def test_clustered_path_matches_oracle_and_all_pairs(dtype, tol):
     for a, b in zip(ga, gb):
         rel = float((a - b).abs().max() / b.abs().max())
         assert rel < 1e-11, rel
+
+
+@pytest.mark.parametrize("n_rays", [3000, 70000])
+def test_ties_go_to_the_lowest_face_index_in_every_trace_mode(n_rays):
+    """tf.argmin picks the first index among equal ray_u (engine.py:1148).  Every face of the
+    scene appears twice (index j and j + M): each hit is an exact tie, and all three kernels
+    must report the lower copy although the clustered ones visit faces out of index order.
+    One pass only: a ray leaving face j would immediately hit its twin j + M."""
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(n_rays, k_front=8, k_back=6)
+    src, fv, sc, _ = _gpu_scene(scene, torch.float32)
+    M = fv.shape[0]
+    fv2 = torch.cat([fv, fv]).detach()
+    dup = lambda t: torch.cat([t, t])
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD
+    single = ops.trace3d(src, fv.detach(), sc, max_passes=1, flags=flags)
+    assert single["active"].shape[1] > 0.8 * n_rays
+    for mode in (False, "group", "sort"):
+        order = ops.cluster_order(fv2) if mode else None
+        sc2 = ops.Scene3DArgs(fv2, dup(sc.catagory), mat_in=dup(sc.mat_in), mat_out=dup(sc.mat_out),
+                              n_table=sc.n_table, cluster_order=order, sort_rays=mode == "sort")
+        o = ops.trace3d(src, fv2, sc2, max_passes=1, flags=flags)
+        assert int(o["active_face"].max()) < M, mode
+        for cls in ("active", "dead"):
+            assert torch.equal(o[cls + "_face"], single[cls + "_face"]), mode
+            assert torch.equal(o[cls], single[cls]), mode
+        assert torch.equal(o["unfinished"], single["unfinished"]), mode
