@@ -1188,7 +1188,8 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     const double* __restrict__ g_act, int64_t cap_act, const double* __restrict__ g_stp,
     int64_t cap_stp, const double* __restrict__ g_dead, int64_t cap_dead,
     double* __restrict__ g_out, int64_t out_stride, double* __restrict__ g_fverts,
-    const int32_t* __restrict__ rperm) {
+    const int32_t* __restrict__ rperm, double* __restrict__ stash_g,
+    int32_t* __restrict__ stash_face) {
   const int n = *n_ptr;
   const int q0 = blockIdx.x * BLOCK + threadIdx.x;
   if (rperm != nullptr) {
@@ -1227,12 +1228,64 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
                                   rec_slot, pass_counts, sc, L, dead_len, g_child, child_stride,
                                   g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead,
                                   g_out, out_stride, gP);
+  if (stash_face != nullptr) {
+    // face gradients are summed by k_face_accumulate: leave this ray's 9 terms and its face
+    stash_face[i] = tri;
+    if (tri >= 0) {
+      double* o = stash_g + 9 * (int64_t)i;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) o[c] = (gP[c] == gP[c]) ? gP[c] : 0.0;  // NaN -> 0
+    }
+    return;
+  }
   if (tri >= 0) {
     double* gp = g_fverts + 9 * (int64_t)tri;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
+#ifdef TFRT_ABLATE_BWD_ATOMICS
+      if (gP[c] == 12345.678) gp[c] = gP[c];  // timing experiment only: no accumulation
+#else
       if (gP[c] == gP[c]) unsafeAtomicAdd(gp + c, gP[c]);  // drop NaN like optimizer.py:229
+#endif
     }
+  }
+}
+
+// Sums the per-ray face-gradient terms left by k_backward3d into g_fverts without hammering
+// memory with contended float64 atomics (9 per ray, up to thousands of rays per face: 93 % of
+// the reverse sweep before).  blockIdx.y owns a window of FACE_WINDOW faces whose 9 sums live
+// in LDS, blockIdx.x a chunk of ray slots; rays that hit a face of the window add their terms
+// with LDS atomics, and the window is flushed once per block.
+constexpr int FACE_WINDOW = 1024;
+
+__global__ __launch_bounds__(1024) void k_face_accumulate(
+    const int32_t* __restrict__ n_ptr, const int32_t* __restrict__ stash_face,
+    const double* __restrict__ stash_g, int chunk, int M, double* __restrict__ g_fverts) {
+  __shared__ double acc[FACE_WINDOW * 9];
+  const int n = *n_ptr;
+  const int lo = blockIdx.x * chunk;
+  if (lo >= n) return;  // block-uniform
+  const int hi = min(n, lo + chunk);
+  const int w0 = blockIdx.y * FACE_WINDOW;
+  const int w1 = min(M, w0 + FACE_WINDOW);
+  for (int k = threadIdx.x; k < FACE_WINDOW * 9; k += 1024) acc[k] = 0.0;
+  __syncthreads();
+  for (int i = lo + threadIdx.x; i < hi; i += 1024) {
+    const int t = stash_face[i];
+    if (t >= w0 && t < w1) {
+      const double* g = stash_g + 9 * (int64_t)i;
+      double* a = acc + 9 * (t - w0);
+#pragma unroll
+      for (int c = 0; c < 9; ++c) {
+        const double v = g[c];
+        if (v != 0.0) unsafeAtomicAdd(a + c, v);
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < (w1 - w0) * 9; k += 1024) {
+    const double v = acc[k];
+    if (v != 0.0) unsafeAtomicAdd(g_fverts + 9 * (int64_t)w0 + k, v);
   }
 }
 
@@ -1429,7 +1482,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, part_t, part_i, prep;
   size_t csphere, cface, clsphere, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
-  size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, total;
+  size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, total;
 };
 
 static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& pl) {
@@ -1468,6 +1521,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.rec_t = take((size_t)P * n * sizeof(double));
   L.rec_cls = take((size_t)P * n);
   L.gbuf = take((size_t)2 * 6 * n * sizeof(double));
+  L.stash_g = take((size_t)9 * n * sizeof(double));
   L.total = o;
   return L;
 }
@@ -1668,6 +1722,15 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   int key_bits = 1;
   while ((1ll << key_bits) < (long long)M + 2) ++key_bits;
   const size_t n = N > 0 ? N : 1;
+  // Windowed LDS accumulation of the face gradients (k_face_accumulate): every window block
+  // scans its chunk's face ids, so it is used while the windows are few; beyond that faces are
+  // so many that scattered atomics see little contention anyway.
+  const int windows = cdiv(M > 0 ? M : 1, FACE_WINDOW);
+  const bool stash = M > 0 && N >= 16384 && windows <= 32 && !coherent;
+  double* stash_g = reinterpret_cast<double*>(ws + lay.stash_g);
+  int32_t* stash_face = vals_in;
+  int acc_chunk = 4096;
+  while ((int64_t)cdiv(N, acc_chunk) * windows > 1024) acc_chunk *= 2;
   for (int p = P - 1; p >= 0; --p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
     const int64_t sin = p == 0 ? src_stride : (int64_t)n;
@@ -1675,7 +1738,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     const double* g_child = (p == P - 1) ? nullptr : gbuf + (size_t)((p + 1) & 1) * 6 * n;
     double* g_out = (p == 0 && g_src != nullptr) ? g_src : gbuf + (size_t)(p & 1) * 6 * n;
     const int64_t out_stride = (p == 0 && g_src != nullptr) ? N : (int64_t)n;
-    if (sorted) {
+    if (sorted && !stash) {
       hipLaunchKernelGGL(k_bwd_keys, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p,
                          rec_tri + (size_t)p * n, M, keys_in, vals_in, (int)N);
       if (sort_pairs_u32_i32(ws + lay.sort_tmp, lay.sort_bytes, keys_in, keys_out, vals_in,
@@ -1688,7 +1751,11 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
                        cap_dead, g_out, out_stride, g_fverts,
-                       (sorted || coherent) ? rperm_all + (size_t)p * n : nullptr);
+                       ((sorted && !stash) || coherent) ? rperm_all + (size_t)p * n : nullptr,
+                       stash ? stash_g : nullptr, stash ? stash_face : nullptr);
+    if (stash)
+      hipLaunchKernelGGL(k_face_accumulate, dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
+                         nrays + p, stash_face, stash_g, acc_chunk, M, g_fverts);
   }
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
