@@ -213,6 +213,44 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
   }
 }
 
+// Level 0 of the grouped filter: one bounding sphere per SUPER consecutive clusters (with a
+// k-d face order every aligned run of SUPER * CLUSTER faces is one subtree, i.e. one patch).
+constexpr int SUPER = 8;
+
+__global__ __launch_bounds__(BLOCK) void k_super_spheres(const float4* __restrict__ clsphere,
+                                                         int n_clusters, int n_super,
+                                                         float4* __restrict__ susphere) {
+  const int s = blockIdx.x * BLOCK + threadIdx.x;
+  if (s >= n_super) return;
+  double mean[3] = {0, 0, 0};
+  int cnt = 0;
+  for (int g = 0; g < SUPER; ++g) {
+    const int c = s * SUPER + g;
+    if (c >= n_clusters) break;
+    const float4 sp = clsphere[c];
+    if (!(sp.w >= 0.f)) continue;
+    mean[0] += sp.x; mean[1] += sp.y; mean[2] += sp.z;
+    ++cnt;
+  }
+  if (cnt == 0) {
+    susphere[s] = make_float4(0.f, 0.f, 0.f, -1.f);
+    return;
+  }
+  for (int q = 0; q < 3; ++q) mean[q] /= cnt;
+  double R = 0.0;
+  for (int g = 0; g < SUPER; ++g) {
+    const int c = s * SUPER + g;
+    if (c >= n_clusters) break;
+    const float4 sp = clsphere[c];
+    if (!(sp.w >= 0.f)) continue;
+    const double d[3] = {sp.x - mean[0], sp.y - mean[1], sp.z - mean[2]};
+    R = fmax(R, sqrt(dot3(d, d)) + sqrt((double)sp.w));  // sp.w = r^2, already rounded up
+  }
+  const double cn = sqrt(dot3(mean, mean));
+  R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
+  susphere[s] = pack_sphere(mean, R);
+}
+
 // ---------------------------------------------------------------------- ray filter state
 
 // Per ray and pass, once: the float32 filter state (an orthonormal pair (a, b) spanning the
@@ -707,12 +745,13 @@ __device__ __forceinline__ void wave_fence() {
 template <typename T, int R>
 __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
-    const int32_t* __restrict__ last_tri, const float4* __restrict__ clsphere,
-    const float4* __restrict__ csphere, const int32_t* __restrict__ cface,
-    const double* __restrict__ fverts, const float* __restrict__ prep, int64_t pstride,
-    int n_clusters, int chunk_clusters, double eps_int, double eps_size, double eps_start,
-    double* __restrict__ part_t, int32_t* __restrict__ part_i, int64_t part_stride) {
-  constexpr int KQ = 4 * R + 8;   // queue slots per lane
+    const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
+    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
+    const int32_t* __restrict__ cface, const double* __restrict__ fverts,
+    const float* __restrict__ prep, int64_t pstride, int n_clusters, int chunk_clusters,
+    double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
+    int32_t* __restrict__ part_i, int64_t part_stride) {
+  constexpr int KQ = 16;          // queue slots per lane (one supercluster can add SUPER)
   constexpr int RW = 64 * R;      // rays per wave
   constexpr int GT = 256;         // cluster spheres per LDS tile
   const int n = *n_ptr;
@@ -723,12 +762,13 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   const int c_lo = blockIdx.y * chunk_clusters;
   const int c_hi = min(n_clusters, c_lo + chunk_clusters);
 
-  __shared__ float4 tile[GT];
-  __shared__ int32_t cand[KQ * BLOCK];
-  __shared__ float prep_l[WAVES][8][RW];
+  __shared__ float4 tile[GT];                // cluster spheres of the current tile
+  __shared__ float4 stile[GT / SUPER];       // their superclusters' spheres
+  __shared__ int32_t cand[WAVES][KQ][64];   // per-lane queues; compacted in place by flush()
+  __shared__ float4 prep_a[WAVES][RW];       // (a, -s.a) of the wave's rays
+  __shared__ float4 prep_b[WAVES][RW];       // (b, -s.b)
   __shared__ unsigned long long best_k[WAVES][RW];
   __shared__ int32_t best_i[WAVES][RW];
-  __shared__ int32_t owners[WAVES][64];
   __shared__ int32_t pair_slot[WAVES][128];
   __shared__ int32_t pair_memb[WAVES][128];
 
@@ -749,14 +789,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       nsb[r] = prep[7 * pstride + i];
     }
     const int slot = r * 64 + lane;
-    prep_l[wave][0][slot] = ax[r];
-    prep_l[wave][1][slot] = ay[r];
-    prep_l[wave][2][slot] = az[r];
-    prep_l[wave][3][slot] = bx[r];
-    prep_l[wave][4][slot] = by[r];
-    prep_l[wave][5][slot] = bz[r];
-    prep_l[wave][6][slot] = nsa[r];
-    prep_l[wave][7][slot] = nsb[r];
+    prep_a[wave][slot] = make_float4(ax[r], ay[r], az[r], nsa[r]);
+    prep_b[wave][slot] = make_float4(bx[r], by[r], bz[r], nsb[r]);
     best_k[wave][slot] = dkey(INFINITY);
     best_i[wave][slot] = -1;
   }
@@ -808,65 +842,78 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     cnt = 0;  // timing experiment only: level 1 alone
     return;
 #endif
+    // 1. compact the lanes' queues into one list (in place, through registers): entry =
+    //    cluster << 8 | ray slot of the wave
+    int32_t* list = &cand[wave][0][0];
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int up = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += up;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (total == 0) return;
+    const int first = incl - cnt;
+    int32_t mine[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) mine[k] = cand[wave][k][lane];
+    wave_fence();
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+      if (k < cnt) list[first + k] = ((mine[k] >> 2) << 8) | ((mine[k] & 3) << 6) | lane;
+    wave_fence();
+    // 2. member tests, 16 queued candidates per step: each 16-lane group takes four; the
+    //    member spheres are fetched first (four independent coalesced loads in flight)
     int pn = 0;  // pairs waiting in pair_slot / pair_memb (wave-uniform)
-    for (int k = 0;; ++k) {
-      const unsigned long long rowmask = __ballot(cnt > k);
-      if (rowmask == 0ull) break;
-      const int n_row = __popcll(rowmask);
-      if (cnt > k) owners[wave][rank_below(rowmask)] = lane;
-      wave_fence();
-      // 16 queued candidates per step: each 16-lane group takes four, their member spheres
-      // are fetched first (four independent coalesced loads in flight), then tested
-      for (int j0 = 0; j0 < n_row; j0 += 16) {
-        float4 sp[4];
-        int slot[4], memb[4];
-        bool act[4];
+    for (int q0 = 0; q0 < total; q0 += 16) {
+      float4 sp[4];
+      int slot[4], memb[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int q = j0 + 4 * u + (lane >> 4);
-          act[u] = q < n_row;
-          const int own = owners[wave][act[u] ? q : 0];
-          const int v = cand[k * BLOCK + wave * 64 + own];
-          memb[u] = (v >> 2) * CLUSTER + (lane & (CLUSTER - 1));
-          slot[u] = (v & 3) * 64 + own;
-          sp[u] = make_float4(0.f, 0.f, 0.f, -1.f);
-          if (act[u]) sp[u] = csphere[memb[u]];
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + 4 * u + (lane >> 4);
+        sp[u] = make_float4(0.f, 0.f, 0.f, -1.f);  // never hit
+        slot[u] = 0;
+        memb[u] = 0;
+        if (q < total) {
+          const int v = list[q];
+          slot[u] = v & 255;
+          memb[u] = (v >> 8) * CLUSTER + (lane & (CLUSTER - 1));
+          sp[u] = csphere[memb[u]];
         }
+      }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int sl = slot[u];
-          const float pa = fmaf(sp[u].x, prep_l[wave][0][sl], fmaf(sp[u].y, prep_l[wave][1][sl],
-                                fmaf(sp[u].z, prep_l[wave][2][sl], prep_l[wave][6][sl])));
-          const float pb = fmaf(sp[u].x, prep_l[wave][3][sl], fmaf(sp[u].y, prep_l[wave][4][sl],
-                                fmaf(sp[u].z, prep_l[wave][5][sl], prep_l[wave][7][sl])));
-          const bool hit = act[u] && fmaf(pa, pa, pb * pb) <= sp[u].w;
-          const unsigned long long hm = __ballot(hit);
+      for (int u = 0; u < 4; ++u) {
+        const float4 fa = prep_a[wave][slot[u]], fb = prep_b[wave][slot[u]];
+        const float pa = fmaf(sp[u].x, fa.x, fmaf(sp[u].y, fa.y, fmaf(sp[u].z, fa.z, fa.w)));
+        const float pb = fmaf(sp[u].x, fb.x, fmaf(sp[u].y, fb.y, fmaf(sp[u].z, fb.z, fb.w)));
+        const bool hit = fmaf(pa, pa, pb * pb) <= sp[u].w;
+        const unsigned long long hm = __ballot(hit);
 #if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 2
-          if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
-          continue;
+        if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
+        continue;
 #endif
-          if (hit) {
-            const int pos = pn + rank_below(hm);
-            pair_slot[wave][pos] = sl;
-            pair_memb[wave][pos] = memb[u];
+        if (hm == 0ull) continue;
+        if (hit) {
+          const int pos = pn + rank_below(hm);
+          pair_slot[wave][pos] = slot[u];
+          pair_memb[wave][pos] = memb[u];
+        }
+        pn += __popcll(hm);
+        if (pn >= 64) {
+          wave_fence();
+          decide(64);
+          int ts = 0, tm = 0;
+          if (lane < pn - 64) {
+            ts = pair_slot[wave][64 + lane];
+            tm = pair_memb[wave][64 + lane];
           }
-          pn += __popcll(hm);
-          if (pn >= 64) {
-            wave_fence();
-            decide(64);
-            int ts = 0, tm = 0;
-            if (lane < pn - 64) {
-              ts = pair_slot[wave][64 + lane];
-              tm = pair_memb[wave][64 + lane];
-            }
-            wave_fence();
-            if (lane < pn - 64) {
-              pair_slot[wave][lane] = ts;
-              pair_memb[wave][lane] = tm;
-            }
-            pn -= 64;
-            wave_fence();
+          wave_fence();
+          if (lane < pn - 64) {
+            pair_slot[wave][lane] = ts;
+            pair_memb[wave][lane] = tm;
           }
+          pn -= 64;
+          wave_fence();
         }
       }
     }
@@ -875,42 +922,49 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     cnt = 0;
   };
 
-  auto test = [&](const float4 sp, const int cluster) {
-    float q[R];
+  static_assert(GT / SUPER == 32, "one 32-bit supercluster mask per ray and tile");
+  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
+  for (int t0 = c_lo; t0 < c_hi; t0 += GT) {  // c_lo is a multiple of SUPER
+    const int nt = min(GT, c_hi - t0);
+    const int ns = (nt + SUPER - 1) / SUPER;
+    __syncthreads();
+    for (int k = tid; k < ns * SUPER; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
+    if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
+    __syncthreads();
+    // level 0: which superclusters of the tile does each ray's line touch (bit mask per ray)
+    unsigned touched[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
-      const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-      q[r] = fmaf(pa, pa, pb * pb);
-    }
-    float qmin = q[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) qmin = fminf(qmin, q[r]);
-    if (qmin <= sp.w) {
+    for (int r = 0; r < R; ++r) touched[r] = 0u;
+    for (int k = 0; k < ns; ++k) {
+      const float4 sp = stile[k];  // same address in every lane: LDS broadcast
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (q[r] <= sp.w) {
-          cand[cnt * BLOCK + tid] = (cluster << 2) | r;
-          ++cnt;
-        }
+        const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+        const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+        touched[r] |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << k;
       }
     }
-  };
-
-  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-  for (int t0 = c_lo; t0 < c_hi; t0 += GT) {
-    const int nt = min(GT, c_hi - t0);
-    const int nt4 = (nt + 3) & ~3;
-    __syncthreads();
-    for (int k = tid; k < nt4; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
-    __syncthreads();
-    for (int j = 0; j < nt4; j += 4) {
-      const float4 s0 = tile[j], s1 = tile[j + 1], s2 = tile[j + 2], s3 = tile[j + 3];
-      test(s0, t0 + j);
-      test(s1, t0 + j + 1);
-      test(s2, t0 + j + 2);
-      test(s3, t0 + j + 3);
-      if (__any(cnt > KQ - 4 * R)) flush();
+    // level 1: the SUPER cluster spheres of every touched supercluster (per-lane LDS reads);
+    // one supercluster per lane and round, the queue is drained between rounds when needed
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      while (__any(touched[r] != 0u)) {
+        if (touched[r] != 0u) {
+          const int k = __ffs(touched[r]) - 1;
+          touched[r] &= touched[r] - 1u;
+#pragma unroll
+          for (int g = 0; g < SUPER; ++g) {
+            const float4 sp = tile[k * SUPER + g];
+            const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+            const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+            if (fmaf(pa, pa, pb * pb) <= sp.w) {
+              cand[wave][cnt][lane] = ((t0 + k * SUPER + g) << 2) | r;
+              ++cnt;
+            }
+          }
+        }
+        if (__any(cnt > KQ - SUPER)) flush();
+      }
     }
   }
   flush();
@@ -1434,6 +1488,7 @@ struct Accel3 {
   float4* csphere;
   int32_t* cface;
   float4* clsphere;
+  float4* susphere;  // one per SUPER clusters
   uint32_t* keys_in;
   uint32_t* keys_out;
   int32_t* vals_in;
@@ -1461,27 +1516,27 @@ static Plan3 make_plan(int64_t N, int64_t M) {
   p.nblk = cdiv(N > 0 ? N : 1, BLOCK);
   // grouped kernel: level 1 is 16x shorter, so favour more workgroups over rays per lane
   const int n_clusters = cdiv(M > 0 ? M : 1, 16);
-  p.gR = (N >= (1 << 21)) ? 4 : (N >= (1 << 19) ? 2 : 1);
+  p.gR = (N >= (1 << 22)) ? 2 : 1;  // measured: 1 ray per lane is best up to a few M rays
   if (const char* env = getenv("TFRT_GROUP_RAYS_PER_LANE")) {
     const int r = atoi(env);
     if (r == 1 || r == 2 || r == 4) p.gR = r;
   }
   p.g_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.gR);
-  int gtarget = 2048;
+  int gtarget = 8192;
   if (const char* env = getenv("TFRT_GROUP_TARGET_BLOCKS")) gtarget = atoi(env) > 0 ? atoi(env) : gtarget;
   int gch = cdiv(gtarget, p.g_blocks);
   const int gmax = cdiv(n_clusters, 64);       // at least 64 clusters (1024 faces) per chunk
   if (gch > gmax) gch = gmax;
   if (gch > p.chunks) gch = p.chunks;           // part_t / part_i are sized for p.chunks
   if (gch < 1) gch = 1;
-  p.g_chunk_clusters = cdiv(n_clusters, gch);
+  p.g_chunk_clusters = (cdiv(n_clusters, gch) + 7) / 8 * 8;  // whole superclusters
   p.g_chunks = cdiv(n_clusters, p.g_chunk_clusters);
   return p;
 }
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
+  size_t csphere, cface, clsphere, susphere, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, total;
 };
 
@@ -1507,6 +1562,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.csphere = take(ncl * CLUSTER * sizeof(float4));
   L.cface = take(ncl * CLUSTER * sizeof(int32_t));
   L.clsphere = take(ncl * sizeof(float4));
+  L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.keys_in = take(n * sizeof(uint32_t));
   L.keys_out = take(n * sizeof(uint32_t));
   L.vals_in = take(n * sizeof(int32_t));
@@ -1571,9 +1627,9 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        fverts, prep, pstride, ac->n_clusters, ei, es, er, part_t, part_i);     \
   else if (grouped)                                                                            \
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
-                       n_ptr, last_tri, ac->clsphere, ac->csphere, ac->cface, fverts, prep,    \
-                       pstride, ac->n_clusters, pl.g_chunk_clusters, ei, es, er, part_t,       \
-                       part_i, part_stride);                                                   \
+                       n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->cface,    \
+                       fverts, prep, pstride, ac->n_clusters, pl.g_chunk_clusters, ei, es, er, \
+                       part_t, part_i, part_stride);                                           \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
@@ -1631,12 +1687,14 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
 
   hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail);
   Accel3 ac;
-  ac.order = (M >= 4 * CLUSTER) ? sc->cluster_order : nullptr;
+  // (the grouped kernel packs cluster index and ray slot into 32 bits: < 2^23 clusters)
+  ac.order = (M >= 4 * CLUSTER && M < (1 << 27)) ? sc->cluster_order : nullptr;
   ac.sort_rays = sc->sort_rays != 0;
   ac.n_clusters = cdiv(M > 0 ? M : 1, CLUSTER);
   ac.csphere = reinterpret_cast<float4*>(ws + lay.csphere);
   ac.cface = reinterpret_cast<int32_t*>(ws + lay.cface);
   ac.clsphere = reinterpret_cast<float4*>(ws + lay.clsphere);
+  ac.susphere = reinterpret_cast<float4*>(ws + lay.susphere);
   ac.keys_in = reinterpret_cast<uint32_t*>(ws + lay.keys_in);
   ac.keys_out = reinterpret_cast<uint32_t*>(ws + lay.keys_out);
   ac.vals_in = reinterpret_cast<int32_t*>(ws + lay.vals_in);
@@ -1645,13 +1703,19 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
   if (M > 0) {
     hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0);
-    if (ac.order != nullptr)
+    if (ac.order != nullptr) {
       hipLaunchKernelGGL(k_cluster_spheres, dim3(cdiv(ac.n_clusters, BLOCK)), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          ac.csphere, ac.cface, ac.clsphere);
-    else
+      if (!ac.sort_rays) {
+        const int n_super = cdiv(ac.n_clusters, SUPER);
+        hipLaunchKernelGGL(k_super_spheres, dim3(cdiv(n_super, BLOCK)), dim3(BLOCK), 0, st,
+                           ac.clsphere, ac.n_clusters, n_super, ac.susphere);
+      }
+    } else {
       hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,
                          c0, sc->size_epsilion, sphere);
+    }
   }
   const int chunks_used = ac.order == nullptr ? pl.chunks : (ac.sort_rays ? 1 : pl.g_chunks);
   const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};

@@ -411,11 +411,12 @@ def morton_order(face_verts):
     return torch.argsort(key, stable=True).to(torch.int32)
 
 
-def cluster_order(face_verts, leaf=16):
-    """Permutation of the faces that makes every run of ``leaf`` consecutive entries a compact
-    patch: recursive median split of the face centroids along the longest axis of their
-    bounding box (left part a multiple of ``leaf``) down to parts of <= ``leaf`` faces.  Pass it
-    as ``cluster_order``.  Unlike a Morton order there are no space-filling-curve jumps inside
+def cluster_order(face_verts, leaf=16, group=128):
+    """Permutation of the faces that makes every aligned run of ``leaf`` consecutive entries
+    (and of ``group`` entries: the kernels' clusters and superclusters) a compact patch:
+    recursive median split of the face centroids along the longest axis of their bounding box,
+    the left part a multiple of ``group`` (of ``leaf`` below that), down to parts of <= ``leaf``
+    faces.  Pass it as ``cluster_order``.  Unlike a Morton order there are no space-filling-curve jumps inside
     a run, so the clusters' bounding spheres stay small (measured on the cfg4 lens: 10 cluster
     hits per ray instead of 17).  Host-side numpy, once per mesh topology (2 s for 1e6 faces)."""
     fv = face_verts.detach().to("cpu", torch.float64).numpy()
@@ -431,7 +432,8 @@ def cluster_order(face_verts, leaf=16):
             continue
         c = cent[idx]
         axis = int(np.argmax(c.max(0) - c.min(0)))
-        n_left = leaf * (((m + leaf - 1) // leaf) // 2)
+        unit = group if m > group else leaf
+        n_left = unit * (((m + unit - 1) // unit) // 2)
         part = np.argpartition(c[:, axis], n_left - 1)
         stack.append((idx[part[n_left:]], at + n_left))
         stack.append((idx[part[:n_left]], at))
