@@ -174,7 +174,8 @@ constexpr int CLUSTER = 16;
 __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
     const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
     const double* __restrict__ c0, double size_eps, int n_clusters,
-    float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere) {
+    float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
+    float4* __restrict__ crec) {
   const int c = blockIdx.x * BLOCK + threadIdx.x;
   if (c >= n_clusters) return;
   double ctr[CLUSTER][3], rad[CLUSTER];
@@ -186,25 +187,50 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
     if (f < 0 || f >= M) f = -1;
     cface[k] = f;
     if (f >= 0) {
-      face_sphere(fverts + 9 * (int64_t)f, c0, size_eps, ctr[g], &rad[g]);
+      const double* P = fverts + 9 * (int64_t)f;
+      face_sphere(P, c0, size_eps, ctr[g], &rad[g]);
       csphere[k] = pack_sphere(ctr[g], rad[g]);
+      if (crec != nullptr) {  // float32 record for the screen: P0 - c0, P1 - P0, P2 - P0
+        crec[3 * (int64_t)k] = make_float4((float)(P[0] - c0[0]), (float)(P[1] - c0[1]),
+                                           (float)(P[2] - c0[2]), 0.f);
+        crec[3 * (int64_t)k + 1] = make_float4((float)(P[3] - P[0]), (float)(P[4] - P[1]),
+                                               (float)(P[5] - P[2]), 0.f);
+        crec[3 * (int64_t)k + 2] = make_float4((float)(P[6] - P[0]), (float)(P[7] - P[1]),
+                                               (float)(P[8] - P[2]), 0.f);
+      }
       for (int q = 0; q < 3; ++q) mean[q] += ctr[g][q];
       ++cnt;
     } else {
       rad[g] = -1.0;
       csphere[k] = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 never holds
+      if (crec != nullptr)
+        for (int q = 0; q < 3; ++q) crec[3 * (int64_t)k + q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   double R = -1.0;
   if (cnt > 0) {
+    // The cluster sphere only has to contain the member TRIANGLES (plus the size_eps margin
+    // by which the exact test accepts points outside them), not the members' own bounding
+    // spheres: a line that reaches a valid hit point passes through it either way.
     for (int q = 0; q < 3; ++q) mean[q] /= cnt;
     R = 0.0;
+    double edge = 0.0;  // longest member edge
     for (int g = 0; g < CLUSTER; ++g) {
       if (rad[g] < 0.0) continue;
-      double d2 = 0;
-      for (int q = 0; q < 3; ++q) d2 += (ctr[g][q] - mean[q]) * (ctr[g][q] - mean[q]);
-      R = fmax(R, sqrt(d2) + rad[g]);
+      const double* P = fverts + 9 * (int64_t)cface[c * CLUSTER + g];
+      for (int v = 0; v < 3; ++v) {
+        double d2 = 0, e2 = 0;
+        for (int q = 0; q < 3; ++q) {
+          const double d = (P[3 * v + q] - c0[q]) - mean[q];
+          d2 += d * d;
+          const double ed = P[3 * ((v + 1) % 3) + q] - P[3 * v + q];
+          e2 += ed * ed;
+        }
+        R = fmax(R, sqrt(d2));
+        edge = fmax(edge, sqrt(e2));
+      }
     }
+    if (size_eps > 0.0) R += 2.0 * size_eps * edge;  // as face_sphere(): size_eps (|E1| + |E2|)
     const double cn = sqrt(dot3(mean, mean));
     R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
     clsphere[c] = pack_sphere(mean, R);
@@ -332,15 +358,17 @@ __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, i
 // face itself (or hits it behind the ray's start): most sphere survivors end here, at ~50
 // float32 ops instead of the ~200 float64 ops (three divisions) of the exact sums.
 //
-// Error model: every quantity is a triple product of float32-rounded differences; its
-// absolute error is below K*2^-24 times the product of the factors' 1-norms (K = 16 covers
-// the ~9 roundings of the fma chains plus the three input roundings).
-__device__ __forceinline__ bool may_hit(const double s[3], const double e[3], const double P[9],
-                                        double eps_size, double eps_start, double best) {
-  const float dx = (float)(e[0] - s[0]), dy = (float)(e[1] - s[1]), dz = (float)(e[2] - s[2]);
-  const float ux = (float)(P[3] - P[0]), uy = (float)(P[4] - P[1]), uz = (float)(P[5] - P[2]);
-  const float vx = (float)(P[6] - P[0]), vy = (float)(P[7] - P[1]), vz = (float)(P[8] - P[2]);
-  const float tx = (float)(s[0] - P[0]), ty = (float)(s[1] - P[1]), tz = (float)(s[2] - P[2]);
+// Error model: every quantity is a triple product of float32-rounded differences.  With
+// u = 2^-24 and 1-norms nd, n1, n2 (edges, ray) and nt (error scale of t), e.g. for t.(d x e2):
+// error of t: 2 u nt nd n2; rounding of d, e2 and of the cross product: <= 10 u |t| nd n2;
+// rounding of the dot product: <= 6 u |t| nd n2 -- below 18 u nt nd n2 in total; K = 32 is used.
+// d = ray end - start, (ux,uy,uz) = P1 - P0, (vx,vy,vz) = P2 - P0, t = start - P0, all float32;
+// nt_err = 1-norm bounding the absolute error of t in units of 2^-24 (|t| itself when t is the
+// rounding of an exact difference; larger when its operands were already rounded).
+__device__ __forceinline__ bool may_hit_core(float dx, float dy, float dz, float ux, float uy,
+                                             float uz, float vx, float vy, float vz, float tx,
+                                             float ty, float tz, float nt_err, float es, float er,
+                                             double best) {
   // p = d x e2, q = t x e1
   const float px = dy * vz - dz * vy, py = dz * vx - dx * vz, pz = dx * vy - dy * vx;
   const float qx = ty * uz - tz * uy, qy = tz * ux - tx * uz, qz = tx * uy - ty * ux;
@@ -351,15 +379,14 @@ __device__ __forceinline__ bool may_hit(const double s[3], const double e[3], co
   const float nd = fabsf(dx) + fabsf(dy) + fabsf(dz);
   const float n1 = fabsf(ux) + fabsf(uy) + fabsf(uz);
   const float n2 = fabsf(vx) + fabsf(vy) + fabsf(vz);
-  const float nt = fabsf(tx) + fabsf(ty) + fabsf(tz);
-  const float k = 16.0f * 5.9604644775390625e-08f;
+  const float nt = nt_err;
+  const float k = 32.0f * 5.9604644775390625e-08f;
   const float e_det = k * nd * n1 * n2, e_u = k * nt * nd * n2, e_v = k * nd * nt * n1;
   const float e_w = k * n2 * nt * n1;
   const float ad = fabsf(det);
   if (!(ad > e_det)) return true;  // too close to parallel to decide here (also NaN/inf)
   const float sg = det > 0.f ? 1.f : -1.f;
   const float lo = ad - e_det, hi = ad + e_det;
-  const float es = (float)eps_size, er = (float)eps_start;
   const float su = sg * bu, sv = sg * bv, sw = sg * bw;
   // trig_u < -eps_size, trig_v < -eps_size
   const float thr = fminf(-es * lo, -es * hi) - 1e-30f;
@@ -376,6 +403,15 @@ __device__ __forceinline__ bool may_hit(const double s[3], const double e[3], co
     if (sw - e_w > fmaxf(bf * lo, bf * hi) + 1e-30f) return false;
   }
   return true;
+}
+
+__device__ __forceinline__ bool may_hit(const double s[3], const double e[3], const double P[9],
+                                        double eps_size, double eps_start, double best) {
+  const float tx = (float)(s[0] - P[0]), ty = (float)(s[1] - P[1]), tz = (float)(s[2] - P[2]);
+  return may_hit_core((float)(e[0] - s[0]), (float)(e[1] - s[1]), (float)(e[2] - s[2]),
+                      (float)(P[3] - P[0]), (float)(P[4] - P[1]), (float)(P[5] - P[2]),
+                      (float)(P[6] - P[0]), (float)(P[7] - P[1]), (float)(P[8] - P[2]), tx, ty, tz,
+                      fabsf(tx) + fabsf(ty) + fabsf(tz), (float)eps_size, (float)eps_start, best);
 }
 
 // ------------------------------------------------------------------------- intersect
@@ -747,7 +783,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
     const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
-    const int32_t* __restrict__ cface, const double* __restrict__ fverts,
+    const float4* __restrict__ crec, const int32_t* __restrict__ cface,
+    const double* __restrict__ fverts, const double* __restrict__ c0,
     const float* __restrict__ prep, int64_t pstride, int n_clusters, int chunk_clusters,
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride) {
@@ -769,15 +806,28 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   __shared__ float4 prep_b[WAVES][RW];       // (b, -s.b)
   __shared__ unsigned long long best_k[WAVES][RW];
   __shared__ int32_t best_i[WAVES][RW];
-  __shared__ int32_t pair_slot[WAVES][128];
-  __shared__ int32_t pair_memb[WAVES][128];
+  constexpr int PAIRS = 64 + 4 * 64;        // waiting pairs: < 64 left over + one step's hits
+  __shared__ int32_t pair_slot[WAVES][PAIRS];
+  __shared__ int32_t pair_memb[WAVES][PAIRS];
+  __shared__ int32_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
+  __shared__ int32_t x_face[WAVES][128];
+  __shared__ T ray_l[WAVES][6][RW];          // the wave's rays (state dtype) for the decisions
+  __shared__ int32_t skip_l[WAVES][RW];      // face each ray starts on (-1: none)
 
+  const double cx = c0[0], cy = c0[1], cz = c0[2];
   float ax[R], ay[R], az[R], bx[R], by[R], bz[R], nsa[R], nsb[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = base + r * BLOCK + tid;
     ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
     nsa[r] = nsb[r] = INFINITY;  // never a candidate
+    {
+      const int slot = r * 64 + lane;
+      const int ii = i < n ? i : 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) ray_l[wave][q][slot] = rays[q * stride + ii];
+      skip_l[wave][slot] = (last_tri != nullptr && i < n) ? last_tri[ii] : -1;
+    }
     if (i < n) {
       ax[r] = prep[i];
       ay[r] = prep[pstride + i];
@@ -797,29 +847,70 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
 
   int cnt = 0;
 
-  // One (ray, face) pair per lane: float32 screen, exact float64 test, LDS min per ray.
+  // Screen: one (ray, member) pair per lane against the face's float32 record (3 gathered
+  // 16-byte loads; the ray comes from LDS).  Survivors -- about a third -- are appended to the
+  // exact list so that the expensive float64 stage always runs on full wavefronts.
+  const float es_f = (float)eps_size, er_f = (float)eps_start;
+  int xn = 0;  // entries waiting in x_slot / x_face (wave-uniform)
+  auto screen = [&](const int nb) {
+    bool keep = false;
+    int j = -1, slot = 0;
+    if (lane < nb) {
+      slot = pair_slot[wave][lane];
+      const int memb = pair_memb[wave][lane];
+      const float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
+                   r2 = crec[3 * (int64_t)memb + 2];
+      j = cface[memb];
+      const double best = dkey_inv(best_k[wave][slot]);
+      double s[3], e[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        s[q] = static_cast<double>(ray_l[wave][q][slot]);
+        e[q] = static_cast<double>(ray_l[wave][3 + q][slot]);
+      }
+      // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t scales
+      // with their magnitudes, not with |t|
+      const float sx = (float)(s[0] - cx), sy = (float)(s[1] - cy), sz = (float)(s[2] - cz);
+      const float tx = sx - r0.x, ty = sy - r0.y, tz = sz - r0.z;
+      const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(sx) + fabsf(sy) + fabsf(sz) +
+                           fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z);
+      keep = j >= 0 && j != skip_l[wave][slot] &&
+             may_hit_core((float)(e[0] - s[0]), (float)(e[1] - s[1]), (float)(e[2] - s[2]), r1.x,
+                          r1.y, r1.z, r2.x, r2.y, r2.z, tx, ty, tz, nt_err, es_f, er_f, best);
+    }
+    const unsigned long long km = __ballot(keep);
+    if (keep) {
+      const int pos = xn + rank_below(km);
+      x_slot[wave][pos] = slot;
+      x_face[wave][pos] = j;
+    }
+    xn += __popcll(km);
+    wave_fence();
+  };
+
+  // Decision: one (ray, face) per lane, exact float64 test; nearest hit per ray kept in LDS
+  // (64-bit min on an order-preserving key of ray_u, ties to the lower face index).
   auto decide = [&](const int nb) {
     bool have = false;
     unsigned long long key = 0, old = 0;
     int j = -1, slot = 0;
     if (lane < nb) {
-      slot = pair_slot[wave][lane];
-      j = cface[pair_memb[wave][lane]];
-      const int i = base + (slot >> 6) * BLOCK + wave * 64 + (slot & 63);
+      slot = x_slot[wave][lane];
+      j = x_face[wave][lane];
       old = best_k[wave][slot];
-      if (j >= 0 && (last_tri == nullptr || last_tri[i] != j)) {
-        double s[3], e[3], P[9];
-        load_ray3(rays, stride, i, s, e);
-        const double* fp = fverts + 9 * (int64_t)j;
+      double s[3], e[3], P[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) P[q] = fp[q];
-        if (may_hit(s, e, P, eps_size, eps_start, dkey_inv(old))) {
-          const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
-          if (h.valid) {
-            have = true;
-            key = dkey(h.ray_u);
-          }
-        }
+      for (int q = 0; q < 3; ++q) {
+        s[q] = static_cast<double>(ray_l[wave][q][slot]);
+        e[q] = static_cast<double>(ray_l[wave][3 + q][slot]);
+      }
+      const double* fp = fverts + 9 * (int64_t)j;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) P[q] = fp[q];
+      const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
+      if (h.valid) {
+        have = true;
+        key = dkey(h.ray_u);
       }
     }
     wave_fence();
@@ -862,112 +953,153 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     for (int k = 0; k < KQ; ++k)
       if (k < cnt) list[first + k] = ((mine[k] >> 2) << 8) | ((mine[k] & 3) << 6) | lane;
     wave_fence();
-    // 2. member tests, 16 queued candidates per step: each 16-lane group takes four; the
-    //    member spheres are fetched first (four independent coalesced loads in flight)
+    // 2. member tests, 16 queued candidates per step: each 16-lane group takes four; their
+    //    member spheres are fetched first (four independent coalesced 256-byte reads in
+    //    flight).  Member hits become (ray, face) pairs; while 64 are waiting -- and once more
+    //    at the end -- they are decided, one per lane.  (One call site each for decide() and
+    //    flush(): the float64 test is big and copies of it only bloat the kernel.)
     int pn = 0;  // pairs waiting in pair_slot / pair_memb (wave-uniform)
     for (int q0 = 0; q0 < total; q0 += 16) {
-      float4 sp[4];
-      int slot[4], memb[4];
+      {
+        float4 sp[4];
+        int slot[4], memb[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int q = q0 + 4 * u + (lane >> 4);
-        sp[u] = make_float4(0.f, 0.f, 0.f, -1.f);  // never hit
-        slot[u] = 0;
-        memb[u] = 0;
-        if (q < total) {
-          const int v = list[q];
-          slot[u] = v & 255;
-          memb[u] = (v >> 8) * CLUSTER + (lane & (CLUSTER - 1));
-          sp[u] = csphere[memb[u]];
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + 4 * u + (lane >> 4);
+          sp[u] = make_float4(0.f, 0.f, 0.f, -1.f);  // never hit
+          slot[u] = 0;
+          memb[u] = 0;
+          if (q < total) {
+            const int v = list[q];
+            slot[u] = v & 255;
+            memb[u] = (v >> 8) * CLUSTER + (lane & (CLUSTER - 1));
+            sp[u] = csphere[memb[u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 fa = prep_a[wave][slot[u]], fb = prep_b[wave][slot[u]];
+          const float pa = fmaf(sp[u].x, fa.x, fmaf(sp[u].y, fa.y, fmaf(sp[u].z, fa.z, fa.w)));
+          const float pb = fmaf(sp[u].x, fb.x, fmaf(sp[u].y, fb.y, fmaf(sp[u].z, fb.z, fb.w)));
+          const bool hit = fmaf(pa, pa, pb * pb) <= sp[u].w;
+          const unsigned long long hm = __ballot(hit);
+#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 2
+          if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
+          continue;
+#endif
+          if (hit) {
+            const int pos = pn + rank_below(hm);
+            pair_slot[wave][pos] = slot[u];
+            pair_memb[wave][pos] = memb[u];
+          }
+          pn += __popcll(hm);
         }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float4 fa = prep_a[wave][slot[u]], fb = prep_b[wave][slot[u]];
-        const float pa = fmaf(sp[u].x, fa.x, fmaf(sp[u].y, fa.y, fmaf(sp[u].z, fa.z, fa.w)));
-        const float pb = fmaf(sp[u].x, fb.x, fmaf(sp[u].y, fb.y, fmaf(sp[u].z, fb.z, fb.w)));
-        const bool hit = fmaf(pa, pa, pb * pb) <= sp[u].w;
-        const unsigned long long hm = __ballot(hit);
-#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 2
-        if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
-        continue;
-#endif
-        if (hm == 0ull) continue;
-        if (hit) {
-          const int pos = pn + rank_below(hm);
-          pair_slot[wave][pos] = slot[u];
-          pair_memb[wave][pos] = memb[u];
-        }
-        pn += __popcll(hm);
-        if (pn >= 64) {
-          wave_fence();
-          decide(64);
+      const bool last = q0 + 16 >= total;
+      while (pn >= 64 || (last && (pn > 0 || xn > 0))) {
+        const int nb = min(pn, 64);
+        wave_fence();
+        if (nb > 0) screen(nb);
+        // keep the rest of the pairs: move them to the front (64 per round)
+        for (int m0 = 0; m0 < pn - nb; m0 += 64) {
           int ts = 0, tm = 0;
-          if (lane < pn - 64) {
-            ts = pair_slot[wave][64 + lane];
-            tm = pair_memb[wave][64 + lane];
+          if (m0 + lane < pn - nb) {
+            ts = pair_slot[wave][nb + m0 + lane];
+            tm = pair_memb[wave][nb + m0 + lane];
           }
           wave_fence();
-          if (lane < pn - 64) {
-            pair_slot[wave][lane] = ts;
-            pair_memb[wave][lane] = tm;
+          if (m0 + lane < pn - nb) {
+            pair_slot[wave][m0 + lane] = ts;
+            pair_memb[wave][m0 + lane] = tm;
           }
-          pn -= 64;
+          wave_fence();
+        }
+        pn -= nb;
+        while (xn >= 64 || (last && pn == 0 && xn > 0)) {
+          const int xb = min(xn, 64);
+          decide(xb);
+          int ts = 0, tf = 0;  // fewer than 64 can remain
+          if (lane < xn - xb) {
+            ts = x_slot[wave][xb + lane];
+            tf = x_face[wave][xb + lane];
+          }
+          wave_fence();
+          if (lane < xn - xb) {
+            x_slot[wave][lane] = ts;
+            x_face[wave][lane] = tf;
+          }
+          xn -= xb;
           wave_fence();
         }
       }
     }
-    wave_fence();
-    if (pn > 0) decide(pn);
     cnt = 0;
   };
 
   static_assert(GT / SUPER == 32, "one 32-bit supercluster mask per ray and tile");
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-  for (int t0 = c_lo; t0 < c_hi; t0 += GT) {  // c_lo is a multiple of SUPER
-    const int nt = min(GT, c_hi - t0);
-    const int ns = (nt + SUPER - 1) / SUPER;
-    __syncthreads();
-    for (int k = tid; k < ns * SUPER; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
-    if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
-    __syncthreads();
-    // level 0: which superclusters of the tile does each ray's line touch (bit mask per ray)
-    unsigned touched[R];
+  unsigned touched[R];  // per ray: superclusters of the current tile its line touches
 #pragma unroll
-    for (int r = 0; r < R; ++r) touched[r] = 0u;
-    for (int k = 0; k < ns; ++k) {
-      const float4 sp = stile[k];  // same address in every lane: LDS broadcast
+  for (int r = 0; r < R; ++r) touched[r] = 0u;
+  int t0 = c_lo - GT;  // c_lo is a multiple of SUPER
+  for (;;) {
+    bool pending = false;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
-        const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-        touched[r] |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << k;
-      }
-    }
-    // level 1: the SUPER cluster spheres of every touched supercluster (per-lane LDS reads);
-    // one supercluster per lane and round, the queue is drained between rounds when needed
+    for (int r = 0; r < R; ++r) pending = pending || __any(touched[r] != 0u);
+    bool drain = false, done = false;
+    if (!pending) {
+      // this wave is through with the tile: next tile (all four waves meet here), or finish
+      t0 += GT;
+      if (t0 >= c_hi) {
+        drain = true;
+        done = true;
+      } else {
+        const int nt = min(GT, c_hi - t0);
+        const int ns = (nt + SUPER - 1) / SUPER;
+        __syncthreads();
+        for (int k = tid; k < ns * SUPER; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
+        if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
+        __syncthreads();
+        // level 0: which superclusters of the tile does each ray's line touch
+        for (int k = 0; k < ns; ++k) {
+          const float4 sp = stile[k];  // same address in every lane: LDS broadcast
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      while (__any(touched[r] != 0u)) {
-        if (touched[r] != 0u) {
-          const int k = __ffs(touched[r]) - 1;
-          touched[r] &= touched[r] - 1u;
-#pragma unroll
-          for (int g = 0; g < SUPER; ++g) {
-            const float4 sp = tile[k * SUPER + g];
+          for (int r = 0; r < R; ++r) {
             const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
             const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-            if (fmaf(pa, pa, pb * pb) <= sp.w) {
-              cand[wave][cnt][lane] = ((t0 + k * SUPER + g) << 2) | r;
-              ++cnt;
+            touched[r] |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << k;
+          }
+        }
+      }
+    } else {
+      // level 1: one touched supercluster per lane and round -- its SUPER cluster spheres
+      // (per-lane LDS reads); clusters the line touches go to the lane's queue
+      bool did = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (!did && __any(touched[r] != 0u)) {
+          did = true;
+          if (touched[r] != 0u) {
+            const int k = __ffs(touched[r]) - 1;
+            touched[r] &= touched[r] - 1u;
+#pragma unroll
+            for (int g = 0; g < SUPER; ++g) {
+              const float4 sp = tile[k * SUPER + g];
+              const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+              const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+              if (fmaf(pa, pa, pb * pb) <= sp.w) {
+                cand[wave][cnt][lane] = ((t0 + k * SUPER + g) << 2) | r;
+                ++cnt;
+              }
             }
           }
         }
-        if (__any(cnt > KQ - SUPER)) flush();
       }
+      drain = __any(cnt > KQ - SUPER);
     }
+    if (drain) flush();
+    if (done) break;
   }
-  flush();
 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1489,6 +1621,7 @@ struct Accel3 {
   int32_t* cface;
   float4* clsphere;
   float4* susphere;  // one per SUPER clusters
+  float4* crec;      // 3 per member: float32 face record for the screen
   uint32_t* keys_in;
   uint32_t* keys_out;
   int32_t* vals_in;
@@ -1522,7 +1655,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
     if (r == 1 || r == 2 || r == 4) p.gR = r;
   }
   p.g_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.gR);
-  int gtarget = 8192;
+  int gtarget = 4096;
   if (const char* env = getenv("TFRT_GROUP_TARGET_BLOCKS")) gtarget = atoi(env) > 0 ? atoi(env) : gtarget;
   int gch = cdiv(gtarget, p.g_blocks);
   const int gmax = cdiv(n_clusters, 64);       // at least 64 clusters (1024 faces) per chunk
@@ -1536,7 +1669,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
+  size_t csphere, cface, clsphere, susphere, crec, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, total;
 };
 
@@ -1563,6 +1696,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.cface = take(ncl * CLUSTER * sizeof(int32_t));
   L.clsphere = take(ncl * sizeof(float4));
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
+  L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
   L.keys_in = take(n * sizeof(uint32_t));
   L.keys_out = take(n * sizeof(uint32_t));
   L.vals_in = take(n * sizeof(int32_t));
@@ -1627,9 +1761,9 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        fverts, prep, pstride, ac->n_clusters, ei, es, er, part_t, part_i);     \
   else if (grouped)                                                                            \
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
-                       n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->cface,    \
-                       fverts, prep, pstride, ac->n_clusters, pl.g_chunk_clusters, ei, es, er, \
-                       part_t, part_i, part_stride);                                           \
+                       n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec,     \
+                       ac->cface, fverts, c0, prep, pstride, ac->n_clusters,                   \
+                       pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride);          \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
@@ -1695,6 +1829,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   ac.cface = reinterpret_cast<int32_t*>(ws + lay.cface);
   ac.clsphere = reinterpret_cast<float4*>(ws + lay.clsphere);
   ac.susphere = reinterpret_cast<float4*>(ws + lay.susphere);
+  ac.crec = reinterpret_cast<float4*>(ws + lay.crec);
   ac.keys_in = reinterpret_cast<uint32_t*>(ws + lay.keys_in);
   ac.keys_out = reinterpret_cast<uint32_t*>(ws + lay.keys_out);
   ac.vals_in = reinterpret_cast<int32_t*>(ws + lay.vals_in);
@@ -1706,7 +1841,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     if (ac.order != nullptr) {
       hipLaunchKernelGGL(k_cluster_spheres, dim3(cdiv(ac.n_clusters, BLOCK)), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
-                         ac.csphere, ac.cface, ac.clsphere);
+                         ac.csphere, ac.cface, ac.clsphere, ac.sort_rays ? nullptr : ac.crec);
       if (!ac.sort_rays) {
         const int n_super = cdiv(ac.n_clusters, SUPER);
         hipLaunchKernelGGL(k_super_spheres, dim3(cdiv(n_super, BLOCK)), dim3(BLOCK), 0, st,
