@@ -264,3 +264,85 @@ def test_ties_go_to_the_lowest_face_index_in_every_trace_mode(n_rays):
             assert torch.equal(o[cls + "_face"], single[cls + "_face"]), mode
             assert torch.equal(o[cls], single[cls]), mode
         assert torch.equal(o["unfinished"], single["unfinished"]), mode
+
+
+def _soup_scene(seed, n_faces, n_rays, dev="cuda:0"):
+    """Random triangle soup (all sizes, some degenerate / duplicated faces, one stop and one
+    target region) and random rays: nothing mesh-like, to stress the conservative filters."""
+    from tensorflowraytrace_amd import ops
+    rng = np.random.default_rng(seed)
+    centre = rng.uniform(-1, 1, (n_faces, 1, 3))
+    size = 10 ** rng.uniform(-2.5, -0.3, (n_faces, 1, 1))
+    tri = centre + size * rng.standard_normal((n_faces, 3, 3))
+    tri[::37, 2] = tri[::37, 1]                         # zero-area faces
+    if n_faces > 50:
+        tri[40:45] = tri[10:15]                         # exact duplicates (ties)
+    fv = torch.tensor(tri.reshape(n_faces, 9), dtype=torch.float64, device=dev)
+    # merged order of the engine (engine.py:971-1018): optical, then stops, then targets
+    cat = torch.zeros(n_faces, dtype=torch.int32, device=dev)
+    cat[int(0.8 * n_faces):int(0.9 * n_faces)] = 1
+    cat[int(0.9 * n_faces):] = 2
+    n_in = torch.tensor(rng.uniform(1.0, 1.7, n_faces), device=dev)
+    n_out = torch.tensor(rng.uniform(1.0, 1.7, n_faces), device=dev)
+    s = rng.uniform(-1.5, 1.5, (3, n_rays))
+    e = s + rng.standard_normal((3, n_rays)) * 0.7
+    rays = torch.tensor(np.concatenate([s, e]), dtype=torch.float32, device=dev)
+
+    def scene(mode):
+        order = None
+        if mode:
+            order = ops.morton_order(fv) if mode == "group-morton" else ops.cluster_order(fv)
+        return ops.Scene3DArgs(fv, cat, n_in=n_in, n_out=n_out, cluster_order=order,
+                               sort_rays=mode == "sort")
+    return rays, fv, scene
+
+
+@pytest.mark.parametrize("seed,n_faces,n_rays", [
+    (1, 64, 1), (2, 65, 63), (3, 100, 257), (4, 129, 5000), (5, 1000, 20000), (6, 4097, 3000),
+    (7, 30000, 700)])
+def test_every_trace_mode_gives_the_all_pairs_result_on_random_soups(seed, n_faces, n_rays):
+    """The sphere hierarchy, the float32 screen and the sorted-ray path may only skip work that
+    cannot change the result: all outputs must equal the all-pairs filter's bit for bit."""
+    from tensorflowraytrace_amd import ops, _lib
+    rays, fv, scene = _soup_scene(seed, n_faces, n_rays)
+    flags = (_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED)
+    ref = ops.trace3d(rays, fv, scene(False), max_passes=4, flags=flags, dead_ray_length=2.0)
+    assert ref["active"].shape[1] > 0 or n_rays < 10
+    for mode in ("group", "group-morton", "sort"):
+        out = ops.trace3d(rays, fv, scene(mode), max_passes=4, flags=flags, dead_ray_length=2.0)
+        assert np.array_equal(out["counts"], ref["counts"]), mode
+        for cls in ("finished", "active", "stopped", "dead"):
+            assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), (mode, cls)
+            assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), (mode, cls)
+            assert torch.equal(out[cls], ref[cls]), (mode, cls)
+        assert torch.equal(out["unfinished"], ref["unfinished"]), mode
+
+
+def test_soup_matches_oracle_in_default_mode():
+    """The same kind of soup against the float64 restatement of the reference (value mode)."""
+    from tensorflowraytrace_amd import ops, _lib
+    rays, fv, scene = _soup_scene(11, 300, 4000)
+    rays = rays.double()
+    sc = scene("group")
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    out = ops.trace3d(rays, fv, sc, max_passes=3, flags=flags)
+    cat = sc.catagory.cpu().long()
+
+    def sub(mask):
+        verts = fv.cpu()[mask].reshape(-1, 3)
+        d = tracer.faces_from_vertices(verts, torch.arange(verts.shape[0]).reshape(-1, 3))
+        d["n_in"] = sc.n_in.cpu()[mask]
+        d["n_out"] = sc.n_out.cpu()[mask]
+        return d
+
+    system = tracer.System(3, optical=sub(cat == 0), stop=sub(cat == 1), target=sub(cat == 2))
+    r = rays.cpu()
+    src = {n: r[i] for i, n in enumerate(("x_start", "y_start", "z_start", "x_end", "y_end", "z_end"))}
+    src["ray_id"] = torch.arange(r.shape[1])
+    ref = tracer.ray_trace(system, src, max_iterations=3, inherit=("ray_id",), index_type="value",
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    for cls in ("finished", "active", "stopped", "dead"):
+        if not ref[cls]:
+            assert out[cls].shape[1] == 0
+            continue
+        _compare_sets(out[cls], out[cls + "_id"], ref[cls], 1e-9, cls)
