@@ -111,6 +111,181 @@ __device__ __forceinline__ int nearest2d(const double s[2], const double e[2],
   return -1;
 }
 
+// ---------------------------------------------------------------------------------------
+// Filtered nearest hit (the trace kernels; the seams keep the plain loop above).
+//
+// As in 3-D, throughput and decisions are separated: every primitive gets a bounding circle
+// (segment: midpoint, half length; arc: the whole circle, or the circle on its chord when it
+// spans less than pi), every ray the unit normal n of its line and the offset s.n; the line can
+// touch the primitive only if (c.n - s.n)^2 <= r_eff^2 -- 6 float32 ops against ~60 float64 ops
+// (two atan2 for an arc) of the exact test.  Survivors (a handful out of hundreds) go to a
+// per-lane LDS queue and are decided exactly, in ascending primitive order, by a wave-uniform
+// flush.  Conservative: r_eff = r (1 + 1e-5) + 64 * 2^-24 (|c| + r), segments are extended by
+// size_eps at both ends (engine.py:722-724), and the reference's tangent snap `|rad| < eps -> 0`
+// (geometry.py:480-483), which lets a line MISS a circle of radius R by up to
+// d = eps R^3 / (8 |ray|^2), is covered by (r + d)^2 <= r^2 + 2 w R^4 + w^2 R^6, w = eps / (8 |ray|^2).
+constexpr int KQ2 = 16;  // queue slots per lane
+
+__device__ __forceinline__ float round_up2(double x) {
+  float f = static_cast<float>(x);
+  f = nextafterf(f, INFINITY);
+  return nextafterf(f, INFINITY);
+}
+
+// filter entry (cx, cy, r_eff^2, R^2) of a segment
+__device__ __forceinline__ float4 filter_segment(const double* g, double es) {
+  const double cx = 0.5 * (g[0] + g[2]), cy = 0.5 * (g[1] + g[3]);
+  const double len = sqrt((g[2] - g[0]) * (g[2] - g[0]) + (g[3] - g[1]) * (g[3] - g[1]));
+  double r = 0.5 * len + (es > 0.0 ? es * len : 0.0);
+  r = r * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (sqrt(cx * cx + cy * cy) + r);
+  if (!(r == r) || r > 1e18) return make_float4(0.f, 0.f, INFINITY, 0.f);  // always a candidate
+  return make_float4((float)cx, (float)cy, round_up2(r * r), 0.f);
+}
+
+__device__ __forceinline__ float4 filter_arc(const double* g) {
+  const double R = fabs(g[4]);
+  double span = g[3] - g[2];
+  if (span < 0.0) span += 2 * PI_D;  // angle_in_interval: geometry.py:790-802
+  double cx = g[0], cy = g[1], r = R;
+  const double h = 0.5 * span;
+  if (h < 0.5 * PI_D) {  // less than a half circle: the circle on the chord contains the arc
+    const double tm = g[2] + h;
+    cx += R * cos(h) * cos(tm);
+    cy += R * cos(h) * sin(tm);
+    r = R * sin(h) + 1e-9 * R;  // + slack for the rounding of cos / sin
+  }
+  r = r * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (sqrt(cx * cx + cy * cy) + r);
+  if (!(r == r) || !(R == R) || r > 1e18 || R > 1e9)
+    return make_float4(0.f, 0.f, INFINITY, 0.f);  // always a candidate
+  return make_float4((float)cx, (float)cy, round_up2(r * r), round_up2(R * R));
+}
+
+template <int STATE_BITS>
+__device__ __forceinline__ int nearest2d_filtered(const double s[2], const double e[2],
+                                                  const double* __restrict__ seg, int Ms,
+                                                  const double* __restrict__ arc, int Ma,
+                                                  double ei, double es, double er, int last_prim,
+                                                  double* lds, float4* filt, int32_t* queue,
+                                                  bool active, double* out_u, double* out_aux) {
+  // float32 state of this lane's ray
+  float nx = 0.f, ny = 0.f, sn = INFINITY, w1 = 0.f, w2 = 0.f;  // sn = inf: never a candidate
+  {
+    const double dx = e[0] - s[0], dy = e[1] - s[1];
+    const double l2 = dx * dx + dy * dy;
+    if (active && l2 > 0.0 && l2 < INFINITY) {
+      const double inv = 1.0 / sqrt(l2);
+      const double ux = -dy * inv, uy = dx * inv;
+      nx = (float)ux;
+      ny = (float)uy;
+      sn = (float)(s[0] * ux + s[1] * uy);
+      const double w = (ei > 0.0 ? ei : 0.0) / (8.0 * l2);
+      w1 = round_up2(2.0 * w * (1.0 + 1e-5));
+      w2 = round_up2(w * w * (1.0 + 1e-5));
+    }
+  }
+  auto touches = [&](const float4 f) {
+    const float t = fmaf(f.x, nx, fmaf(f.y, ny, -sn));
+    const float lim = fmaf(f.w * f.w, fmaf(w2, f.w, w1), f.z);
+    return t * t <= lim;
+  };
+  const int tid = threadIdx.x;
+  int cnt = 0;
+  double su = INFINITY, au = INFINITY, aang = 0.0;
+  int sj = -1, aj = -1;
+
+  for (int t0 = 0; t0 < Ms; t0 += TILE2) {
+    const int nt = min(TILE2, Ms - t0);
+    const int nt4 = (nt + 3) & ~3;
+    __syncthreads();
+    for (int k = tid; k < nt * 4; k += BLOCK) lds[k] = seg[(int64_t)t0 * 4 + k];
+    __syncthreads();
+    for (int k = tid; k < nt4; k += BLOCK)
+      filt[k] = k < nt ? filter_segment(lds + 4 * k, es) : make_float4(0.f, 0.f, -1.f, 0.f);
+    __syncthreads();
+    auto flush = [&]() {
+      for (int k = 0; k < cnt; ++k) {
+        const int j = queue[k * BLOCK + tid];
+        if (t0 + j == last_prim) continue;  // the segment the ray starts on
+        const Hit2 h = exact_segment(s, e, lds + 4 * j, ei, es, er);
+        if (h.valid && h.ray_u < su) {
+          su = h.ray_u;
+          sj = t0 + j;
+        }
+      }
+      cnt = 0;
+    };
+    for (int j = 0; j < nt4; j += 4) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (touches(filt[j + g])) {
+          queue[cnt * BLOCK + tid] = j + g;
+          ++cnt;
+        }
+      }
+      if (__any(cnt > KQ2 - 4)) flush();
+    }
+    flush();  // the queue refers to this tile's LDS copy
+  }
+  for (int t0 = 0; t0 < Ma; t0 += TILE2) {
+    const int nt = min(TILE2, Ma - t0);
+    const int nt4 = (nt + 3) & ~3;
+    __syncthreads();
+    for (int k = tid; k < nt * 5; k += BLOCK) lds[k] = arc[(int64_t)t0 * 5 + k];
+    __syncthreads();
+    for (int k = tid; k < nt4; k += BLOCK)
+      filt[k] = k < nt ? filter_arc(lds + 5 * k) : make_float4(0.f, 0.f, -1.f, 0.f);
+    __syncthreads();
+    auto flush = [&]() {
+      for (int k = 0; k < cnt; ++k) {
+        const int j = queue[k * BLOCK + tid];
+        double er_j = er;
+        if (STATE_BITS < 53 && Ms + t0 + j == last_prim) {
+          // a rounded (float32 / float16) start sits up to ~1 ulp off the arc it left: do not
+          // let the near root (u ~ 0) count as a new hit
+          const double dl = sqrt((e[0] - s[0]) * (e[0] - s[0]) + (e[1] - s[1]) * (e[1] - s[1]));
+          const double mag = fabs(s[0]) + fabs(s[1]) + fabs(lds[5 * j + 4]);
+          er_j = fmax(er, 64.0 * ldexp(1.0, -STATE_BITS) * mag / fmax(dl, 1e-300));
+        }
+        const Hit2 h = exact_arc(s, e, lds + 5 * j, ei, er_j);
+        if (h.valid && h.ray_u < au) {
+          au = h.ray_u;
+          aj = t0 + j;
+          aang = h.prim_u;
+        }
+      }
+      cnt = 0;
+    };
+    for (int j = 0; j < nt4; j += 4) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (touches(filt[j + g])) {
+          queue[cnt * BLOCK + tid] = j + g;
+          ++cnt;
+        }
+      }
+      if (__any(cnt > KQ2 - 4)) flush();
+    }
+    flush();
+  }
+  // engine.py:652-657
+  if (sj >= 0 && aj >= 0) {
+    if (su < au) aj = -1; else sj = -1;
+  }
+  if (sj >= 0) {
+    *out_u = su;
+    *out_aux = 0.0;
+    return sj;
+  }
+  if (aj >= 0) {
+    *out_u = au;
+    *out_aux = aang;
+    return Ms + aj;
+  }
+  *out_u = INFINITY;
+  *out_aux = 0.0;
+  return -1;
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_intersect2d(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
@@ -121,6 +296,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect2d(
   const int base = blockIdx.x * BLOCK;
   if (base >= n) return;
   __shared__ double lds[TILE2 * 5];
+  __shared__ float4 filt[TILE2];
+  __shared__ int32_t queue[KQ2 * BLOCK];
   __shared__ int wc[WAVES][NBIN];
   const int i = base + threadIdx.x;
   const bool active = i < n;
@@ -129,9 +306,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect2d(
   const int lp = (active && last_prim) ? last_prim[i] : -1;
   const int Ms = (int)sc.n_segments, Ma = (int)sc.n_arcs;
   double u, aux;
-  const int prim = nearest2d<(sizeof(T) == 8 ? 53 : (sizeof(T) == 4 ? 24 : 11))>(s, e, sc.seg, Ms, sc.arc, Ma, sc.intersect_epsilion,
-                                            sc.size_epsilion, sc.ray_start_epsilion, lp, lds,
-                                            active, &u, &aux);
+  const int prim = nearest2d_filtered<(sizeof(T) == 8 ? 53 : (sizeof(T) == 4 ? 24 : 11))>(
+      s, e, sc.seg, Ms, sc.arc, Ma, sc.intersect_epsilion, sc.size_epsilion,
+      sc.ray_start_epsilion, lp, lds, filt, queue, active, &u, &aux);
   int bin = -1;
   if (active) {
     if (prim < 0) {

@@ -224,3 +224,83 @@ def test_config1_single_pass_api():
     ang = torch.atan2(new["y_end"] - new["y_start"], new["x_end"] - new["x_start"]).cpu().numpy()
     np.testing.assert_allclose(np.sort(np.abs(ang)),
                                np.sort([0.10188, 0.07819, 0.05531, 0.03297, 0.01096] * 2), atol=2e-5)
+
+
+@pytest.mark.parametrize("seed,n_seg,n_arc,n_rays", [(1, 0, 300, 3000), (2, 500, 0, 3000),
+                                                     (3, 257, 65, 6000), (4, 3, 2, 40000)])
+def test_bounding_circle_filter_never_loses_a_hit_on_random_soups(seed, n_seg, n_arc, n_rays):
+    """Random segments (all lengths) and arcs (all spans: tiny, > pi, wrapping through +-pi,
+    negative radii), many of them grazed tangentially: the float32 bounding-circle filter in
+    front of the exact tests must not change any hit, class or order (one pass, float64
+    state, against the oracle's dense evaluation)."""
+    from tensorflowraytrace_amd import ops, _lib
+    rng = np.random.default_rng(seed)
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    sets = {}
+    if n_seg:
+        c = rng.uniform(-3, 3, (n_seg, 2))
+        half = 10 ** rng.uniform(-2.5, 0.3, (n_seg, 1)) * rng.standard_normal((n_seg, 2))
+        cat = rng.integers(0, 3, n_seg)
+        for name, k in (("optical", 0), ("stop", 1), ("target", 2)):
+            m = cat == k
+            if not m.any():
+                continue
+            d = dict(x_start=t((c - half)[m, 0]), y_start=t((c - half)[m, 1]),
+                     x_end=t((c + half)[m, 0]), y_end=t((c + half)[m, 1]))
+            if k == 0:
+                d["mat_in"] = torch.ones(int(m.sum()), dtype=torch.int64)
+                d["mat_out"] = torch.zeros(int(m.sum()), dtype=torch.int64)
+            sets[f"{name}_segments"] = d
+    if n_arc:
+        a1 = rng.uniform(-PI, PI, n_arc)
+        span = np.where(rng.random(n_arc) < 0.5, 10 ** rng.uniform(-2, 0, n_arc),
+                        rng.uniform(0.1, 2 * PI - 0.01, n_arc))
+        a2 = a1 + span
+        a2 = np.where(a2 > PI, a2 - 2 * PI, a2)              # wrap through +-pi
+        rad = 10 ** rng.uniform(-1.5, 0.7, n_arc) * rng.choice([-1, 1], n_arc)
+        cat = rng.integers(0, 3, n_arc)
+        ctr = rng.uniform(-3, 3, (n_arc, 2))
+        for name, k in (("optical", 0), ("stop", 1), ("target", 2)):
+            m = cat == k
+            if not m.any():
+                continue
+            d = dict(x_center=t(ctr[m, 0]), y_center=t(ctr[m, 1]), angle_start=t(a1[m]),
+                     angle_end=t(a2[m]), radius=t(rad[m]))
+            if k == 0:
+                d["mat_in"] = torch.ones(int(m.sum()), dtype=torch.int64)
+                d["mat_out"] = torch.zeros(int(m.sum()), dtype=torch.int64)
+            sets[f"{name}_arcs"] = d
+    s = rng.uniform(-4, 4, (2, n_rays))
+    ang = rng.uniform(-PI, PI, n_rays)
+    e = s + np.stack([np.cos(ang), np.sin(ang)]) * 10 ** rng.uniform(-2, 1, n_rays)
+    rays = np.concatenate([s, e])
+    if n_arc:  # a fifth of the rays graze some arc's circle: tangent to it, then nudged by ~1e-9
+        k = n_rays // 5
+        j = rng.integers(0, n_arc, k)
+        th = rng.uniform(-PI, PI, k)
+        radial = np.stack([np.cos(th), np.sin(th)], 1) * (1 + rng.normal(size=(k, 1)) * 1e-9)
+        p = ctr[j] + np.abs(rad[j])[:, None] * radial
+        tan = np.stack([-np.sin(th), np.cos(th)], 1)
+        rays[:2, :k] = (p - 2.0 * tan).T
+        rays[2:, :k] = (p - 1.0 * tan).T
+    wl = np.full(n_rays, 550.0)
+    scene, _, _ = _gpu_scene(sets, wl)
+    src = torch.tensor(rays, dtype=torch.float64, device=DEV)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    out = ops.trace2d(src, scene, max_passes=1, flags=flags)
+    ref = tracer.ray_trace(_oracle_system(sets), _src2(rays, wl, False), max_iterations=1,
+                           inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    hit = 0
+    for cls in ("finished", "active", "stopped", "dead"):
+        r = ref[cls]
+        n_ref = r["x_start"].shape[0] if r else 0
+        assert out[cls].shape[1] == n_ref, f"{cls}: {out[cls].shape[1]} vs oracle {n_ref}"
+        if n_ref == 0:
+            continue
+        assert np.array_equal(out[cls + "_id"].cpu().numpy(), r["ray_id"].numpy().astype(np.int64)), cls
+        got = out[cls].cpu().numpy()
+        want = np.stack([r[f].numpy() for f in ("x_start", "y_start", "x_end", "y_end")])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
+        hit += n_ref if cls != "dead" else 0
+    assert hit > 0.2 * n_rays
