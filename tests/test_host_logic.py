@@ -353,3 +353,60 @@ def test_sphere_mesh_is_closed_and_outward():
     assert (np.sum(n * (tri.mean(1) - [1.0, -2.0, 0.25]), axis=1) > 0).all()
     with pytest.raises(ValueError):
         mt.sphere(1.0, theta_resolution=2)
+
+
+def test_cluster_order_is_a_permutation_with_compact_aligned_runs():
+    """ops.cluster_order (host side of the sphere hierarchy): a permutation whose aligned runs
+    of 16 and 128 faces are spatially compact (k-d subtrees)."""
+    from tensorflowraytrace_amd import ops
+    import tfrt.mesh_tools as mt
+    mesh = mt.hexagonal_mesh(1.0, 20)                     # 2400 faces
+    tri = torch.tensor(mesh.points[mesh.triangles()].reshape(-1, 9))
+    order = ops.cluster_order(tri).numpy()
+    assert np.array_equal(np.sort(order), np.arange(tri.shape[0]))
+    cent = tri.reshape(-1, 3, 3).mean(1).numpy()[order]
+
+    def mean_radius(run):
+        n = cent.shape[0] // run * run
+        c = cent[:n].reshape(-1, run, 3)
+        return np.linalg.norm(c - c.mean(1, keepdims=True), axis=2).max(1).mean()
+
+    edge = 1.0 / 20
+    assert mean_radius(16) < 4 * edge                     # ~4x4 face patches
+    assert mean_radius(128) < 10 * edge
+    shuffled = np.random.default_rng(0).permutation(cent.shape[0])
+    cent_shuffled = cent[shuffled]
+    c = cent_shuffled[:2400 // 16 * 16].reshape(-1, 16, 3)
+    assert mean_radius(16) < 0.2 * np.linalg.norm(c - c.mean(1, keepdims=True), axis=2).max(1).mean()
+    # tiny inputs
+    assert ops.cluster_order(tri[:5]).numel() == 5 and ops.cluster_order(tri[:0]).numel() == 0
+
+
+def test_deferred_scalar_behaves_like_the_float_the_reference_returns():
+    from tensorflowraytrace_amd.optimizer import DeferredScalar
+    d = DeferredScalar(torch.tensor(2.5, dtype=torch.float64))
+    assert float(d) == 2.5 and d == 2.5 and d < 3 and d >= 2.5 and abs(-d) == 2.5
+    assert d + 1 == 3.5 and 1 + d == 3.5 and d * 2 == 5.0 and 5 / d == 2.0 and d - 0.5 == 2.0
+    assert f"{d:.2f}" == "2.50" and repr(d) == "2.5" and np.isfinite(d) and bool(d)
+    assert np.asarray(d).dtype == np.float64 and d.numpy() == 2.5 and d.item() == 2.5
+    assert np.mean([d, DeferredScalar(torch.tensor(3.5))]) == 3.0
+
+
+def test_engine_trace_mode_selection():
+    import tfrt.engine as engine
+    import tfrt.operation as operation
+
+    class Sys:
+        def __init__(self, m):
+            self._merged_face_verts = torch.zeros((m, 9))
+
+    e3 = engine.OpticalEngine(3, [operation.StandardReaction()])
+    assert e3._trace_mode(Sys(10)) == "all-pairs" and e3._trace_mode(Sys(64)) == "group"
+    for setting, want in ((False, "all-pairs"), ("all-pairs", "all-pairs"), (True, "sort"),
+                          ("sort", "sort"), ("group", "group")):
+        e = engine.OpticalEngine(3, [operation.StandardReaction()], accelerate=setting)
+        assert e._trace_mode(Sys(5000)) == want
+    e2 = engine.OpticalEngine(2, [operation.StandardReaction()], accelerate="group")
+    assert e2._trace_mode(Sys(5000)) == "all-pairs"       # 2-D has its own filter
+    with pytest.raises(ValueError):
+        engine.OpticalEngine(3, [operation.StandardReaction()], accelerate="fastest")
