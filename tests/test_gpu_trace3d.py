@@ -346,3 +346,20 @@ def test_soup_matches_oracle_in_default_mode():
             assert out[cls].shape[1] == 0
             continue
         _compare_sets(out[cls], out[cls + "_id"], ref[cls], 1e-9, cls)
+
+
+@pytest.mark.parametrize("rays_per_lane", ["2", "4"])
+def test_grouped_kernel_with_several_rays_per_lane(rays_per_lane, monkeypatch):
+    """k_intersect_group<T,2> / <T,4> are chosen only beyond 4M rays; force them on a small
+    scene (TFRT_GROUP_RAYS_PER_LANE) and require the all-pairs result bit for bit."""
+    from tensorflowraytrace_amd import ops, _lib
+    rays, fv, scene = _soup_scene(21, 2000, 9000)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    ref = ops.trace3d(rays, fv, scene(False), max_passes=3, flags=flags)
+    monkeypatch.setenv("TFRT_GROUP_RAYS_PER_LANE", rays_per_lane)
+    monkeypatch.setenv("TFRT_GROUP_TARGET_BLOCKS", "64")      # several cluster chunks as well
+    out = ops.trace3d(rays, fv, scene("group"), max_passes=3, flags=flags)
+    assert np.array_equal(out["counts"], ref["counts"])
+    for cls in ("finished", "active", "stopped", "dead"):
+        assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
+        assert torch.equal(out[cls], ref[cls]), cls
