@@ -363,3 +363,25 @@ def test_grouped_kernel_with_several_rays_per_lane(rays_per_lane, monkeypatch):
     for cls in ("finished", "active", "stopped", "dead"):
         assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
         assert torch.equal(out[cls], ref[cls]), cls
+
+
+@pytest.mark.parametrize("mode", ["group", "sort"])
+def test_empty_and_tiny_inputs_in_the_cluster_modes(mode):
+    from tensorflowraytrace_amd import ops, _lib
+    rays, fv, scene = _soup_scene(31, 200, 300)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    sc = scene(mode)
+    out = ops.trace3d(rays[:, :0].contiguous(), fv, sc, max_passes=3, flags=flags)
+    assert all(out[c].shape[1] == 0 for c in ("finished", "active", "stopped", "dead"))
+    assert out["n_tests"] == 0
+    one = ops.trace3d(rays[:, :1].contiguous(), fv, sc, max_passes=3, flags=flags)
+    ref = ops.trace3d(rays[:, :1].contiguous(), fv, scene(False), max_passes=3, flags=flags)
+    for cls in ("finished", "active", "stopped", "dead"):
+        assert torch.equal(one[cls], ref[cls])
+    # rays that miss everything: all dead after one pass
+    far = rays.clone()
+    far[:3] += 100.0
+    far[3:] += 100.0
+    far[5] += 1.0
+    miss = ops.trace3d(far, fv, sc, max_passes=3, flags=flags)
+    assert miss["dead"].shape[1] == far.shape[1] and miss["active"].shape[1] == 0
