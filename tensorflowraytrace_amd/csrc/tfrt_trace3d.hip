@@ -166,9 +166,17 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
   sphere[j] = pack_sphere(cc, reff);
 }
 
-// Clustered path: faces are visited in `order` (spatially coherent groups of CLUSTER faces).
-// One thread per cluster writes its members' spheres (cluster order, padded with never-hit
-// entries), the member -> face map and the cluster's own bounding sphere.
+// Hierarchy modes: faces are visited in `order` (spatially coherent groups of CLUSTER faces).
+// 16 lanes per cluster, one member face each: the lane writes its member's sphere (cluster
+// order; padding entries never hit), the member -> face map and the float32 face record; the
+// group then builds the cluster's bounding sphere together.
+//
+// The cluster sphere only has to contain the member TRIANGLES (plus the size_eps margin by
+// which the exact test accepts points outside them), not the members' own bounding spheres:
+// a line that reaches a valid hit point passes through it either way.  Its centre starts at the
+// mean of the member centres and takes 12 Badoiu-Clarkson steps (move towards the farthest
+// vertex by 1/(k+1)) towards the minimal enclosing ball of the 48 vertices: ~10 % less radius,
+// ~20 % fewer rays per cluster.
 constexpr int CLUSTER = 16;
 
 __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
@@ -176,66 +184,91 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
     const double* __restrict__ c0, double size_eps, int n_clusters,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
     float4* __restrict__ crec) {
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= n_clusters) return;
-  double ctr[CLUSTER][3], rad[CLUSTER];
-  double mean[3] = {0, 0, 0};
-  int cnt = 0;
-  for (int g = 0; g < CLUSTER; ++g) {
-    const int k = c * CLUSTER + g;
-    int f = (k < M) ? order[k] : -1;
-    if (f < 0 || f >= M) f = -1;
-    cface[k] = f;
-    if (f >= 0) {
-      const double* P = fverts + 9 * (int64_t)f;
-      face_sphere(P, c0, size_eps, ctr[g], &rad[g]);
-      csphere[k] = pack_sphere(ctr[g], rad[g]);
-      if (crec != nullptr) {  // float32 record for the screen: P0 - c0, P1 - P0, P2 - P0
-        crec[3 * (int64_t)k] = make_float4((float)(P[0] - c0[0]), (float)(P[1] - c0[1]),
-                                           (float)(P[2] - c0[2]), 0.f);
-        crec[3 * (int64_t)k + 1] = make_float4((float)(P[3] - P[0]), (float)(P[4] - P[1]),
-                                               (float)(P[5] - P[2]), 0.f);
-        crec[3 * (int64_t)k + 2] = make_float4((float)(P[6] - P[0]), (float)(P[7] - P[1]),
-                                               (float)(P[8] - P[2]), 0.f);
-      }
-      for (int q = 0; q < 3; ++q) mean[q] += ctr[g][q];
-      ++cnt;
-    } else {
-      rad[g] = -1.0;
-      csphere[k] = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 never holds
-      if (crec != nullptr)
-        for (int q = 0; q < 3; ++q) crec[3 * (int64_t)k + q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int k = blockIdx.x * BLOCK + threadIdx.x;  // member slot = cluster * CLUSTER + member
+  const int c = k / CLUSTER;
+  const bool in_range = c < n_clusters;            // uniform over the 16 lanes of a cluster
+  int f = (in_range && k < M) ? order[k] : -1;
+  if (f < 0 || f >= M) f = -1;
+  double V[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // vertices relative to c0
+  double ctr[3] = {0, 0, 0}, rad = -1.0, edge = 0.0;
+  if (f >= 0) {
+    const double* P = fverts + 9 * (int64_t)f;
+    face_sphere(P, c0, size_eps, ctr, &rad);
+    for (int v = 0; v < 3; ++v)
+      for (int q = 0; q < 3; ++q) V[v][q] = P[3 * v + q] - c0[q];
+    for (int v = 0; v < 3; ++v) {
+      double e2 = 0;
+      for (int q = 0; q < 3; ++q) e2 += (V[(v + 1) % 3][q] - V[v][q]) * (V[(v + 1) % 3][q] - V[v][q]);
+      edge = fmax(edge, sqrt(e2));
     }
   }
-  double R = -1.0;
-  if (cnt > 0) {
-    // The cluster sphere only has to contain the member TRIANGLES (plus the size_eps margin
-    // by which the exact test accepts points outside them), not the members' own bounding
-    // spheres: a line that reaches a valid hit point passes through it either way.
-    for (int q = 0; q < 3; ++q) mean[q] /= cnt;
-    R = 0.0;
-    double edge = 0.0;  // longest member edge
-    for (int g = 0; g < CLUSTER; ++g) {
-      if (rad[g] < 0.0) continue;
-      const double* P = fverts + 9 * (int64_t)cface[c * CLUSTER + g];
+  if (in_range) {
+    cface[k] = f;
+    csphere[k] = f >= 0 ? pack_sphere(ctr, rad) : make_float4(0.f, 0.f, 0.f, -1.f);
+    if (crec != nullptr) {  // float32 record for the screen: P0 - c0, P1 - P0, P2 - P0
+      crec[3 * (int64_t)k] = make_float4((float)V[0][0], (float)V[0][1], (float)V[0][2], 0.f);
+      crec[3 * (int64_t)k + 1] = make_float4((float)(V[1][0] - V[0][0]), (float)(V[1][1] - V[0][1]),
+                                             (float)(V[1][2] - V[0][2]), 0.f);
+      crec[3 * (int64_t)k + 2] = make_float4((float)(V[2][0] - V[0][0]), (float)(V[2][1] - V[0][1]),
+                                             (float)(V[2][2] - V[0][2]), 0.f);
+    }
+  }
+  // reductions over the 16 lanes of the cluster (xor shuffles stay inside aligned groups of 16)
+  auto sum16 = [&](double v) {
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+  };
+  auto max16 = [&](double v) {
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+  };
+  const double cnt = sum16(f >= 0 ? 1.0 : 0.0);
+  double mean[3];
+  for (int q = 0; q < 3; ++q) mean[q] = sum16(f >= 0 ? ctr[q] : 0.0) / fmax(cnt, 1.0);
+  const int lane = threadIdx.x & 63;
+  double R = 0.0;
+  for (int it = 1; it <= 13; ++it) {
+    // this lane's farthest vertex from the current centre
+    double best = -1.0;
+    int bv = 0;
+    if (f >= 0) {
       for (int v = 0; v < 3; ++v) {
-        double d2 = 0, e2 = 0;
-        for (int q = 0; q < 3; ++q) {
-          const double d = (P[3 * v + q] - c0[q]) - mean[q];
-          d2 += d * d;
-          const double ed = P[3 * ((v + 1) % 3) + q] - P[3 * v + q];
-          e2 += ed * ed;
+        double d2 = 0;
+        for (int q = 0; q < 3; ++q) d2 += (V[v][q] - mean[q]) * (V[v][q] - mean[q]);
+        if (d2 > best) {
+          best = d2;
+          bv = v;
         }
-        R = fmax(R, sqrt(d2));
-        edge = fmax(edge, sqrt(e2));
       }
     }
-    if (size_eps > 0.0) R += 2.0 * size_eps * edge;  // as face_sphere(): size_eps (|E1| + |E2|)
-    const double cn = sqrt(dot3(mean, mean));
-    R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
-    clsphere[c] = pack_sphere(mean, R);
-  } else {
-    clsphere[c] = make_float4(0.f, 0.f, 0.f, -1.f);
+    const double top = max16(best);
+    if (it == 13) {  // final radius about the final centre
+      R = sqrt(fmax(top, 0.0));
+      break;
+    }
+    // the lowest lane of the group holding the maximum provides the vertex
+    const unsigned long long holders = __ballot(best == top && f >= 0);
+    const int group0 = lane & ~(CLUSTER - 1);
+    const unsigned long long mine = (holders >> group0) & 0xFFFFull;
+    const int src = group0 + (mine ? __ffsll((long long)mine) - 1 : 0);
+    for (int q = 0; q < 3; ++q) {
+      const double mine_q = bv == 0 ? V[0][q] : (bv == 1 ? V[1][q] : V[2][q]);  // no dynamic index
+      const double fq = __shfl(mine_q, src, 64);
+      mean[q] += (fq - mean[q]) / (it + 1);
+    }
+  }
+  const double max_edge = max16(edge);
+  if (in_range && (threadIdx.x & (CLUSTER - 1)) == 0) {
+    if (cnt > 0.0) {
+      if (size_eps > 0.0) R += 2.0 * size_eps * max_edge;  // as face_sphere(): size_eps (|E1| + |E2|)
+      const double cn = sqrt(dot3(mean, mean));
+      R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
+      clsphere[c] = pack_sphere(mean, R);
+    } else {
+      clsphere[c] = make_float4(0.f, 0.f, 0.f, -1.f);
+    }
   }
 }
 
@@ -1839,7 +1872,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   if (M > 0) {
     hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0);
     if (ac.order != nullptr) {
-      hipLaunchKernelGGL(k_cluster_spheres, dim3(cdiv(ac.n_clusters, BLOCK)), dim3(BLOCK), 0, st,
+      hipLaunchKernelGGL(k_cluster_spheres, dim3(cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK)),
+                         dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          ac.csphere, ac.cface, ac.clsphere, ac.sort_rays ? nullptr : ac.crec);
       if (!ac.sort_rays) {
