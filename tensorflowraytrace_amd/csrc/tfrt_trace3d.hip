@@ -834,15 +834,17 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
 
   __shared__ float4 tile[GT];                // cluster spheres of the current tile
   __shared__ float4 stile[GT / SUPER];       // their superclusters' spheres
-  __shared__ int32_t cand[WAVES][KQ][64];   // per-lane queues; compacted in place by flush()
+  // per-lane queues of (tile-local cluster << 2 | ray of the lane), compacted in place by
+  // flush() into (tile-local cluster << 8 | ray slot of the wave): 16 bits, because the queue
+  // is always drained before the tile changes (LDS footprint decides the waves in flight)
+  __shared__ uint16_t cand[WAVES][KQ][64];
   __shared__ float4 prep_a[WAVES][RW];       // (a, -s.a) of the wave's rays
   __shared__ float4 prep_b[WAVES][RW];       // (b, -s.b)
   __shared__ unsigned long long best_k[WAVES][RW];
   __shared__ int32_t best_i[WAVES][RW];
   constexpr int PAIRS = 64 + 4 * 64;        // waiting pairs: < 64 left over + one step's hits
-  __shared__ int32_t pair_slot[WAVES][PAIRS];
-  __shared__ int32_t pair_memb[WAVES][PAIRS];
-  __shared__ int32_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
+  __shared__ int32_t pairs[WAVES][PAIRS];    // member slot << 8 | ray slot (member slot < 2^24)
+  __shared__ uint8_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
   __shared__ int32_t x_face[WAVES][128];
   __shared__ T ray_l[WAVES][6][RW];          // the wave's rays (state dtype) for the decisions
   __shared__ int32_t skip_l[WAVES][RW];      // face each ray starts on (-1: none)
@@ -879,6 +881,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   }
 
   int cnt = 0;
+  int t0 = c_lo - GT;  // first cluster of the current tile (c_lo is a multiple of SUPER)
 
   // Screen: one (ray, member) pair per lane against the face's float32 record (3 gathered
   // 16-byte loads; the ray comes from LDS).  Survivors -- about a third -- are appended to the
@@ -889,8 +892,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     bool keep = false;
     int j = -1, slot = 0;
     if (lane < nb) {
-      slot = pair_slot[wave][lane];
-      const int memb = pair_memb[wave][lane];
+      const int pr = pairs[wave][lane];
+      slot = pr & 255;
+      const int memb = pr >> 8;
       const float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
                    r2 = crec[3 * (int64_t)memb + 2];
       j = cface[memb];
@@ -914,7 +918,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     const unsigned long long km = __ballot(keep);
     if (keep) {
       const int pos = xn + rank_below(km);
-      x_slot[wave][pos] = slot;
+      x_slot[wave][pos] = (uint8_t)slot;
       x_face[wave][pos] = j;
     }
     xn += __popcll(km);
@@ -967,8 +971,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     return;
 #endif
     // 1. compact the lanes' queues into one list (in place, through registers): entry =
-    //    cluster << 8 | ray slot of the wave
-    int32_t* list = &cand[wave][0][0];
+    //    tile-local cluster << 8 | ray slot of the wave
+    uint16_t* list = &cand[wave][0][0];
     int incl = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -984,14 +988,15 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     wave_fence();
 #pragma unroll
     for (int k = 0; k < KQ; ++k)
-      if (k < cnt) list[first + k] = ((mine[k] >> 2) << 8) | ((mine[k] & 3) << 6) | lane;
+      if (k < cnt)
+        list[first + k] = (uint16_t)(((mine[k] >> 2) << 8) | ((mine[k] & 3) << 6) | lane);
     wave_fence();
     // 2. member tests, 16 queued candidates per step: each 16-lane group takes four; their
     //    member spheres are fetched first (four independent coalesced 256-byte reads in
     //    flight).  Member hits become (ray, face) pairs; while 64 are waiting -- and once more
     //    at the end -- they are decided, one per lane.  (One call site each for decide() and
     //    flush(): the float64 test is big and copies of it only bloat the kernel.)
-    int pn = 0;  // pairs waiting in pair_slot / pair_memb (wave-uniform)
+    int pn = 0;  // entries waiting in pairs[] (wave-uniform)
     for (int q0 = 0; q0 < total; q0 += 16) {
       {
         float4 sp[4];
@@ -1005,7 +1010,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           if (q < total) {
             const int v = list[q];
             slot[u] = v & 255;
-            memb[u] = (v >> 8) * CLUSTER + (lane & (CLUSTER - 1));
+            memb[u] = (t0 + (v >> 8)) * CLUSTER + (lane & (CLUSTER - 1));
             sp[u] = csphere[memb[u]];
           }
         }
@@ -1020,11 +1025,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
           continue;
 #endif
-          if (hit) {
-            const int pos = pn + rank_below(hm);
-            pair_slot[wave][pos] = slot[u];
-            pair_memb[wave][pos] = memb[u];
-          }
+          if (hit) pairs[wave][pn + rank_below(hm)] = (memb[u] << 8) | slot[u];
           pn += __popcll(hm);
         }
       }
@@ -1035,16 +1036,10 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
         if (nb > 0) screen(nb);
         // keep the rest of the pairs: move them to the front (64 per round)
         for (int m0 = 0; m0 < pn - nb; m0 += 64) {
-          int ts = 0, tm = 0;
-          if (m0 + lane < pn - nb) {
-            ts = pair_slot[wave][nb + m0 + lane];
-            tm = pair_memb[wave][nb + m0 + lane];
-          }
+          int tp = 0;
+          if (m0 + lane < pn - nb) tp = pairs[wave][nb + m0 + lane];
           wave_fence();
-          if (m0 + lane < pn - nb) {
-            pair_slot[wave][m0 + lane] = ts;
-            pair_memb[wave][m0 + lane] = tm;
-          }
+          if (m0 + lane < pn - nb) pairs[wave][m0 + lane] = tp;
           wave_fence();
         }
         pn -= nb;
@@ -1058,7 +1053,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           }
           wave_fence();
           if (lane < xn - xb) {
-            x_slot[wave][lane] = ts;
+            x_slot[wave][lane] = (uint8_t)ts;
             x_face[wave][lane] = tf;
           }
           xn -= xb;
@@ -1074,17 +1069,17 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   unsigned touched[R];  // per ray: superclusters of the current tile its line touches
 #pragma unroll
   for (int r = 0; r < R; ++r) touched[r] = 0u;
-  int t0 = c_lo - GT;  // c_lo is a multiple of SUPER
   for (;;) {
     bool pending = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) pending = pending || __any(touched[r] != 0u);
     bool drain = false, done = false;
-    if (!pending) {
-      // this wave is through with the tile: next tile (all four waves meet here), or finish
+    if (!pending && __any(cnt > 0)) {
+      drain = true;  // through with the tile: empty the queue while its entries refer to it
+    } else if (!pending) {
+      // next tile (all four waves meet here), or finish
       t0 += GT;
       if (t0 >= c_hi) {
-        drain = true;
         done = true;
       } else {
         const int nt = min(GT, c_hi - t0);
@@ -1121,7 +1116,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
               const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
               const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
               if (fmaf(pa, pa, pb * pb) <= sp.w) {
-                cand[wave][cnt][lane] = ((t0 + k * SUPER + g) << 2) | r;
+                cand[wave][cnt][lane] = (uint16_t)(((k * SUPER + g) << 2) | r);
                 ++cnt;
               }
             }
@@ -1854,8 +1849,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
 
   hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail);
   Accel3 ac;
-  // (the grouped kernel packs cluster index and ray slot into 32 bits: < 2^23 clusters)
-  ac.order = (M >= 4 * CLUSTER && M < (1 << 27)) ? sc->cluster_order : nullptr;
+  // (the grouped kernel packs member slot and ray slot into 32 bits: member slots < 2^24)
+  ac.order = (M >= 4 * CLUSTER && M < (1 << 24) - CLUSTER) ? sc->cluster_order : nullptr;
   ac.sort_rays = sc->sort_rays != 0;
   ac.n_clusters = cdiv(M > 0 ? M : 1, CLUSTER);
   ac.csphere = reinterpret_cast<float4*>(ws + lay.csphere);
