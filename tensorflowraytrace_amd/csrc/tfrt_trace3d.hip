@@ -843,7 +843,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   __shared__ unsigned long long best_k[WAVES][RW];
   __shared__ int32_t best_i[WAVES][RW];
   constexpr int PAIRS = 64 + 4 * 64;        // waiting pairs: < 64 left over + one step's hits
-  __shared__ int32_t pairs[WAVES][PAIRS];    // member slot << 8 | ray slot (member slot < 2^24)
+  __shared__ uint32_t pairs[WAVES][PAIRS];   // member slot << 8 | ray slot (member slot < 2^24)
   __shared__ uint8_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
   __shared__ int32_t x_face[WAVES][128];
   __shared__ T ray_l[WAVES][6][RW];          // the wave's rays (state dtype) for the decisions
@@ -892,9 +892,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     bool keep = false;
     int j = -1, slot = 0;
     if (lane < nb) {
-      const int pr = pairs[wave][lane];
-      slot = pr & 255;
-      const int memb = pr >> 8;
+      const uint32_t pr = pairs[wave][lane];
+      slot = (int)(pr & 255u);
+      const int memb = (int)(pr >> 8);
       const float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
                    r2 = crec[3 * (int64_t)memb + 2];
       j = cface[memb];
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
           continue;
 #endif
-          if (hit) pairs[wave][pn + rank_below(hm)] = (memb[u] << 8) | slot[u];
+          if (hit) pairs[wave][pn + rank_below(hm)] = ((uint32_t)memb[u] << 8) | (uint32_t)slot[u];
           pn += __popcll(hm);
         }
       }
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
         if (nb > 0) screen(nb);
         // keep the rest of the pairs: move them to the front (64 per round)
         for (int m0 = 0; m0 < pn - nb; m0 += 64) {
-          int tp = 0;
+          uint32_t tp = 0;
           if (m0 + lane < pn - nb) tp = pairs[wave][nb + m0 + lane];
           wave_fence();
           if (m0 + lane < pn - nb) pairs[wave][m0 + lane] = tp;
