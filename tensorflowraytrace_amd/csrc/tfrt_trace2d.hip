@@ -168,7 +168,8 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
                                                   double* lds, float4* filt, int32_t* queue,
                                                   bool active, double* out_u, double* out_aux) {
   // float32 state of this lane's ray
-  float nx = 0.f, ny = 0.f, sn = INFINITY, w1 = 0.f, w2 = 0.f;  // sn = inf: never a candidate
+  // sn = NaN: a lane without a (valid) ray never passes the test, whatever the radius
+  float nx = 0.f, ny = 0.f, sn = __builtin_nanf(""), w1 = 0.f, w2 = 0.f;
   {
     const double dx = e[0] - s[0], dy = e[1] - s[1];
     const double l2 = dx * dx + dy * dy;

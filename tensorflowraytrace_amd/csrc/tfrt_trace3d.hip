@@ -333,7 +333,8 @@ __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, i
     return;
   }
   uint32_t key = 0x3FFFFFFFu;
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, INFINITY, INFINITY};  // never a candidate
+  // a zero-length or non-finite ray can hit nothing (den = 0): NaN offsets never pass d2 <= r2
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, __builtin_nanf(""), __builtin_nanf("")};
   double s[3], e[3];
   load_ray3(rays, stride, i, s, e);
   const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
@@ -478,7 +479,10 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
     bt[r] = INFINITY;
     bi[r] = -1;
     ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
-    nsa[r] = nsb[r] = INFINITY;  // never a candidate
+    // NaN, not +inf: a lane without a ray must never pass `d2 <= r2`, even for a face whose
+    // inflated radius overflowed to +inf (size_eps = 1e300 does that); an inf here let ray-less
+    // lanes queue candidates and read ray slots >= n
+    nsa[r] = nsb[r] = __builtin_nanf("");
     if (i < n) {
       ax[r] = prep[i];
       ay[r] = prep[pstride + i];
@@ -505,6 +509,7 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
       const int j = v >> 2;
       const int r = v & 3;
       const int i = base + r * BLOCK + tid;
+      if (i >= n) continue;  // (cannot happen: ray-less lanes never queue)
       if (last_tri != nullptr && last_tri[i] == j) continue;  // face the ray starts on
       double s[3], e[3], P[9];
       load_ray3(rays, stride, i, s, e);
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_cull(
     bi[r] = -1;
     slot[r] = -1;
     ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
-    nsa[r] = nsb[r] = INFINITY;
+    nsa[r] = nsb[r] = __builtin_nanf("");  // never a candidate (see k_intersect3d)
     if (q < n) {
       const int i = rperm[q];
       slot[r] = i;
@@ -855,7 +860,10 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   for (int r = 0; r < R; ++r) {
     const int i = base + r * BLOCK + tid;
     ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
-    nsa[r] = nsb[r] = INFINITY;  // never a candidate
+    // NaN, not +inf: a lane without a ray must never pass `d2 <= r2`, even for a face whose
+    // inflated radius overflowed to +inf (size_eps = 1e300 does that); an inf here let ray-less
+    // lanes queue candidates and read ray slots >= n
+    nsa[r] = nsb[r] = __builtin_nanf("");
     {
       const int slot = r * 64 + lane;
       const int ii = i < n ? i : 0;

@@ -385,3 +385,21 @@ def test_empty_and_tiny_inputs_in_the_cluster_modes(mode):
     far[5] += 1.0
     miss = ops.trace3d(far, fv, sc, max_passes=3, flags=flags)
     assert miss["dead"].shape[1] == far.shape[1] and miss["active"].shape[1] == 0
+
+
+def test_lanes_without_rays_never_queue_candidates():
+    """Regression: size_epsilion = 1e300 inflates every bounding sphere to +inf; lanes without
+    a ray used +inf offsets, passed `inf <= inf`, queued candidates and read ray slots >= n
+    (an intermittent out-of-bounds fault in the 1-ray seam calls of the golden test).  With
+    a handful of rays in a 256-lane workgroup the results must equal the plain evaluation."""
+    from tensorflowraytrace_amd import ops, _lib
+    rays, fv, scene = _soup_scene(41, 200, 5)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    for mode in (False, "group", "sort"):
+        sc = scene(mode)
+        sc.eps = (1e-10, 1e300, 1e-10)           # size_epsilion: every face becomes "all space"
+        out = ops.trace3d(rays, fv, sc, max_passes=2, flags=flags)
+        total = sum(out[c].shape[1] for c in ("finished", "stopped", "dead")) + out["unfinished"].shape[1]
+        assert total == 5, mode
+    x, y, z, valid, ray_u, tu, tv, gi = ops.intersect3d(rays.double(), fv, 1e-10, 1e300, -1e300)
+    assert valid.shape[0] == 5 and bool(valid.all())    # with these epsilons every plane is hit
