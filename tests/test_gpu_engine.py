@@ -236,3 +236,57 @@ def test_ghost_through_goes_straight():
     want_y = src["y_start"] + t * d[:, 1]
     ids = ghost.last_trace["finished_id"].long()
     np.testing.assert_allclose(fin["y_end"].detach().cpu().numpy(), want_y[ids].cpu().numpy(), atol=1e-9)
+
+
+def test_stops_and_technical_intersections_through_the_engine():
+    """A stop plate in front of the lens: stopped rays are compiled, and with
+    compile_technical_intersections the stop / target boundary data is gathered to the rays
+    that hit them (engine.py:2135-2191); classes and end points equal the oracle's."""
+    import tfrt.boundaries as boundaries
+    import tfrt.engine as engine
+    import tfrt.materials as materials
+    import tfrt.mesh_tools as mt
+    import tfrt.operation as operation
+    eng0, system0, lens, target, source = _build_lens(3000, k=3, ray_dtype=torch.float64)
+    stop = boundaries.ManualTriangleBoundary(
+        mesh=mt.plane(center=(-1.0, 0.25, 0.0), direction=(1, 0, 0), i_size=0.3, j_size=0.3))
+    system = engine.OpticalSystem3D()
+    system.optical = lens.surfaces
+    system.stops = [stop]
+    system.targets = [target]
+    system.sources = [source]
+    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
+    system.update()
+    eng = engine.OpticalEngine(
+        3, [operation.StandardReaction()], compile_stopped_rays=True, compile_dead_rays=True,
+        compile_technical_intersections=True, simple_ray_inheritance={"wavelength"},
+        ray_dtype=torch.float64)
+    eng.optical_system = system
+    eng.validate_system()
+
+    eng.ray_trace(4)
+    params = [p.detach().cpu().clone() for p in lens.parameters]
+    surfs = [_oracle_surface(s, p) for s, p in zip(lens.surfaces, params)]
+    faces_of = lambda b: tracer.faces_from_vertices(b._vertices.detach().cpu(), b._faces[:, 1:])
+    osys = tracer.System(3, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"]],
+                         optical=tracer.amalgamate(surfs), stop=faces_of(stop),
+                         target=faces_of(target))
+    src = {k: v.detach().cpu().double() for k, v in system._amalgamated_sources.items()
+           if k in ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end", "wavelength")}
+    ref = tracer.ray_trace(osys, src, max_iterations=4, inherit=("wavelength",),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    n_stopped = ref["stopped"]["x_start"].shape[0]
+    assert 20 < n_stopped < 1500
+    for name, got in (("stopped", eng.stopped_rays), ("finished", eng.finished_rays)):
+        for f in ("x_start", "y_end", "z_end"):
+            np.testing.assert_allclose(got[f].detach().cpu().numpy(), ref[name][f].numpy(),
+                                       rtol=0, atol=1e-9, err_msg=f"{name}.{f}")
+    # technical boundary data of the first pass: stop norm for every stopped ray
+    eng.clear_ray_history()
+    eng.single_pass(dict(system._amalgamated_sources))
+    res = eng.last_projection_result
+    assert res["rays"]["stopped"]["x_start"].shape[0] == n_stopped
+    assert set(res["stop"].keys()) >= {"xp", "x1", "z2", "norm"}
+    assert res["stop"]["norm"].shape == (n_stopped, 3)
+    np.testing.assert_allclose(res["stop"]["norm"].detach().abs().cpu().numpy()[:, 0], 1.0, atol=1e-12)
+    assert "target" not in res or res["target"]["xp"].shape[0] == 0   # nothing reaches it in pass 1
