@@ -3,16 +3,25 @@
 //
 // Structure of one pass (reference: tfrt/engine.py:2193-2302 single_pass):
 //
-//   k_intersect3d  grid (ray blocks, face chunks).  lane = R rays.  The chunk's faces stream
-//                  through an LDS tile as 16-byte bounding spheres; the hot loop is a
-//                  conservative float32 line-vs-sphere rejection test (10 VALU ops per
-//                  ray-face pair, Pluecker form |c x d^ - m|^2 <= r^2).  Pairs that survive
-//                  are queued per lane in LDS and then decided EXACTLY in float64 with the
-//                  reference's own Cramer sums and epsilons (trace_math.h exact_triangle),
-//                  so hit/miss and nearest-hit decisions are the float64 reference's
-//                  decisions; the float32 filter only ever removes pairs that cannot hit.
-//                  Running (ray_u, face) minimum lives in registers: no cross-lane reduce.
-//   k_classify3d   min over face chunks (first index wins ties, like tf.argmin), boundary
+//   k_rayprep      per ray: float64 ray -> 8 float32 numbers (an orthonormal pair (a, b) spanning
+//                  the plane perpendicular to the ray, and -s.a, -s.b in a mesh-centred frame).
+//   intersect      decides every ray-face pair of the pass.  The unit of throughput is a
+//                  conservative float32 line-vs-sphere test, (c.a - s.a)^2 + (c.b - s.b)^2 <= r^2
+//                  (8 FMA-class ops); whatever it lets through is screened by a float32
+//                  Moeller-Trumbore evaluation with error bounds (may_hit) and then decided
+//                  EXACTLY in float64 with the reference's own Cramer sums and epsilons
+//                  (trace_math.h exact_triangle), so hit/miss and nearest-hit decisions are the
+//                  float64 reference's decisions; the float32 stages only remove pairs that
+//                  cannot hit.  Three kernels share that scheme:
+//        k_intersect_group  (default, scenes of >= 64 faces) sphere hierarchy over k-d face
+//                           clusters: 8-cluster superclusters -> 16-face clusters -> faces;
+//                           lanes queue the clusters their rays touch, the wave drains the
+//                           queues together (member tests, screen, float64 decisions, each on
+//                           compacted full wavefronts).
+//        k_intersect3d      every pair through the sphere filter: grid (ray blocks, face
+//                           chunks), lane = R rays, spheres stream through an LDS tile.
+//        k_intersect_cull   clusters + rays visited in a sorted, coherent order.
+//   k_classify3d   min over chunks (lowest face index wins ties, like tf.argmin), boundary
 //                  catagory -> ray class, per-block class histogram.
 //   k_scan3d       one block: exclusive scan of the histograms -> stable output slots,
 //                  per-pass counts, running totals, next pass's ray count (all on device:
@@ -22,8 +31,8 @@
 //                  (float64 Snell) into the next pass's ray block, records the tape.
 //
 // Backward: k_backward3d walks the tape pass by pass in reverse, recomputes the per-ray
-// forward in float64 and applies the hand-derived adjoint (trace_math.h adjoint3d); face
-// gradients are accumulated with float64 hardware atomics.
+// forward in float64 and applies the hand-derived adjoint (trace_math.h adjoint3d); the face
+// gradients of the rays are summed in LDS face windows (k_face_accumulate).
 #include <vector>
 
 #include "tfrt_common.h"
