@@ -143,6 +143,11 @@ def test_float16_ray_state_experiment():
     scene = scene_util.lens_scene(3000, k_front=5, k_back=4)
     src, fv, sc, _ = _gpu_scene(scene, torch.float16)
     out = ops.trace3d(src, fv, sc, max_passes=4)
+    # the same float16 state through the default (grouped) kernel: identical to all-pairs
+    srcg, fvg, scg, _ = _gpu_scene(scene, torch.float16, cluster="group")
+    outg = ops.trace3d(srcg, fvg, scg, max_passes=4)
+    assert torch.equal(outg["finished"], out["finished"])
+    assert torch.equal(outg["finished_id"], out["finished_id"])
     src64, fv64, sc64, _ = _gpu_scene(scene, torch.float64)
     ref = ops.trace3d(src64, fv64, sc64, max_passes=4)
     n16, n64 = out["finished"].shape[1], ref["finished"].shape[1]
