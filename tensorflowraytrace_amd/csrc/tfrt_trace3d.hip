@@ -377,6 +377,37 @@ __global__ __launch_bounds__(SUPER * CLUSTER) void k_super_spheres(
 // plane perpendicular to the ray and the offsets -s.a, -s.b, in the c0 frame), 8 floats per
 // ray stored SoA.  Computing it here instead of in every (ray block, face chunk) workgroup of
 // k_intersect3d keeps the float64 sqrt/divide work off the hot kernel when faces are chunked.
+// o[0..5] = (a, b), o[6..7] = (-s.a, -s.b).  Returns false (NaN offsets: never a candidate)
+// for a zero-length or non-finite ray, which can hit nothing (den = 0).
+__device__ __forceinline__ bool ray_filter_state(const double s[3], const double e[3],
+                                                 const double* __restrict__ c0, float o[8],
+                                                 double u[3], double sc[3]) {
+  for (int k = 0; k < 6; ++k) o[k] = 0.f;
+  o[6] = o[7] = __builtin_nanf("");
+  const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
+  const double l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  if (!(l2 > 0.0 && l2 < INFINITY)) return false;
+  const double inv = 1.0 / sqrt(l2);
+  for (int k = 0; k < 3; ++k) {
+    u[k] = d[k] * inv;
+    sc[k] = s[k] - c0[k];
+  }
+  // a = normalize(u x e_k) with e_k the axis least aligned with u; b = u x a
+  const double f0 = fabs(u[0]), f1 = fabs(u[1]), f2 = fabs(u[2]);
+  const bool k0 = (f0 <= f1 && f0 <= f2), k1 = !k0 && (f1 <= f2);
+  const double ek[3] = {k0 ? 1.0 : 0.0, k1 ? 1.0 : 0.0, (!k0 && !k1) ? 1.0 : 0.0};
+  double a[3], b[3];
+  cross3(u, ek, a);
+  const double ia = 1.0 / sqrt(dot3(a, a));
+  a[0] *= ia; a[1] *= ia; a[2] *= ia;
+  cross3(u, a, b);
+  o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)a[2];
+  o[3] = (float)b[0]; o[4] = (float)b[1]; o[5] = (float)b[2];
+  o[6] = -(float)dot3(sc, a);
+  o[7] = -(float)dot3(sc, b);
+  return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, int64_t stride,
                                                    const int32_t* __restrict__ n_ptr,
@@ -394,45 +425,24 @@ __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, i
     return;
   }
   uint32_t key = 0x3FFFFFFFu;
-  // a zero-length or non-finite ray can hit nothing (den = 0): NaN offsets never pass d2 <= r2
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, __builtin_nanf(""), __builtin_nanf("")};
-  double s[3], e[3];
+  float o[8];
+  double s[3], e[3], u[3], sc[3];
   load_ray3(rays, stride, i, s, e);
-  const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
-  const double l2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-  if (l2 > 0.0 && l2 < INFINITY) {
-    const double inv = 1.0 / sqrt(l2);
-    const double u[3] = {d[0] * inv, d[1] * inv, d[2] * inv};
-    const double sc[3] = {s[0] - c0[0], s[1] - c0[1], s[2] - c0[2]};
-    // a = normalize(u x e_k) with e_k the axis least aligned with u; b = u x a
-    const double f0 = fabs(u[0]), f1 = fabs(u[1]), f2 = fabs(u[2]);
-    const bool k0 = (f0 <= f1 && f0 <= f2), k1 = !k0 && (f1 <= f2);
-    const double ek[3] = {k0 ? 1.0 : 0.0, k1 ? 1.0 : 0.0, (!k0 && !k1) ? 1.0 : 0.0};
-    double a[3], b[3];
-    cross3(u, ek, a);
-    const double ia = 1.0 / sqrt(dot3(a, a));
-    a[0] *= ia; a[1] *= ia; a[2] *= ia;
-    cross3(u, a, b);
-    o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)a[2];
-    o[3] = (float)b[0]; o[4] = (float)b[1]; o[5] = (float)b[2];
-    o[6] = -(float)dot3(sc, a);
-    o[7] = -(float)dot3(sc, b);
-    if (keys != nullptr) {
-      // sort key: Morton code of the foot of the perpendicular from the mesh centre to the
-      // ray's line -- rays whose lines pass close to each other near the mesh sort together
-      const double su = dot3(sc, u);
-      const double inv_r = 1.0 / fmax(c0[3], 1e-300);
-      key = 0;
-      for (int k = 0; k < 3; ++k) {
-        double q = ((sc[k] - su * u[k]) * inv_r * 0.5 + 0.5) * 1023.0;
-        q = fmin(fmax(q, 0.0), 1023.0);
-        uint32_t v = (uint32_t)q;
-        v = (v | (v << 16)) & 0x030000FFu;
-        v = (v | (v << 8)) & 0x0300F00Fu;
-        v = (v | (v << 4)) & 0x030C30C3u;
-        v = (v | (v << 2)) & 0x09249249u;
-        key |= v << k;
-      }
+  if (ray_filter_state(s, e, c0, o, u, sc) && keys != nullptr) {
+    // sort key: Morton code of the foot of the perpendicular from the mesh centre to the
+    // ray's line -- rays whose lines pass close to each other near the mesh sort together
+    const double su = dot3(sc, u);
+    const double inv_r = 1.0 / fmax(c0[3], 1e-300);
+    key = 0;
+    for (int k = 0; k < 3; ++k) {
+      double q = ((sc[k] - su * u[k]) * inv_r * 0.5 + 0.5) * 1023.0;
+      q = fmin(fmax(q, 0.0), 1023.0);
+      uint32_t v = (uint32_t)q;
+      v = (v | (v << 16)) & 0x030000FFu;
+      v = (v | (v << 8)) & 0x0300F00Fu;
+      v = (v | (v << 4)) & 0x030C30C3u;
+      v = (v | (v << 2)) & 0x09249249u;
+      key |= v << k;
     }
   }
 #pragma unroll
@@ -1354,7 +1364,8 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
     tfrt_scene3d sc, double L, double dead_len, uint32_t flags, T* __restrict__ rays_out,
     int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_tri_out,
     int32_t* __restrict__ rec_slot, tfrt_ray_out fin, tfrt_ray_out act, tfrt_ray_out stp,
-    tfrt_ray_out dead, int32_t* __restrict__ err) {
+    tfrt_ray_out dead, int32_t* __restrict__ err, float* __restrict__ prep_next, int64_t pstride,
+    const double* __restrict__ c0) {
   const int n = *n_ptr;
   const int base = blockIdx.x * BLOCK;
   if (base >= n) return;
@@ -1415,6 +1426,19 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
       ray_id_out[slot] = rid;
       last_tri_out[slot] = tri;
       rec_slot[i] = slot;
+      if (prep_next != nullptr) {
+        // the child's filter state for the next pass (saves a k_rayprep launch and a re-read of
+        // the ray block), from the child AS STORED: the exact tests see the rounded state
+        double sr[3], er[3], u[3], scv[3];
+        for (int k = 0; k < 3; ++k) {
+          sr[k] = static_cast<double>(static_cast<T>(h[k]));
+          er[k] = static_cast<double>(static_cast<T>(e2[k]));
+        }
+        float o[8];
+        ray_filter_state(sr, er, c0, o, u, scv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) prep_next[k * pstride + slot] = o[k];
+      }
     }
   }
   if (!ok) atomicOr(err, ERR_CAPACITY);
@@ -1827,13 +1851,15 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                             const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
                             const double* fverts, const double* c0, float* prep, int64_t pstride,
                             int M, double ei, double es, double er, double* part_t,
-                            int32_t* part_i, int64_t part_stride, const Accel3* ac, int n_cap) {
+                            int32_t* part_i, int64_t part_stride, const Accel3* ac, int n_cap,
+                            bool prep_ready = false) {
   const bool accel = ac != nullptr && ac->order != nullptr;
   const bool clustered = accel && ac->sort_rays;
   const bool grouped = accel && !ac->sort_rays;
-  hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
-                     prep, pstride, clustered ? ac->keys_in : nullptr,
-                     clustered ? ac->vals_in : nullptr, n_cap);
+  if (!prep_ready || clustered)  // (sorted-ray mode also needs the sort keys)
+    hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
+                       prep, pstride, clustered ? ac->keys_in : nullptr,
+                       clustered ? ac->vals_in : nullptr, n_cap);
   if (clustered) {
     if (sort_pairs_u32_i32(ac->sort_tmp, ac->sort_bytes, ac->keys_in, ac->keys_out, ac->vals_in,
                            ac->rperm, (size_t)n_cap, 32, st) != 0)
@@ -1961,7 +1987,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     ac.rperm = rperm_all + (size_t)p * n;
     if (launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, prep,
                             (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion,
-                            sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac, (int)N) != 0)
+                            sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac, (int)N,
+                            /*prep_ready=*/p > 0) != 0)
       return TFRT_E_LAUNCH;
     hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, chunks_used,
                        part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
@@ -1975,7 +2002,9 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, flags, rout,
                        (int64_t)n, rayid + (size_t)p * n, lasttri + (size_t)p * n,
                        rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
-                       stp ? *stp : none, dead ? *dead : none, tail + 6);
+                       stp ? *stp : none, dead ? *dead : none, tail + 6,
+                       (p + 1 < P && !(ac.order != nullptr && ac.sort_rays)) ? prep : nullptr,
+                       (int64_t)n, c0);
   }
   if (unfinished != nullptr && P > 0) {
     hipLaunchKernelGGL((k_copy_rays<T>), dim3(pl.nblk), dim3(BLOCK), 0, st,
