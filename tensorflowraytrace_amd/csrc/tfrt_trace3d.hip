@@ -1466,24 +1466,6 @@ __device__ __forceinline__ int backward_ray(
     const double* __restrict__ g_stp, int64_t cap_stp, const double* __restrict__ g_dead,
     int64_t cap_dead, double* __restrict__ g_out, int64_t out_stride, double gP[9]);
 
-// Sort keys of the reverse sweep: the face each ray slot hit (rays that miss sort last), so
-// that neighbouring lanes accumulate into the same face and can be summed across the wave.
-__global__ __launch_bounds__(BLOCK) void k_bwd_keys(const int32_t* __restrict__ n_ptr,
-                                                    const int32_t* __restrict__ rec_tri, int M,
-                                                    uint32_t* __restrict__ keys,
-                                                    int32_t* __restrict__ vals, int n_cap) {
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n_cap) return;
-  const int n = *n_ptr;
-  uint32_t k = (uint32_t)M + 1u;  // unused slot
-  if (i < n) {
-    const int t = rec_tri[i];
-    k = (t >= 0) ? (uint32_t)t : (uint32_t)M;
-  }
-  keys[i] = k;
-  vals[i] = i;
-}
-
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_backward3d(
     const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
@@ -2036,21 +2018,15 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   const uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
   double* gbuf = reinterpret_cast<double*>(ws + lay.gbuf);
   int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
-  uint32_t* keys_in = reinterpret_cast<uint32_t*>(ws + lay.keys_in);
-  uint32_t* keys_out = reinterpret_cast<uint32_t*>(ws + lay.keys_out);
   int32_t* vals_in = reinterpret_cast<int32_t*>(ws + lay.vals_in);
-  // Face-sorted order (one radix sort per pass, then gradients summed across the wave) pays
-  // off when many rays pile onto each face: measured 10.6 -> 3.6 ms at 4M rays x 974 faces,
-  // but a small loss at 1M rays x 10574 faces, where plain scattered atomics are cheaper.
-  const bool sorted = M > 0 && N >= 65536 && N / M >= 512;
-  // the clustered forward left its Morton ray order in rperm: coherent enough to aggregate
+  // the sorted-ray forward left its Morton ray order in rperm: neighbouring lanes then mostly hit
+  // the same few faces and k_backward3d sums their face gradients across the wave
   const bool coherent = sc->cluster_order != nullptr && sc->sort_rays != 0 && M >= 4 * CLUSTER;
-  int key_bits = 1;
-  while ((1ll << key_bits) < (long long)M + 2) ++key_bits;
   const size_t n = N > 0 ? N : 1;
   // Windowed LDS accumulation of the face gradients (k_face_accumulate): every window block
-  // scans its chunk's face ids, so it is used while the windows are few; beyond that faces are
-  // so many that scattered atomics see little contention anyway.
+  // scans its chunk's face ids, so it is used while the windows are few; beyond that (and for
+  // small ray counts) k_backward3d adds straight into g_fverts with float64 atomics -- faces are
+  // then so many that they see little contention.
   const int windows = cdiv(M > 0 ? M : 1, FACE_WINDOW);
   const bool stash = M > 0 && N >= 16384 && windows <= 32 && !coherent;
   double* stash_g = reinterpret_cast<double*>(ws + lay.stash_g);
@@ -2067,20 +2043,13 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     const double* g_child = (p == P - 1) ? nullptr : gbuf + (size_t)((p + 1) & 1) * 6 * n;
     double* g_out = (p == 0 && g_src != nullptr) ? g_src : gbuf + (size_t)(p & 1) * 6 * n;
     const int64_t out_stride = (p == 0 && g_src != nullptr) ? N : (int64_t)n;
-    if (sorted && !stash) {
-      hipLaunchKernelGGL(k_bwd_keys, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p,
-                         rec_tri + (size_t)p * n, M, keys_in, vals_in, (int)N);
-      if (sort_pairs_u32_i32(ws + lay.sort_tmp, lay.sort_bytes, keys_in, keys_out, vals_in,
-                             rperm_all + (size_t)p * n, (size_t)N, key_bits, st) != 0)
-        return TFRT_E_LAUNCH;
-    }
     hipLaunchKernelGGL((k_backward3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
                        idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
                        rec_cls + (size_t)p * n, rec_slot + (size_t)p * n,
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
                        cap_dead, g_out, out_stride, g_fverts,
-                       ((sorted && !stash) || coherent) ? rperm_all + (size_t)p * n : nullptr,
+                       coherent ? rperm_all + (size_t)p * n : nullptr,
                        stash ? stash_g : nullptr, stash ? stash_face : nullptr);
     if (stash)
       hipLaunchKernelGGL(k_face_accumulate, dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
