@@ -897,7 +897,6 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     const float* __restrict__ prep, int64_t pstride, int n_clusters, int chunk_clusters,
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride) {
-  constexpr int KQ = 16;          // queue slots per lane (one supercluster can add SUPER)
   constexpr int RW = 64 * R;      // rays per wave
   constexpr int GT = 256;         // cluster spheres per LDS tile
   const int n = *n_ptr;
@@ -910,10 +909,12 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
 
   __shared__ float4 tile[GT];                // cluster spheres of the current tile
   __shared__ float4 stile[GT / SUPER];       // their superclusters' spheres
-  // per-lane queues of (tile-local cluster << 2 | ray of the lane), compacted in place by
-  // flush() into (tile-local cluster << 8 | ray slot of the wave): 16 bits, because the queue
-  // is always drained before the tile changes (LDS footprint decides the waves in flight)
-  __shared__ uint16_t cand[WAVES][KQ][64];
+  // candidate list of the wave: (tile-local cluster << 8 | ray slot), 16 bits because it is
+  // always drained before the tile changes (LDS footprint decides the waves in flight)
+  constexpr int LIST_CAP = 1024;
+  __shared__ uint16_t clist[WAVES][LIST_CAP];
+  // (tile-local supercluster << 8 | ray slot) pairs waiting for their cluster tests
+  __shared__ uint16_t rlist[WAVES][128];
   __shared__ float4 prep_a[WAVES][RW];       // (a, -s.a) of the wave's rays
   __shared__ float4 prep_b[WAVES][RW];       // (b, -s.b)
   __shared__ unsigned long long best_k[WAVES][RW];
@@ -959,7 +960,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     best_i[wave][slot] = -1;
   }
 
-  int cnt = 0;
+  int ln = 0;          // entries in clist (wave-uniform)
+  int rn = 0;          // entries in rlist (wave-uniform)
   int t0 = c_lo - GT;  // first cluster of the current tile (c_lo is a multiple of SUPER)
 
   // Screen: one (ray, member) pair per lane against the face's float32 record (3 gathered
@@ -1043,33 +1045,14 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     wave_fence();
   };
 
-  // Drain every lane's queue with the whole wave.
+  // Drain the wave's candidate list.
   auto flush = [&]() {
+    const uint16_t* list = &clist[wave][0];
+    const int total = ln;
 #if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 1
-    cnt = 0;  // timing experiment only: level 1 alone
+    ln = 0;  // timing experiment only: levels 0 and 1 alone
     return;
 #endif
-    // 1. compact the lanes' queues into one list (in place, through registers): entry =
-    //    tile-local cluster << 8 | ray slot of the wave
-    uint16_t* list = &cand[wave][0][0];
-    int incl = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int up = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += up;
-    }
-    const int total = __shfl(incl, 63, 64);
-    if (total == 0) return;
-    const int first = incl - cnt;
-    int32_t mine[KQ];
-#pragma unroll
-    for (int k = 0; k < KQ; ++k) mine[k] = cand[wave][k][lane];
-    wave_fence();
-#pragma unroll
-    for (int k = 0; k < KQ; ++k)
-      if (k < cnt)
-        list[first + k] = (uint16_t)(((mine[k] >> 2) << 8) | ((mine[k] & 3) << 6) | lane);
-    wave_fence();
     // 2. member tests, 16 queued candidates per step: each 16-lane group takes four; their
     //    member spheres are fetched first (four independent coalesced 256-byte reads in
     //    flight).  Member hits become (ray, face) pairs; while 64 are waiting -- and once more
@@ -1101,7 +1084,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           const bool hit = fmaf(pa, pa, pb * pb) <= sp[u].w;
           const unsigned long long hm = __ballot(hit);
 #if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 2
-          if (hm == 0x5A5A5A5A5A5A5A5Aull) cnt = -1;  // timing experiment only: no decisions
+          if (hm == 0x5A5A5A5A5A5A5A5Aull) rn = -1;  // timing experiment only: no decisions
           continue;
 #endif
           if (hit) pairs[wave][pn + rank_below(hm)] = ((uint32_t)memb[u] << 8) | (uint32_t)slot[u];
@@ -1140,72 +1123,90 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
         }
       }
     }
-    cnt = 0;
+    ln = 0;
   };
 
   static_assert(GT / SUPER == 32, "one 32-bit supercluster mask per ray and tile");
+  static_assert(SUPER == 8, "8-lane groups test the 8 clusters of a supercluster");
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
   unsigned touched[R];  // per ray: superclusters of the current tile its line touches
 #pragma unroll
   for (int r = 0; r < R; ++r) touched[r] = 0u;
+  // One wave-uniform action per iteration (so flush() and the batch below have one call site):
+  //   flush   when the candidate list is nearly full, or the tile is finished and it is not empty
+  //   batch   8 lanes per waiting (ray, supercluster) pair test its 8 cluster spheres, one each
+  //           (LDS tile); touched clusters are appended to the candidate list (ballot + rank)
+  //   round   every lane with a touched supercluster left moves one to the pair list
+  //   tile    stage the next tile and run level 0 on it (all four waves meet here), or finish
   for (;;) {
     bool pending = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) pending = pending || __any(touched[r] != 0u);
-    bool drain = false, done = false;
-    if (!pending && __any(cnt > 0)) {
-      drain = true;  // through with the tile: empty the queue while its entries refer to it
-    } else if (!pending) {
-      // next tile (all four waves meet here), or finish
-      t0 += GT;
-      if (t0 >= c_hi) {
-        done = true;
-      } else {
-        const int nt = min(GT, c_hi - t0);
-        const int ns = (nt + SUPER - 1) / SUPER;
-        __syncthreads();
-        for (int k = tid; k < ns * SUPER; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
-        if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
-        __syncthreads();
-        // level 0: which superclusters of the tile does each ray's line touch
-        for (int k = 0; k < ns; ++k) {
-          const float4 sp = stile[k];  // same address in every lane: LDS broadcast
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
-            const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-            touched[r] |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << k;
-          }
+    if (ln > LIST_CAP - 64 * SUPER || (!pending && rn == 0 && ln > 0)) {
+      flush();
+    } else if (rn >= 64 || (!pending && rn > 0)) {
+      const int nb = min(rn, 64);
+      for (int q0 = 0; q0 < nb; q0 += 8) {
+        const int q = q0 + (lane >> 3);
+        bool hit = false;
+        int entry = 0;
+        if (q < nb) {
+          const int v = rlist[wave][q];
+          const int cl = (v >> 8) * SUPER + (lane & (SUPER - 1));
+          const int sl = v & 255;
+          const float4 sp = tile[cl];
+          const float4 fa = prep_a[wave][sl], fb = prep_b[wave][sl];
+          const float pa = fmaf(sp.x, fa.x, fmaf(sp.y, fa.y, fmaf(sp.z, fa.z, fa.w)));
+          const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
+          hit = fmaf(pa, pa, pb * pb) <= sp.w;
+          entry = (cl << 8) | sl;
         }
+        const unsigned long long hm = __ballot(hit);
+        if (hit) clist[wave][ln + rank_below(hm)] = (uint16_t)entry;
+        ln += __popcll(hm);
       }
-    } else {
-      // level 1: one touched supercluster per lane and round -- its SUPER cluster spheres
-      // (per-lane LDS reads); clusters the line touches go to the lane's queue
-      bool did = false;
+      // keep the rest of the pairs (fewer than 64) at the front
+      int keep = 0;
+      if (lane < rn - nb) keep = rlist[wave][nb + lane];
+      wave_fence();
+      if (lane < rn - nb) rlist[wave][lane] = (uint16_t)keep;
+      rn -= nb;
+      wave_fence();
+    } else if (pending) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (!did && __any(touched[r] != 0u)) {
-          did = true;
-          if (touched[r] != 0u) {
+        const bool has = touched[r] != 0u;
+        const unsigned long long m = __ballot(has);
+        if (m != 0ull && rn < 64) {  // (rn < 64: room for one more round of up to 64 pairs)
+          if (has) {
             const int k = __ffs(touched[r]) - 1;
             touched[r] &= touched[r] - 1u;
-#pragma unroll
-            for (int g = 0; g < SUPER; ++g) {
-              const float4 sp = tile[k * SUPER + g];
-              const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
-              const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-              if (fmaf(pa, pa, pb * pb) <= sp.w) {
-                cand[wave][cnt][lane] = (uint16_t)(((k * SUPER + g) << 2) | r);
-                ++cnt;
-              }
-            }
+            rlist[wave][rn + rank_below(m)] = (uint16_t)((k << 8) | (r * 64 + lane));
           }
+          rn += __popcll(m);
         }
       }
-      drain = __any(cnt > KQ - SUPER);
+      wave_fence();
+    } else {
+      t0 += GT;
+      if (t0 >= c_hi) break;
+      const int nt = min(GT, c_hi - t0);
+      const int ns = (nt + SUPER - 1) / SUPER;
+      __syncthreads();
+      for (int k = tid; k < ns * SUPER; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
+      if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
+      __syncthreads();
+      // level 0: which superclusters of the tile does each ray's line touch
+      for (int k = 0; k < ns; ++k) {
+        const float4 sp = stile[k];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+          const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+          touched[r] |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << k;
+        }
+      }
     }
-    if (drain) flush();
-    if (done) break;
   }
 
 #pragma unroll
