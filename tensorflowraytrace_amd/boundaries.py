@@ -283,10 +283,25 @@ class BoundaryBase(RecursivelyUpdatable):
         raise NotImplementedError
 
     def _update_materials(self, count, device):
-        for field, value in self.material_dict.items():
-            value = _as_field(value, device)
+        """Broadcast scalar material entries to one value per primitive (boundaries.py:423-428).
+        The broadcast tensor is kept while value, count and device stay the same: update() runs
+        every optimiser step, and a new tensor each time would look like a changed scene to the
+        engine's caches (material columns, cluster order)."""
+        cache = self.__dict__.setdefault("_material_cache", {})
+        for field, raw in self.material_dict.items():
+            scalar = None
+            if not isinstance(raw, torch.Tensor) and np.ndim(raw) == 0:
+                scalar = raw.item() if hasattr(raw, "item") else raw   # host value: no device read
+            key = (scalar, type(scalar), int(count), str(device))
+            hit = cache.get(field) if scalar is not None else None
+            if hit is not None and hit[0] == key:
+                self[field] = hit[1]
+                continue
+            value = _as_field(raw, device)
             if value.dim() < 1:
                 value = value.expand(count).clone()
+                if scalar is not None:
+                    cache[field] = (key, value)
             self[field] = value
 
     def keys(self):

@@ -35,8 +35,10 @@ def _uniform(n, low=0.0, high=1.0):
     global _generator
     if _generator is None:
         seed(1234)
-    u = torch.rand(int(n), dtype=torch.float64, generator=_generator)
-    return (low + (high - low) * u).to(config.get_device())
+    # drawn on the host (one reproducible stream whatever the device), scaled on the device: CPU
+    # elementwise ops cost milliseconds when torch has more threads than the process has cores
+    u = torch.rand(int(n), dtype=torch.float64, generator=_generator).to(config.get_device())
+    return low + (high - low) * u
 
 
 def _f64(x):

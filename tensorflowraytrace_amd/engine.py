@@ -359,12 +359,16 @@ class OpticalSystem3D(OpticalSystemBase):
         s = self._scene_cache[1]
         order = None
         if cluster:
-            # spatial face order for the clustered trace; computed once per scene topology
+            # spatial face order for the sphere hierarchy; computed once per scene topology
             # (faces move a little every step, the clusters' bounding spheres are recomputed
-            # from the current vertices inside every trace, so a stale order is still exact)
-            if s.get("cluster_order") is None:
-                s["cluster_order"] = ops.cluster_order(self._merged_face_verts)
-            order = s["cluster_order"]
+            # from the current vertices inside every trace, so a stale order is still exact).
+            # Keyed on the boundary objects and face counts only, not on material fields.
+            topo = tuple(self._scene_cache[0][i][:3] for i in range(len(self._scene_cache[0]) - 1))
+            cached = getattr(self, "_cluster_cache", None)
+            if cached is None or cached[0] != topo:
+                cached = (topo, ops.cluster_order(self._merged_face_verts))
+                self._cluster_cache = cached
+            order = cached[1]
         kw = dict(intersect_epsilion=self.intersect_epsilion, size_epsilion=self.size_epsilion,
                   ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"],
                   cluster_order=order, sort_rays=bool(sort_rays and order is not None))
