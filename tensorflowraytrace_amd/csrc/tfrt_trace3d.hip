@@ -56,16 +56,20 @@ constexpr int ERR_CAPACITY = 1;
 
 // ------------------------------------------------------------------------------ prep
 
-// c0 = mean of the face corner P0 over all faces: origin of the filter's coordinate frame
-// (keeps |c| small so the float32 rounding margin stays far below the sphere radii).
+// c0 = mean of the face corner P0 over (a sample of) the faces: origin of the filter's
+// coordinate frame (keeps |c| small so the float32 rounding margin stays far below the sphere
+// radii).  Any point near the mesh serves, so at most ~2048 evenly spaced faces are read.
 __global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fverts, int M,
                                                  double* __restrict__ c0) {
   __shared__ double red[3][1024];
+  const int step = M > 2048 ? M / 2048 : 1;
+  const int ns = M > 0 ? (M + step - 1) / step : 0;  // samples j * step, j < ns
   double a[3] = {0, 0, 0};
-  for (int j = threadIdx.x; j < M; j += 1024) {
-    a[0] += fverts[9 * (int64_t)j];
-    a[1] += fverts[9 * (int64_t)j + 1];
-    a[2] += fverts[9 * (int64_t)j + 2];
+  for (int j = threadIdx.x; j < ns; j += 1024) {
+    const double* P = fverts + 9 * (int64_t)j * step;
+    a[0] += P[0];
+    a[1] += P[1];
+    a[2] += P[2];
   }
   for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = a[k];
   __syncthreads();
@@ -76,18 +80,19 @@ __global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fver
   }
   __shared__ double ctr[3];
   if (threadIdx.x < 3) {
-    ctr[threadIdx.x] = (M > 0) ? red[threadIdx.x][0] / M : 0.0;
+    ctr[threadIdx.x] = (ns > 0) ? red[threadIdx.x][0] / ns : 0.0;
     c0[threadIdx.x] = ctr[threadIdx.x];
   }
   __syncthreads();
-  // c0[3] = length scale for the ray sort keys of the clustered path: twice the RMS distance
-  // of the faces from c0 (robust against a few huge faces such as a distant target plane;
-  // rays passing farther out simply clamp to the border cell)
+  // c0[3] = length scale for the ray sort keys of the sorted-ray mode: twice the RMS distance
+  // of the sampled faces from c0 (robust against a few huge faces such as a distant target
+  // plane; rays passing farther out simply clamp to the border cell)
   double acc = 0.0;
-  for (int j = threadIdx.x; j < M; j += 1024) {
+  for (int j = threadIdx.x; j < ns; j += 1024) {
+    const double* P = fverts + 9 * (int64_t)j * step;
     double d2 = 0.0;
     for (int k = 0; k < 3; ++k) {
-      const double d = fverts[9 * (int64_t)j + k] - ctr[k];
+      const double d = P[k] - ctr[k];
       d2 += d * d;
     }
     acc += d2;
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fver
     if ((int)threadIdx.x < s) red[0][threadIdx.x] += red[0][threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) c0[3] = 2.0 * sqrt(red[0][0] / (M > 0 ? M : 1));
+  if (threadIdx.x == 0) c0[3] = 2.0 * sqrt(red[0][0] / (ns > 0 ? ns : 1));
 }
 
 // Smallest enclosing sphere of a triangle, inflated so that the float32 filter is
