@@ -372,6 +372,19 @@ class OpticalSystem3D(OpticalSystemBase):
         kw = dict(intersect_epsilion=self.intersect_epsilion, size_epsilion=self.size_epsilion,
                   ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"],
                   cluster_order=order, sort_rays=bool(sort_rays and order is not None))
+        # the argument object (and the ctypes struct it caches) only depends on tensors that stay
+        # the same from step to step; the face tensor is passed separately to every trace
+        memo_key = (id(s), id(n_table), bool(index_mode), bool(ghost), id(order), kw["sort_rays"],
+                    self.intersect_epsilion, self.size_epsilion, self.ray_start_epsilion)
+        memo = getattr(self, "_scene_args_memo", None)
+        if memo is not None and memo[0] == memo_key:
+            memo[1].face_verts = self._merged_face_verts
+            return memo[1]
+        args = self._build_scene_args(s, n_table, index_mode, ghost, kw)
+        self._scene_args_memo = (memo_key, args, s, n_table, order)  # keep the ids alive
+        return args
+
+    def _build_scene_args(self, s, n_table, index_mode, ghost, kw):
         if ghost:
             ones = torch.ones(s["catagory"].shape[0], dtype=torch.float64, device=s["catagory"].device)
             return ops.Scene3DArgs(self._merged_face_verts, s["catagory"], n_in=ones, n_out=ones, **kw)

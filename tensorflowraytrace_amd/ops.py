@@ -32,7 +32,15 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t):
+    """The current HIP stream of ``t``'s device as a ``void*`` (the raw accessor avoids building
+    a ``torch.cuda.Stream`` object per C call: ~8 us each, eight calls per optimiser step)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return ctypes.c_void_p(_raw_stream(idx if idx is not None else torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -165,8 +173,14 @@ class Scene3DArgs:
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
-        sc = Scene3D()
         M = face_verts.shape[0]
+        cached = getattr(self, "_struct_cache", None)
+        if cached is not None and cached[0] == M:
+            # every other field points at tensors this object owns: only the face pointer moves
+            sc = cached[1]
+            sc.face_verts = face_verts.data_ptr() if M else None
+            return sc
+        sc = Scene3D()
         sc.face_verts = face_verts.data_ptr() if M else None
         sc.catagory = self.catagory.data_ptr() if M else None
         for name in ("mat_in", "mat_out", "n_in", "n_out"):
@@ -187,6 +201,7 @@ class Scene3DArgs:
             raise TfrtError("cluster_order must be a permutation of the M face indices")
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
         sc.sort_rays = 1 if self.sort_rays else 0
+        self._struct_cache = (M, sc)
         return sc
 
 
