@@ -237,22 +237,25 @@ class _Trace3D(torch.autograd.Function):
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
         counts = torch.zeros(_lib.COUNTS_PER_PASS * (P + 1), dtype=torch.int32, device=dev)
 
-        new = torch.zeros if opts.get("zero_init") else torch.empty
+        # With speculative slicing (predicted counts) rows beyond the true counts may be read
+        # before the prediction is verified: the index arrays must then hold valid indices
+        # (zeros); the ray blocks may hold anything, a wrong guess is re-evaluated anyway.
+        new_idx = torch.zeros if opts.get("zero_init") else torch.empty
 
         def alloc(flag, cap):
             if not (flags & flag):
                 return None, None, None
-            return (new((6, cap), dtype=src.dtype, device=dev),
-                    new(cap, dtype=torch.int32, device=dev),
-                    new(cap, dtype=torch.int32, device=dev))
+            return (torch.empty((6, cap), dtype=src.dtype, device=dev),
+                    new_idx(cap, dtype=torch.int32, device=dev),
+                    new_idx(cap, dtype=torch.int32, device=dev))
 
         capN = max(N, 1)
         fin = alloc(_lib.COMPILE_FINISHED, capN)
         act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
         stp = alloc(_lib.COMPILE_STOPPED, capN)
         dead = alloc(_lib.COMPILE_DEAD, capN)
-        unf = new((6, capN), dtype=src.dtype, device=dev)
-        unf_id = new(capN, dtype=torch.int32, device=dev)
+        unf = torch.empty((6, capN), dtype=src.dtype, device=dev)
+        unf_id = new_idx(capN, dtype=torch.int32, device=dev)
         sc = scene.struct(face_verts)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace3d_forward(
@@ -578,7 +581,7 @@ class _Trace2D(torch.autograd.Function):
         def alloc(flag, cap):
             if not (flags & flag):
                 return None, None, None
-            return (new((4, cap), dtype=src.dtype, device=dev),
+            return (torch.empty((4, cap), dtype=src.dtype, device=dev),  # (see _Trace3D.forward)
                     new(cap, dtype=torch.int32, device=dev),
                     new(cap, dtype=torch.int32, device=dev))
 
@@ -587,7 +590,7 @@ class _Trace2D(torch.autograd.Function):
         act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
         stp = alloc(_lib.COMPILE_STOPPED, capN)
         dead = alloc(_lib.COMPILE_DEAD, capN)
-        unf = new((4, capN), dtype=src.dtype, device=dev)
+        unf = torch.empty((4, capN), dtype=src.dtype, device=dev)
         unf_id = new(capN, dtype=torch.int32, device=dev)
         sc = scene.struct(seg_geo, arc_geo)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
