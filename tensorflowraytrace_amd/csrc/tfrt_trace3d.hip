@@ -1758,7 +1758,8 @@ static Plan3 make_plan(int64_t N, int64_t M) {
   p.nblk = cdiv(N > 0 ? N : 1, BLOCK);
   // grouped kernel: level 1 is 16x shorter, so favour more workgroups over rays per lane
   const int n_clusters = cdiv(M > 0 ? M : 1, 16);
-  p.gR = (N >= (1 << 22)) ? 2 : 1;  // measured: 1 ray per lane is best up to a few M rays
+  p.gR = 1;  // measured: one ray per lane wins at every size (16M rays: 11.9 vs 17.7 ms for 2;
+             // more rays per lane cost LDS, i.e. workgroups per CU); 2 / 4 stay selectable
   if (const char* env = getenv("TFRT_GROUP_RAYS_PER_LANE")) {
     const int r = atoi(env);
     if (r == 1 || r == 2 || r == 4) p.gR = r;
