@@ -1765,7 +1765,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
     if (r == 1 || r == 2 || r == 4) p.gR = r;
   }
   p.g_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.gR);
-  int gtarget = 4096;
+  int gtarget = 2048;
   if (const char* env = getenv("TFRT_GROUP_TARGET_BLOCKS")) gtarget = atoi(env) > 0 ? atoi(env) : gtarget;
   int gch = cdiv(gtarget, p.g_blocks);
   const int gmax = cdiv(n_clusters, 64);       // at least 64 clusters (1024 faces) per chunk
