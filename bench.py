@@ -39,7 +39,7 @@ BYTES_PER_RAY_FWD = 64     # 32 B read + 32 B written per 
 BYTES_PER_FACE = 48
 
 
-def build_scene(n_rays, k_front, k_back, ray_dtype, accelerate=False):
+def build_scene(n_rays, k_front, k_back, ray_dtype, accelerate="auto"):
     import tensorflowraytrace_amd as tfa
     import tfrt.boundaries as boundaries
     import tfrt.distributions as distributions
