@@ -924,7 +924,11 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   __shared__ float4 prep_b[WAVES][RW];       // (b, -s.b)
   __shared__ unsigned long long best_k[WAVES][RW];
   __shared__ int32_t best_i[WAVES][RW];
-  constexpr int PAIRS = 64 + 4 * 64;        // waiting pairs: < 64 left over + one step's hits
+#ifndef TFRT_MEMBER_UNROLL
+#define TFRT_MEMBER_UNROLL 4
+#endif
+  constexpr int MU = TFRT_MEMBER_UNROLL;    // 16-lane groups' candidates in flight per step
+  constexpr int PAIRS = 64 + MU * 64;       // waiting pairs: < 64 left over + one step's hits
   __shared__ uint32_t pairs[WAVES][PAIRS];   // member slot << 8 | ray slot (member slot < 2^24)
   __shared__ uint8_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
   __shared__ int32_t x_face[WAVES][128];
@@ -1064,12 +1068,12 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     //    at the end -- they are decided, one per lane.  (One call site each for decide() and
     //    flush(): the float64 test is big and copies of it only bloat the kernel.)
     int pn = 0;  // entries waiting in pairs[] (wave-uniform)
-    for (int q0 = 0; q0 < total; q0 += 16) {
+    for (int q0 = 0; q0 < total; q0 += 4 * MU) {
       {
-        float4 sp[4];
-        int slot[4], memb[4];
+        float4 sp[MU];
+        int slot[MU], memb[MU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MU; ++u) {
           const int q = q0 + 4 * u + (lane >> 4);
           sp[u] = make_float4(0.f, 0.f, 0.f, -1.f);  // never hit
           slot[u] = 0;
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < MU; ++u) {
           const float4 fa = prep_a[wave][slot[u]], fb = prep_b[wave][slot[u]];
           const float pa = fmaf(sp[u].x, fa.x, fmaf(sp[u].y, fa.y, fmaf(sp[u].z, fa.z, fa.w)));
           const float pb = fmaf(sp[u].x, fb.x, fmaf(sp[u].y, fb.y, fmaf(sp[u].z, fb.z, fb.w)));
@@ -1096,7 +1100,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           pn += __popcll(hm);
         }
       }
-      const bool last = q0 + 16 >= total;
+      const bool last = q0 + 4 * MU >= total;
       while (pn >= 64 || (last && (pn > 0 || xn > 0))) {
         const int nb = min(pn, 64);
         wave_fence();
