@@ -147,3 +147,60 @@ def test_empty_and_bad_inputs():
         geometry.line_intersect(one, one, one, one[:2], one, one, one, one, 1e-10)
     with pytest.raises(TfrtError):
         geometry.raw_line_intersect(*[torch.ones(3, dtype=torch.float64)] * 8, 1e-10)   # CPU tensors
+
+
+class _DeviceGeom:
+    """Stand-in for ``oracle.geom`` that routes the calls of the reference-property tests
+    through the HIP geometry functions (numpy in, CPU tensors out)."""
+
+    @staticmethod
+    def _in(args):
+        return [torch.as_tensor(np.asarray(a), dtype=torch.float64).to(DEV) for a in args]
+
+    def raw_line_intersect(self, *args):
+        import tfrt.geometry as geometry
+        return tuple(o.cpu() for o in geometry.raw_line_intersect(*self._in(args[:-1]), args[-1]))
+
+    def raw_line_circle_intersect(self, *args):
+        import tfrt.geometry as geometry
+        plus, minus = geometry.raw_line_circle_intersect(*self._in(args[:-1]), args[-1])
+        return ({k: v.cpu() for k, v in plus.items()}, {k: v.cpu() for k, v in minus.items()})
+
+    def angle_in_interval(self, angle, start, end):
+        import tfrt.geometry as geometry
+        a, s, e = self._in((angle, start, end))
+        return geometry.angle_in_interval(a, s, e).cpu()
+
+
+def test_reference_own_test_properties_hold_on_the_device(monkeypatch):
+    """Every property the reference's own geometry tests check (restated in
+    tests/test_oracle_reference_properties.py to pin the oracle) also holds for the HIP
+    functions: common intersection point, unit square, parallel => invalid, 2 / 1 / 0 circle
+    roots, the 9 x 9 angle_in_interval grid."""
+    import itertools
+    import test_oracle_reference_properties as props
+    monkeypatch.setattr(props, "geom", _DeviceGeom())
+    ran = 0
+    for name in sorted(dir(props)):
+        if not name.startswith("test_"):
+            continue
+        fn = getattr(props, name)
+        marks = [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]
+        if not marks:
+            fn()
+            ran += 1
+            continue
+        names, values = [], []
+        for m in marks:
+            names.append([n.strip() for n in m.args[0].split(",")])
+            values.append(list(m.args[1]))
+        for combo in itertools.product(*values):
+            kwargs = {}
+            for ns, val in zip(names, combo):
+                if len(ns) == 1:
+                    kwargs[ns[0]] = val
+                else:
+                    kwargs.update(dict(zip(ns, val)))
+            fn(**kwargs)
+            ran += 1
+    assert ran >= 80
