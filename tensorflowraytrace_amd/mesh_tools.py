@@ -457,3 +457,192 @@ def get_flat_initial(mesh, axis=0):
     init = mesh.points[:, axis].copy()
     mesh.points[:, axis] = 0.0
     return init
+
+
+# ------------------------------------------------------------------------------------------
+# small topology helpers (tfrt/mesh_tools.py:28-217, 335, 956-1160)
+
+def pack_faces(faces):
+    """(F,3) vertex indices -> the flat VTK layout ``[3,i,j,k, 3,...]`` (tfrt/mesh_tools.py:1143-1150)."""
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    return np.concatenate([np.full((faces.shape[0], 1), 3, dtype=np.int64), faces],
+                          axis=1).reshape(-1)
+
+
+def unpack_faces(faces):
+    """Flat VTK layout -> (F,3) vertex indices (tfrt/mesh_tools.py:1152-1160)."""
+    return np.asarray(faces, dtype=np.int64).reshape(-1, 4)[:, 1:]
+
+
+def gaussian_weights(sigma, count):
+    """Ring weights for ``mesh_smoothing_tool``: a half Gaussian sampled at 0..count-1
+    (tfrt/mesh_tools.py:335-343); not normalised, the smoothing tool does that."""
+    return np.exp(-0.5 * (np.arange(count, dtype=np.float64) / sigma) ** 2)
+
+
+def get_unique_edges_1p(mesh):
+    """Set of 2-element frozensets, one per undirected edge (tfrt/mesh_tools.py:84-102)."""
+    tri = mesh.triangles()
+    edges = set()
+    for a, b in ((0, 1), (1, 2), (2, 0)):
+        edges.update(frozenset((int(p), int(q))) for p, q in zip(tri[:, a], tri[:, b]))
+    return edges
+
+
+get_unique_edges = get_unique_edges_1p
+
+
+def neighbors_from_edges(start, edges):
+    """Vertices one edge away from ``start`` (tfrt/mesh_tools.py:105-115)."""
+    out = set()
+    for edge in edges:
+        if start in edge:
+            out |= edge
+    out.discard(start)
+    return out
+
+
+def neighbors_from_faces(point, faces):
+    """Same, from a list of face sets (tfrt/mesh_tools.py:119-130)."""
+    out = set()
+    for face in faces:
+        if point in face:
+            out |= set(face)
+    out.discard(point)
+    return out
+
+
+def find_generations(top_parent, mesh):
+    """Breadth-first rings around ``top_parent``: ``generations[k]`` is the set of vertices
+    ``k`` edges away (tfrt/mesh_tools.py:195-217).  The sweep ends when a ring comes back empty,
+    so vertices of other connected components are simply absent."""
+    neighbors = _vertex_neighbors(mesh)
+    seen = {int(top_parent)}
+    generations = [set(seen)]
+    while len(seen) < mesh.n_points:
+        ring = set()
+        for v in generations[-1]:
+            ring |= neighbors[v]
+        ring -= seen
+        if not ring:
+            break
+        seen |= ring
+        generations.append(ring)
+    return generations
+
+
+def find_all_relationships_1p(top_parent, mesh, edges):
+    """Single-parent spanning tree of the mesh rooted at ``top_parent``
+    (tfrt/mesh_tools.py:133-187): a breadth-first sweep in which the pending vertices are
+    always expanded nearest-to-the-root first and every vertex is claimed by the first vertex
+    that reaches it.  Returns per-vertex lists of sets (descendants, children, parents,
+    ancestors)."""
+    points = mesh.points
+    n = points.shape[0]
+    root = points[top_parent]
+    adjacency = [set() for _ in range(n)]
+    for edge in edges:
+        a, b = tuple(edge)
+        adjacency[a].add(b)
+        adjacency[b].add(a)
+    children = [set() for _ in range(n)]
+    parents = [set() for _ in range(n)]
+    ancestors = [set() for _ in range(n)]
+    unclaimed = set(range(n)) - {top_parent}
+    queue, order = [top_parent], []
+    while queue:
+        parent = queue.pop(0)
+        order.append(parent)
+        mine = adjacency[parent] & unclaimed
+        unclaimed -= mine
+        children[parent] = mine
+        for child in mine:
+            queue.append(child)
+            parents[child] = {parent}
+            ancestors[child] = {parent} | ancestors[parent]
+        if queue:
+            d = np.sum((points[queue] - root) ** 2, axis=1)
+            queue = [queue[k] for k in np.argsort(d, kind="stable")]
+    descendants = [set(c) for c in children]
+    for v in reversed(order):
+        for child in children[v]:
+            descendants[v] |= descendants[child]
+    return descendants, children, parents, ancestors
+
+
+def gradient_accumulator_1p(mesh, origin=(0, 0, 0)):
+    """Accumulator matrix from the single-parent tree around the vertex nearest ``origin``
+    (tfrt/mesh_tools.py:28-72): row i sums the gradient of vertex i and all its descendants.
+    Returns (accumulator (V,V), relationship dict)."""
+    top_parent = get_closest_point(mesh, np.array(origin, dtype=np.float64))
+    edges = get_unique_edges_1p(mesh)
+    out = {"top_parent": top_parent, "unique_edges": edges}
+    out["descendant"], out["child"], out["parent"], out["ancestor"] = \
+        find_all_relationships_1p(top_parent, mesh, edges)
+    return connections_to_array(out["descendant"]), out
+
+
+def clean_mesh_raw(vertices, faces, distance_tolerance=1e-6):
+    """Merge vertices whose *squared* distance is below ``distance_tolerance`` (that is the
+    quantity the reference compares; the lowest index of a cluster survives), drop the merged
+    vertices, then drop faces that became degenerate or that repeat an earlier face's vertex
+    set; the surviving faces keep their winding (tfrt/mesh_tools.py:1073-1140).  The reference
+    builds the dense (V,V) distance matrix; a k-d tree finds the same pairs in O(V log V).
+    ``faces`` is (F,3).  Returns (vertices, faces)."""
+    from scipy.spatial import cKDTree
+
+    points = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+    faces = np.asarray(faces, dtype=np.int64).reshape(-1, 3)
+    n = points.shape[0]
+    target = np.arange(n)
+    if n > 1:
+        pairs = cKDTree(points).query_pairs(math.sqrt(distance_tolerance), output_type="ndarray")
+        if pairs.size:      # the tree's test is <=, the reference's is <
+            d2 = np.sum((points[pairs[:, 0]] - points[pairs[:, 1]]) ** 2, axis=1)
+            pairs = pairs[d2 < distance_tolerance]
+        # a vertex maps to the smallest index it is (transitively) within tolerance of
+        if pairs.size:
+            lo, hi = pairs.min(axis=1), pairs.max(axis=1)
+            changed = True
+            while changed:
+                before = target.copy()
+                np.minimum.at(target, hi, target[lo])
+                np.minimum.at(target, lo, target[hi])
+                target = target[target]
+                changed = not np.array_equal(before, target)
+    kept = np.unique(target)
+    new_index = np.full(n, -1, dtype=np.int64)
+    new_index[kept] = np.arange(kept.shape[0])
+    faces = new_index[target[faces]] if faces.size else faces
+    good = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
+    faces = faces[good]
+    if faces.shape[0]:
+        _, first = np.unique(np.sort(faces, axis=1), axis=0, return_index=True)
+        faces = faces[np.sort(first)]
+    return points[kept], faces
+
+
+def clean_mesh(mesh, distance_tolerance=1e-6):
+    """``clean_mesh_raw`` on a mesh object; returns a new ``PolyData``
+    (tfrt/mesh_tools.py:1041-1070)."""
+    points, faces = clean_mesh_raw(mesh.points, mesh.triangles(), distance_tolerance)
+    return PolyData(points, pack_faces(faces))
+
+
+def planar_interpolated_remesh(input_mesh, base_mesh, range_axis=2, interp_fill_value=0.0,
+                               flatten=True):
+    """Re-mesh ``input_mesh`` on the (planar, regular) triangulation of ``base_mesh``: the
+    height of the input vertices along ``range_axis`` is interpolated linearly over the other
+    two coordinates and sampled at the base vertices (tfrt/mesh_tools.py:956-1031).  With
+    ``flatten`` returns (flat copy of the base mesh, heights) - zero points plus initial
+    parameters - otherwise the displaced copy."""
+    from scipy.interpolate import griddata
+
+    if range_axis not in (0, 1, 2):
+        raise ValueError("planar_interpolated_remesh: axis must be in {0, 1, 2}.")
+    domain = [a for a in (0, 1, 2) if a != range_axis]
+    heights = griddata(input_mesh.points[:, domain], input_mesh.points[:, range_axis],
+                       base_mesh.points[:, domain], fill_value=interp_fill_value)
+    out = base_mesh.copy()
+    out.points[:, range_axis] = 0.0 if flatten else heights
+    return (out, heights) if flatten else out

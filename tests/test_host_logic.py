@@ -410,3 +410,106 @@ def test_engine_trace_mode_selection():
     assert e2._trace_mode(Sys(5000)) == "all-pairs"       # 2-D has its own filter
     with pytest.raises(ValueError):
         engine.OpticalEngine(3, [operation.StandardReaction()], accelerate="fastest")
+
+
+# ------------------------------------------------------------------------------------------
+# mesh helpers (tfrt/mesh_tools.py:28-217, 956-1160)
+
+def test_pack_unpack_faces_round_trip():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    m = mt.hexagonal_mesh(1.0, 3)
+    tri = mt.unpack_faces(m.faces)
+    np.testing.assert_array_equal(tri, m.triangles())
+    np.testing.assert_array_equal(mt.pack_faces(tri), m.faces)
+    assert mt.pack_faces(np.zeros((0, 3), dtype=np.int64)).shape == (0,)
+
+
+def test_gaussian_weights():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    w = mt.gaussian_weights(2.0, 4)
+    np.testing.assert_allclose(w, np.exp(-0.5 * (np.arange(4) / 2.0) ** 2), rtol=0, atol=0)
+    assert w[0] == 1.0 and np.all(np.diff(w) < 0)
+
+
+def test_neighbour_helpers_and_generations_of_hexagonal_mesh():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    m = mt.hexagonal_mesh(1.0, 4)
+    edges = mt.get_unique_edges_1p(m)
+    # Euler: V - E + F = 1 for a disc
+    assert m.n_points - len(edges) + m.n_faces == 1
+    faces = mt.get_faces_as_sets(m)
+    for v in (0, 5, m.n_points - 1):
+        assert mt.neighbors_from_edges(v, edges) == mt.neighbors_from_faces(v, faces)
+    assert len(mt.neighbors_from_edges(0, edges)) == 6           # hexagon centre
+    gens = mt.find_generations(0, m)
+    assert [len(g) for g in gens] == [1, 6, 12, 18, 24]           # rings of 6k vertices
+    assert set().union(*gens) == set(range(m.n_points))
+    r = np.linalg.norm(m.points, axis=1)
+    for k, g in enumerate(gens):                                  # ring k sits at hexagonal radius k/4
+        assert np.all(r[list(g)] <= k / 4 + 1e-12)
+
+
+def test_single_parent_relationships_form_a_spanning_tree():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    m = mt.hexagonal_mesh(1.0, 3)
+    acc, rel = mt.gradient_accumulator_1p(m, origin=(0, 0, 0))
+    top = rel["top_parent"]
+    assert top == 0
+    n = m.n_points
+    assert all(len(p) == 1 for i, p in enumerate(rel["parent"]) if i != top)
+    assert rel["parent"][top] == set() and rel["descendant"][top] == set(range(n)) - {top}
+    assert sum(len(c) for c in rel["child"]) == n - 1
+    for v in range(n):                                            # ancestor/descendant are inverse relations
+        for a in rel["ancestor"][v]:
+            assert v in rel["descendant"][a]
+    # accumulator = identity + descendants; the root row sums everything
+    assert acc.shape == (n, n) and np.all(acc[top] == 1)
+    assert acc.sum() == n + sum(len(d) for d in rel["descendant"])
+
+
+def test_clean_mesh_merges_vertices_and_drops_bad_faces():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    m = mt.hexagonal_mesh(1.0, 3)
+    tri = m.triangles()
+    nv = m.n_points
+    # five near-copies of existing vertices, used by some faces; duplicate + degenerate faces
+    pts = np.concatenate([m.points, m.points[:5] + 2e-4])
+    dirty = tri.copy()
+    for k in range(5):
+        rows = np.nonzero((dirty == k).any(axis=1))[0][:2]
+        sub = dirty[rows]
+        sub[sub == k] = nv + k
+        dirty[rows] = sub
+    dirty = np.concatenate([dirty, dirty[:4][:, [1, 2, 0]], [[0, 0, 1]], [[2, nv + 2, 3]]])
+    v, f = mt.clean_mesh_raw(pts, dirty.copy(), distance_tolerance=1e-6)   # (2e-4)^2*3 < 1e-6
+    assert v.shape == (nv, 3)
+    np.testing.assert_array_equal(v, m.points)
+    np.testing.assert_array_equal(f, tri)                          # order and winding preserved
+    # squared-distance semantics of the reference: the same offsets survive a tighter tolerance
+    v2, f2 = mt.clean_mesh_raw(pts, dirty.copy(), distance_tolerance=1e-8)
+    assert v2.shape[0] == nv + 5
+    cleaned = mt.clean_mesh(mt.PolyData(pts, mt.pack_faces(dirty)), 1e-6)
+    assert cleaned.n_points == nv and cleaned.n_faces == m.n_faces
+
+
+def test_planar_interpolated_remesh_reproduces_a_plane_and_a_paraboloid():
+    import tensorflowraytrace_amd.mesh_tools as mt
+    src = mt.hexagonal_mesh(1.0, 12)
+    src.points[:, 2] = 0.3 * src.points[:, 0] - 0.2 * src.points[:, 1] + 0.1
+    base = mt.hexagonal_mesh(0.8, 5)
+    flat, h = mt.planar_interpolated_remesh(src, base)
+    np.testing.assert_allclose(h, 0.3 * base.points[:, 0] - 0.2 * base.points[:, 1] + 0.1, atol=1e-12)
+    assert np.all(flat.points[:, 2] == 0) and np.all(base.points[:, 2] == 0)
+    bowl = mt.hexagonal_mesh(1.0, 24)
+    bowl.points = bowl.points[:, [2, 0, 1]]                                # into the y-z plane
+    bowl.points[:, 0] = bowl.points[:, 1] ** 2 + bowl.points[:, 2] ** 2    # height along x
+    base_x = mt.hexagonal_mesh(0.8, 5)
+    base_x.points = base_x.points[:, [2, 0, 1]]
+    out = mt.planar_interpolated_remesh(bowl, base_x, range_axis=0, flatten=False)
+    want = out.points[:, 1] ** 2 + out.points[:, 2] ** 2
+    assert np.abs(out.points[:, 0] - want).max() < 5e-3
+    far = mt.PolyData(np.array([[5.0, 5.0, 0.0]]), np.zeros(0, dtype=np.int64))
+    _, fill = mt.planar_interpolated_remesh(src, far, interp_fill_value=-7.0)
+    assert fill[0] == -7.0
+    with pytest.raises(ValueError):
+        mt.planar_interpolated_remesh(src, base, range_axis=3)
