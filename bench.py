@@ -10,9 +10,11 @@ H(9) = 486 faces) + a 2-triangle target = 10,574 merged faces; one step = one
 Synthetic, deterministic inputs (golden-spiral source points).
 
 Metric: ray-surface intersection tests/s (fwd+bwd), tests = sum over passes of
-N_active(pass) x M_merged (counted by the kernels).  With N GPUs the same 1M rays are sharded
-contiguously over the ranks (strong scaling) and the per-step parameter gradients are summed
-with one RCCL all-reduce.
+N_active(pass) x M_merged (counted by the kernels).  With N GPUs the source rays are sharded
+contiguously over the ranks and the per-step parameter gradients are summed with one RCCL
+all-reduce.  Default is weak scaling: every GPU traces 1M rays of a global source of N x 1M
+(value = tests of all ranks / max-over-ranks time); the line also carries `strong_scaling`, the
+N=1 workload itself split over the ranks (`--scaling strong` makes that the headline).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -141,7 +143,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=1_000_000, help="global ray count")
+    ap.add_argument("--rays", type=int, default=1_000_000,
+                    help="rays per GPU (weak scaling) or in total (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every GPU traces --rays rays of a global source of rays x N; "
+                         "strong: --rays rays are split over the GPUs")
     ap.add_argument("--k-front", type=int, default=41)
     ap.add_argument("--k-back", type=int, default=9)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
@@ -174,13 +180,6 @@ def main():
 
     if args.accelerate:
         args.trace_mode = "sort"
-    eng, system, params = build_scene(args.rays, args.k_front, args.k_back, ray_dtype,
-                                      accelerate=args.trace_mode)
-    mode = eng._trace_mode(system)
-    opt = optimizer.SGD_Optimizer(eng, params, error_function, trace_depth=3,
-                                  learning_rate=1e-6, grad_clip=1e-3)
-    opt.suppress_warnings = True
-    M = int(system._merged_face_verts.shape[0])
     lib = _lib.lib()
 
     def barrier():
@@ -189,37 +188,65 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        opt.single_step(None)
-    barrier()
-    lib.tfrt_profile_enable(1)
-    tests_local = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        opt.single_step(None)
-        tests_local += eng.last_trace["n_tests"]
-    barrier()
-    dt = time.perf_counter() - t0
-    import ctypes
-    buf = (ctypes.c_float * 4096)()
-    nrec = lib.tfrt_profile_read(buf, 4096)
-    lib.tfrt_profile_enable(0)
-    kernel_ms = [buf[i] for i in range(max(nrec, 0))]
-
-    stats = torch.tensor([dt, float(tests_local)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = stats[:1].clone()
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        tsum = stats[1:].clone()
-        torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
-        dt, tests_total = float(tmax.item()), float(tsum.item())
-    else:
+    def timed_leg(global_rays, trace_mode, profile):
+        """Build the scene with `global_rays` source rays (each rank traces its contiguous
+        shard), run warmup + exactly `steps` optimiser steps between barriers and return
+        (max-over-ranks seconds, tests summed over ranks, engine, faces, mode, launch ms)."""
+        eng, system, params = build_scene(global_rays, args.k_front, args.k_back, ray_dtype,
+                                          accelerate=trace_mode)
+        opt = optimizer.SGD_Optimizer(eng, params, error_function, trace_depth=3,
+                                      learning_rate=1e-6, grad_clip=1e-3)
+        opt.suppress_warnings = True
+        for _ in range(args.warmup):
+            opt.single_step(None)
+        barrier()
+        if profile:
+            lib.tfrt_profile_enable(1)
+        tests_local = 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            opt.single_step(None)
+            tests_local += eng.last_trace["n_tests"]
+        barrier()
+        dt = time.perf_counter() - t0
+        kernel_ms = []
+        if profile:
+            import ctypes
+            buf = (ctypes.c_float * 4096)()
+            nrec = lib.tfrt_profile_read(buf, 4096)
+            lib.tfrt_profile_enable(0)
+            kernel_ms = [buf[i] for i in range(max(nrec, 0))]
         tests_total = float(tests_local)
+        if world > 1:
+            stats = torch.tensor([dt, float(tests_local)], dtype=torch.float64, device="cuda")
+            tmax = stats[:1].clone()
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+            tsum = stats[1:].clone()
+            torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+            dt, tests_total = float(tmax.item()), float(tsum.item())
+        return dt, tests_total, eng, int(system._merged_face_verts.shape[0]), \
+            eng._trace_mode(system), kernel_ms
+
+    # weak scaling (default): every GPU traces `--rays` rays, the global source has rays x N;
+    # strong: the same `--rays` rays are split over the GPUs
+    global_rays = args.rays * world if args.scaling == "weak" else args.rays
+    dt, tests_total, eng, M, mode, kernel_ms = timed_leg(global_rays, args.trace_mode, True)
+    counts = eng.last_trace["counts"]
+    del eng
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_extra_legs:
+        # separately reported (never `value`): the N=1 workload itself split over the ranks
+        torch.cuda.empty_cache()
+        dts, tests_s, eng_s, _, _, _ = timed_leg(args.rays, args.trace_mode, False)
+        del eng_s
+        strong = {"global_rays": args.rays, "ms_per_step": dts / args.steps * 1e3,
+                  "tests_per_s": tests_s / dts,
+                  "note": "the N=1 workload split over the ranks; the step is host-bound below "
+                          "~250k rays per rank (DESIGN.md section 6)"}
 
     if rank != 0:
         return
 
-    counts = eng.last_trace["counts"]
     n_active = [int(c[:4].sum()) for c in counts]          # rays entering each pass (rank 0)
     launches = len(kernel_ms)
     avg_ms = float(np.mean(kernel_ms)) if launches else float("nan")
@@ -268,7 +295,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": args.dtype + " ray state, f32 filter + f64 decisions",
         "data": "synthetic",
@@ -276,7 +303,8 @@ def main():
             "workload": "cfg4: 1M-ray aperture source x 2-surface parametric hex lens "
                         "(10086+486 faces) + 2-face target, SGD_Optimizer.single_step, "
                         "trace_depth 3",
-            "global_rays": args.rays, "faces": M, "trace_depth": 3,
+            "rays_per_gpu": global_rays // world, "global_rays": global_rays, "faces": M,
+            "trace_depth": 3,
             "trace_mode": {"all-pairs": "all-pairs float32 sphere filter",
                            "group": "sphere hierarchy over k-d face clusters (default)",
                            "sort": "face clusters + Morton-sorted rays"}[mode],
@@ -284,10 +312,11 @@ def main():
         },
         "roofline": roofline,
     }
+    if strong is not None:
+        line["strong_scaling"] = strong
     if world == 1 and not args.no_extra_legs:
         # separately reported legs (never `value`): the same step in the other trace modes.
         # Results are bit-identical in every mode; pairs = N_active x M as in `value`.
-        del eng, system, params, opt
         legs = {}
         for other in ("all-pairs", "group", "sort"):
             if other == mode:
