@@ -513,3 +513,69 @@ def test_planar_interpolated_remesh_reproduces_a_plane_and_a_paraboloid():
     assert fill[0] == -7.0
     with pytest.raises(ValueError):
         mt.planar_interpolated_remesh(src, base, range_axis=3)
+
+
+# ------------------------------------------------------------------------------------------
+# analysis helpers (tfrt/analyze.py)
+
+def test_histogram2d_matches_numpy_and_clips_outliers_into_edge_bins():
+    import tfrt.analyze as analyze
+    rng = np.random.default_rng(5)
+    x, y = rng.uniform(-1, 1, 5000), rng.uniform(-2, 2, 5000)
+    H = analyze.histogram2D(torch.tensor(x), torch.tensor(y), ((-1, 1), (-2, 2)), x_bins=8, y_bins=5)
+    assert H.shape == (5, 8) and H.dtype == torch.int32           # y is the first index
+    want, _, _ = np.histogram2d(y, x, bins=(5, 8), range=((-2, 2), (-1, 1)))
+    np.testing.assert_array_equal(H.numpy(), want.astype(np.int32))
+    # tf.histogram_fixed_width semantics: out-of-range points are counted in the edge bins
+    H2 = analyze.histogram2D(torch.tensor([-9.0, 9.0, 0.1]), torch.tensor([0.0, 9.0, -9.0]),
+                             ((-1, 1), (-1, 1)), x_bins=4)
+    assert H2.shape == (4, 4) and int(H2.sum()) == 3
+    assert H2[2, 0] == 1 and H2[3, 3] == 1 and H2[0, 2] == 1
+    assert analyze.histogram2D(torch.zeros(0), torch.zeros(0), ((0, 1), (0, 1)), 3).sum() == 0
+
+
+def test_inner_product_and_imaging_test_without_display():
+    import tfrt.analyze as analyze
+    a = np.array([[1.0, 2.0], [3.0, 4.0]])
+    assert abs(analyze.inner_product(a, 3 * a) - 1.0) < 1e-15
+    assert abs(analyze.inner_product([[1.0, 0.0]], [[0.0, 1.0]])) < 1e-15
+    rng = np.random.default_rng(1)
+    calls = []
+
+    def get_samples():
+        calls.append(1)
+        return torch.tensor(rng.uniform(-1, 1, (100, 2)))
+
+    h, xe, ye, image = analyze.imaging_test(get_samples, ((-1, 1), (-1, 1)), batch_count=4, bins=16,
+                                            verbose=False, display=False)
+    assert len(calls) == 4 and h.shape == (16, 16) and h.sum() == 400 and image is None
+    assert xe.shape == (17,) and ye[0] == -1 and ye[-1] == 1
+
+
+def test_distribution_differential_prefers_the_goal_distribution():
+    import tfrt.analyze as analyze
+    rng = np.random.default_rng(2)
+    goal = lambda gx, gy: torch.exp(-(gx ** 2 + gy ** 2) / (2 * 0.3 ** 2))     # noqa: E731
+    dd = analyze.DistributionDifferential(goal, ((-1, 1), (-1, 1)), x_bins=20)
+    good = rng.normal(0, 0.3, (2, 40000))
+    flat = rng.uniform(-1, 1, (2, 40000))
+    q_good = float(dd(torch.tensor(good[0]), torch.tensor(good[1])))
+    assert dd.saved_histo.shape == (20, 20)
+    q_flat = float(dd(torch.tensor(flat[0]), torch.tensor(flat[1])))
+    assert 0 <= q_good < 0.02 < q_flat
+    # array goal + out-of-bounds penalty: mean of penalty(distance to the domain centre)
+    arr = torch.ones(6, 6, dtype=torch.float64)
+    pen = analyze.DistributionDifferential(arr, ((0, 2), (0, 2)), oob_penalty=lambda d: 2.0 * d)
+    inside = rng.uniform(0, 2, (2, 20000))
+    x = torch.tensor(np.concatenate([inside[0], [5.0, 1.0]]))
+    y = torch.tensor(np.concatenate([inside[1], [1.0, -3.0]]))
+    base = analyze.DistributionDifferential(arr, ((0, 2), (0, 2)))
+    q0 = float(base(torch.tensor(inside[0]), torch.tensor(inside[1])))
+    assert abs(float(pen(x, y)) - (q0 + 2.0 * 4.0)) < 1e-12           # both strays are 4 away
+    assert abs(float(pen(torch.tensor(inside[0]), torch.tensor(inside[1]))) - q0) < 1e-12
+    with pytest.raises(ValueError):
+        analyze.DistributionDifferential(torch.ones(3), ((0, 1), (0, 1)))
+    with pytest.raises(ValueError):
+        analyze.DistributionDifferential(arr, (0, 1))
+    with pytest.raises(ValueError):
+        analyze.DistributionDifferential(arr, ((0, 1), (0, 1)), oob_penalty=lambda d: d.nope)

@@ -7,7 +7,7 @@ import importlib
 import sys
 
 _MODULES = ("engine", "boundaries", "sources", "distributions", "operation", "materials",
-            "optimizer", "update", "geometry", "mesh_tools", "drawing")
+            "optimizer", "update", "geometry", "mesh_tools", "drawing", "analyze")
 for _m in _MODULES:
     _mod = importlib.import_module("tensorflowraytrace_amd." + _m)
     sys.modules[__name__ + "." + _m] = _mod
