@@ -785,12 +785,24 @@ class OpticalEngine:
         from the source set by source-ray index (simple inheritance, engine.py:2242-2281)."""
         geo = _GEO3 if self.dimension == 3 else _GEO2
         rays = out[cls]
-        ids = out[cls + "_id"].long()
-        fields = {g: rays[i] for i, g in enumerate(geo)}
+        rows = out.get(cls + "_rows")
         carry = set(src.keys()) - set(geo)
         if not only_first_pass:
             carry &= self.simple_ray_inheritance
-        return LazyFields(fields, {f: (lambda f=f: src[f][ids]) for f in carry})
+        memo = {}
+
+        def ids():     # int64 source-ray indices, converted when a field is first gathered
+            if "ids" not in memo:
+                memo["ids"] = out[cls + "_id"].long()
+            return memo["ids"]
+
+        lazy = {f: (lambda f=f: src[f][ids()]) for f in carry}
+        if rows is None:
+            return LazyFields({g: rays[i] for i, g in enumerate(geo)}, lazy)
+        # per-row autograd outputs, cut on first use: the gradient of a field stays one row
+        geo_lazy = {g: (lambda i=i: rows[i]) for i, g in enumerate(geo)}
+        geo_lazy.update(lazy)
+        return LazyFields({}, geo_lazy)
 
     def ray_trace(self, max_iterations=25):
         """Trace the optical system (engine.py:2311-2330): all passes in one fused launch

@@ -301,6 +301,45 @@ def _ray_out(rays, ids, faces):
     return o
 
 
+def _with_rows(blocks):
+    """Outputs of a trace Function: the class blocks followed by every block's rows (views of
+    the same memory).  A consumer that differentiates single fields of a class (``y_end`` of the
+    finished rays, say) takes the row outputs: autograd then hands backward() that row's
+    gradient alone instead of assembling a dense zero-padded block per field it touched
+    (select_backward + slice_backward + add over (rows, capacity): ~90 us per step at 1M rays)."""
+    rows = []
+    for b in blocks:
+        rows.extend(b.unbind(0))
+    return tuple(blocks) + tuple(rows)
+
+
+def _class_grads(ctx_present, caps, n_rows, dev, grads):
+    """Float64 (rows, capacity) gradient block per class from the block / row gradients that
+    autograd delivered (None where the class took no gradient at all)."""
+    blocks, rows = grads[:4], grads[4:]
+    out = []
+    for k, present in enumerate(ctx_present):
+        gb, gr = blocks[k], rows[n_rows * k:n_rows * (k + 1)]
+        if not present or (gb is None and all(g is None for g in gr)):
+            out.append(None)
+            continue
+        if all(g is None for g in gr):
+            out.append(_c(gb, torch.float64))
+            continue
+        if gb is None:
+            blk = torch.zeros((n_rows, caps[k]), dtype=torch.float64, device=dev)
+        else:
+            blk = gb.to(torch.float64, copy=True).contiguous()
+        for i, g in enumerate(gr):
+            if g is not None:
+                if gb is None:
+                    blk[i].copy_(g)
+                else:
+                    blk[i].add_(g)
+        out.append(blk)
+    return out
+
+
 class _Trace3D(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, face_verts, scene, opts):
@@ -362,19 +401,18 @@ class _Trace3D(torch.autograd.Function):
         empty = torch.empty((6, 0), dtype=src.dtype, device=dev)
         rays = [o[0] if o[0] is not None else empty for o in (fin, act, stp, dead)]
         ctx.present = [o[0] is not None for o in (fin, act, stp, dead)]
-        return tuple(rays)
+        ctx.set_materialize_grads(False)
+        return _with_rows(rays)
 
     @staticmethod
-    def backward(ctx, g_fin, g_act, g_stp, g_dead):
+    def backward(ctx, *grads):
         t = ctx.tape
         dev = t.src.device
         M = t.face_verts.shape[0]
         g_fv = torch.zeros((M, 9), dtype=torch.float64, device=dev)
         need_src = ctx.needs_input_grad[0]
         g_src = torch.zeros((6, t.src.shape[1]), dtype=torch.float64, device=dev) if need_src else None
-        gs = []
-        for g, present in zip((g_fin, g_act, g_stp, g_dead), ctx.present):
-            gs.append(_c(g, torch.float64) if (present and g is not None) else None)
+        gs = _class_grads(ctx.present, t.caps, 6, dev, grads)
         sc = t.scene.struct(t.face_verts)
         check(_lib.lib().tfrt_trace3d_backward(
             _p(t.src), t.src.shape[1], t.src.shape[1], ctypes.byref(sc),
@@ -386,6 +424,25 @@ class _Trace3D(torch.autograd.Function):
         if g_src is not None:
             g_src = g_src.to(t.src.dtype)
         return g_src, g_fv, None, None
+
+
+_CLASS_NAMES = ("finished", "active", "stopped", "dead")
+
+
+class _LazyRows:
+    """``rows[i]`` = the first n entries of row i of a class block, cut on first use."""
+
+    def __init__(self, rows, n):
+        self._rows, self._n, self._cut = rows, n, {}
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __getitem__(self, i):
+        r = self._cut.get(i)
+        if r is None:
+            r = self._cut[i] = self._rows[i][:self._n]
+        return r
 
 
 def _slice_outputs(full, aux, counts, P, ncols_prefix=None):
@@ -404,6 +461,8 @@ def _slice_outputs(full, aux, counts, P, ncols_prefix=None):
             continue
         n = min(totals[name], rays.shape[1])
         out[name] = rays[:, :n]
+        if name + "_rows" in aux:   # the same rows as separate autograd outputs (see _with_rows)
+            out[name + "_rows"] = _LazyRows(aux[name + "_rows"], n)
         out[name + "_id"] = aux[name + "_id"][:n]
         out[name + "_face"] = aux[name + "_face"][:n]
     n_unf = int(out["counts"][P - 1, 0]) if P > 0 else 0
@@ -461,9 +520,11 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
                 dead_ray_length=dead_ray_length, flags=flags,
                 zero_init=predicted_counts is not None)
-    fin, act, stp, dead = _Trace3D.apply(src, face_verts, scene, opts)
+    outs = _Trace3D.apply(src, face_verts, scene, opts)
     aux = opts.pop("_aux")
-    full = {"finished": fin, "active": act, "stopped": stp, "dead": dead}
+    full = dict(zip(_CLASS_NAMES, outs[:4]))
+    for k, name in enumerate(_CLASS_NAMES):
+        aux[name + "_rows"] = outs[4 + 6 * k:10 + 6 * k]
     return _finish_trace(full, aux, int(max_passes), predicted_counts)
 
 
@@ -695,19 +756,18 @@ class _Trace2D(torch.autograd.Function):
         }
         empty = torch.empty((4, 0), dtype=src.dtype, device=dev)
         ctx.present = [o[0] is not None for o in (fin, act, stp, dead)]
-        return tuple(o[0] if o[0] is not None else empty for o in (fin, act, stp, dead))
+        ctx.set_materialize_grads(False)
+        return _with_rows([o[0] if o[0] is not None else empty for o in (fin, act, stp, dead)])
 
     @staticmethod
-    def backward(ctx, g_fin, g_act, g_stp, g_dead):
+    def backward(ctx, *grads):
         t = ctx.tape
         dev = t.src.device
         g_seg = None if t.seg is None else torch.zeros_like(t.seg)
         g_arc = None if t.arc is None else torch.zeros_like(t.arc)
         need_src = ctx.needs_input_grad[0]
         g_src = torch.zeros((4, t.src.shape[1]), dtype=torch.float64, device=dev) if need_src else None
-        gs = []
-        for g, present in zip((g_fin, g_act, g_stp, g_dead), ctx.present):
-            gs.append(_c(g, torch.float64) if (present and g is not None) else None)
+        gs = _class_grads(ctx.present, t.caps, 4, dev, grads)
         sc = t.scene.struct(t.seg, t.arc)
         check(_lib.lib().tfrt_trace2d_backward(
             _p(t.src), t.src.shape[1], t.src.shape[1], ctypes.byref(sc),
@@ -730,9 +790,11 @@ def trace2d(src, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
                 zero_init=predicted_counts is not None)
     seg_geo = None if scene.segments is None else scene.segments["geo"]
     arc_geo = None if scene.arcs is None else scene.arcs["geo"]
-    fin, act, stp, dead = _Trace2D.apply(src, seg_geo, arc_geo, scene, opts)
+    outs = _Trace2D.apply(src, seg_geo, arc_geo, scene, opts)
     aux = opts.pop("_aux")
-    full = {"finished": fin, "active": act, "stopped": stp, "dead": dead}
+    full = dict(zip(_CLASS_NAMES, outs[:4]))
+    for k, name in enumerate(_CLASS_NAMES):
+        aux[name + "_rows"] = outs[4 + 4 * k:8 + 4 * k]
     out = _finish_trace(full, aux, int(max_passes), predicted_counts)
     out["n_segments"] = 0 if seg_geo is None else seg_geo.shape[0]
     return out
