@@ -82,6 +82,23 @@ int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_
                               const uint8_t* update_mask, int64_t n_faces, int64_t n_vertices,
                               double* grad_vertices, void* stream);
 
+/* Parametric surface: parameters -> per-face data in one launch.
+ * Replaces ParametricTriangleBoundary._update, tfrt/boundaries.py:1065-1078
+ * (`zero_points + parameters[:,None] * vectors`, boundaries.py:1080-1092) followed by
+ * update_fields_from_vertices (boundaries.py:890-923); bit-identical with the two-step path
+ * (product and sum stay separate roundings).
+ *
+ *   zero_points, vectors  (V,3) f64 row-major;  parameters (V,) f64
+ * The reverse ACCUMULATES into grad_parameters (V,) (caller zeroes): per face corner that
+ * update_mask lets through, dot(grad of that corner, vectors[vertex]). */
+int tfrt_param_faces_forward(const double* zero_points, const double* vectors,
+                             const double* parameters, int64_t n_vertices, const int32_t* faces,
+                             int64_t n_faces, double* face_verts, double* norm, void* stream);
+int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_norm,
+                              const double* face_verts, const int32_t* faces,
+                              const uint8_t* update_mask, const double* vectors, int64_t n_faces,
+                              int64_t n_vertices, double* grad_parameters, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser step, parameter side (SGD_Optimizer.process_gradient / single_step,
  * tfrt/optimizer.py:223-257 and :316).

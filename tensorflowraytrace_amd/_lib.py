@@ -59,6 +59,9 @@ SIGNATURES = {
     "tfrt_profile_read": (c_i32, [c_vp, c_i32]),
     "tfrt_build_faces_forward": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tfrt_build_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "tfrt_param_faces_forward": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "tfrt_param_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
+                                          c_vp]),
     "tfrt_line_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_f64,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_line_triangle_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,

@@ -595,19 +595,22 @@ class TriangleBoundaryBase(BoundaryBase):
         self._faces = np.concatenate([np.full((tri.shape[0], 1), 3, dtype=np.int64), tri], axis=1)
         self._faces_i32 = None
 
-    def update_fields_from_vertices(self):
-        """vertices -> (F,9) face tensor + unit normals, in HIP (boundaries.py:890-923)."""
-        if self._faces is None or self._vertices is None:
-            return
-        dev = self._vertices.device
+    def _device_face_tables(self, dev):
+        """(F,3) int32 vertex indices and the uint8 vertex_update_map (or None) on ``dev``."""
         if self._faces_i32 is None or self._faces_i32.device != dev:
             self._faces_i32 = torch.as_tensor(self._faces[:, 1:].astype(np.int32), device=dev)
         if self._vertex_update_map is not None and (
                 self._mask_u8 is None or self._mask_u8.device != dev):
             self._mask_u8 = torch.as_tensor(
                 self._vertex_update_map.astype(np.uint8), device=dev).contiguous()
-        mask = self._mask_u8 if self._vertex_update_map is not None else None
-        self._face_verts, self._norm = ops.build_faces(self._vertices, self._faces_i32, mask)
+        return self._faces_i32, (self._mask_u8 if self._vertex_update_map is not None else None)
+
+    def update_fields_from_vertices(self):
+        """vertices -> (F,9) face tensor + unit normals, in HIP (boundaries.py:890-923)."""
+        if self._faces is None or self._vertices is None:
+            return
+        faces, mask = self._device_face_tables(self._vertices.device)
+        self._face_verts, self._norm = ops.build_faces(self._vertices, faces, mask)
         for k in list(_TRI_COLS) + ["norm"]:
             self._fields.pop(k, None)
 
@@ -672,10 +675,41 @@ class ParametricTriangleBoundary(TriangleBoundaryBase):
         return []
 
     def _update(self):
-        self._vertices = self._update_internal(self._zero_points, self._vectors, self.parameters)
+        fused = (type(self)._update_internal is ParametricTriangleBoundary._update_internal
+                 and self._faces is not None and self._zero_points.is_cuda
+                 and isinstance(self.parameters, torch.Tensor) and self.parameters.is_cuda)
+        if not fused:
+            self._vertices = self._update_internal(self._zero_points, self._vectors, self.parameters)
+            if self.auto_update_mesh:
+                self.update_mesh_from_vertices()
+            self.update_fields_from_vertices()
+            return
+        # one launch: parameters -> faces (ops.param_faces); the (V,3) vertex tensor is only
+        # formed when somebody reads it (drawing, saving, a regulariser)
+        self._vertices_pending = True
+        faces, mask = self._device_face_tables(self._zero_points.device)
+        self._face_verts, self._norm = ops.param_faces(
+            self.parameters, self._zero_points, self._vectors, faces, mask)
+        for k in list(_TRI_COLS) + ["norm"]:
+            self._fields.pop(k, None)
         if self.auto_update_mesh:
             self.update_mesh_from_vertices()
-        self.update_fields_from_vertices()
+
+    # ``_vertices`` of a parametric surface is computed on demand from the parameters when the
+    # fused update ran (same expression as the two-step path, differentiable)
+    @property
+    def _vertices(self):
+        d = self.__dict__
+        if d.get("_vertices_pending"):
+            d["_vertices_value"] = self._update_internal(
+                self._zero_points, self._vectors, self.parameters)
+            d["_vertices_pending"] = False
+        return d.get("_vertices_value")
+
+    @_vertices.setter
+    def _vertices(self, value):
+        self.__dict__["_vertices_value"] = value
+        self.__dict__["_vertices_pending"] = False
 
     @staticmethod
     def _update_internal(zero, vectors, parameter):

@@ -77,6 +77,91 @@ __global__ __launch_bounds__(BLOCK) void k_build_faces_bwd(
   }
 }
 
+// Parametric surfaces (boundaries.py:1065-1078): vertices = zero_points + parameters * vectors
+// followed by the face gather above, in one launch; the reverse folds the scatter through the
+// gather, the per-corner stop_gradient mask and the product with `vectors` into one atomic per
+// corner.  The reference runs the product and the sum as separate ops: keep them unfused so the
+// faces are bit-identical with the two-step path.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(BLOCK) void k_param_faces(
+    const double* __restrict__ zero, const double* __restrict__ vectors,
+    const double* __restrict__ params, int64_t V, const int32_t* __restrict__ faces, int64_t F,
+    double* __restrict__ fverts, double* __restrict__ norm) {
+  const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (f >= F) return;
+  double P[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int64_t v = faces[3 * f + c];
+    if (v < 0 || v >= V) v = 0;  // host validates; keep the access in range regardless
+    const double p = params[v];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double step = p * vectors[3 * v + k];
+      P[3 * c + k] = zero[3 * v + k] + step;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) fverts[9 * f + q] = P[q];
+  if (norm != nullptr) {
+    double N[3], C[3], clen;
+    face_normal(P, N, C, &clen);
+    norm[3 * f] = N[0];
+    norm[3 * f + 1] = N[1];
+    norm[3 * f + 2] = N[2];
+  }
+}
+
+// shared by the two reverse kernels: gradient of the 9 face coordinates including the part
+// that arrives through the unit normal
+__device__ inline void face_grad(const double* __restrict__ g_fverts,
+                                 const double* __restrict__ g_norm,
+                                 const double* __restrict__ fverts, int64_t f, double g[9]) {
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g[q] = g_fverts ? g_fverts[9 * f + q] : 0.0;
+  if (g_norm != nullptr) {
+    // N = C/|C|, C = A x B, A = P1-P0, B = P2-P1
+    double P[9], N[3], C[3], clen;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) P[q] = fverts[9 * f + q];
+    face_normal(P, N, C, &clen);
+    const double gn[3] = {g_norm[3 * f], g_norm[3 * f + 1], g_norm[3 * f + 2]};
+    const double nn = dot3(N, gn);
+    double Cb[3];
+    for (int k = 0; k < 3; ++k) Cb[k] = (gn[k] - N[k] * nn) / clen;
+    const double A[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]};
+    const double B[3] = {P[6] - P[3], P[7] - P[4], P[8] - P[5]};
+    double Ab[3], Bb[3];
+    cross3(B, Cb, Ab);
+    cross3(Cb, A, Bb);
+    for (int k = 0; k < 3; ++k) {
+      g[k] -= Ab[k];
+      g[3 + k] += Ab[k] - Bb[k];
+      g[6 + k] += Bb[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_param_faces_bwd(
+    const double* __restrict__ g_fverts, const double* __restrict__ g_norm,
+    const double* __restrict__ fverts, const int32_t* __restrict__ faces,
+    const uint8_t* __restrict__ mask, const double* __restrict__ vectors, int64_t F, int64_t V,
+    double* __restrict__ g_params) {
+  const int64_t f = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (f >= F) return;
+  double g[9];
+  face_grad(g_fverts, g_norm, fverts, f, g);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (mask != nullptr && mask[3 * f + c] == 0) continue;
+    const int64_t v = faces[3 * f + c];
+    if (v < 0 || v >= V) continue;
+    const double x = g[3 * c] * vectors[3 * v] + g[3 * c + 1] * vectors[3 * v + 1] +
+                     g[3 * c + 2] * vectors[3 * v + 2];
+    if (x != 0.0) unsafeAtomicAdd(g_params + v, x);
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_snell3d(int64_t n, const double* xs, const double* ys,
                                                    const double* zs, const double* xe,
                                                    const double* ye, const double* ze,
@@ -148,6 +233,34 @@ int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_
   hipLaunchKernelGGL(k_build_faces_bwd, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
                      static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
                      faces, update_mask, n_faces, n_vertices, grad_vertices);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_param_faces_forward(const double* zero_points, const double* vectors,
+                             const double* parameters, int64_t n_vertices, const int32_t* faces,
+                             int64_t n_faces, double* face_verts, double* norm, void* stream) {
+  if (n_faces < 0 || n_vertices < 0) return TFRT_E_BADARG;
+  if (n_faces == 0) return 0;
+  if (!zero_points || !vectors || !parameters || !faces || !face_verts || n_vertices == 0)
+    return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_param_faces, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), zero_points, vectors, parameters,
+                     n_vertices, faces, n_faces, face_verts, norm);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_norm,
+                              const double* face_verts, const int32_t* faces,
+                              const uint8_t* update_mask, const double* vectors, int64_t n_faces,
+                              int64_t n_vertices, double* grad_parameters, void* stream) {
+  if (n_faces < 0 || n_vertices < 0) return TFRT_E_BADARG;
+  if (n_faces == 0) return 0;
+  if (!faces || !vectors || !grad_parameters || (!grad_face_verts && !grad_norm) ||
+      (grad_norm && !face_verts))
+    return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_param_faces_bwd, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
+                     faces, update_mask, vectors, n_faces, n_vertices, grad_parameters);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 

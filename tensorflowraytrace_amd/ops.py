@@ -96,6 +96,54 @@ def build_faces(vertices, faces, update_mask=None):
     return _BuildFaces.apply(vertices, faces, update_mask)
 
 
+class _ParamFaces(torch.autograd.Function):
+    """parameters (V,) -> face_verts (F,9), norm (F,3) of ``zero + parameters[:,None] * vectors``
+    (boundaries.py:1065-1092 + 890-923) in one launch each way; see tfrt_param_faces_*."""
+
+    @staticmethod
+    def forward(ctx, parameters, zero_points, vectors, faces, update_mask):
+        _need_gpu(parameters, zero_points, vectors, faces, update_mask)
+        parameters = _c(parameters, torch.float64).reshape(-1)
+        V, F = zero_points.shape[0], faces.shape[0]
+        if parameters.shape[0] != V or vectors.shape != zero_points.shape:
+            raise TfrtError("param_faces: parameters (V,), zero_points (V,3) and vectors (V,3) "
+                            "must describe the same vertices")
+        fv = torch.empty((F, 9), dtype=torch.float64, device=parameters.device)
+        norm = torch.empty((F, 3), dtype=torch.float64, device=parameters.device)
+        check(_lib.lib().tfrt_param_faces_forward(
+            _p(zero_points), _p(vectors), _p(parameters), V, _p(faces), F, _p(fv), _p(norm),
+            _stream(parameters)), "tfrt_param_faces_forward")
+        ctx.save_for_backward(fv, faces, update_mask, vectors)
+        ctx.shape = parameters.shape
+        ctx.set_materialize_grads(False)
+        return fv, norm
+
+    @staticmethod
+    def backward(ctx, g_fv, g_norm):
+        fv, faces, update_mask, vectors = ctx.saved_tensors
+        gp = torch.zeros(ctx.shape, dtype=torch.float64, device=fv.device)
+        g_fv = _c(g_fv, torch.float64)
+        g_norm = _c(g_norm, torch.float64)
+        if g_fv is not None or g_norm is not None:
+            check(_lib.lib().tfrt_param_faces_backward(
+                _p(g_fv), _p(g_norm), _p(fv), _p(faces), _p(update_mask), _p(vectors),
+                faces.shape[0], vectors.shape[0], _p(gp), _stream(fv)),
+                "tfrt_param_faces_backward")
+        return gp, None, None, None, None
+
+
+def param_faces(parameters, zero_points, vectors, faces, update_mask=None):
+    """Faces of the parametric surface ``zero_points + parameters[:,None] * vectors``:
+    (face_verts (F,9), norm (F,3)), differentiable w.r.t. ``parameters`` only (zero points and
+    vectors are constants between reparametrisations, boundaries.py:1084-1085)."""
+    faces = _c(faces, torch.int32)
+    zero_points = _c(zero_points.detach(), torch.float64)
+    vectors = _c(vectors.detach(), torch.float64)
+    if update_mask is not None:
+        update_mask = _c(update_mask, torch.uint8)
+    return _ParamFaces.apply(parameters, zero_points, vectors, faces, update_mask)
+
+
 # ------------------------------------------------------------------- pairwise geometry
 
 def _ptr_array(tensors):

@@ -103,3 +103,94 @@ def test_optimizer_step_with_accumulator_and_smoother_matches_dense_host_math():
     assert float(err) > 0
     for p, w in zip(params, want):
         np.testing.assert_allclose(p.detach().cpu().numpy(), w.cpu().numpy(), rtol=1e-12, atol=1e-14)
+
+
+# ------------------------------------------------------------------------------------------
+# parameters -> faces in one launch (tfrt_param_faces_*, boundaries.py:1065-1092 + 890-923)
+
+def _param_surface(k, flip, seed):
+    import tensorflowraytrace_amd.mesh_tools as mt
+    mesh = mt.hexagonal_mesh(1.0, k)
+    mesh.rotate_y(90)
+    rng = np.random.default_rng(seed)
+    V = mesh.n_points
+    zero = torch.tensor(mesh.points).cuda()
+    vec = torch.tensor(rng.standard_normal((V, 3))).cuda()
+    faces = torch.tensor(mesh.triangles()[:, ::-1].copy() if flip else mesh.triangles(),
+                         dtype=torch.int32).cuda()
+    p = torch.tensor(rng.uniform(-0.2, 0.2, V)).cuda()
+    return zero, vec, faces, p
+
+
+@pytest.mark.parametrize("k,flip,masked", [(1, False, False), (7, True, True), (24, False, True)])
+def test_param_faces_is_bit_identical_with_the_two_step_path_and_matches_its_gradient(k, flip, masked):
+    from tensorflowraytrace_amd import ops
+    zero, vec, faces, p0 = _param_surface(k, flip, 11 * k)
+    F = faces.shape[0]
+    mask = None
+    if masked:
+        mask = (torch.rand(F, 3, generator=torch.Generator().manual_seed(k)) < 0.6).to(torch.uint8).cuda()
+    p1 = p0.clone().requires_grad_(True)
+    fv1, n1 = ops.param_faces(p1, zero, vec, faces, mask)
+    p2 = p0.clone().requires_grad_(True)
+    fv2, n2 = ops.build_faces(zero + p2.reshape(-1, 1) * vec, faces, mask)
+    assert torch.equal(fv1, fv2) and torch.equal(n1, n2)
+    gen = torch.Generator().manual_seed(5)
+    w_fv = torch.randn(F, 9, generator=gen, dtype=torch.float64).cuda()
+    w_n = torch.randn(F, 3, generator=gen, dtype=torch.float64).cuda()
+    for use_fv, use_n in ((True, False), (False, True), (True, True)):
+        def loss(fv, n):
+            out = 0.0
+            if use_fv:
+                out = out + (fv * w_fv).sum()
+            if use_n:
+                out = out + (n * w_n).sum()
+            return out
+        g1, = torch.autograd.grad(loss(fv1, n1), p1, retain_graph=True)
+        g2, = torch.autograd.grad(loss(fv2, n2), p2, retain_graph=True)
+        scale = float(g2.abs().max())
+        assert float((g1 - g2).abs().max()) <= 1e-13 * max(scale, 1.0)
+    if masked:      # corners the map switches off take no gradient at all
+        only = torch.zeros(F, 9, dtype=torch.float64).cuda()
+        only[:, :3] = (1 - mask[:, :1].double())
+        g, = torch.autograd.grad((fv1 * only).sum(), p1, retain_graph=True)
+        assert float(g.abs().max()) == 0.0
+
+
+def test_param_faces_rejects_mismatched_shapes_and_handles_empty_meshes():
+    from tensorflowraytrace_amd import ops
+    from tensorflowraytrace_amd._lib import TfrtError
+    zero, vec, faces, p = _param_surface(2, False, 3)
+    with pytest.raises(TfrtError):
+        ops.param_faces(p[:-1], zero, vec, faces)
+    with pytest.raises(TfrtError):
+        ops.param_faces(p, zero, vec[:-1], faces)
+    fv, n = ops.param_faces(p, zero, vec, faces[:0])
+    assert fv.shape == (0, 9) and n.shape == (0, 3)
+
+
+def test_parametric_boundary_uses_the_fused_update_and_serves_vertices_on_demand():
+    import tensorflowraytrace_amd.boundaries as boundaries
+    import tensorflowraytrace_amd.mesh_tools as mt
+    from tensorflowraytrace_amd import ops
+    zp = mt.hexagonal_mesh(1.0, 6)
+    zp.rotate_y(90)
+    surf = boundaries.ParametricTriangleBoundary(
+        zp, boundaries.FromVectorVG((1, 0, 0)), initial_parameters=0.0,
+        material_dict={"mat_in": 1, "mat_out": 0})
+    with torch.no_grad():
+        surf.parameters.copy_(torch.linspace(-0.1, 0.2, surf.parameters.shape[0]).cuda())
+    surf.update()
+    assert surf.__dict__.get("_vertices_pending") is True        # nothing formed (V,3) yet
+    verts = surf.vertices
+    want = surf._zero_points + surf.parameters.reshape(-1, 1) * surf.vectors
+    assert torch.equal(verts, want) and verts.requires_grad
+    faces = torch.as_tensor(surf.faces[:, 1:].astype(np.int32)).cuda()
+    fv, nrm = ops.build_faces(want, faces)
+    assert torch.equal(surf.face_verts, fv) and torch.equal(surf["norm"], nrm)
+    assert torch.equal(surf["x1"], fv[:, 3])
+    g, = torch.autograd.grad(surf.face_verts.sum() + surf["norm"][:, 0].sum(), surf.parameters)
+    g2, = torch.autograd.grad(fv.sum() + nrm[:, 0].sum(), surf.parameters)
+    assert float((g - g2).abs().max()) < 1e-13
+    surf.update_mesh_from_vertices()
+    np.testing.assert_array_equal(surf.mesh.points, want.detach().cpu().numpy())
