@@ -349,6 +349,33 @@ def _ray_out(rays, ids, faces):
     return o
 
 
+class _IntPool:
+    """The int32 outputs of one trace (counts + per-class source ids and faces) cut from one
+    allocation: one fill instead of one per array when they must start as zeros."""
+
+    def __init__(self, dev, zero_all, n_counts, flags, cap_n, passes):
+        caps = ((_lib.COMPILE_FINISHED, cap_n), (_lib.COMPILE_ACTIVE, cap_n * max(passes, 1)),
+                (_lib.COMPILE_STOPPED, cap_n), (_lib.COMPILE_DEAD, cap_n))
+        pad = self._pad
+        total = pad(n_counts) + pad(cap_n) + sum(2 * pad(c) for f, c in caps if flags & f)
+        if zero_all:
+            self._buf = torch.zeros(total, dtype=torch.int32, device=dev)
+        else:
+            self._buf = torch.empty(total, dtype=torch.int32, device=dev)
+            self._buf[:n_counts].zero_()
+        self.counts = self._buf[:n_counts]
+        self._at = pad(n_counts)
+
+    @staticmethod
+    def _pad(n):          # every array starts on a 256-byte boundary, like its own allocation
+        return (n + 63) & ~63
+
+    def take(self, n):
+        out = self._buf[self._at:self._at + n]
+        self._at += self._pad(n)
+        return out
+
+
 def _with_rows(blocks):
     """Outputs of a trace Function: the class blocks followed by every block's rows (views of
     the same memory).  A consumer that differentiates single fields of a class (``y_end`` of the
@@ -404,27 +431,26 @@ class _Trace3D(torch.autograd.Function):
         L = _lib.lib()
         wsb = L.tfrt_trace3d_workspace_bytes(N, face_verts.shape[0], P, dt)
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
-        counts = torch.zeros(_lib.COUNTS_PER_PASS * (P + 1), dtype=torch.int32, device=dev)
-
         # With speculative slicing (predicted counts) rows beyond the true counts may be read
         # before the prediction is verified: the index arrays must then hold valid indices
         # (zeros); the ray blocks may hold anything, a wrong guess is re-evaluated anyway.
-        new_idx = torch.zeros if opts.get("zero_init") else torch.empty
+        capN = max(N, 1)
+        ints = _IntPool(dev, bool(opts.get("zero_init")), _lib.COUNTS_PER_PASS * (P + 1), flags,
+                        capN, P)
+        counts = ints.counts
 
         def alloc(flag, cap):
             if not (flags & flag):
                 return None, None, None
-            return (torch.empty((6, cap), dtype=src.dtype, device=dev),
-                    new_idx(cap, dtype=torch.int32, device=dev),
-                    new_idx(cap, dtype=torch.int32, device=dev))
+            return (torch.empty((6, cap), dtype=src.dtype, device=dev), ints.take(cap),
+                    ints.take(cap))
 
-        capN = max(N, 1)
         fin = alloc(_lib.COMPILE_FINISHED, capN)
         act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
         stp = alloc(_lib.COMPILE_STOPPED, capN)
         dead = alloc(_lib.COMPILE_DEAD, capN)
         unf = torch.empty((6, capN), dtype=src.dtype, device=dev)
-        unf_id = new_idx(capN, dtype=torch.int32, device=dev)
+        unf_id = ints.take(capN)
         sc = scene.struct(face_verts)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace3d_forward(
@@ -765,24 +791,23 @@ class _Trace2D(torch.autograd.Function):
         Ma = 0 if arc_geo is None else arc_geo.shape[0]
         wsb = L.tfrt_trace2d_workspace_bytes(N, Ms, Ma, P, dt)
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
-        counts = torch.zeros(_lib.COUNTS_PER_PASS * (P + 1), dtype=torch.int32, device=dev)
-
-        new = torch.zeros if opts.get("zero_init") else torch.empty
+        capN = max(N, 1)
+        ints = _IntPool(dev, bool(opts.get("zero_init")), _lib.COUNTS_PER_PASS * (P + 1), flags,
+                        capN, P)
+        counts = ints.counts
 
         def alloc(flag, cap):
             if not (flags & flag):
                 return None, None, None
             return (torch.empty((4, cap), dtype=src.dtype, device=dev),  # (see _Trace3D.forward)
-                    new(cap, dtype=torch.int32, device=dev),
-                    new(cap, dtype=torch.int32, device=dev))
+                    ints.take(cap), ints.take(cap))
 
-        capN = max(N, 1)
         fin = alloc(_lib.COMPILE_FINISHED, capN)
         act = alloc(_lib.COMPILE_ACTIVE, capN * max(P, 1))
         stp = alloc(_lib.COMPILE_STOPPED, capN)
         dead = alloc(_lib.COMPILE_DEAD, capN)
         unf = torch.empty((4, capN), dtype=src.dtype, device=dev)
-        unf_id = new(capN, dtype=torch.int32, device=dev)
+        unf_id = ints.take(capN)
         sc = scene.struct(seg_geo, arc_geo)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace2d_forward(

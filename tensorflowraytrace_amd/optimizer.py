@@ -126,7 +126,9 @@ class SGD_Optimizer:
         # them from the previous step and verify after the gradient has been enqueued
         self.speculative = speculative
         self.speculation_misses = 0
-        self._miss_rate = 0.0
+        # start pessimistic: the first steps read the ray counts (blocking) and speculation
+        # begins once they have repeated (5 equal steps), instead of paying for wrong guesses
+        self._miss_rate = 1.0
         self._last_counts = None
         self._velocity = [None] * len(self.parameters)
         self.momentum = momentum
