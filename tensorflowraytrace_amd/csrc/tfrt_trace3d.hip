@@ -193,6 +193,16 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
 // ~20 % fewer rays per cluster.
 constexpr int CLUSTER = 16;
 
+// Funnel counters of k_intersect_group for tuning builds (-DTFRT_GROUP_STATS; never in the
+// shipped library): [0] level-0 tests, [1] (ray, supercluster) pairs, [2] queued clusters,
+// [3] member-sphere hits, [4] pairs past the float32 screen, [5] float64 decisions that hit.
+#ifdef TFRT_GROUP_STATS
+__device__ unsigned long long g_group_stats[8];
+#define TFRT_STAT(k, v) do { if (lane_id() == 0) atomicAdd(&g_group_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define TFRT_STAT(k, v) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
     const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
     const double* __restrict__ c0, double size_eps, int n_clusters,
@@ -1012,6 +1022,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       x_face[wave][pos] = j;
     }
     xn += __popcll(km);
+    TFRT_STAT(4, __popcll(km));
     wave_fence();
   };
 
@@ -1040,6 +1051,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
         key = dkey(h.ray_u);
       }
     }
+    TFRT_STAT(5, __popcll(__ballot(have)));
     wave_fence();
     if (have) atomicMin(&best_k[wave][slot], key);
     wave_fence();
@@ -1098,6 +1110,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
 #endif
           if (hit) pairs[wave][pn + rank_below(hm)] = ((uint32_t)memb[u] << 8) | (uint32_t)slot[u];
           pn += __popcll(hm);
+          TFRT_STAT(3, __popcll(hm));
         }
       }
       const bool last = q0 + 4 * MU >= total;
@@ -1173,6 +1186,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
         const unsigned long long hm = __ballot(hit);
         if (hit) clist[wave][ln + rank_below(hm)] = (uint16_t)entry;
         ln += __popcll(hm);
+        TFRT_STAT(2, __popcll(hm));
       }
       // keep the rest of the pairs (fewer than 64) at the front
       int keep = 0;
@@ -1193,6 +1207,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
             rlist[wave][rn + rank_below(m)] = (uint16_t)((k << 8) | (r * 64 + lane));
           }
           rn += __popcll(m);
+          TFRT_STAT(1, __popcll(m));
         }
       }
       wave_fence();
@@ -1206,6 +1221,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
       __syncthreads();
       // level 0: which superclusters of the tile does each ray's line touch
+      TFRT_STAT(0, (long long)ns * __popcll(__ballot(base + tid < n)));
       for (int k = 0; k < ns; ++k) {
         const float4 sp = stile[k];  // same address in every lane: LDS broadcast
 #pragma unroll
@@ -2231,5 +2247,14 @@ int tfrt_profile_read(float* ms, int32_t max_records) {
   }
   return n;
 }
+
+#ifdef TFRT_GROUP_STATS
+// tuning builds only: read (and clear) the funnel counters of k_intersect_group
+int tfrt_debug_group_stats(unsigned long long* out8) {
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_group_stats), sizeof(zero)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_group_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"
