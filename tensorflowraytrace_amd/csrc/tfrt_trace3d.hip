@@ -203,12 +203,12 @@ __device__ unsigned long long g_group_stats[8];
 #define TFRT_STAT(k, v) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
-    const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
+__device__ __forceinline__ void cluster_spheres_block(
+    const int block, const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
     const double* __restrict__ c0, double size_eps, int n_clusters,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
     float4* __restrict__ crec) {
-  const int k = blockIdx.x * BLOCK + threadIdx.x;  // member slot = cluster * CLUSTER + member
+  const int k = block * BLOCK + threadIdx.x;  // member slot = cluster * CLUSTER + member
   const int c = k / CLUSTER;
   const bool in_range = c < n_clusters;            // uniform over the 16 lanes of a cluster
   int f = (in_range && k < M) ? order[k] : -1;
@@ -304,13 +304,13 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
 // superclusters touched per ray, and the per-lane cluster loop runs once per touched one).
 constexpr int SUPER = 8;
 
-__global__ __launch_bounds__(SUPER * CLUSTER) void k_super_spheres(
-    const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
+__device__ __forceinline__ void super_spheres_block(
+    const int s, const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
     const double* __restrict__ c0, double size_eps, float4* __restrict__ susphere) {
-  constexpr int NT = SUPER * CLUSTER;  // 128 threads = 2 waves
+  constexpr int NT = SUPER * CLUSTER;  // 128 threads = 2 waves (the caller retires the others)
   __shared__ double red[NT / 64][4];
   __shared__ double pick[3];
-  const int s = blockIdx.x, t = threadIdx.x;
+  const int t = threadIdx.x;
   const int k = s * NT + t;
   int f = k < M ? order[k] : -1;
   if (f < 0 || f >= M) f = -1;
@@ -383,6 +383,33 @@ __global__ __launch_bounds__(SUPER * CLUSTER) void k_super_spheres(
     const double cn = sqrt(dot3(mean, mean));
     R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
     susphere[s] = pack_sphere(mean, R);
+  }
+}
+
+// The sorted-ray mode only needs the cluster level.
+__global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
+    const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
+    const double* __restrict__ c0, double size_eps, int n_clusters,
+    float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
+    float4* __restrict__ crec) {
+  cluster_spheres_block(blockIdx.x, fverts, M, order, c0, size_eps, n_clusters, csphere, cface,
+                        clsphere, crec);
+}
+
+// Both sphere levels of the grouped filter in one launch (each is a latency-bound ~12 us
+// kernel on its own and neither reads the other's output): blocks [0, n_super) walk one
+// supercluster ball each with their first 128 threads, the rest do 16 clusters each.
+__global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
+    const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
+    const double* __restrict__ c0, double size_eps, int n_clusters, int n_super,
+    float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
+    float4* __restrict__ crec, float4* __restrict__ susphere) {
+  if ((int)blockIdx.x < n_super) {
+    if (threadIdx.x >= SUPER * CLUSTER) return;  // (whole waves: 128 is a multiple of 64)
+    super_spheres_block(blockIdx.x, fverts, M, order, c0, size_eps, susphere);
+  } else {
+    cluster_spheres_block(blockIdx.x - n_super, fverts, M, order, c0, size_eps, n_clusters,
+                          csphere, cface, clsphere, crec);
   }
 }
 
@@ -902,6 +929,10 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+__device__ __forceinline__ int cat_to_cls(int cat) {
+  return cat == CAT_OPTICAL ? CLS_ACTIVE : (cat == CAT_TARGET ? CLS_FINISHED : CLS_STOPPED);
+}
+
 template <typename T, int R>
 __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
@@ -911,7 +942,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     const double* __restrict__ fverts, const double* __restrict__ c0,
     const float* __restrict__ prep, int64_t pstride, int n_clusters, int chunk_clusters,
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
-    int32_t* __restrict__ part_i, int64_t part_stride) {
+    int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
+    int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
+    int32_t* __restrict__ blockcnt) {
   constexpr int RW = 64 * R;      // rays per wave
   constexpr int GT = 256;         // cluster spheres per LDS tile
   const int n = *n_ptr;
@@ -1234,22 +1267,50 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     }
   }
 
+  if (rec_cls == nullptr) {  // several cluster chunks: k_classify3d merges the partial results
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = base + r * BLOCK + tid;
+      if (i < n) {
+        const int slot = r * 64 + lane;
+        part_t[blockIdx.y * part_stride + i] = dkey_inv(best_k[wave][slot]);
+        part_i[blockIdx.y * part_stride + i] = best_i[wave][slot];
+      }
+    }
+    return;
+  }
+  // One cluster chunk: this workgroup has seen every face, so the nearest hit is final.  Do
+  // k_classify3d's work here (hit record, class, per-256-ray class histogram for the scan).
+  __shared__ int wc[WAVES][4];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = base + r * BLOCK + tid;
+    int cls = -1;
     if (i < n) {
       const int slot = r * 64 + lane;
-      part_t[blockIdx.y * part_stride + i] = dkey_inv(best_k[wave][slot]);
-      part_i[blockIdx.y * part_stride + i] = best_i[wave][slot];
+      const int bi = best_i[wave][slot];
+      cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
+      rec_tri[i] = bi;
+      rec_t[i] = dkey_inv(best_k[wave][slot]);
+      rec_cls[i] = (uint8_t)cls;
     }
+    if (base + r * BLOCK >= n) break;  // block-uniform: no rays in this 256-ray slice
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (lane == 0) wc[wave][c] = __popcll(m);
+    }
+    __syncthreads();
+    if (tid < 4) {
+      int sum = 0;
+      for (int w = 0; w < WAVES; ++w) sum += wc[w][tid];
+      blockcnt[(blockIdx.x * R + r) * 4 + tid] = sum;
+    }
+    __syncthreads();
   }
 }
 
 // -------------------------------------------------------------------------- classify
-
-__device__ __forceinline__ int cat_to_cls(int cat) {
-  return cat == CAT_OPTICAL ? CLS_ACTIVE : (cat == CAT_TARGET ? CLS_FINISHED : CLS_STOPPED);
-}
 
 __global__ __launch_bounds__(BLOCK) void k_classify3d(
     const int32_t* __restrict__ n_ptr, int chunks, const double* __restrict__ part_t,
@@ -1855,16 +1916,31 @@ struct ProfRec {
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
+// Where the grouped kernel leaves the classified hit records when it runs as one cluster chunk
+// (it then does k_classify3d's work in its epilogue).
+struct Classify3 {
+  const int32_t* catagory = nullptr;
+  int32_t* rec_tri = nullptr;
+  double* rec_t = nullptr;
+  uint8_t* rec_cls = nullptr;
+  int32_t* blockcnt = nullptr;
+};
+
 template <typename T>
 static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int64_t stride,
                             const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
                             const double* fverts, const double* c0, float* prep, int64_t pstride,
                             int M, double ei, double es, double er, double* part_t,
                             int32_t* part_i, int64_t part_stride, const Accel3* ac, int n_cap,
-                            bool prep_ready = false) {
+                            bool prep_ready = false, const Classify3* classify = nullptr,
+                            bool* classified = nullptr) {
   const bool accel = ac != nullptr && ac->order != nullptr;
   const bool clustered = accel && ac->sort_rays;
   const bool grouped = accel && !ac->sort_rays;
+  Classify3 fz;
+  if (grouped && pl.g_chunks == 1 && classify != nullptr && classify->rec_cls != nullptr)
+    fz = *classify;
+  if (classified != nullptr) *classified = fz.rec_cls != nullptr;
   if (!prep_ready || clustered)  // (sorted-ray mode also needs the sort keys)
     hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
                        prep, pstride, clustered ? ac->keys_in : nullptr,
@@ -1895,7 +1971,8 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
                        n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec,     \
                        ac->cface, fverts, c0, prep, pstride, ac->n_clusters,                   \
-                       pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride);          \
+                       pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride,           \
+                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt);            \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
@@ -1971,14 +2048,16 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   if (M > 0) {
     hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0);
     if (ac.order != nullptr) {
-      hipLaunchKernelGGL(k_cluster_spheres, dim3(cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK)),
-                         dim3(BLOCK), 0, st,
-                         sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
-                         ac.csphere, ac.cface, ac.clsphere, ac.sort_rays ? nullptr : ac.crec);
-      if (!ac.sort_rays) {
+      const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
+      if (ac.sort_rays) {
+        hipLaunchKernelGGL(k_cluster_spheres, dim3(cl_blocks), dim3(BLOCK), 0, st,
+                           sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
+                           ac.csphere, ac.cface, ac.clsphere, (float4*)nullptr);
+      } else {
         const int n_super = cdiv(ac.n_clusters, SUPER);
-        hipLaunchKernelGGL(k_super_spheres, dim3(n_super), dim3(SUPER * CLUSTER), 0, st,
-                           sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.susphere);
+        hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
+                           sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
+                           n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere);
       }
     } else {
       hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,
@@ -1994,14 +2073,22 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     const int32_t* ltin = p == 0 ? nullptr : lasttri + (size_t)(p - 1) * n;
     T* rout = rays_ws + (size_t)p * 6 * n;
     ac.rperm = rperm_all + (size_t)p * n;
+    Classify3 fz;
+    fz.catagory = sc->catagory;
+    fz.rec_tri = rec_tri + (size_t)p * n;
+    fz.rec_t = rec_t + (size_t)p * n;
+    fz.rec_cls = rec_cls + (size_t)p * n;
+    fz.blockcnt = blockcnt;
+    bool classified = false;
     if (launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, prep,
                             (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion,
                             sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac, (int)N,
-                            /*prep_ready=*/p > 0) != 0)
+                            /*prep_ready=*/p > 0, &fz, &classified) != 0)
       return TFRT_E_LAUNCH;
-    hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, chunks_used,
-                       part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
-                       rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt);
+    if (!classified)
+      hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, chunks_used,
+                         part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
+                         rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt);
     hipLaunchKernelGGL(k_scan3d, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt, blockoff,
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, tail, nrays + p + 1,
                        reinterpret_cast<unsigned long long*>(tail + 4), M);
