@@ -370,6 +370,30 @@ def test_grouped_kernel_with_several_rays_per_lane(rays_per_lane, monkeypatch):
         assert torch.equal(out[cls], ref[cls]), cls
 
 
+@pytest.mark.parametrize("rays_per_lane", ["1", "2", "4"])
+@pytest.mark.parametrize("n_rays", [1, 255, 257, 9001])
+def test_grouped_kernel_classifies_in_its_epilogue_when_it_runs_as_one_chunk(rays_per_lane, n_rays,
+                                                                            monkeypatch):
+    """With a single cluster chunk (big traces; forced here with TFRT_GROUP_TARGET_BLOCKS=1)
+    k_intersect_group writes the hit records, classes and block histograms itself instead of
+    k_classify3d: counts, order and rays must equal the all-pairs path, also for ray counts
+    that leave the last 256-ray slice partly or wholly empty."""
+    from tensorflowraytrace_amd import ops, _lib
+    rays, fv, scene = _soup_scene(77, 1500, 9001)
+    rays = rays[:, :n_rays].contiguous()
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    ref = ops.trace3d(rays, fv, scene(False), max_passes=3, flags=flags)
+    monkeypatch.setenv("TFRT_GROUP_RAYS_PER_LANE", rays_per_lane)
+    monkeypatch.setenv("TFRT_GROUP_TARGET_BLOCKS", "1")
+    out = ops.trace3d(rays, fv, scene("group"), max_passes=3, flags=flags)
+    assert np.array_equal(out["counts"], ref["counts"])
+    assert out["n_tests"] == ref["n_tests"]
+    for cls in ("finished", "active", "stopped", "dead"):
+        assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), cls
+        assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
+        assert torch.equal(out[cls], ref[cls]), cls
+
+
 @pytest.mark.parametrize("mode", ["group", "sort"])
 def test_empty_and_tiny_inputs_in_the_cluster_modes(mode):
     from tensorflowraytrace_amd import ops, _lib
