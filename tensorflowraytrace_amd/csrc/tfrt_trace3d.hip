@@ -1646,15 +1646,32 @@ __global__ __launch_bounds__(1024) void k_face_accumulate(
   const int w1 = min(M, w0 + FACE_WINDOW);
   for (int k = threadIdx.x; k < FACE_WINDOW * 9; k += 1024) acc[k] = 0.0;
   __syncthreads();
-  for (int i = lo + threadIdx.x; i < hi; i += 1024) {
-    const int t = stash_face[i];
-    if (t >= w0 && t < w1) {
-      const double* g = stash_g + 9 * (int64_t)i;
-      double* a = acc + 9 * (t - w0);
+  // The block is a chain of dependent round trips (face -> 9 terms -> LDS add): fetch the
+  // faces of four slots first, then the terms of those that fall into the window, then add.
+  constexpr int U = 4;
+  for (int base = lo + threadIdx.x; base < hi; base += 1024 * U) {
+    int t[U];
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        const double v = g[c];
-        if (v != 0.0) unsafeAtomicAdd(a + c, v);
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 1024;
+      t[u] = i < hi ? stash_face[i] : -1;
+    }
+    double g[U][9];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t[u] >= w0 && t[u] < w1) {
+        const double* src = stash_g + 9 * (int64_t)(base + u * 1024);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) g[u][c] = src[c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t[u] >= w0 && t[u] < w1) {
+        double* a = acc + 9 * (t[u] - w0);
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+          if (g[u][c] != 0.0) unsafeAtomicAdd(a + c, g[u][c]);
       }
     }
   }
