@@ -1553,6 +1553,9 @@ __device__ __forceinline__ int backward_ray(
     const double* __restrict__ g_stp, int64_t cap_stp, const double* __restrict__ g_dead,
     int64_t cap_dead, double* __restrict__ g_out, int64_t out_stride, double gP[9]);
 
+// (106 VGPRs = 4 waves per SIMD; the kernel is bound by float64 VALU issue -- ~2,000 executed
+// instructions per ray, 28 of them divisions -- and forcing 5 or 6 waves with
+// amdgpu_waves_per_eu spills: 55/66 us for the lens passes became 62/74 and 89/103)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_backward3d(
     const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
@@ -2162,10 +2165,12 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   const bool stash = M > 0 && N >= 16384 && windows <= 32 && !coherent;
   double* stash_g = reinterpret_cast<double*>(ws + lay.stash_g);
   int32_t* stash_face = vals_in;
-  // ray slots per accumulate block: small chunks = many blocks; measured at 1M rays x 11 windows
-  // (us for the three passes): 4096 -> 15/48/58, 16384 -> 12/100/90 (the LDS atomics of a block
-  // serialise, so more, shorter blocks win although each flushes its window)
-  int acc_chunk = 4096;
+  // ray slots per accumulate block, measured at 1M rays x 11 windows (us for the three passes,
+  // target pass first): 2048 -> 37/50/54, 4096 -> 21/33/38, 8192 -> 15/37/34, 16384 -> 12/49/36.
+  // Every block zeroes and flushes its window, so big chunks win while the blocks still fill
+  // the chip (two 1024-thread blocks per CU).
+  int acc_chunk = 8192;
+  while (acc_chunk > 1024 && (int64_t)cdiv(N, acc_chunk) * windows < 1024) acc_chunk /= 2;
   if (const char* env = getenv("TFRT_ACC_CHUNK")) acc_chunk = atoi(env) > 0 ? atoi(env) : acc_chunk;
   for (int p = P - 1; p >= 0; --p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
