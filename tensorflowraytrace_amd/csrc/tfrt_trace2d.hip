@@ -218,10 +218,10 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
     for (int j = 0; j < nt4; j += 4) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (touches(filt[j + g])) {
-          queue[cnt * BLOCK + tid] = j + g;
-          ++cnt;
-        }
+        // always store, count only hits: no branch per test (the slot index stays below KQ2
+        // because the queue is drained whenever fewer than four slots are free)
+        queue[cnt * BLOCK + tid] = j + g;
+        cnt += touches(filt[j + g]) ? 1 : 0;
       }
       if (__any(cnt > KQ2 - 4)) flush();
     }
@@ -259,10 +259,10 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
     for (int j = 0; j < nt4; j += 4) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (touches(filt[j + g])) {
-          queue[cnt * BLOCK + tid] = j + g;
-          ++cnt;
-        }
+        // always store, count only hits: no branch per test (the slot index stays below KQ2
+        // because the queue is drained whenever fewer than four slots are free)
+        queue[cnt * BLOCK + tid] = j + g;
+        cnt += touches(filt[j + g]) ? 1 : 0;
       }
       if (__any(cnt > KQ2 - 4)) flush();
     }
