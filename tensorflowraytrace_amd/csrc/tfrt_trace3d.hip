@@ -955,7 +955,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   const int c_lo = blockIdx.y * chunk_clusters;
   const int c_hi = min(n_clusters, c_lo + chunk_clusters);
 
-  __shared__ float4 tile[GT];                // cluster spheres of the current tile
+  // cluster spheres of the current tile; one float4 of padding after every supercluster's 8 so
+  // that lanes working on different superclusters read from different LDS banks
+  __shared__ float4 tile[GT + GT / SUPER];
   __shared__ float4 stile[GT / SUPER];       // their superclusters' spheres
   // candidate list of the wave: (tile-local cluster << 8 | ray slot), 16 bits because it is
   // always drained before the tile changes (LDS footprint decides the waves in flight)
@@ -1201,23 +1203,35 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       flush();
     } else if (rn >= 64 || (!pending && rn > 0)) {
       const int nb = min(rn, 64);
-      for (int q0 = 0; q0 < nb; q0 += 8) {
-        const int q = q0 + (lane >> 3);
-        bool hit = false;
-        int entry = 0;
-        if (q < nb) {
-          const int v = rlist[wave][q];
-          const int cl = (v >> 8) * SUPER + (lane & (SUPER - 1));
-          const int sl = v & 255;
-          const float4 sp = tile[cl];
-          const float4 fa = prep_a[wave][sl], fb = prep_b[wave][sl];
+      // One waiting (ray, supercluster) pair per lane: its 8 cluster spheres in turn, hits
+      // collected in a per-lane mask and then moved to the candidate list one per lane and
+      // round (ballot + rank).  (8 lanes per pair with one append per step cost ~345
+      // instructions per 64 pairs, this ~160.)
+      unsigned hits = 0u;
+      int cl0 = 0, sl = 0;
+      if (lane < nb) {
+        const int v = rlist[wave][lane];
+        cl0 = (v >> 8) * SUPER;
+        sl = v & 255;
+        const float4 fa = prep_a[wave][sl], fb = prep_b[wave][sl];
+        const float4* row = &tile[cl0 + (cl0 >> 3)];
+#pragma unroll
+        for (int c = 0; c < SUPER; ++c) {
+          const float4 sp = row[c];
           const float pa = fmaf(sp.x, fa.x, fmaf(sp.y, fa.y, fmaf(sp.z, fa.z, fa.w)));
           const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
-          hit = fmaf(pa, pa, pb * pb) <= sp.w;
-          entry = (cl << 8) | sl;
+          hits |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << c;
         }
-        const unsigned long long hm = __ballot(hit);
-        if (hit) clist[wave][ln + rank_below(hm)] = (uint16_t)entry;
+      }
+      for (;;) {
+        const bool has = hits != 0u;
+        const unsigned long long hm = __ballot(has);
+        if (hm == 0ull) break;
+        if (has) {
+          const int k = __ffs(hits) - 1;
+          hits &= hits - 1u;
+          clist[wave][ln + rank_below(hm)] = (uint16_t)(((cl0 + k) << 8) | sl);
+        }
         ln += __popcll(hm);
         TFRT_STAT(2, __popcll(hm));
       }
@@ -1250,7 +1264,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       const int nt = min(GT, c_hi - t0);
       const int ns = (nt + SUPER - 1) / SUPER;
       __syncthreads();
-      for (int k = tid; k < ns * SUPER; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
+      for (int k = tid; k < ns * SUPER; k += BLOCK)
+        tile[k + (k >> 3)] = (k < nt) ? clsphere[t0 + k] : never;
       if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
       __syncthreads();
       // level 0: which superclusters of the tile does each ray's line touch
