@@ -752,17 +752,27 @@ class OpticalEngine:
         # the ray block and the n(lambda) table depend only on the input tensors: reuse them
         # while the caller hands in the very same tensors (static sources between steps)
         key = tuple((id(rays[f]), rays[f]._version) for f in geo) + (dt,)
-        if index_mode:
-            wl = rays["wavelength"]
-            key += (id(wl), wl._version, tuple(id(m) for m in system.materials))
         cache = getattr(self, "_input_cache", None)
         if (cache is not None and cache[0] == key
                 and not any(rays[f].requires_grad for f in geo)):
-            block, n_table = cache[1], cache[2]
+            block = cache[1]
         else:
             block = torch.stack([rays[f] for f in geo]).to(dt)
-            n_table = system.material_table(rays["wavelength"].detach()) if index_mode else None
-            self._input_cache = (key, block, n_table, [rays[f] for f in geo])
+            self._input_cache = (key, block, [rays[f] for f in geo])
+        n_table = None
+        if index_mode:
+            # keyed by the wavelengths' memory, not by the tensor object: a random source makes a
+            # new (expanded) view of the same constant wavelength list every step.  The cache
+            # holds the tensor, so its storage cannot be recycled under the key.
+            wl = rays["wavelength"].detach()
+            wkey = (wl.data_ptr(), tuple(wl.shape), wl.stride(), wl._version, wl.dtype,
+                    tuple(id(m) for m in system.materials))
+            tcache = getattr(self, "_table_cache", None)
+            if tcache is not None and tcache[0] == wkey:
+                n_table = tcache[1]
+            else:
+                n_table = system.material_table(wl)
+                self._table_cache = (wkey, n_table, wl)
         mode = self._trace_mode(system)
         if self.dimension == 3:
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",

@@ -61,13 +61,30 @@ class SourceBase(RecursivelyUpdatable, ABC):
     def make_vars(self, internal_vars):
         out = {}
         for name, (domain, var) in internal_vars.items():
-            var = _f64(var)
+            var = self._as_tensor(name, var)
             if self.dense:
                 var = var[self._domain_gathers[domain]]
             elif var.dim() < 2:
                 var = var.expand(self._domain_sizes["whole"])
             out[name] = var
         return out
+
+    def _as_tensor(self, name, var):
+        """float64 device tensor of an internal variable; python lists / numbers are converted
+        once per value (the same constant wavelength list every step then stays one tensor,
+        which lets the engine reuse everything derived from it)."""
+        if isinstance(var, torch.Tensor):
+            return _f64(var)
+        try:
+            key = (tuple(np.ravel(np.asarray(var, dtype=np.float64)).tolist()), np.shape(var),
+                   str(config.get_device()))
+        except (TypeError, ValueError):
+            return _f64(var)
+        memo = self.__dict__.setdefault("_const_tensors", {})
+        entry = memo.get(name)
+        if entry is None or entry[0] != key:
+            entry = memo[name] = (key, _f64(var))
+        return entry[1]
 
     def resize(self):
         self._needs_resize = True
