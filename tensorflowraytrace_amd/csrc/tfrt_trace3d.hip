@@ -1215,12 +1215,27 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
         sl = v & 255;
         const float4 fa = prep_a[wave][sl], fb = prep_b[wave][sl];
         const float4* row = &tile[cl0 + (cl0 >> 3)];
+        // The sphere tests are line tests; a cluster wholly behind the ray's start cannot hold
+        // a valid hit (ray_u > 0) either.  Rays that leave a surface see half of the clusters
+        // around them that way, and rays that graze a long wall (a light guide) many more.
+        // u = a x b is the ray direction; t = (c - s).u + (error bound of the start's part)
+        // must be below -r.  The centre's part of the rounding error (< 10 * 2^-24 |c|) is
+        // inside the 64 * 2^-24 (|c| + r) the spheres are inflated by.
+        const float ux = fa.y * fb.z - fa.z * fb.y, uy = fa.z * fb.x - fa.x * fb.z,
+                    uz = fa.x * fb.y - fa.y * fb.x;
+        const float sx = (float)(static_cast<double>(ray_l[wave][0][sl]) - cx),
+                    sy = (float)(static_cast<double>(ray_l[wave][1][sl]) - cy),
+                    sz = (float)(static_cast<double>(ray_l[wave][2][sl]) - cz);
+        const float t_off = fmaf(-sx, ux, fmaf(-sy, uy, -sz * uz)) +
+                            (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
 #pragma unroll
         for (int c = 0; c < SUPER; ++c) {
           const float4 sp = row[c];
           const float pa = fmaf(sp.x, fa.x, fmaf(sp.y, fa.y, fmaf(sp.z, fa.z, fa.w)));
           const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
-          hits |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << c;
+          const float tq = fmaf(sp.x, ux, fmaf(sp.y, uy, fmaf(sp.z, uz, t_off)));
+          const bool behind = tq < 0.f && tq * tq > sp.w;
+          hits |= ((fmaf(pa, pa, pb * pb) <= sp.w && !behind) ? 1u : 0u) << c;
         }
       }
       for (;;) {
