@@ -1,6 +1,12 @@
 """One-off stress: random soups with nasty scales / offsets / grazing rays, float64 ray state,
 default trace mode vs the CPU oracle (dense float64 evaluation of the reference algorithm):
-classes, order and hit faces must be identical (the float32 screen must never drop a hit)."""
+classes, order and hit faces must be identical (the float32 screen must never drop a hit).
+
+Known benign mismatch: seed 35 (dead class, ray 453).  The scene generator puts a third of the
+faces in one plane; two overlapping coplanar faces (32 and 57) then tie in ray_u up to the last
+bit, the GPU and the oracle enter that pass with rays that differ in the last bit (their Snell
+steps round differently) and pick different faces (scratch/debug_seed.py 35 shows both candidates;
+the previous library gives the same result, and the all-pairs mode agrees with the hierarchy)."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np, torch
@@ -9,7 +15,7 @@ from oracle import tracer
 dev = "cuda:0"
 flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
 bad = 0; t0 = time.time(); cases = 0
-for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
+for seed in range(int(sys.argv[2]) if len(sys.argv) > 2 else 0, int(sys.argv[1]) if len(sys.argv) > 1 else 24):
     rng = np.random.default_rng(5000 + seed)
     n_faces = int(rng.choice([64, 97, 300, 640]))
     n_rays = int(rng.choice([50, 700, 2500]))
@@ -56,6 +62,9 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 24):
                 err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-300)
                 ok = err < 1e-9
         if not ok:
+            if out[cls].shape[1] == n_ref and n_ref:
+                ids_ok = np.array_equal(out[cls + "_id"].cpu().numpy(), r["ray_id"].numpy().astype(np.int64))
+                print("  ids equal:", ids_ok, "rel err:", (err if ids_ok else None))
             bad += 1; print("MISMATCH seed", seed, cls, n_faces, n_rays, f"scale {scale:.3g} off {np.abs(offset).max():.3g}", out[cls].shape[1], n_ref, flush=True)
     cases += 1
 print(f"{cases} cases, {bad} mismatches, {time.time()-t0:.1f} s")
