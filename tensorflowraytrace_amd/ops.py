@@ -376,26 +376,41 @@ class _IntPool:
         return out
 
 
-def _with_rows(blocks):
-    """Outputs of a trace Function: the class blocks followed by every block's rows (views of
-    the same memory).  A consumer that differentiates single fields of a class (``y_end`` of the
-    finished rays, say) takes the row outputs: autograd then hands backward() that row's
+def _with_rows(blocks, present):
+    """Outputs of a trace Function: the class blocks followed by the rows of every compiled class
+    (views of the same memory).  A consumer that differentiates single fields of a class (``y_end``
+    of the finished rays, say) takes the row outputs: autograd then hands backward() that row's
     gradient alone instead of assembling a dense zero-padded block per field it touched
     (select_backward + slice_backward + add over (rows, capacity): ~90 us per step at 1M rays)."""
     rows = []
-    for b in blocks:
-        rows.extend(b.unbind(0))
+    for b, p in zip(blocks, present):
+        if p:
+            rows.extend(b.unbind(0))
     return tuple(blocks) + tuple(rows)
+
+
+def _split_rows(outs, present, n_rows):
+    """(class blocks, {class name: its row outputs}) from the outputs of a trace Function."""
+    rows, at = {}, 4
+    for name, p in zip(_CLASS_NAMES, present):
+        if p:
+            rows[name] = outs[at:at + n_rows]
+            at += n_rows
+    return outs[:4], rows
 
 
 def _class_grads(ctx_present, caps, n_rows, dev, grads):
     """Float64 (rows, capacity) gradient block per class from the block / row gradients that
     autograd delivered (None where the class took no gradient at all)."""
     blocks, rows = grads[:4], grads[4:]
-    out = []
+    out, at = [], 0
     for k, present in enumerate(ctx_present):
-        gb, gr = blocks[k], rows[n_rows * k:n_rows * (k + 1)]
-        if not present or (gb is None and all(g is None for g in gr)):
+        if not present:
+            out.append(None)
+            continue
+        gb, gr = blocks[k], rows[at:at + n_rows]
+        at += n_rows
+        if gb is None and all(g is None for g in gr):
             out.append(None)
             continue
         if all(g is None for g in gr):
@@ -476,7 +491,7 @@ class _Trace3D(torch.autograd.Function):
         rays = [o[0] if o[0] is not None else empty for o in (fin, act, stp, dead)]
         ctx.present = [o[0] is not None for o in (fin, act, stp, dead)]
         ctx.set_materialize_grads(False)
-        return _with_rows(rays)
+        return _with_rows(rays, ctx.present)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -596,9 +611,10 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
                 zero_init=predicted_counts is not None)
     outs = _Trace3D.apply(src, face_verts, scene, opts)
     aux = opts.pop("_aux")
-    full = dict(zip(_CLASS_NAMES, outs[:4]))
-    for k, name in enumerate(_CLASS_NAMES):
-        aux[name + "_rows"] = outs[4 + 6 * k:10 + 6 * k]
+    blocks, rows = _split_rows(outs, [aux[name + "_id"] is not None for name in _CLASS_NAMES], 6)
+    full = dict(zip(_CLASS_NAMES, blocks))
+    for name, r in rows.items():
+        aux[name + "_rows"] = r
     return _finish_trace(full, aux, int(max_passes), predicted_counts)
 
 
@@ -830,7 +846,8 @@ class _Trace2D(torch.autograd.Function):
         empty = torch.empty((4, 0), dtype=src.dtype, device=dev)
         ctx.present = [o[0] is not None for o in (fin, act, stp, dead)]
         ctx.set_materialize_grads(False)
-        return _with_rows([o[0] if o[0] is not None else empty for o in (fin, act, stp, dead)])
+        return _with_rows([o[0] if o[0] is not None else empty for o in (fin, act, stp, dead)],
+                          ctx.present)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -865,9 +882,10 @@ def trace2d(src, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
     arc_geo = None if scene.arcs is None else scene.arcs["geo"]
     outs = _Trace2D.apply(src, seg_geo, arc_geo, scene, opts)
     aux = opts.pop("_aux")
-    full = dict(zip(_CLASS_NAMES, outs[:4]))
-    for k, name in enumerate(_CLASS_NAMES):
-        aux[name + "_rows"] = outs[4 + 4 * k:8 + 4 * k]
+    blocks, rows = _split_rows(outs, [aux[name + "_id"] is not None for name in _CLASS_NAMES], 4)
+    full = dict(zip(_CLASS_NAMES, blocks))
+    for name, r in rows.items():
+        aux[name + "_rows"] = r
     out = _finish_trace(full, aux, int(max_passes), predicted_counts)
     out["n_segments"] = 0 if seg_geo is None else seg_geo.shape[0]
     return out
