@@ -1,0 +1,165 @@
+"""BASELINE.json's full-size workload (configs[3]: 1,000,000 rays x 10,574 faces, 3 passes) through
+size-independent properties: the dense oracle cannot run at this size, so the checks are
+
+* conservation: every ray entering a pass leaves it in exactly one class; the test counter is
+  sum(N_active) x M; source-ray ids inside a class are strictly increasing (the reference's
+  boolean_mask keeps the order);
+* trace-mode independence: the sphere hierarchy and the all-pairs filter give bit-identical rays,
+  ids and faces;
+* a random sample of the 1M rays traced by the oracle (256 rays x 10,574 faces is seconds of CPU)
+  agrees ray by ray with the full-size run (float32 state: 1e-5 relative);
+* shard additivity: the two halves of the ray set traced separately give the same rays, and their
+  parameter gradients sum to the gradient of the whole (the multi-GPU ray sharding relies on it);
+* permutation invariance: the same rays in another order give the same per-ray result.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_util
+import scene_util
+from oracle import tracer
+from test_gpu_trace3d import _gpu_scene
+
+pytestmark = pytest.mark.gpu
+
+N_FULL, K_FRONT, K_BACK, PASSES = 1_000_000, 41, 9, 3
+
+
+@pytest.fixture(scope="module")
+def full():
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(N_FULL, k_front=K_FRONT, k_back=K_BACK)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, params = _gpu_scene(scene, torch.float32, cluster="group")
+    out = ops.trace3d(src, fv, sc, max_passes=PASSES, flags=flags)
+    return dict(scene=scene, src=src, fv=fv, sc=sc, params=params, out=out, flags=flags)
+
+
+def test_full_size_conservation_and_order(full):
+    out, M = full["out"], full["fv"].shape[0]
+    assert M == 10_574
+    counts = out["counts"]                                    # (P, 8): per-pass class counts + bases
+    n_in = N_FULL
+    for p in range(PASSES):
+        assert int(counts[p, :4].sum()) == n_in               # nothing lost, nothing duplicated
+        n_in = int(counts[p, 0])                              # the active rays go on
+    assert out["n_tests"] == int(counts[:, :4].sum()) * M
+    assert out["finished"].shape[1] > 800_000                 # the lens images most of the beam
+    assert out["finished"].shape[1] == int(counts[:, 1].sum())
+    assert out["dead"].shape[1] == int(counts[:, 3].sum())
+    # inside a class the rays of one pass keep the source order (boolean_mask semantics)
+    for col, cls in ((1, "finished"), (2, "stopped"), (3, "dead")):
+        ids = out[cls + "_id"].long()
+        assert torch.unique(ids).numel() == ids.numel()       # one entry per ray at most
+        base = 0
+        for p in range(PASSES):
+            seg = ids[base:base + int(counts[p, col])]
+            assert bool((seg[1:] > seg[:-1]).all()), (cls, p)
+            base += int(counts[p, col])
+        assert base == ids.numel()
+    # per pass the active history keeps the source order
+    act = out["active_id"].long()
+    base = 0
+    for p in range(PASSES):
+        n = int(counts[p, 0])
+        seg = act[base:base + n]
+        assert bool((seg[1:] > seg[:-1]).all())
+        base += n
+    fin = out["finished"].detach()
+    assert bool(torch.isfinite(fin).all())
+    assert float((fin[3] - 10.0).abs().max()) < 1e-5          # finished rays end on the target plane
+
+
+def test_full_size_hierarchy_equals_all_pairs(full):
+    from tensorflowraytrace_amd import ops
+    src, fv, sc_all, _ = _gpu_scene(full["scene"], torch.float32, cluster=False)
+    ref = ops.trace3d(src, fv, sc_all, max_passes=PASSES, flags=full["flags"])
+    out = full["out"]
+    assert np.array_equal(out["counts"], ref["counts"]) and out["n_tests"] == ref["n_tests"]
+    for cls in ("finished", "active", "stopped", "dead"):
+        assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), cls
+        assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
+        assert torch.equal(out[cls], ref[cls]), cls
+
+
+def test_full_size_sample_against_the_oracle(full):
+    scene, out = full["scene"], full["out"]
+    rng = np.random.default_rng(17)
+    pick = np.sort(rng.choice(N_FULL, 256, replace=False))
+    system, _, _ = oracle_util.lens_oracle(scene)
+    ref = tracer.ray_trace(
+        system, oracle_util.source_dict(scene["rays"][:, pick], scene["wavelength"][pick], np.float32),
+        max_iterations=PASSES, inherit=("wavelength", "ray_id"),
+        flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    checked = 0
+    for cls in ("finished", "dead"):
+        if not ref[cls] or ref[cls]["ray_id"].shape[0] == 0:
+            continue
+        want_ids = pick[ref[cls]["ray_id"].numpy().astype(np.int64)]
+        ids = out[cls + "_id"].long().cpu().numpy()
+        where = np.full(N_FULL, -1, dtype=np.int64)          # row of every source ray in the class
+        where[ids] = np.arange(ids.shape[0])
+        pos = where[want_ids]
+        assert (pos >= 0).all(), f"{cls}: a sampled ray is in this class for the oracle only"
+        assert np.array_equal(ids[pos], want_ids), f"{cls}: sampled rays classified differently"
+        got = out[cls].detach()[:, torch.as_tensor(pos, device=out[cls].device)].cpu().double().numpy()
+        want = oracle_util.block(ref[cls])
+        rel = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        assert rel <= 1e-5, f"{cls}: {rel:.2e}"
+        checked += want_ids.shape[0]
+    assert checked >= 250
+
+
+def _loss_and_grads(out, scene, params):
+    fin = out["finished"]
+    goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fin.device)[out["finished_id"].long()]
+    loss = ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
+    return loss, torch.autograd.grad(loss, params)
+
+
+def test_full_size_shards_add_up(full):
+    """Two contiguous halves of the ray set (what two ranks would trace) against the whole."""
+    from tensorflowraytrace_amd import ops
+    scene, out = full["scene"], full["out"]
+    loss, (g_f, g_b) = _loss_and_grads(out, scene, full["params"])
+    half = N_FULL // 2
+    parts, fin_rows, fin_ids = [], [], []
+    for lo, hi in ((0, half), (half, N_FULL)):
+        sub = dict(scene)
+        sub["rays"] = scene["rays"][:, lo:hi]
+        sub["wavelength"] = scene["wavelength"][lo:hi]
+        sub["goal"] = scene["goal"][lo:hi]
+        src, fv, sc, params = _gpu_scene(sub, torch.float32, cluster="group")
+        o = ops.trace3d(src, fv, sc, max_passes=PASSES, flags=full["flags"])
+        parts.append(_loss_and_grads(o, sub, params))
+        fin_rows.append(o["finished"])
+        fin_ids.append(o["finished_id"].long() + lo)
+    ids, rows = torch.cat(fin_ids), torch.cat(fin_rows, dim=1)
+    a, b = torch.argsort(ids), torch.argsort(out["finished_id"].long())    # (classes are per-pass blocks)
+    assert torch.equal(ids[a], out["finished_id"].long()[b])
+    assert torch.equal(rows[:, a], out["finished"][:, b])                   # same rays, bit for bit
+    total = parts[0][0] + parts[1][0]
+    assert abs(float((total - loss).detach())) <= 1e-12 * abs(float(loss.detach()))
+    for k, g in enumerate((g_f, g_b)):
+        s = parts[0][1][k] + parts[1][1][k]
+        assert float((s - g).abs().max()) <= 1e-11 * float(g.abs().max())
+
+
+def test_full_size_permutation_invariance(full):
+    from tensorflowraytrace_amd import ops
+    scene, out = full["scene"], full["out"]
+    perm = torch.randperm(N_FULL, generator=torch.Generator().manual_seed(3)).numpy()
+    sub = dict(scene)
+    sub["rays"] = scene["rays"][:, perm]
+    sub["wavelength"] = scene["wavelength"][perm]
+    src, fv, sc, _ = _gpu_scene(sub, torch.float32, cluster="group")
+    o = ops.trace3d(src, fv, sc, max_passes=PASSES, flags=full["flags"])
+    assert np.array_equal(o["counts"][:, :4], out["counts"][:, :4])
+    perm_t = torch.as_tensor(perm, device=o["finished_id"].device)
+    orig_ids = perm_t[o["finished_id"].long()]                  # source ids of the permuted run's rows
+    order = torch.argsort(orig_ids)
+    ref_order = torch.argsort(out["finished_id"].long())        # (classes are per-pass blocks)
+    assert torch.equal(orig_ids[order], out["finished_id"].long()[ref_order])
+    assert torch.equal(o["finished"].detach()[:, order], out["finished"].detach()[:, ref_order])
+    assert torch.equal(o["finished_face"][order], out["finished_face"][ref_order])
