@@ -163,3 +163,85 @@ def test_full_size_permutation_invariance(full):
     assert torch.equal(orig_ids[order], out["finished_id"].long()[ref_order])
     assert torch.equal(o["finished"].detach()[:, order], out["finished"].detach()[:, ref_order])
     assert torch.equal(o["finished_face"][order], out["finished_face"][ref_order])
+
+
+# ------------------------------------------------------------------------------------------
+# 2-D at cfg5b's size: 4,000,000 rays x (256 segments + 64 arcs), 4 passes
+
+def _scene_5b(n_rays, seed=0):
+    import math
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    na = 64
+    xc = np.linspace(-16, 16, na)
+    xs = np.linspace(-18, 18, 256)
+    ys = 6.0 + 0.3 * np.sin(xs)
+    sets = {
+        "optical_arcs": dict(x_center=t(xc), y_center=t(np.full(na, 3.0)),
+                             angle_start=t(np.full(na, -math.pi + 0.3)), angle_end=t(np.full(na, -0.3)),
+                             radius=t(np.full(na, 0.6)), mat_in=torch.ones(na, dtype=torch.int64),
+                             mat_out=torch.zeros(na, dtype=torch.int64)),
+        "optical_segments": dict(x_start=t(xs[:-1]), y_start=t(ys[:-1]), x_end=t(xs[1:]), y_end=t(ys[1:]),
+                                 mat_in=torch.full((255,), 2, dtype=torch.int64),
+                                 mat_out=torch.zeros(255, dtype=torch.int64)),
+        "target_segments": dict(x_start=t([20.0]), y_start=t([-1.0]), x_end=t([20.0]), y_end=t([9.0])),
+    }
+    rng = np.random.default_rng(seed)
+    ang = rng.uniform(0.3 * math.pi, 0.7 * math.pi, n_rays)
+    x0 = rng.uniform(-15, 15, n_rays)
+    rays = np.stack([x0, np.zeros(n_rays), x0 + np.cos(ang), np.sin(ang)])
+    wl = np.full(n_rays, 550.0)
+    return sets, rays, wl
+
+
+def test_full_size_2d_conservation_sample_and_shards():
+    from tensorflowraytrace_amd import ops, _lib
+    import test_gpu_trace2d as t2
+    N, P = 4_000_000, 4
+    sets, rays, wl = _scene_5b(N)
+    scene, _, _ = t2._gpu_scene(sets, wl)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src = torch.tensor(rays, dtype=torch.float32, device="cuda:0")
+    out = ops.trace2d(src, scene, max_passes=P, flags=flags)
+    counts = out["counts"]
+    n_in = N
+    for p in range(P):
+        assert int(counts[p, :4].sum()) == n_in
+        n_in = int(counts[p, 0])
+    assert out["n_tests"] == int(counts[:, :4].sum()) * 320
+    assert out["unfinished"].shape[1] == n_in
+    assert out["dead"].shape[1] == int(counts[:, 3].sum()) > 3_000_000     # most rays leave the scene
+
+    # 256 sampled rays through the oracle: same class, same geometry (float32 state: 1e-5)
+    pick = np.sort(np.random.default_rng(5).choice(N, 256, replace=False))
+    ref = tracer.ray_trace(t2._oracle_system(sets), t2._src2(rays[:, pick], wl[pick], True),
+                           max_iterations=P, inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    checked = 0
+    for cls in ("finished", "dead"):
+        r = ref[cls]
+        if not r or r["ray_id"].shape[0] == 0:
+            continue
+        want_ids = pick[r["ray_id"].numpy().astype(np.int64)]
+        ids = out[cls + "_id"].long().cpu().numpy()
+        where = np.full(N, -1, dtype=np.int64)
+        where[ids] = np.arange(ids.shape[0])
+        pos = where[want_ids]
+        assert (pos >= 0).all(), cls
+        got = out[cls].detach()[:, torch.as_tensor(pos, device="cuda:0")].cpu().double().numpy()
+        want = oracle_util.block(r, dim=2)
+        assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) <= 1e-5, cls
+        checked += want_ids.shape[0]
+    assert checked >= 200
+
+    # halves of the ray set reproduce the whole, ray for ray
+    half = N // 2
+    ids_parts, rows_parts = [], []
+    for lo, hi in ((0, half), (half, N)):
+        sc_h, _, _ = t2._gpu_scene(sets, wl[lo:hi])
+        o = ops.trace2d(src[:, lo:hi].contiguous(), sc_h, max_passes=P, flags=flags)
+        ids_parts.append(o["dead_id"].long() + lo)
+        rows_parts.append(o["dead"].detach())
+    ids, rows = torch.cat(ids_parts), torch.cat(rows_parts, dim=1)
+    a, b = torch.argsort(ids), torch.argsort(out["dead_id"].long())
+    assert torch.equal(ids[a], out["dead_id"].long()[b])
+    assert torch.equal(rows[:, a], out["dead"].detach()[:, b])
