@@ -829,7 +829,14 @@ class OpticalEngine:
         if shard is not None:
             n = src["x_start"].shape[0]
             lo, hi = tdist.shard_bounds(n, *shard)
-            src = {f: v[lo:hi] for f, v in src.items()}
+            # the same views for the same source tensors: everything cached per input tensor
+            # (ray block, n(lambda) table) then also holds for a rank's shard of a static source
+            skey = tuple((f, id(v), getattr(v, "_version", None)) for f, v in src.items()) + (lo, hi)
+            cached = getattr(self, "_shard_cache", None)
+            if cached is None or cached[0] != skey:
+                cached = (skey, {f: v[lo:hi] for f, v in src.items()}, list(src.values()))
+                self._shard_cache = cached
+            src = cached[1]
         predicted = None
         sig = (src["x_start"].shape[0], int(max_iterations), self._flags())
         if self.speculative_counts and self._predicted is not None and self._predicted[0] == sig:
