@@ -1228,14 +1228,26 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
                     sz = (float)(static_cast<double>(ray_l[wave][2][sl]) - cz);
         const float t_off = fmaf(-sx, ux, fmaf(-sy, uy, -sz * uz)) +
                             (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
+        // (first pass of a trace -- no ray starts on a face yet: sources normally sit outside
+        // the scene, nothing lies behind them and the test would only cost; wave-uniform)
+        if (last_tri != nullptr) {
 #pragma unroll
-        for (int c = 0; c < SUPER; ++c) {
-          const float4 sp = row[c];
-          const float pa = fmaf(sp.x, fa.x, fmaf(sp.y, fa.y, fmaf(sp.z, fa.z, fa.w)));
-          const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
-          const float tq = fmaf(sp.x, ux, fmaf(sp.y, uy, fmaf(sp.z, uz, t_off)));
-          const bool behind = tq < 0.f && tq * tq > sp.w;
-          hits |= ((fmaf(pa, pa, pb * pb) <= sp.w && !behind) ? 1u : 0u) << c;
+          for (int c = 0; c < SUPER; ++c) {
+            const float4 sp = row[c];
+            const float pa = fmaf(sp.x, fa.x, fmaf(sp.y, fa.y, fmaf(sp.z, fa.z, fa.w)));
+            const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
+            const float tq = fmaf(sp.x, ux, fmaf(sp.y, uy, fmaf(sp.z, uz, t_off)));
+            const bool behind = tq < 0.f && tq * tq > sp.w;
+            hits |= ((fmaf(pa, pa, pb * pb) <= sp.w && !behind) ? 1u : 0u) << c;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < SUPER; ++c) {
+            const float4 sp = row[c];
+            const float pa = fmaf(sp.x, fa.x, fmaf(sp.y, fa.y, fmaf(sp.z, fa.z, fa.w)));
+            const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
+            hits |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << c;
+          }
         }
       }
       for (;;) {
