@@ -49,4 +49,87 @@ __device__ __forceinline__ int rank_below(unsigned long long mask) {
 inline int cdiv(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// Exclusive scan of per-ray-block histograms (rows of NB counters, NB = 4 or 8) over a grid of
+// 1024-thread workgroups, one row per thread: coalesced int4 loads and stores, a wave scan by
+// shuffles and one exchange through LDS.  `off` receives the offsets *within the row's
+// workgroup*; the workgroup that finishes last (a ticket) turns the per-workgroup sums `rowtot`
+// into the bases `rowbase` (the consumer adds rowbase[(row >> 10) * NB + c]) and gets the column
+// sums in `total` (LDS, NB ints): the function returns true there and false everywhere else.
+// One workgroup scanning everything could not keep enough loads in flight: 54 us for the
+// 15.6k rows of a 4M-ray pass.  `ticket` must be 0 on entry and is left 0.
+template <int NB>
+__device__ __forceinline__ bool scan_rows_grid(const int32_t* __restrict__ cnt,
+                                               int32_t* __restrict__ off, int nrows,
+                                               int32_t* __restrict__ rowtot,
+                                               int32_t* __restrict__ rowbase,
+                                               unsigned int* __restrict__ ticket, int* total) {
+  static_assert(NB == 4 || NB == 8, "rows are one or two int4");
+  constexpr int Q = NB / 4;
+  __shared__ int wsum[16][NB];
+  __shared__ int wbase[16][NB];
+  __shared__ int is_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 1024 + (int)threadIdx.x;
+  const int4* cnt4 = reinterpret_cast<const int4*>(cnt);
+  int4* off4 = reinterpret_cast<int4*>(off);
+  int v[NB], pre[NB];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int4 x = r < nrows ? cnt4[(int64_t)r * Q + q] : make_int4(0, 0, 0, 0);
+    v[4 * q] = x.x;
+    v[4 * q + 1] = x.y;
+    v[4 * q + 2] = x.z;
+    v[4 * q + 3] = x.w;
+  }
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    int x = v[c];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(x, d, 64);
+      if (lane >= d) x += o;
+    }
+    pre[c] = x - v[c];  // exclusive within the wave
+    if (lane == 63) wsum[wave][c] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < NB) {
+    int run = 0;
+    for (int w = 0; w < 16; ++w) {
+      wbase[w][threadIdx.x] = run;
+      run += wsum[w][threadIdx.x];
+    }
+    rowtot[blockIdx.x * NB + threadIdx.x] = run;
+  }
+  __syncthreads();
+  if (r < nrows) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+      off4[(int64_t)r * Q + q] =
+          make_int4(wbase[wave][4 * q] + pre[4 * q], wbase[wave][4 * q + 1] + pre[4 * q + 1],
+                    wbase[wave][4 * q + 2] + pre[4 * q + 2], wbase[wave][4 * q + 3] + pre[4 * q + 3]);
+  }
+  // the last workgroup to arrive sees every rowtot (release / acquire through the ticket)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, 1u);
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return false;
+  __threadfence();
+  if (threadIdx.x < NB) {
+    int run = 0;
+    for (unsigned int b = 0; b < gridDim.x; ++b) {
+      rowbase[b * NB + threadIdx.x] = run;
+      run += __atomic_load_n(&rowtot[b * NB + threadIdx.x], __ATOMIC_RELAXED);
+    }
+    total[threadIdx.x] = run;
+  }
+  if (threadIdx.x == 0) *ticket = 0u;  // ready for the next pass
+  __syncthreads();
+  return true;
+}
+
 }  // namespace tfrt

@@ -338,7 +338,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect2d(
   }
 }
 
-__global__ __launch_bounds__(1024) void k_scan2d(const int32_t* __restrict__ n_ptr,
+// One block of 1024 threads scans every ray block's histogram (up to SCAN_GRID_MIN_ROWS rows;
+// the offsets it writes are global, k_react2d gets no rowbase).
+__global__ __launch_bounds__(1024) void k_scan2d_one(const int32_t* __restrict__ n_ptr,
                                                  const int32_t* __restrict__ blockcnt,
                                                  int32_t* __restrict__ blockoff,
                                                  int32_t* __restrict__ pass_counts,
@@ -402,6 +404,39 @@ __global__ __launch_bounds__(1024) void k_scan2d(const int32_t* __restrict__ n_p
   if (threadIdx.x == 0) *n_tests += (unsigned long long)n * (unsigned long long)M;
 }
 
+// From SCAN_GRID_MIN_ROWS ray blocks on (its ticket and fences cost ~13 us whatever the size; the
+// single block takes 54 us for the 15.6k rows of a 4M-ray pass, this 20 us):
+constexpr int SCAN_GRID_MIN_ROWS = 8192;
+__global__ __launch_bounds__(1024) void k_scan2d(const int32_t* __restrict__ n_ptr,
+                                                 const int32_t* __restrict__ blockcnt,
+                                                 int32_t* __restrict__ blockoff,
+                                                 int32_t* __restrict__ rowtot,
+                                                 int32_t* __restrict__ rowbase,
+                                                 unsigned int* __restrict__ ticket,
+                                                 int32_t* __restrict__ pass_counts,
+                                                 int32_t* __restrict__ bin_counts,
+                                                 int32_t* __restrict__ totals,
+                                                 int32_t* __restrict__ n_next,
+                                                 unsigned long long* __restrict__ n_tests,
+                                                 int M) {
+  // grid of 1024-thread workgroups, one ray block per thread (scan_rows_grid); the workgroup
+  // that finishes last closes the pass
+  const int n = *n_ptr;
+  const int nblk = (n + BLOCK - 1) / BLOCK;
+  __shared__ int total[NBIN];
+  if (!scan_rows_grid<NBIN>(blockcnt, blockoff, nblk, rowtot, rowbase, ticket, total)) return;
+  if (threadIdx.x < NBIN) bin_counts[threadIdx.x] = total[threadIdx.x];
+  if (threadIdx.x < 4) {
+    const int c = threadIdx.x;
+    const int t = (c == CLS_DEAD) ? total[BIN_DEAD] : total[2 * c] + total[2 * c + 1];
+    pass_counts[c] = t;
+    pass_counts[4 + c] = totals[c];
+    totals[c] += t;
+    if (c == CLS_ACTIVE) *n_next = t;
+  }
+  if (threadIdx.x == 0) *n_tests += (unsigned long long)n * (unsigned long long)M;
+}
+
 __device__ __forceinline__ void prim_indices(const tfrt_scene2d& sc, int prim, int rid,
                                              double* n_in, double* n_out) {
   const int Ms = (int)sc.n_segments;
@@ -435,6 +470,7 @@ __global__ __launch_bounds__(BLOCK) void k_react2d(
     const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_prim,
     const double* __restrict__ rec_u, const double* __restrict__ rec_aux,
     const uint8_t* __restrict__ rec_bin, const int32_t* __restrict__ blockoff,
+    const int32_t* __restrict__ rowbase,
     const int32_t* __restrict__ pass_counts, const int32_t* __restrict__ bin_counts,
     tfrt_scene2d sc, double L, double dead_len, uint32_t flags, T* __restrict__ rays_out,
     int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_prim_out,
@@ -459,7 +495,8 @@ __global__ __launch_bounds__(BLOCK) void k_react2d(
   for (int w = 0; w < wave; ++w) rank += wc[w][bin];
   const int cls = (bin == BIN_DEAD) ? CLS_DEAD : (bin >> 1);
   const int kind = bin & 1;
-  int slot = blockoff[blockIdx.x * NBIN + bin] + rank;
+  int slot = blockoff[blockIdx.x * NBIN + bin] +
+             (rowbase != nullptr ? rowbase[(blockIdx.x >> 10) * NBIN + bin] : 0) + rank;
   if (cls != CLS_DEAD && kind == 1) slot += bin_counts[2 * cls];  // arcs after segments
   const int64_t gslot = (int64_t)pass_counts[4 + cls] + slot;
 
@@ -590,9 +627,10 @@ __global__ __launch_bounds__(BLOCK) void k_backward2d(
   }
 }
 
-__global__ void k_init2(int32_t* nrays0, int n, int32_t* tail8) {
+__global__ void k_init2(int32_t* nrays0, int n, int32_t* tail8, unsigned int* scan_ticket) {
   if (threadIdx.x == 0) *nrays0 = n;
   if (threadIdx.x < 8) tail8[threadIdx.x] = 0;
+  if (threadIdx.x == 0) *scan_ticket = 0u;
 }
 
 template <typename T>
@@ -656,7 +694,7 @@ __global__ __launch_bounds__(BLOCK) void k_seam2d(const T* __restrict__ rays, in
 }
 
 struct Layout2 {
-  size_t nrays, blockcnt, blockoff, bincnt, rays, rayid, lastprim, rec_prim, rec_slot, rec_u,
+  size_t nrays, blockcnt, blockoff, rowtot, rowbase, ticket, bincnt, rays, rayid, lastprim, rec_prim, rec_slot, rec_u,
       rec_aux, rec_bin, gbuf, total;
   int nblk;
 };
@@ -675,6 +713,9 @@ static Layout2 make_layout2(int64_t N, int P, int dtype) {
   L.nrays = take((P + 2) * sizeof(int32_t));
   L.blockcnt = take((size_t)L.nblk * NBIN * sizeof(int32_t));
   L.blockoff = take((size_t)L.nblk * NBIN * sizeof(int32_t));
+  L.rowtot = take((size_t)cdiv(L.nblk, 1024) * NBIN * sizeof(int32_t));
+  L.rowbase = take((size_t)cdiv(L.nblk, 1024) * NBIN * sizeof(int32_t));
+  L.ticket = take(sizeof(unsigned int));
   L.bincnt = take((size_t)(P + 1) * NBIN * sizeof(int32_t));
   L.rays = take((size_t)P * 4 * n * esz);
   L.rayid = take((size_t)P * n * sizeof(int32_t));
@@ -717,6 +758,9 @@ static int trace2d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* nrays = reinterpret_cast<int32_t*>(ws + lay.nrays);
   int32_t* blockcnt = reinterpret_cast<int32_t*>(ws + lay.blockcnt);
   int32_t* blockoff = reinterpret_cast<int32_t*>(ws + lay.blockoff);
+  int32_t* rowtot = reinterpret_cast<int32_t*>(ws + lay.rowtot);
+  int32_t* rowbase = reinterpret_cast<int32_t*>(ws + lay.rowbase);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(ws + lay.ticket);
   int32_t* bincnt = reinterpret_cast<int32_t*>(ws + lay.bincnt);
   T* rays_ws = reinterpret_cast<T*>(ws + lay.rays);
   int32_t* rayid = reinterpret_cast<int32_t*>(ws + lay.rayid);
@@ -729,7 +773,7 @@ static int trace2d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* tail = counts + (size_t)P * TFRT_COUNTS_PER_PASS;
   const size_t n = N > 0 ? N : 1;
   const int M = (int)(sc->n_segments + sc->n_arcs);
-  hipLaunchKernelGGL(k_init2, dim3(1), dim3(64), 0, st, nrays, (int)N, tail);
+  hipLaunchKernelGGL(k_init2, dim3(1), dim3(64), 0, st, nrays, (int)N, tail, ticket);
   const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};
   for (int p = 0; p < P; ++p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 4 * n;
@@ -739,12 +783,20 @@ static int trace2d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     hipLaunchKernelGGL((k_intersect2d<T>), dim3(lay.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
                        lpin, *sc, rec_prim + (size_t)p * n, rec_u + (size_t)p * n,
                        rec_aux + (size_t)p * n, rec_bin + (size_t)p * n, blockcnt);
-    hipLaunchKernelGGL(k_scan2d, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt, blockoff,
-                       counts + (size_t)p * TFRT_COUNTS_PER_PASS, bincnt + (size_t)p * NBIN, tail,
-                       nrays + p + 1, reinterpret_cast<unsigned long long*>(tail + 4), M);
+    const bool grid_scan = lay.nblk >= SCAN_GRID_MIN_ROWS;
+    if (grid_scan)
+      hipLaunchKernelGGL(k_scan2d, dim3(cdiv(lay.nblk, 1024)), dim3(1024), 0, st, nrays + p,
+                         blockcnt, blockoff, rowtot, rowbase, ticket,
+                         counts + (size_t)p * TFRT_COUNTS_PER_PASS, bincnt + (size_t)p * NBIN, tail,
+                         nrays + p + 1, reinterpret_cast<unsigned long long*>(tail + 4), M);
+    else
+      hipLaunchKernelGGL(k_scan2d_one, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt, blockoff,
+                         counts + (size_t)p * TFRT_COUNTS_PER_PASS, bincnt + (size_t)p * NBIN, tail,
+                         nrays + p + 1, reinterpret_cast<unsigned long long*>(tail + 4), M);
     hipLaunchKernelGGL((k_react2d<T>), dim3(lay.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
                        idin, rec_prim + (size_t)p * n, rec_u + (size_t)p * n,
                        rec_aux + (size_t)p * n, rec_bin + (size_t)p * n, blockoff,
+                       grid_scan ? rowbase : static_cast<int32_t*>(nullptr),
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, bincnt + (size_t)p * NBIN, *sc, L,
                        dead_len, flags, rays_ws + (size_t)p * 4 * n, (int64_t)n,
                        rayid + (size_t)p * n, lastprim + (size_t)p * n, rec_slot + (size_t)p * n,
