@@ -245,3 +245,37 @@ def test_full_size_2d_conservation_sample_and_shards():
     a, b = torch.argsort(ids), torch.argsort(out["dead_id"].long())
     assert torch.equal(ids[a], out["dead_id"].long()[b])
     assert torch.equal(rows[:, a], out["dead"].detach()[:, b])
+
+
+def test_3d_trace_beyond_8192_ray_blocks_matches_its_halves():
+    """From 8192 ray blocks (2.1M rays) on the per-pass offsets come from the grid scan
+    (k_scan3d, a ticket across workgroups) instead of the single-block one: 2.3M rays in one trace
+    against the same rays traced as two halves, which take the single-block path."""
+    from tensorflowraytrace_amd import ops, _lib
+    N = 2_300_000
+    scene = scene_util.lens_scene(N, k_front=6, k_back=5)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, _ = _gpu_scene(scene, torch.float32, cluster="group")
+    out = ops.trace3d(src, fv, sc, max_passes=4, flags=flags)
+    counts = out["counts"]
+    n_in = N
+    for p in range(4):
+        assert int(counts[p, :4].sum()) == n_in
+        n_in = int(counts[p, 0])
+    half = N // 2
+    parts = {c: ([], []) for c in ("finished", "dead", "active")}
+    for lo, hi in ((0, half), (half, N)):
+        sub = dict(scene)
+        sub["rays"] = scene["rays"][:, lo:hi]
+        sub["wavelength"] = scene["wavelength"][lo:hi]
+        s2, f2, c2, _ = _gpu_scene(sub, torch.float32, cluster="group")
+        o = ops.trace3d(s2, f2, c2, max_passes=4, flags=flags)
+        for c in parts:
+            parts[c][0].append(o[c + "_id"].long() + lo)
+            parts[c][1].append(o[c].detach())
+    for c in ("finished", "dead"):
+        ids, rows = torch.cat(parts[c][0]), torch.cat(parts[c][1], dim=1)
+        a, b = torch.argsort(ids), torch.argsort(out[c + "_id"].long())
+        assert torch.equal(ids[a], out[c + "_id"].long()[b]), c
+        assert torch.equal(rows[:, a], out[c].detach()[:, b]), c
+    assert out["active"].shape[1] == sum(x.shape[1] for x in parts["active"][1])
