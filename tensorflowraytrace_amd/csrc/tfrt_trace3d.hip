@@ -1230,7 +1230,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
                             (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
         // (first pass of a trace -- no ray starts on a face yet: sources normally sit outside
         // the scene, nothing lies behind them and the test would only cost; wave-uniform)
-        if (last_tri != nullptr) {
+        // (and only while hits must lie ahead of the start: ray_start_epsilion >= 0)
+        if (last_tri != nullptr && eps_start >= 0.0) {
 #pragma unroll
           for (int c = 0; c < SUPER; ++c) {
             const float4 sp = row[c];

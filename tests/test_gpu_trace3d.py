@@ -432,3 +432,26 @@ def test_lanes_without_rays_never_queue_candidates():
         assert total == 5, mode
     x, y, z, valid, ray_u, tu, tv, gi = ops.intersect3d(rays.double(), fv, 1e-10, 1e300, -1e300)
     assert valid.shape[0] == 5 and bool(valid.all())    # with these epsilons every plane is hit
+
+
+def test_negative_ray_start_epsilon_keeps_hits_just_behind_the_start():
+    """The grouped filter drops clusters behind a ray's start from the second pass on -- only
+    while ray_start_epsilion >= 0.  With a negative epsilon the reference accepts hits at
+    slightly negative ray_u (the face a ray has just left is excluded by index, its neighbours in
+    the same plane are not): every trace mode must still agree with the all-pairs filter."""
+    from tensorflowraytrace_amd import ops, _lib
+    rays, fv, scene = _soup_scene(5, 900, 6000)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+
+    def run(mode):
+        sc = scene(mode)
+        sc.eps = (sc.eps[0], sc.eps[1], -0.05)          # ray_start_epsilion
+        sc._struct_cache = None
+        return ops.trace3d(rays, fv, sc, max_passes=3, flags=flags)
+
+    ref = run(False)
+    out = run("group")
+    assert np.array_equal(out["counts"], ref["counts"])
+    for cls in ("finished", "active", "stopped", "dead"):
+        assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
+        assert torch.equal(out[cls], ref[cls]), cls
