@@ -4,7 +4,7 @@ set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles_new; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py > $O/bench_line.json 2> $O/bench_err.log
-rm -rf /tmp/prof; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --steps 5 --no-cpu-baseline --no-extra-legs > $O/bench_prof_line.json 2>/dev/null
+rm -rf /tmp/prof; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-cpu-baseline --no-extra-legs > $O/bench_prof_line.json 2>/dev/null
 cp $(ls /tmp/prof/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
 export ONE_PASS=1
 i=0
