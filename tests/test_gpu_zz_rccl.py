@@ -1,0 +1,55 @@
+"""The N > 1 code path of the sharded optimiser step through RCCL, with a process group of one rank
+(a 1-GPU box cannot hold two RCCL ranks): shard bounds, the fused float64 gradient buffer, the
+`nccl` all-reduce and the device-side error count must reproduce the plain single-process step.
+(Runs last: it creates and destroys the default process group.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_step_through_rccl_with_one_rank(monkeypatch):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import tfrt.optimizer as optimizer
+    from tensorflowraytrace_amd import distributed as tdist
+    if not dist.is_nccl_available() or dist.is_initialized():
+        pytest.skip("needs a fresh process without a default process group and the nccl backend")
+
+    def run(steps):
+        eng, system, params = bench.build_scene(60_000, 9, 5, torch.float32)
+        opt = optimizer.SGD_Optimizer(eng, params, bench.error_function, trace_depth=3,
+                                      learning_rate=1e-5, grad_clip=1e-3)
+        opt.suppress_warnings = True
+        errs = [float(opt.single_step(None)) for _ in range(steps)]
+        return errs, [p.detach().clone() for p in params]
+
+    plain_e, plain_p = run(4)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    except Exception as exc:                      # the environment's business, not the product's
+        pytest.skip(f"RCCL process group could not be created here: {exc}")
+    try:
+        monkeypatch.setattr(tdist, "is_distributed", lambda: True)     # force the N > 1 path
+        dist_e, dist_p = run(4)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(plain_e, dist_e):
+        assert abs(a - b) <= 1e-12 * abs(a)
+    for a, b in zip(plain_p, dist_p):
+        assert float((a - b).abs().max()) <= 1e-14
