@@ -15,7 +15,7 @@
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TFRT_HD __host__ __device__ __forceinline__
 #else
 #define TFRT_HD inline

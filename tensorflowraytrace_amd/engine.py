@@ -350,10 +350,14 @@ class OpticalSystem3D(OpticalSystemBase):
 
             gmask = torch.cat([torch.full((n,), 1 if g else 0, dtype=torch.uint8)
                                for (c, n, _), g in zip(cats, grads)]).to(dev)
+            # the key holds ids and versions: keep the keyed objects alive next to it, so that a
+            # freed tensor's id cannot come back as a different tensor under the same key
+            held = [b for _, _, b in cats] + [
+                b[f] for _, _, b in cats for f in ("mat_in", "mat_out", "n_in", "n_out") if f in b]
             self._scene_cache = (key, dict(
                 catagory=catagory, mat_in=col("mat_in", torch.int32),
                 mat_out=col("mat_out", torch.int32), n_in=col("n_in", torch.float64),
-                n_out=col("n_out", torch.float64), face_grad_mask=gmask))
+                n_out=col("n_out", torch.float64), face_grad_mask=gmask), held)
 
     def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False):
         s = self._scene_cache[1]
@@ -404,7 +408,10 @@ class OpticalSystem3D(OpticalSystemBase):
         """Nearest triangle per ray (engine.py:1020-1078), via tfrt_intersect3d."""
         result = {}
         if self._merged_face_verts is not None:
-            block = torch.stack([rays[f] for f in _GEO3]).to(config.get_ray_dtype())
+            # the seam keeps the caller's precision (the reference's is float64 throughout)
+            block = torch.stack([rays[f] for f in _GEO3])
+            if block.dtype not in (torch.float32, torch.float64, torch.float16):
+                block = block.to(torch.float64)
             (result["x"], result["y"], result["z"], result["valid"], result["ray_u"],
              result["trig_u"], result["trig_v"], result["gather_trig"]) = ops.intersect3d(
                 block, self._merged_face_verts.detach(), self.intersect_epsilion,

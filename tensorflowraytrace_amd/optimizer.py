@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import distributed as tdist
+from . import ops
 
 
 class DeferredScalar:
@@ -248,22 +249,13 @@ class SGD_Optimizer:
         return fixed, error_sum, n_terms
 
     def _matrix_product(self, cache, key, matrix, vec):
-        """``matrix @ vec`` for an accumulator / smoother.  On a HIP device the matrix is
-        converted to CSR once (cached on the object it came from) and multiplied by the
-        tfrt_csr_matvec kernel; CPU tensors (host-logic tests) use a dense torch product."""
-        shape = vec.shape
-        if vec.is_cuda:
-            from . import ops
-            entry = cache.get(key)
-            if entry is None or entry[0] is not matrix:
-                entry = (matrix, ops.CsrMatrix(matrix, vec.device))
-                cache[key] = entry
-            return entry[1].matvec(vec)
-        m = matrix if isinstance(matrix, torch.Tensor) else torch.as_tensor(np.asarray(matrix))
-        m = m.to(device=vec.device)
-        if m.layout != torch.strided:
-            m = m.to_dense()
-        return torch.matmul(m.to(vec.dtype), vec.reshape(-1, 1)).reshape(shape)
+        """``matrix @ vec`` for an accumulator / smoother: the matrix is converted to CSR once
+        (cached on the object it came from) and multiplied by the tfrt_csr_matvec kernel."""
+        entry = cache.get(key)
+        if entry is None or entry[0] is not matrix:
+            entry = (matrix, ops.CsrMatrix(matrix, vec.device))
+            cache[key] = entry
+        return entry[1].matvec(vec)
 
     def process_gradient(self, accumulators, *args, lr_scale=1.0, **kwargs):
         """optimizer.py:187-258.  Returns (processed grads, mean error)."""
@@ -283,20 +275,13 @@ class SGD_Optimizer:
                 clp = self.grad_clip
             else:
                 clp = self.individual_lr[i] * self.clip_scale * self.learning_rate * lr_scale
-            if grad.is_cuda:
-                from . import ops
-                p = self.parameters[i]
-                fuse = (apply and plain_sgd and accumulators[i] is None and p.is_contiguous()
-                        and p.dtype == grad.dtype and p.shape == grad.shape)
-                with torch.no_grad():
-                    grad = ops.sgd_process(grad, scale, clp, param=p if fuse else None,
-                                           sgd_learning_rate=self.sgd_learning_rate)
-                applied.append(fuse)
-            else:  # host tensors (CPU logic tests): the same arithmetic as eager torch ops
-                grad = torch.where(torch.isfinite(grad), grad, torch.zeros_like(grad))
-                grad = grad * scale
-                grad = torch.clamp(grad, -clp, clp)
-                applied.append(False)
+            p = self.parameters[i]
+            fuse = (apply and plain_sgd and accumulators[i] is None and p.is_contiguous()
+                    and p.dtype == grad.dtype and p.shape == grad.shape)
+            with torch.no_grad():
+                grad = ops.sgd_process(grad, scale, clp, param=p if fuse else None,
+                                       sgd_learning_rate=self.sgd_learning_rate)
+            applied.append(fuse)
             if accumulators[i] is not None:
                 grad = self._matrix_product(self._acc_cache, i, accumulators[i], grad)
             processed.append(grad)
@@ -313,23 +298,14 @@ class SGD_Optimizer:
         """optimizer.py:261-282: ``parameters <- smoother @ parameters`` in place."""
         if smoother is not None:
             with torch.no_grad():
-                if parameters.is_cuda:
-                    from . import ops
-                    cache = SGD_Optimizer._smoother_cache
-                    entry = cache.get(id(smoother))
-                    if entry is None or entry[0] is not smoother:
-                        if len(cache) > 64:
-                            cache.clear()
-                        entry = (smoother, ops.CsrMatrix(smoother, parameters.device))
-                        cache[id(smoother)] = entry
-                    parameters.copy_(entry[1].matvec(parameters.detach()))
-                    return
-                s = smoother if isinstance(smoother, torch.Tensor) else torch.as_tensor(
-                    np.asarray(smoother))
-                s = s.to(device=parameters.device, dtype=parameters.dtype)
-                if s.layout != torch.strided:
-                    s = s.to_dense()
-                parameters.copy_((s @ parameters.reshape(-1, 1)).reshape(parameters.shape))
+                cache = SGD_Optimizer._smoother_cache
+                entry = cache.get(id(smoother))
+                if entry is None or entry[0] is not smoother:
+                    if len(cache) > 64:
+                        cache.clear()
+                    entry = (smoother, ops.CsrMatrix(smoother, parameters.device))
+                    cache[id(smoother)] = entry
+                parameters.copy_(entry[1].matvec(parameters.detach()))
 
     def apply_gradients(self, grads, skip=None):
         with torch.no_grad():

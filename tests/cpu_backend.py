@@ -1,5 +1,6 @@
 """
-TEST-ONLY stand-ins for the two HIP-backed ops the host logic calls, built on the oracle, so
+TEST-ONLY stand-ins for the HIP-backed ops the host logic calls (face build, trace, gradient
+processing, CSR product), built on the oracle, so
 the Python host layer (engine field assembly, inheritance, optimizer, ray sharding, gradient
 all-reduce) can be exercised in a container without a GPU.  Installed by the ``cpu_backend``
 fixture via monkeypatch; never imported by the product package.
@@ -93,9 +94,37 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     return out
 
 
+def sgd_process(grad, scale, clip, param=None, sgd_learning_rate=0.0):
+    """optimizer.py:223-247 (+ :316 with ``param``) as eager torch ops (what tfrt_sgd_process does
+    on the device)."""
+    out = torch.where(torch.isfinite(grad), grad, torch.zeros_like(grad)) * scale
+    out = torch.clamp(out, -clip, clip)
+    if param is not None:
+        with torch.no_grad():
+            param.add_(out, alpha=-sgd_learning_rate)
+    return out
+
+
+class CsrMatrix:
+    """Dense stand-in of ops.CsrMatrix (optimizer.py:250-255, 277-282 multiply dense matrices)."""
+
+    def __init__(self, matrix, device):
+        m = matrix if isinstance(matrix, torch.Tensor) else torch.as_tensor(np.asarray(matrix))
+        if m.layout != torch.strided:
+            m = m.to_dense()
+        self._m = m.to(device=device, dtype=torch.float64)
+        self.shape = tuple(self._m.shape)
+
+    def matvec(self, x):
+        y = torch.matmul(self._m, x.reshape(-1, 1).to(torch.float64)).reshape(-1)
+        return y.reshape(x.shape).to(x.dtype) if self.shape[0] == self.shape[1] else y
+
+
 def install(monkeypatch):
     import tensorflowraytrace_amd as tfa
     from tensorflowraytrace_amd import ops
     tfa.set_device("cpu")
     monkeypatch.setattr(ops, "build_faces", build_faces)
     monkeypatch.setattr(ops, "trace3d", trace3d)
+    monkeypatch.setattr(ops, "sgd_process", sgd_process)
+    monkeypatch.setattr(ops, "CsrMatrix", CsrMatrix)
