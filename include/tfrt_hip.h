@@ -290,6 +290,18 @@ int tfrt_snell2d(int64_t n, const double* x_start, const double* y_start, const 
                  const double* y_end, const double* norm, const double* n_in,
                  const double* n_out, double new_ray_length, double* out4, void* stream);
 
+/* Arithmetic self-test (no reference counterpart): out[i] = a[i] / b[i], sqrt(a[i]),
+ * 1.0 / sqrt(a[i]) or a[i] + b[i] * b[i] (product and sum rounded separately), evaluated on the
+ * device with the library's own compile flags.  The decisions of the trace (valid masks, nearest
+ * hit, ties) equal the reference's eager float64 TensorFlow ops only if these are correctly
+ * rounded; tests compare them with the host's IEEE results bit for bit. */
+#define TFRT_SELFTEST_DIV 0
+#define TFRT_SELFTEST_SQRT 1
+#define TFRT_SELFTEST_RSQRT 2
+#define TFRT_SELFTEST_MULADD 3
+int tfrt_selftest_f64(int op, int64_t n, const double* a, const double* b, double* out,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * 2-D: segments + arcs (OpticalSystem2D, tfrt/engine.py:254-866).
  */

@@ -42,7 +42,7 @@ def _const(n):
 
 
 def acrylic(x):
-    return torch.sqrt(
+    return geom.sqrt(
         2.1778 + 6.1209e-9 * x ** 2 - 1.5004e-15 * x ** 4 + 2.3678e4 * x ** -2
         - 4.2137e9 * x ** -4 + 7.3417e14 * x ** -6 - 4.5042e19 * x ** -8
     )
@@ -53,7 +53,7 @@ def _sellmeier(terms):
         acc = 1
         for b, c in terms:
             acc = acc + b * x ** 2 / (x ** 2 - c)
-        return torch.sqrt(acc)
+        return geom.sqrt(acc)
     return f
 
 
@@ -108,7 +108,8 @@ def faces_from_vertices(vertices, faces, vertex_update_map=None):
         pts = [torch.where(m[:, c:c + 1], p, p.detach()) for c, p in enumerate(pts)]
     first, second, third = pts
     cross = torch.linalg.cross(second - first, third - second, dim=1)
-    norm = cross / torch.linalg.norm(cross, dim=1, keepdim=True)
+    # tf.linalg.normalize (boundaries.py:918): x / sqrt(reduce_sum(x * x)), correctly rounded sqrt
+    norm = cross / geom.sqrt(torch.sum(cross * cross, dim=1, keepdim=True))
     out = {"norm": norm}
     for name, p in zip(("p", "1", "2"), pts):
         out["x" + name], out["y" + name], out["z" + name] = p[:, 0], p[:, 1], p[:, 2]

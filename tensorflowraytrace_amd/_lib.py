@@ -83,6 +83,7 @@ SIGNATURES = {
         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_snell3d": (c_i32, [c_i64] + [c_vp] * 9 + [c_f64, c_vp, c_vp]),
     "tfrt_snell2d": (c_i32, [c_i64] + [c_vp] * 7 + [c_f64, c_vp, c_vp]),
+    "tfrt_selftest_f64": (c_i32, [c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_segment_intersection": (c_i32, [
         c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,
         c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

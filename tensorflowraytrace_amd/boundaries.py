@@ -467,7 +467,8 @@ class ParametricMultiSegmentBoundary(SegmentBoundaryBase):
         ]
         self.constraints = constraints
         for i, (surface, constraint) in enumerate(zip(self.surfaces, constraints)):
-            if getattr(constraint, "parent", None) != "zero":
+            # (a ClipConstraint has no parent and takes the surface itself, like parent="zero")
+            if getattr(constraint, "parent", "zero") != "zero":
                 surface.update_handles.append(constraint.make(i, self.surfaces))
             else:
                 surface.update_handles.append(constraint.make(surface, None))
@@ -824,7 +825,7 @@ class ParametricMultiTriangleBoundary(TriangleBoundaryBase):
         ]
         self.constraints = constraints
         for i, (surface, constraint) in enumerate(zip(self._surfaces, constraints)):
-            if getattr(constraint, "parent", None) != "zero":
+            if getattr(constraint, "parent", "zero") != "zero":
                 surface.update_handles.append(constraint.make(i, self._surfaces))
             else:
                 surface.update_handles.append(constraint.make(surface, None))

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void k_snell3d(int64_t n, const double* xs, 
   const Snell3 f = snell3d(s, h, N, n_in[i], n_out[i]);
   for (int k = 0; k < 3; ++k) {
     out[k * n + i] = h[k];
-    out[(3 + k) * n + i] = h[k] + L * f.w[k];
+    out[(3 + k) * n + i] = advance(h[k], L, f.w[k]);
   }
 }
 
@@ -187,8 +187,27 @@ __global__ __launch_bounds__(BLOCK) void k_snell2d(int64_t n, const double* xs, 
   const double a = snell2d_angle(xs[i], ys[i], xe[i], ye[i], norm[i], n_in[i], n_out[i]);
   out[i] = xe[i];
   out[n + i] = ye[i];
-  out[2 * n + i] = xe[i] + L * cos(a);
-  out[3 * n + i] = ye[i] + L * sin(a);
+  out[2 * n + i] = advance(xe[i], L, cos(a));
+  out[3 * n + i] = advance(ye[i], L, sin(a));
+}
+
+// Arithmetic self-test: the float64 primitives the decisions rest on, one result per element,
+// compiled with this library's flags.  Parity with the reference's eager float64 ops needs each
+// of them correctly rounded (IEEE 754), like the host's.
+__global__ __launch_bounds__(BLOCK) void k_selftest_f64(int op, int64_t n, const double* a,
+                                                        const double* b, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b ? b[i] : 0.0;
+  double r;
+  switch (op) {
+    case TFRT_SELFTEST_DIV: r = x / y; break;
+    case TFRT_SELFTEST_SQRT: r = sqrt(x); break;
+    case TFRT_SELFTEST_RSQRT: r = 1.0 / sqrt(x); break;          // l2_normalize3's scale
+    case TFRT_SELFTEST_MULADD: r = advance(x, y, y); break;       // x + y*y, two roundings
+    default: r = 0.0;
+  }
+  out[i] = r;
 }
 
 }  // namespace tfrt
@@ -289,6 +308,17 @@ int tfrt_snell2d(int64_t n, const double* x_start, const double* y_start, const 
   hipLaunchKernelGGL(k_snell2d, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0,
                      static_cast<hipStream_t>(stream), n, x_start, y_start, x_end, y_end, norm,
                      n_in, n_out, new_ray_length, out4);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_selftest_f64(int op, int64_t n, const double* a, const double* b, double* out,
+                      void* stream) {
+  if (n < 0 || op < TFRT_SELFTEST_DIV || op > TFRT_SELFTEST_MULADD) return TFRT_E_BADARG;
+  if (n == 0) return 0;
+  if (!a || !out || (!b && (op == TFRT_SELFTEST_DIV || op == TFRT_SELFTEST_MULADD)))
+    return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_selftest_f64, dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), op, n, a, b, out);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 

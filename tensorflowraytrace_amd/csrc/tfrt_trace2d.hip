@@ -509,7 +509,7 @@ __global__ __launch_bounds__(BLOCK) void k_react2d(
     if (flags & TFRT_COMPILE_DEAD) {
       double e2[2] = {e[0], e[1]};
       if (dead_len != 0.0)
-        for (int k = 0; k < 2; ++k) e2[k] = s[k] + dead_len * (e[k] - s[k]);
+        for (int k = 0; k < 2; ++k) e2[k] = advance_between(s[k], dead_len, e[k]);
       ok = emit2<T>(dead, gslot, s, e2, rid, -1);
     }
     rec_slot[i] = (int32_t)gslot;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(BLOCK) void k_react2d(
       double n_in, n_out;
       prim_indices(sc, prim, rid, &n_in, &n_out);
       const double a = snell2d_angle(s[0], s[1], h[0], h[1], norm, n_in, n_out);
-      const double e2[2] = {h[0] + L * cos(a), h[1] + L * sin(a)};
+      const double e2[2] = {advance(h[0], L, cos(a)), advance(h[1], L, sin(a))};
       store_ray2(rays_out, stride_out, slot, h, e2);
       ray_id_out[slot] = rid;
       last_prim_out[slot] = prim;

@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
     if (flags & TFRT_COMPILE_DEAD) {
       double e2[3] = {e[0], e[1], e[2]};
       if (dead_len != 0.0)
-        for (int k = 0; k < 3; ++k) e2[k] = s[k] + dead_len * (e[k] - s[k]);
+        for (int k = 0; k < 3; ++k) e2[k] = advance_between(s[k], dead_len, e[k]);
       ok = emit<T>(dead, gslot, s, e2, rid, -1);
     }
     rec_slot[i] = (int32_t)gslot;
@@ -1588,7 +1588,7 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
       face_indices(sc, tri, rid, &n_in, &n_out);
       const Snell3 f = snell3d(s, h, N, n_in, n_out);
       double e2[3];
-      for (int k = 0; k < 3; ++k) e2[k] = h[k] + L * f.w[k];
+      for (int k = 0; k < 3; ++k) e2[k] = advance(h[k], L, f.w[k]);
       store_ray3(rays_out, stride_out, slot, h, e2);
       ray_id_out[slot] = rid;
       last_tri_out[slot] = tri;

@@ -72,6 +72,21 @@ TFRT_HD void hit_point(const double s[3], const double e[3], double ray_u, doubl
   h[2] = s[2] - ray_u * (s[2] - e[2]);
 }
 
+// new ray end = hit + L * w (geometry.py:751-752) and the shortened dead ray
+// start + L * (end - start) (engine.py:2043-2049): a product and a sum, rounded separately like
+// the reference's eager ops.  (Written inline in a kernel these contract to one fma under hipcc's
+// default -ffp-contract=fast, and the child ray's end then differs from the reference's in the
+// last bit -- enough to flip a nearest-hit tie between coplanar overlapping faces a pass later.)
+TFRT_HD double advance(double origin, double L, double dir) {
+#pragma clang fp contract(off)
+  return origin + L * dir;
+}
+
+TFRT_HD double advance_between(double s, double L, double e) {
+#pragma clang fp contract(off)
+  return s + L * (e - s);
+}
+
 TFRT_HD void cross3(const double a[3], const double b[3], double o[3]) {
 #pragma clang fp contract(off)
   o[0] = a[1] * b[2] - a[2] * b[1];

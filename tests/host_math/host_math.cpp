@@ -25,7 +25,19 @@ void hm_snell3d(int64_t n, const double* s, const double* h, const double* P,
     double N[3], C[3], clen;
     tfrt::face_normal(P + 9 * i, N, C, &clen);
     tfrt::Snell3 f = tfrt::snell3d(s + 3 * i, h + 3 * i, N, n_in[i], n_out[i]);
-    for (int k = 0; k < 3; ++k) e_new[3 * i + k] = h[3 * i + k] + L * f.w[k];
+    for (int k = 0; k < 3; ++k) e_new[3 * i + k] = tfrt::advance(h[3 * i + k], L, f.w[k]);
+  }
+}
+
+// the seam form (geometry.py:671-673): the caller supplies the normal; writes the 6 x n block
+void hm_snell3d_norm(int64_t n, const double* s, const double* h, const double* norm,
+                     const double* n_in, const double* n_out, double L, double* out6) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::Snell3 f = tfrt::snell3d(s + 3 * i, h + 3 * i, norm + 3 * i, n_in[i], n_out[i]);
+    for (int k = 0; k < 3; ++k) {
+      out6[k * n + i] = h[3 * i + k];
+      out6[(3 + k) * n + i] = tfrt::advance(h[3 * i + k], L, f.w[k]);
+    }
   }
 }
 

@@ -149,3 +149,46 @@ def test_arc_exact_matches_oracle(host_math):
             assert abs(float(ray_u[0]) - ru[i]) < 1e-13 and abs(float(arc_u[0]) - au[i]) < 1e-13
             assert abs(float(tracer.get_arc_norm(tt(arc[:, 4]), arc_u, g)[0]) - nm[i]) < 1e-13
     assert 100 < seen < n
+
+
+def test_snell3d_restatement_is_bit_identical_to_the_oracle(host_math):
+    """csrc/trace_math.h::snell3d + advance against oracle.geom.snells_law_3D (geometry.py:715-753)
+    on 20,000 random rays incl. TIR, mirrors and n_out = 0: every bit equal.  (The same comparison
+    runs on the device in tests/test_gpu_stress.py.)"""
+    rng = np.random.default_rng(77)
+    n = 20_000
+    s = rng.uniform(-3, 3, (n, 3)) * 10 ** rng.uniform(-2, 2, (n, 1))
+    h = s + rng.standard_normal((n, 3)) * 10 ** rng.uniform(-2, 1, (n, 1))
+    norm = rng.standard_normal((n, 3)) * 10 ** rng.uniform(-3, 3, (n, 1))
+    n_in = rng.uniform(1.0, 1.8, n)
+    n_out = rng.uniform(1.0, 1.8, n)
+    n_in[:500] = 0.0
+    n_out[500:800] = 0.0
+    L = 0.37
+    t = lambda a: torch.tensor(a, dtype=torch.float64)
+    want = torch.stack(geom.snells_law_3D(
+        t(s[:, 0]), t(s[:, 1]), t(s[:, 2]), t(h[:, 0]), t(h[:, 1]), t(h[:, 2]), t(norm), t(n_in),
+        t(n_out), L)).numpy()
+    got = np.zeros((6, n))
+    host_math.hm_snell3d_norm(I(n), P(s), P(h), P(norm), P(n_in), P(n_out), D(L), P(got))
+    assert int((got != want).any(axis=0).sum()) == 0
+
+
+def test_oracle_square_root_is_correctly_rounded():
+    """oracle.geom.sqrt = IEEE sqrt (what TensorFlow's CPU kernels compute); torch.sqrt of this
+    image is not, which is why the oracle does not use it."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(1.0, 2.0, 200_000) * 2.0 ** rng.integers(-40, 40, 200_000)
+    xt = torch.tensor(x, requires_grad=True)
+    y = geom.sqrt(xt)
+    assert np.array_equal(y.detach().numpy(), np.sqrt(x))
+    # correctly rounded: x lies between the squares of the midpoints to y's two neighbours
+    yn = y.detach().numpy()
+    lo, hi = np.nextafter(yn, 0.0), np.nextafter(yn, np.inf)
+    import decimal
+    decimal.getcontext().prec = 80
+    d = lambda v: decimal.Decimal(float(v))
+    for k in rng.choice(x.size, 300, replace=False):
+        assert ((d(lo[k]) + d(yn[k])) / 2) ** 2 <= d(x[k]) <= ((d(hi[k]) + d(yn[k])) / 2) ** 2
+    (g,) = torch.autograd.grad(y.sum(), [xt])
+    np.testing.assert_allclose(g.numpy(), 0.5 / np.sqrt(x), rtol=1e-15)
