@@ -107,7 +107,13 @@ def faces_from_vertices(vertices, faces, vertex_update_map=None):
         m = torch.as_tensor(vertex_update_map, dtype=torch.bool)
         pts = [torch.where(m[:, c:c + 1], p, p.detach()) for c, p in enumerate(pts)]
     first, second, third = pts
-    cross = torch.linalg.cross(second - first, third - second, dim=1)
+    # tf.linalg.cross (boundaries.py:919): products and differences rounded one by one.  Spelled
+    # out because this image's torch.linalg.cross kernel is compiled with fused multiply-adds
+    # (one rounding fewer per component: half of all normals then differ in the last bit).
+    a, b = second - first, third - second
+    cross = torch.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1],
+                         a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2],
+                         a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], dim=1)
     # tf.linalg.normalize (boundaries.py:918): x / sqrt(reduce_sum(x * x)), correctly rounded sqrt
     norm = cross / geom.sqrt(torch.sum(cross * cross, dim=1, keepdim=True))
     out = {"norm": norm}

@@ -29,6 +29,13 @@ void hm_snell3d(int64_t n, const double* s, const double* h, const double* P,
   }
 }
 
+void hm_face_normal(int64_t n, const double* P, double* norm) {
+  for (int64_t i = 0; i < n; ++i) {
+    double C[3], clen;
+    tfrt::face_normal(P + 9 * i, norm + 3 * i, C, &clen);
+  }
+}
+
 // the seam form (geometry.py:671-673): the caller supplies the normal; writes the 6 x n block
 void hm_snell3d_norm(int64_t n, const double* s, const double* h, const double* norm,
                      const double* n_in, const double* n_out, double L, double* out6) {
