@@ -115,6 +115,12 @@ int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_
 int tfrt_sgd_process(const void* grad, void* processed, void* param, int64_t n, int32_t dtype,
                      double scale, double clip, double sgd_learning_rate, void* stream);
 
+/* Same, with {scale, clip, sgd_learning_rate} read from three float64 on the DEVICE: the values
+ * change from step to step (learning-rate schedules, optimizer.py:384-389) while a captured
+ * launch graph of the step replays unchanged. */
+int tfrt_sgd_process_dev(const void* grad, void* processed, void* param, int64_t n, int32_t dtype,
+                         const double* hyper, void* stream);
+
 /* y = A x, A in CSR form (int64 indices, f64 values): the accumulator (optimizer.py:250-255)
  * and smoother (optimizer.py:277-282) products for the sparse matrices the mesh tools
  * produce (mesh_tools.py:221-421).  x and y must not alias. */
@@ -214,6 +220,33 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
                           const double* grad_dead, int64_t cap_dead, double* grad_face_verts,
                           double* grad_src_rays, const int32_t* counts, void* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* Built-in image-forming error of the reference's optimisation scripts
+ * (dev/hexalens.py:144-168: output = stack(finished[field_c]), goal = f(inherited source
+ * fields), error = tf.math.squared_difference(output, goal)) evaluated on the device, with its
+ * gradient seed, so that an optimiser step reads no ray count back and is a fixed launch
+ * sequence.  Replaces the user error function + the first node of tape.gradient
+ * (tfrt/optimizer.py:216-220) for error functions of that form.
+ *
+ *   finished_rays  6 x capacity ray block written by tfrt_trace3d_forward (state dtype)
+ *   finished_id    (capacity) source-ray index per finished row (tfrt_ray_out.ray_id)
+ *   n_finished     device pointer to the number of finished rows: counts + 8*max_passes + 1
+ *   fields[c]      row of the ray block (0..5 = x_start..z_end) compared with goal column c
+ *   goal           n_fields x goal_stride f64, goal[c * goal_stride + source_ray]
+ *   grad_finished  6 x capacity f64: rows fields[c] receive 2 * (output - goal) for the
+ *                  finished rows; other rows and rows beyond n_finished are left untouched
+ *                  (zero them once: tfrt_trace3d_backward reads finished rows only)
+ *   error_out      3 f64: {sum of the error terms, number of terms, sum / max(terms, 1)}; the
+ *                  sum is formed in a fixed order (bit-identical from run to run)
+ *   workspace      tfrt_goal_error3d_workspace_bytes(capacity) bytes, zero-filled before the
+ *                  first call; a call leaves it ready for the next one
+ */
+size_t tfrt_goal_error3d_workspace_bytes(int64_t capacity);
+int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
+                      int32_t state_dtype, const int32_t* n_finished, const int32_t* fields,
+                      int32_t n_fields, const double* goal, int64_t goal_stride,
+                      double* grad_finished, double* error_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 
 /* Benchmark instrumentation (the only global state in the library; not used by the product
  * path).  While enabled, every launch of the dominant kernel (k_intersect3d) made by

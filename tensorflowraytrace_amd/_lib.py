@@ -69,6 +69,7 @@ SIGNATURES = {
     "tfrt_line_circle_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                            c_f64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_sgd_process": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f64, c_f64, c_f64, c_vp]),
+    "tfrt_sgd_process_dev": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "tfrt_csr_matvec": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tfrt_trace3d_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
     "tfrt_trace3d_forward": (c_i32, [
@@ -77,6 +78,9 @@ SIGNATURES = {
     "tfrt_trace3d_backward": (c_i32, [
         c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32,
         c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_goal_error3d_workspace_bytes": (c_sz, [c_i64]),
+    "tfrt_goal_error3d": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp,
+                                  c_vp, c_vp, c_sz, c_vp]),
     "tfrt_intersect3d_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "tfrt_intersect3d": (c_i32, [
         c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,

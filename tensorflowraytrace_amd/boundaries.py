@@ -41,6 +41,26 @@ def amalgamate(stuff, signature=None):
     return {f: torch.cat([s[f] for s in items], 0) for f in signature}
 
 
+def tap(parameters):
+    """A fresh non-leaf alias of a parameter tensor, through which ``update()`` reads it.
+
+    Differentiating the faces w.r.t. the alias gives the gradient w.r.t. the parameters without
+    routing anything into the leaf's gradient accumulator.  That node lives as long as ANY old
+    autograd graph of the parameter does and remembers the stream it was created on; a backward
+    pass inside a HIP-graph capture (fused_step.FusedStep) that reaches an accumulator of another
+    stream forks the capture onto that stream (the legacy stream, typically) and the runtime then
+    crashes ending the capture.  The aliases of the current update are listed on the tensor as
+    ``_tfrt_taps`` (a parameter may feed several boundaries)."""
+    if not (isinstance(parameters, torch.Tensor) and parameters.requires_grad):
+        return parameters
+    alias = parameters.view_as(parameters)
+    taps = parameters.__dict__.get("_tfrt_taps")
+    if taps is None:
+        taps = parameters.__dict__["_tfrt_taps"] = []
+    taps.append(alias)
+    return alias
+
+
 # ============================================================================ constraints
 
 class Constraint(ABC):
@@ -396,7 +416,7 @@ class ParametricSegmentBoundary(SegmentBoundaryBase):
 
     def _update(self):
         self["x_start"], self["y_start"], self["x_end"], self["y_end"] = self._update_internal(
-            self._zero_distribution.points, self._one_distribution.points, self.parameters,
+            self._zero_distribution.points, self._one_distribution.points, tap(self.parameters),
             self.flip_norm)
 
     @staticmethod
@@ -680,7 +700,8 @@ class ParametricTriangleBoundary(TriangleBoundaryBase):
                  and self._faces is not None and self._zero_points.is_cuda
                  and isinstance(self.parameters, torch.Tensor) and self.parameters.is_cuda)
         if not fused:
-            self._vertices = self._update_internal(self._zero_points, self._vectors, self.parameters)
+            self._vertices = self._update_internal(self._zero_points, self._vectors,
+                                                   tap(self.parameters))
             if self.auto_update_mesh:
                 self.update_mesh_from_vertices()
             self.update_fields_from_vertices()
@@ -688,9 +709,12 @@ class ParametricTriangleBoundary(TriangleBoundaryBase):
         # one launch: parameters -> faces (ops.param_faces); the (V,3) vertex tensor is only
         # formed when somebody reads it (drawing, saving, a regulariser)
         self._vertices_pending = True
+        # (drop the previous vertex tensor now: it would keep its autograd graph -- and the
+        # parameters' gradient accumulator of whatever stream built it -- alive indefinitely)
+        self.__dict__["_vertices_value"] = None
         faces, mask = self._device_face_tables(self._zero_points.device)
         self._face_verts, self._norm = ops.param_faces(
-            self.parameters, self._zero_points, self._vectors, faces, mask)
+            tap(self.parameters), self._zero_points, self._vectors, faces, mask)
         for k in list(_TRI_COLS) + ["norm"]:
             self._fields.pop(k, None)
         if self.auto_update_mesh:
@@ -775,7 +799,7 @@ class MasterSlaveParametricTriangleBoundary(ParametricTriangleBoundary):
     def _update(self):
         if self._gather is None:  # called from the parent constructor before the map exists
             return ParametricTriangleBoundary._update(self)
-        params = self.parameters[self._gather].reshape(-1, 1)
+        params = tap(self.parameters)[self._gather].reshape(-1, 1)
         self._vertices = self._zero_points + params * self.vectors
         if self.auto_update_mesh:
             self.update_mesh_from_vertices()
@@ -922,7 +946,7 @@ class ParametricCylindricalGuide(TriangleBoundaryBase):
 
     def _update(self):
         self._constraint()
-        p = self.parameters
+        p = tap(self.parameters)
         if self._rotationally_symmetric:
             p = p.repeat_interleave(self._theta_res)
         pads = []

@@ -1,0 +1,140 @@
+// Built-in image-forming error over the finished rays and its gradient seed, on the device.
+//
+// The error functions of the reference's optimisation scripts have one shape
+// (dev/hexalens.py:144-168, dev/light_guide.py, the hexalens "inner / outer goal"):
+//
+//     output = stack(finished[field_0], finished[field_1], ...)           one row per finished ray
+//     goal   = f(inherited source fields of that ray)
+//     error  = squared_difference(output, goal)                           tf.math.squared_difference
+//
+// `goal` only depends on fields a finished ray inherits unchanged from its source ray
+// (engine.py:2242-2281), so it is a table with one row per SOURCE ray, looked up through the
+// source-ray index the trace carries along.  With that table on the device the whole optimiser
+// step needs no data-dependent host code: no ray counts are read back, nothing is sliced, and the
+// launch sequence is identical from step to step (hipGraph-capturable).
+//
+// k_goal_error: one lane per finished-ray slot (the number of finished rays is read from the
+// device-side counters of the trace).  Writes d(sum error)/d(field) = 2 (output - goal) into the
+// matching rows of the (6 x capacity) float64 seed block tfrt_trace3d_backward consumes, and the
+// error sum in a FIXED summation order (per-workgroup partial sums, combined by the workgroup that
+// finishes last), so two runs give bit-identical errors.  HBM-bound: 4-8 B x n_fields read + 8 B x
+// n_fields written per finished ray.
+#include "tfrt_common.h"
+
+namespace tfrt {
+
+struct GoalFields {
+  int32_t n;
+  int32_t row[6];  // row of the ray block (0..5: x_start .. z_end) compared with goal column c
+};
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_goal_error(
+    const T* __restrict__ fin, int64_t cap, const int32_t* __restrict__ fin_id,
+    const int32_t* __restrict__ n_ptr, GoalFields gf, const double* __restrict__ goal,
+    int64_t goal_stride, double* __restrict__ g_fin, double* __restrict__ partial,
+    unsigned int* __restrict__ ticket, double* __restrict__ err_out) {
+  // the reference's squared_difference and reduce_sum are separate ops: no contraction
+#pragma clang fp contract(off)
+  __shared__ double wsum[WAVES];
+  __shared__ int is_last;
+  const int n = *n_ptr;
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  double acc = 0.0;
+  if (i < n) {
+    const int64_t id = fin_id[i];
+    for (int c = 0; c < gf.n; ++c) {
+      const int64_t at = (int64_t)gf.row[c] * cap + i;
+      const double r = ldd(fin, at) - goal[(int64_t)c * goal_stride + id];
+      g_fin[at] = 2.0 * r;
+      acc += r * r;
+    }
+  }
+  // fixed-shape reduction: xor butterflies inside the wave, waves in index order
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < WAVES; ++w) s += wsum[w];
+    partial[blockIdx.x] = s;
+    __threadfence();
+    const unsigned int t = atomicAdd(ticket, 1u);
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  // the last workgroup sums the partials: lane t takes t, t + BLOCK, ... in order, then the same
+  // butterfly / wave-order combination as above -- independent of which workgroup came last
+  double s = 0.0;
+  for (unsigned int b = threadIdx.x; b < gridDim.x; b += BLOCK)
+    s += partial[b];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  __syncthreads();
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < WAVES; ++w) tot += wsum[w];
+    err_out[0] = tot;
+    const double terms = (double)n * (double)gf.n;
+    err_out[1] = terms;
+    err_out[2] = tot / (terms > 1.0 ? terms : 1.0);  // reduce_mean of optimizer.py:257
+    *ticket = 0u;  // ready for the next call
+  }
+}
+
+}  // namespace tfrt
+
+using namespace tfrt;
+
+extern "C" {
+
+size_t tfrt_goal_error3d_workspace_bytes(int64_t capacity) {
+  if (capacity < 0) return 0;
+  return align_up(sizeof(unsigned int)) + align_up((size_t)cdiv(capacity > 0 ? capacity : 1, BLOCK) *
+                                                   sizeof(double));
+}
+
+int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
+                      int32_t state_dtype, const int32_t* n_finished, const int32_t* fields,
+                      int32_t n_fields, const double* goal, int64_t goal_stride,
+                      double* grad_finished, double* error_out, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  if (capacity < 0 || n_fields < 1 || n_fields > 6 || !fields || !n_finished || !error_out ||
+      !workspace || workspace_bytes < tfrt_goal_error3d_workspace_bytes(capacity))
+    return TFRT_E_BADARG;
+  if (capacity > 0 && (!finished_rays || !finished_id || !goal || !grad_finished))
+    return TFRT_E_BADARG;
+  GoalFields gf;
+  gf.n = n_fields;
+  for (int c = 0; c < 6; ++c) {
+    gf.row[c] = c < n_fields ? fields[c] : 0;
+    if (gf.row[c] < 0 || gf.row[c] > 5) return TFRT_E_BADARG;
+  }
+  unsigned int* ticket = static_cast<unsigned int*>(workspace);
+  double* partial =
+      reinterpret_cast<double*>(static_cast<char*>(workspace) + align_up(sizeof(unsigned int)));
+  const dim3 grid(cdiv(capacity > 0 ? capacity : 1, BLOCK));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define TFRT_GOAL(T)                                                                           \
+  hipLaunchKernelGGL((k_goal_error<T>), grid, dim3(BLOCK), 0, st,                              \
+                     static_cast<const T*>(finished_rays), capacity, finished_id, n_finished,  \
+                     gf, goal, goal_stride, grad_finished, partial, ticket, error_out)
+  if (state_dtype == TFRT_F32) {
+    TFRT_GOAL(float);
+  } else if (state_dtype == TFRT_F64) {
+    TFRT_GOAL(double);
+  } else if (state_dtype == TFRT_F16) {
+    TFRT_GOAL(_Float16);
+  } else {
+    return TFRT_E_BADARG;
+  }
+#undef TFRT_GOAL
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -614,10 +614,10 @@ __global__ __launch_bounds__(BLOCK) void k_backward2d(
       if (is_arc) {
         if (g_arc != nullptr)
           for (int q = 0; q < 5; ++q)
-            if (gp[q] == gp[q] && gp[q] != 0.0) unsafeAtomicAdd(g_arc + (int64_t)(prim - Ms) * 5 + q, gp[q]);
+            if (gp[q] != 0.0) unsafeAtomicAdd(g_arc + (int64_t)(prim - Ms) * 5 + q, gp[q]);
       } else if (g_seg != nullptr) {
         for (int q = 0; q < 4; ++q)
-          if (gp[q] == gp[q] && gp[q] != 0.0) unsafeAtomicAdd(g_seg + (int64_t)prim * 4 + q, gp[q]);
+          if (gp[q] != 0.0) unsafeAtomicAdd(g_seg + (int64_t)prim * 4 + q, gp[q]);
       }
     }
   }

@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
       const unsigned long long grp = __ballot(mine);
 #pragma unroll
       for (int c = 0; c < 9; ++c) {
-        double v = (mine && gP[c] == gP[c]) ? gP[c] : 0.0;  // drop NaN like optimizer.py:229
+        double v = mine ? gP[c] : 0.0;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
         if ((int)lane_id() == leader && v != 0.0) unsafeAtomicAdd(g_fverts + 9 * (int64_t)k + c, v);
@@ -1693,7 +1693,7 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     if (tri >= 0) {
       double* o = stash_g + 9 * (int64_t)i;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) o[c] = (gP[c] == gP[c]) ? gP[c] : 0.0;  // NaN -> 0
+      for (int c = 0; c < 9; ++c) o[c] = gP[c];
     }
     return;
   }
@@ -1704,12 +1704,16 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
 #ifdef TFRT_ABLATE_BWD_ATOMICS
       if (gP[c] == 12345.678) gp[c] = gP[c];  // timing experiment only: no accumulation
 #else
-      if (gP[c] == gP[c]) unsafeAtomicAdd(gp + c, gP[c]);  // drop NaN like optimizer.py:229
+      if (gP[c] != 0.0) unsafeAtomicAdd(gp + c, gP[c]);
 #endif
     }
   }
 }
 
+// (A ray whose terms are NaN / Inf poisons the sums it enters, exactly as in the reference's
+// tape; SGD_Optimizer zeroes non-finite entries of the summed parameter gradient afterwards,
+// optimizer.py:226-229.  `x != 0.0` is true for NaN, so the adds below let it through.)
+//
 // Sums the per-ray face-gradient terms left by k_backward3d into g_fverts without hammering
 // memory with contended float64 atomics (9 per ray, up to thousands of rays per face: 93 % of
 // the reverse sweep before).  blockIdx.y owns a window of FACE_WINDOW faces whose 9 sums live

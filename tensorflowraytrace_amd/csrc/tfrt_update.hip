@@ -21,9 +21,15 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_sgd_process(const T* __restrict__ grad,
                                                        T* __restrict__ processed,
                                                        T* __restrict__ param, int64_t n, T scale,
-                                                       T clip, T sgd_lr) {
+                                                       T clip, T sgd_lr,
+                                                       const double* __restrict__ hyper) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
+  if (hyper != nullptr) {  // step-dependent values live on the device (replayed launch graphs)
+    scale = static_cast<T>(hyper[0]);
+    clip = static_cast<T>(hyper[1]);
+    sgd_lr = static_cast<T>(hyper[2]);
+  }
   T g = grad[i];
   // optimizer.py:226-229 (tf.where(is_finite(g), g, 0)), :233 scale, :236-247 clip_by_value
   g = isfinite(g) ? g : T(0);
@@ -55,23 +61,37 @@ using namespace tfrt;
 
 extern "C" {
 
-int tfrt_sgd_process(const void* grad, void* processed, void* param, int64_t n, int32_t dtype,
-                     double scale, double clip, double sgd_learning_rate, void* stream) {
-  if (n < 0 || (n > 0 && !grad) || clip < 0.0 || (dtype != TFRT_F32 && dtype != TFRT_F64))
-    return TFRT_E_BADARG;
+static int sgd_process_launch(const void* grad, void* processed, void* param, int64_t n,
+                              int32_t dtype, double scale, double clip, double sgd_learning_rate,
+                              const double* hyper, void* stream) {
   if (n == 0) return 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(cdiv(n, BLOCK));
   if (dtype == TFRT_F64)
     hipLaunchKernelGGL((k_sgd_process<double>), grid, dim3(BLOCK), 0, st,
                        static_cast<const double*>(grad), static_cast<double*>(processed),
-                       static_cast<double*>(param), n, scale, clip, sgd_learning_rate);
+                       static_cast<double*>(param), n, scale, clip, sgd_learning_rate, hyper);
   else
     hipLaunchKernelGGL((k_sgd_process<float>), grid, dim3(BLOCK), 0, st,
                        static_cast<const float*>(grad), static_cast<float*>(processed),
                        static_cast<float*>(param), n, (float)scale, (float)clip,
-                       (float)sgd_learning_rate);
+                       (float)sgd_learning_rate, hyper);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_sgd_process(const void* grad, void* processed, void* param, int64_t n, int32_t dtype,
+                     double scale, double clip, double sgd_learning_rate, void* stream) {
+  if (n < 0 || (n > 0 && !grad) || clip < 0.0 || (dtype != TFRT_F32 && dtype != TFRT_F64))
+    return TFRT_E_BADARG;
+  return sgd_process_launch(grad, processed, param, n, dtype, scale, clip, sgd_learning_rate,
+                            nullptr, stream);
+}
+
+int tfrt_sgd_process_dev(const void* grad, void* processed, void* param, int64_t n, int32_t dtype,
+                         const double* hyper, void* stream) {
+  if (n < 0 || (n > 0 && !grad) || !hyper || (dtype != TFRT_F32 && dtype != TFRT_F64))
+    return TFRT_E_BADARG;
+  return sgd_process_launch(grad, processed, param, n, dtype, 0.0, 0.0, 0.0, hyper, stream);
 }
 
 int tfrt_csr_matvec(const int64_t* crow_indices, const int64_t* col_indices, const double* values,

@@ -583,9 +583,10 @@ class OpticalEngine:
         # the error function).  Off by default: ray_trace() then returns exact sets.
         self.speculative_counts = False
         self._predicted = None
+        self._pending_trace = None
+        self._last_trace = None
         self.clear_ray_history()
         self.last_projection_result = {}
-        self.last_trace = None
 
         self.input_signature = set()
         self.output_signature = set()
@@ -722,18 +723,45 @@ class OpticalEngine:
     def clear_ray_history(self):
         self._history = {c: [] for c in _CLASSES}
         self._unfinished_rays = {}
+        self._pending_trace = None
+
+    # A fused optimiser step (fused_step.FusedStep) leaves the trace's outputs on the device and
+    # never reads the ray counts; the ray sets are cut (one host read of the counts) when
+    # somebody first asks for them.
+    def _resolve_pending(self):
+        pending = self._pending_trace
+        if pending is not None:
+            self._pending_trace = None
+            self._history = {c: [] for c in _CLASSES}
+            self._unfinished_rays = {}
+            self._publish(pending())
+
+    @property
+    def last_trace(self):
+        self._resolve_pending()
+        return self._last_trace
+
+    @last_trace.setter
+    def last_trace(self, value):
+        self._last_trace = value
 
     def _set(self, cls):
+        self._resolve_pending()
         return ReadOnlySet(amalgamate(self._history[cls]))
 
     active_rays = property(lambda self: self._set("active"))
     finished_rays = property(lambda self: self._set("finished"))
     dead_rays = property(lambda self: self._set("dead"))
     stopped_rays = property(lambda self: self._set("stopped"))
-    unfinished_rays = property(lambda self: self._unfinished_rays)
+
+    @property
+    def unfinished_rays(self):
+        self._resolve_pending()
+        return self._unfinished_rays
 
     @property
     def all_rays(self):
+        self._resolve_pending()
         h = self._history
         return ReadOnlySet(amalgamate(h["active"] + h["finished"] + h["dead"] + h["stopped"]))
 
@@ -750,8 +778,9 @@ class OpticalEngine:
             f |= _lib.COMPILE_DEAD
         return f
 
-    def _run(self, rays, max_passes, flags, predicted=None):
-        """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
+    def _trace_inputs(self, rays):
+        """(ray block, scene arguments, merged face tensor) of a trace over the ray set ``rays``;
+        ray block, n(lambda) table and scene arguments are cached per input tensor identity."""
         system = self.optical_system
         geo = _GEO3 if self.dimension == 3 else _GEO2
         dt = self.ray_dtype or config.get_ray_dtype()
@@ -786,16 +815,21 @@ class OpticalEngine:
                                       sort_rays=mode == "sort")
         else:
             scene = system.scene_args(n_table, index_mode, ghost)
+        fv = None
         if self.dimension == 3:
             fv = system._merged_face_verts
             if fv is None:
                 fv = torch.zeros((0, 9), dtype=torch.float64, device=block.device)
-            out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
-                              self.dead_ray_length, flags, predicted_counts=predicted)
-        else:
-            out = ops.trace2d(block, scene, max_passes, self.new_ray_length,
-                              self.dead_ray_length, flags, predicted_counts=predicted)
-        return out
+        return block, scene, fv
+
+    def _run(self, rays, max_passes, flags, predicted=None):
+        """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
+        block, scene, fv = self._trace_inputs(rays)
+        if self.dimension == 3:
+            return ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
+                               self.dead_ray_length, flags, predicted_counts=predicted)
+        return ops.trace2d(block, scene, max_passes, self.new_ray_length,
+                           self.dead_ray_length, flags, predicted_counts=predicted)
 
     def _fields_from(self, out, cls, src, only_first_pass):
         """Field dict of one output class: geometry from the kernels, everything else gathered
@@ -827,9 +861,25 @@ class OpticalEngine:
         if not bool(self.optical_system):
             return
         self.clear_ray_history()
-        src = self.optical_system._amalgamated_sources
+        src = self._source_set()
         if not src:
             return
+        predicted = None
+        sig = (src["x_start"].shape[0], int(max_iterations), self._flags())
+        if self.speculative_counts and self._predicted is not None and self._predicted[0] == sig:
+            predicted = self._predicted[1]
+        out = self._run(src, int(max_iterations), self._flags(), predicted)
+        self._trace_sig, self._trace_src = sig, src
+        self._publish(out)
+        if "pending" not in out:
+            self._predicted = (sig, out["raw_counts"])
+
+    def _source_set(self):
+        """The source rays this process traces: all of them, or this rank's contiguous block
+        (``ray_shard``)."""
+        src = self.optical_system._amalgamated_sources
+        if not src:
+            return src
         shard = self.ray_shard
         if shard == "auto":
             shard = (tdist.rank(), tdist.world_size()) if tdist.is_distributed() else None
@@ -844,21 +894,13 @@ class OpticalEngine:
                 cached = (skey, {f: v[lo:hi] for f, v in src.items()}, list(src.values()))
                 self._shard_cache = cached
             src = cached[1]
-        predicted = None
-        sig = (src["x_start"].shape[0], int(max_iterations), self._flags())
-        if self.speculative_counts and self._predicted is not None and self._predicted[0] == sig:
-            predicted = self._predicted[1]
-        out = self._run(src, int(max_iterations), self._flags(), predicted)
-        self._trace_sig, self._trace_src = sig, src
-        self._publish(out)
-        if "pending" not in out:
-            self._predicted = (sig, out["raw_counts"])
+        return src
 
     def verify_trace(self):
         """Resolve a speculative ray_trace(): returns True if the predicted counts were right;
         otherwise the ray sets have been rebuilt with the true counts (and the caller must
         re-evaluate whatever it derived from them)."""
-        out = self.last_trace
+        out = self._last_trace
         if out is None or "pending" not in out:
             return True
         ok, actual, fixed = out["pending"].resolve()
@@ -873,7 +915,7 @@ class OpticalEngine:
 
     def _publish(self, out):
         src = self._trace_src
-        self.last_trace = out
+        self._last_trace = out
         counts = out["counts"]
         for k, cls in enumerate(_CLASSES):
             if cls not in out or out[cls].shape[1] == 0:

@@ -1,0 +1,441 @@
+"""
+The optimiser step as ONE fixed launch sequence (no host read inside, hipGraph-replayable).
+
+``SGD_Optimizer.single_step`` of the reference (tfrt/optimizer.py:187-320) is
+
+    system.update() -> engine.ray_trace(depth) -> error_function(engine) -> tape.gradient
+    -> non-finite -> 0, scale, clip, accumulate -> SGD apply
+
+The generic path of this package keeps the user's ``error_function`` arbitrary torch code, which
+costs a blocking read of the ray counts (the finished set has a data-dependent length), ~25
+stock torch kernels for the error and its reverse, and autograd bookkeeping: ~0.75 ms per step
+whatever the ray count -- the part that caps ray-parallel strong scaling.
+
+The error functions of the reference's optimisation scripts all have one form
+(dev/hexalens.py:144-168):  ``squared_difference(stack(finished[fields]), goal)`` with ``goal``
+a function of fields the finished rays inherit unchanged from their source rays.  ``GoalError``
+states that form declaratively; an optimiser given a ``GoalError`` runs ``FusedStep``:
+
+    system.update()                     constraints, parameters -> faces   (torch + tfrt_param_faces_*)
+    tfrt_trace3d_forward                into persistent buffers, counts stay on the device
+    tfrt_goal_error3d                   error sum (fixed order) + gradient seed 2 (output - goal)
+    tfrt_trace3d_backward               -> d error / d faces
+    autograd through update()           -> d error / d parameters           (tfrt_param_faces_backward ...)
+    [one all-reduce over ray shards]
+    tfrt_sgd_process_dev / tfrt_csr_matvec   non-finite -> 0, scale, clip, accumulate, SGD apply
+
+Every launch has step-independent arguments (learning-rate dependent scalars live in a small
+device table), so after a few eager steps the sequence is captured once in a HIP graph
+(``torch.cuda.CUDAGraph``) and replayed: one graph launch per step.  With ray shards over several
+processes the collective splits it in two graphs (RCCL is called eagerly between them).
+
+``GoalError`` is also an ordinary error function (``__call__(engine)``): the generic path gives
+the same numbers, which is what the parity tests compare.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from . import distributed as tdist
+from ._lib import RayOut, check
+
+_GEO3 = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
+_CLASS_FLAGS = (("finished", _lib.COMPILE_FINISHED), ("active", _lib.COMPILE_ACTIVE),
+                ("stopped", _lib.COMPILE_STOPPED), ("dead", _lib.COMPILE_DEAD))
+
+
+class GoalError:
+    """``error = squared_difference(stack([finished[f] for f in fields], axis=1), goal)``.
+
+    ``goal``: a callable taking the field dict of the SOURCE rays and returning one goal row per
+    source ray, shape (N, len(fields)) (or (N,) for a single field); or such a tensor.  Finished
+    rays look their row up through the source-ray index the trace carries, which equals
+    evaluating the same expression on the fields a finished ray inherits (engine.py:2242-2281).
+
+    Example (dev/hexalens.py:154-157, magnification m)::
+
+        erf = GoalError(("y_end", "z_end"), lambda src: -m * src["object_coords"][:, 1:])
+    """
+
+    def __init__(self, fields=("y_end", "z_end"), goal=None):
+        self.fields = tuple(fields)
+        if not self.fields or any(f not in _GEO3 for f in self.fields):
+            raise ValueError(f"GoalError: fields must be taken from {_GEO3}, got {fields!r}")
+        if goal is None:
+            raise ValueError("GoalError: a goal (callable or tensor) is required")
+        self.rows = [_GEO3.index(f) for f in self.fields]
+        self.goal = goal
+        self._cache = None
+
+    def table(self, src):
+        """(len(fields), N) contiguous float64 goal table of the source set ``src``."""
+        vals = list(src.values()) if hasattr(src, "values") else [src[k] for k in src.keys()]
+        key = tuple((id(v), getattr(v, "_version", None)) for v in vals)
+        if self._cache is not None and self._cache[0] == key:
+            return self._cache[1]
+        g = self.goal(src) if callable(self.goal) else self.goal
+        n = src["x_start"].shape[0]
+        g = torch.as_tensor(g, dtype=torch.float64, device=src["x_start"].device).detach()
+        if g.dim() == 1:
+            g = g.reshape(-1, 1)
+        if tuple(g.shape) != (n, len(self.fields)):
+            raise ValueError(f"GoalError: goal has shape {tuple(g.shape)}, expected "
+                             f"({n}, {len(self.fields)}) -- one row per source ray")
+        table = g.t().contiguous()
+        self._cache = (key, table, vals)     # the keyed tensors stay alive with the key
+        return table
+
+    def __call__(self, engine):
+        """The same error through the generic path (arbitrary-error-function contract)."""
+        fin = engine.finished_rays
+        if not bool(fin):
+            return torch.zeros((0, len(self.fields)), dtype=torch.float64)
+        ids = engine.last_trace["finished_id"].long()
+        table = self.table(engine._trace_src)
+        out = torch.stack([fin[f] for f in self.fields], dim=1).double()
+        return (out - table[:, ids].t()) ** 2
+
+
+class _HyperTable:
+    """(n_parameters, 3) float64 {scale, clip, sgd_learning_rate} on the device, refreshed through
+    a ring of pinned host buffers only when a value changes."""
+
+    def __init__(self, n, device, slots=8):
+        self.dev = torch.zeros((n, 3), dtype=torch.float64, device=device)
+        self._host = [torch.zeros((n, 3), dtype=torch.float64).pin_memory() for _ in range(slots)]
+        self._events = [None] * slots
+        self._at = 0
+        self._current = None
+
+    def set(self, rows):
+        if rows == self._current:
+            return
+        k = self._at
+        self._at = (k + 1) % len(self._host)
+        if self._events[k] is not None:
+            self._events[k].synchronize()     # the copy that last used this buffer is long done
+        self._host[k].copy_(torch.tensor(rows, dtype=torch.float64))
+        self.dev.copy_(self._host[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev.device))
+        self._events[k] = ev
+        self._current = rows
+
+
+class FusedStep:
+    """Runs ``SGD_Optimizer.single_step`` for a ``GoalError`` as a fixed launch sequence; see the
+    module docstring.  One instance per optimizer."""
+
+    def __init__(self, optimizer, graph="auto", graph_warmup=3):
+        self.opt = optimizer
+        self.graph_mode = graph           # "auto" / True: capture after the warm-up; False: never
+        self.graph_warmup = int(graph_warmup)
+        self._state = None                # persistent buffers of the current signature
+        self._graphs = None               # (signature, graph A, graph B or None)
+        self._eager_steps = 0
+        self.tests_total = None           # device int64: ray-face tests of all fused steps
+        self.steps = 0
+        self.graph_replays = 0
+        self.capture_error = None
+        self.untapped = False             # a parameter reached the faces without boundaries.tap
+
+    # ------------------------------------------------------------------------ eligibility
+    @staticmethod
+    def eligible(optimizer, args, kwargs):
+        eng = optimizer.engine
+        if not isinstance(optimizer.error_function, GoalError) or args or kwargs:
+            return False
+        if eng.dimension != 3 or not bool(eng.optical_system):
+            return False
+        if optimizer.apply_momentum and optimizer.momentum > 0.0:
+            return False
+        try:
+            eng._reaction()
+        except RuntimeError:
+            return False
+        return all(isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float64
+                   and p.is_contiguous() for p in optimizer.parameters)
+
+    # -------------------------------------------------------------------------- buffers
+    def _buffers(self, block, fv, P, flags, dt):
+        """Persistent outputs / tape / seeds of the trace for this (N, M, P, dtype, flags)."""
+        N, M = block.shape[1], fv.shape[0]
+        sig = (N, M, P, dt, flags, str(block.device))
+        st = self._state
+        if st is not None and st["sig"] == sig:
+            return st
+        dev = block.device
+        L = _lib.lib()
+        wsb = L.tfrt_trace3d_workspace_bytes(N, M, P, dt)
+        capN = max(N, 1)
+        ints = ops._IntPool(dev, True, _lib.COUNTS_PER_PASS * (P + 1), flags, capN, P)
+        caps = {"finished": capN, "active": capN * max(P, 1), "stopped": capN, "dead": capN}
+        full, aux, outs = {}, {"counts": ints.counts}, {}
+        for name, flag in _CLASS_FLAGS:
+            if flags & flag:
+                rays = torch.empty((6, caps[name]), dtype=block.dtype, device=dev)
+                ids, faces = ints.take(caps[name]), ints.take(caps[name])
+                full[name], aux[name + "_id"], aux[name + "_face"] = rays, ids, faces
+                outs[name] = ops._ray_out(rays, ids, faces)
+            else:
+                aux[name + "_id"] = aux[name + "_face"] = None
+                outs[name] = ops._ray_out(None, None, None)
+        aux["unfinished"] = torch.empty((6, capN), dtype=block.dtype, device=dev)
+        aux["unfinished_id"] = ints.take(capN)
+        gws = L.tfrt_goal_error3d_workspace_bytes(capN)
+        st = dict(
+            sig=sig, N=N, M=M, P=P, dt=dt, flags=flags, capN=capN, full=full, aux=aux, outs=outs,
+            ws=torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev), wsb=wsb,
+            counts=ints.counts, ints=ints,
+            g_fin=torch.zeros((6, capN), dtype=torch.float64, device=dev),
+            g_fv=torch.zeros((max(M, 1), 9), dtype=torch.float64, device=dev),
+            err=torch.zeros(3, dtype=torch.float64, device=dev),
+            goal_ws=torch.zeros(max(gws, 1), dtype=torch.uint8, device=dev), gws=gws,
+            fields=(ctypes.c_int32 * 6)(*(self.opt.error_function.rows + [0] * 6)[:6]),
+        )
+        self._state = st
+        self._graphs = None
+        if self.tests_total is None or self.tests_total.device != dev:
+            self.tests_total = torch.zeros(1, dtype=torch.int64, device=dev)
+        return st
+
+    # ---------------------------------------------------------------- the launch sequence
+    def _enqueue_gradient(self):
+        """update -> trace -> error -> reverse sweep -> parameter gradients.  Returns
+        (grads, error tensor {sum, terms, mean}).  Nothing here waits for the device."""
+        opt, eng = self.opt, self.opt.engine
+        system = eng.optical_system
+        eng.clear_ray_history()
+        for p in opt.parameters:
+            p.__dict__["_tfrt_taps"] = []
+        system.update()
+        src = eng._source_set()
+        if not src:
+            raise RuntimeError("FusedStep: the optical system has no source rays")
+        erf = opt.error_function
+        goal = erf.table(src)
+        block, scene, fv = eng._trace_inputs(src)
+        P, flags = int(opt.trace_depth), eng._flags() | _lib.COMPILE_FINISHED
+        dt = ops._DT[block.dtype]
+        fvc = fv.detach()
+        if fvc.dtype != torch.float64 or not fvc.is_contiguous():
+            raise RuntimeError("FusedStep: merged faces must be contiguous float64")
+        st = self._buffers(block, fvc, P, flags, dt)
+        L = _lib.lib()
+        stream = ops._stream(block)
+        sc = scene.struct(fvc)
+        o = st["outs"]
+        check(L.tfrt_trace3d_forward(
+            ops._p(block), block.shape[1], st["N"], ctypes.byref(sc), float(eng.new_ray_length),
+            float(eng.dead_ray_length or 0.0), P, dt, flags, ctypes.byref(o["finished"]),
+            ctypes.byref(o["active"]), ctypes.byref(o["stopped"]), ctypes.byref(o["dead"]),
+            ops._p(st["aux"]["unfinished"]), ops._p(st["aux"]["unfinished_id"]),
+            ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream), "tfrt_trace3d_forward")
+        fin = st["full"]["finished"]
+        n_fin_ptr = ctypes.c_void_p(st["counts"].data_ptr() + 4 * (P * _lib.COUNTS_PER_PASS + 1))
+        check(L.tfrt_goal_error3d(
+            ops._p(fin), st["capN"], ops._p(st["aux"]["finished_id"]), dt, n_fin_ptr,
+            st["fields"], len(erf.rows), ops._p(goal), goal.shape[1], ops._p(st["g_fin"]),
+            ops._p(st["err"]), ops._p(st["goal_ws"]), st["gws"], stream), "tfrt_goal_error3d")
+        # running total of ray-face tests (uint64 split over two int32 counters), for reporting
+        tail = st["counts"][P * _lib.COUNTS_PER_PASS + 4:P * _lib.COUNTS_PER_PASS + 6]
+        self.tests_total.add_(tail.view(torch.int64))
+        grads = [None] * len(opt.parameters)
+        if fv.requires_grad and st["M"] > 0:
+            st["g_fv"].zero_()
+            check(L.tfrt_trace3d_backward(
+                ops._p(block), block.shape[1], st["N"], ctypes.byref(sc),
+                float(eng.new_ray_length), float(eng.dead_ray_length or 0.0), P, dt,
+                ops._p(st["g_fin"]), st["capN"], None, 0, None, 0, None, 0, ops._p(st["g_fv"]),
+                None, ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream),
+                "tfrt_trace3d_backward")
+            # differentiate w.r.t. the aliases update() read the parameters through (see
+            # boundaries.tap), not w.r.t. the leaves; a parameter nobody tapped falls back to the
+            # leaf, which is correct but must not be captured in a graph
+            inputs, owner = [], []
+            for i, p in enumerate(opt.parameters):
+                taps = p.__dict__.get("_tfrt_taps") or [p]
+                if taps[0] is p:
+                    self.untapped = True
+                inputs.extend(taps)
+                owner.extend([i] * len(taps))
+            with torch.autograd.set_multithreading_enabled(False):
+                got = torch.autograd.grad([fv], inputs, grad_outputs=[st["g_fv"]],
+                                          allow_unused=True)
+            for i, g in zip(owner, got):
+                if g is not None:
+                    grads[i] = g if grads[i] is None else grads[i] + g
+        self._publish_lazily(st, src, P, flags)
+        return grads, st["err"]
+
+    def _publish_lazily(self, st, src, P, flags):
+        eng = self.opt.engine
+        eng._trace_src = src
+        eng._trace_sig = (src["x_start"].shape[0], P, flags)
+        full, aux = st["full"], st["aux"]
+        eng._pending_trace = lambda: ops._finish_trace(dict(full), dict(aux), P, None)
+
+    def _enqueue_apply(self, grads, accumulators):
+        """non-finite -> 0, scale, clip, accumulate, SGD apply (optimizer.py:223-257, 316) with
+        the step-dependent scalars read from the device table."""
+        opt = self.opt
+        L = _lib.lib()
+        for i, (g, p) in enumerate(zip(grads, opt.parameters)):
+            hyper = ctypes.c_void_p(self._hyper.dev.data_ptr() + 24 * i)
+            stream = ops._stream(p)
+            with torch.no_grad():
+                if accumulators[i] is None:
+                    check(L.tfrt_sgd_process_dev(ops._p(g), None, ops._p(p), g.numel(), _lib.F64,
+                                                 hyper, stream), "tfrt_sgd_process_dev")
+                else:
+                    processed = torch.empty_like(g)
+                    check(L.tfrt_sgd_process_dev(ops._p(g), ops._p(processed), None, g.numel(),
+                                                 _lib.F64, hyper, stream), "tfrt_sgd_process_dev")
+                    acc = opt._matrix_product(opt._acc_cache, i, accumulators[i], processed)
+                    apply_row = ctypes.c_void_p(self._hyper_apply.dev.data_ptr() + 24 * i)
+                    check(L.tfrt_sgd_process_dev(ops._p(acc.contiguous()), None, ops._p(p),
+                                                 acc.numel(), _lib.F64, apply_row, stream),
+                          "tfrt_sgd_process_dev")
+
+    def _fix_grads(self, grads):
+        opt = self.opt
+        out = []
+        for g, p in zip(grads, opt.parameters):
+            if g is None:
+                if not opt.suppress_warnings:
+                    print("Warning: SGD_Optimizer.process_gradient encountered a possible issue:  "
+                          "The gradient was likely None, which can mean that the error does not "
+                          "depend on it.  The gradient will be set to zero and future instances "
+                          "of this message will be suppressed.")
+                    opt.suppress_warnings = True
+                g = torch.zeros_like(p)
+            out.append(g.contiguous())
+        return out
+
+    def _sequence(self, accumulators, world):
+        """The whole step; with several ranks the collective sits between the two halves."""
+        grads, err = self._enqueue_gradient()
+        grads = self._fix_grads(grads)
+        if world > 1:
+            self._flat = torch.cat([g.reshape(-1) for g in grads] + [err[:2]])
+            return grads
+        self._enqueue_apply(grads, accumulators)
+        self._err_view = err
+        return grads
+
+    def _after_reduce(self, grads, accumulators):
+        flat, o, red = self._flat, 0, []
+        for g in grads:
+            red.append(flat[o:o + g.numel()].reshape(g.shape))
+            o += g.numel()
+        self._enqueue_apply(red, accumulators)
+        mean = flat[o] / torch.clamp(flat[o + 1], min=1.0)
+        self._err_view = torch.stack([flat[o], flat[o + 1], mean])
+
+    # ------------------------------------------------------------------------------ step
+    def _hyper_rows(self, lr_scale):
+        opt = self.opt
+        rows, apply_rows = [], []
+        for i in range(len(opt.parameters)):
+            scale = float(lr_scale * opt.individual_lr[i] * opt.learning_rate)
+            clip = float(opt.grad_clip if opt.clip_mode == "common" else
+                         opt.individual_lr[i] * opt.clip_scale * opt.learning_rate * lr_scale)
+            rows.append((scale, clip, float(opt.sgd_learning_rate)))
+            apply_rows.append((1.0, float("inf"), float(opt.sgd_learning_rate)))
+        return tuple(rows), tuple(apply_rows)
+
+    def _signature(self, accumulators):
+        """Everything a captured graph has baked in and the caller could have changed."""
+        opt, eng = self.opt, self.opt.engine
+        src = eng.optical_system._amalgamated_sources
+        return (tuple(id(a) for a in accumulators), tuple(p.data_ptr() for p in opt.parameters),
+                tuple(id(src[f]) for f in _GEO3) if src else (), int(opt.trace_depth),
+                eng._flags(), eng.new_ray_length, eng.dead_ray_length, eng._trace_mode(),
+                id(opt.error_function.goal), opt.error_function.fields, tdist.world_size())
+
+    def step(self, accumulators, lr_scale):
+        """One optimiser step.  Returns the error tensor {sum, n_terms, mean} (device)."""
+        opt = self.opt
+        dev = opt.parameters[0].device
+        world = tdist.world_size() if tdist.is_distributed() else 1
+        if getattr(self, "_hyper", None) is None:
+            self._hyper = _HyperTable(len(opt.parameters), dev)
+            self._hyper_apply = _HyperTable(len(opt.parameters), dev)
+        rows, apply_rows = self._hyper_rows(lr_scale)
+        self._hyper.set(rows)
+        self._hyper_apply.set(apply_rows)
+        self.steps += 1
+
+        sig = self._signature(accumulators)
+        want_graph = self.graph_mode in ("auto", True) and self.capture_error is None
+        if want_graph and self._graphs is not None and self._graphs[0] == sig:
+            return self._replay()
+        if (want_graph and self._eager_steps >= self.graph_warmup and self._stable(sig)
+                and not self.untapped):
+            try:
+                return self._capture(sig, accumulators, world)
+            except Exception as e:  # capture is an optimisation: fall back to the eager sequence
+                self.capture_error = e
+                self._graphs = None
+                torch.cuda.synchronize()
+        self._eager(accumulators, world)
+        self._eager_steps += 1
+        self._last_sig = sig
+        return self._err_view
+
+    def _eager(self, accumulators, world):
+        grads = self._sequence(accumulators, world)
+        if world > 1:
+            torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
+            self._after_reduce(grads, accumulators)
+
+    def _replay(self):
+        _, ga, gb, _grads = self._graphs
+        ga.replay()
+        if gb is not None:
+            torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
+            gb.replay()
+        self.graph_replays += 1
+        self._republish()
+        return self._err_view
+
+    def _stable(self, sig):
+        return getattr(self, "_last_sig", None) == sig
+
+    def _republish(self):
+        st = self._state
+        eng = self.opt.engine
+        eng.clear_ray_history()
+        self._publish_lazily(st, eng._trace_src, st["P"], st["flags"])
+
+    def _capture(self, sig, accumulators, world):
+        """Run THIS step eagerly on the capture stream, then capture the sequence there (capturing
+        executes nothing).  The eager run on that stream matters: autograd remembers the stream
+        on which a leaf's gradient accumulator was created; accumulators left over from steps on
+        the caller's stream would make the backward inside the capture fork to that stream, and
+        ending the capture then crashes inside the HIP runtime."""
+        dev = self.opt.parameters[0].device
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream(dev)
+        side, cur = self._stream, torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._eager(accumulators, world)
+            err_now = self._err_view.clone()
+        cur.wait_stream(side)
+        self._last_sig = sig
+        torch.cuda.synchronize(dev)
+        pool = torch.cuda.graph_pool_handle()
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga, pool=pool, stream=side):
+            grads = self._sequence(accumulators, world)
+        gb = None
+        if world > 1:
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=pool, stream=side):
+                self._after_reduce(grads, accumulators)
+        self._graphs = (sig, ga, gb, grads)
+        self._republish()
+        return err_now

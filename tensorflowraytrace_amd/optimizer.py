@@ -20,6 +20,7 @@ import torch
 
 from . import distributed as tdist
 from . import ops
+from .fused_step import FusedStep, GoalError  # noqa: F401  (GoalError is public API)
 
 
 class DeferredScalar:
@@ -113,7 +114,8 @@ class DeferredScalar:
 class SGD_Optimizer:
     def __init__(self, engine, parameters, error_function, trace_depth, momentum=0.0,
                  learning_rate=1.0, individual_lr=None, grad_clip="default", clip_mode="common",
-                 clip_scale=10.0, sgd_learning_rate=0.01, apply_momentum=False, speculative=True):
+                 clip_scale=10.0, sgd_learning_rate=0.01, apply_momentum=False, speculative=True,
+                 fused="auto", graph="auto"):
         self.engine = engine
         if type(parameters) is list or type(parameters) is tuple:
             self.parameters = parameters
@@ -142,6 +144,13 @@ class SGD_Optimizer:
         self.iterations = 0
         self.last_error_terms = 0
         self._acc_cache = {}
+        # ``fused``: run a step whose error function is a ``GoalError`` as one fixed launch
+        # sequence (fused_step.FusedStep: no host read of the ray counts, built-in error and seed
+        # kernel); ``graph``: replay that sequence from a captured HIP graph after a few steps.
+        # "auto" = whenever possible; False = always the generic path.
+        self.fused = fused
+        self.graph = graph
+        self._fused_step = None
 
     @property
     def momentum(self):
@@ -328,6 +337,16 @@ class SGD_Optimizer:
         """optimizer.py:284-320."""
         self.momentum = momentum
         accumulators = self.convert_to_plist(accumulators)
+        if self.fused in ("auto", True) and FusedStep.eligible(self, args, kwargs):
+            if self._fused_step is None:
+                self._fused_step = FusedStep(self, graph=self.graph)
+            err3 = self._fused_step.step(accumulators, lr_scale)   # {sum, n_terms, mean}, device
+            self.iterations += 1
+            self.last_error_terms = err3[1]
+            err = DeferredScalar(err3[2].clone())
+            if verbose:
+                print(f"step {self.iterations} error: {err}")
+            return err
         grads, error, applied = self._process(accumulators, args, kwargs, lr_scale, apply=True)
         self.apply_gradients(grads, skip=applied)
         self.iterations += 1

@@ -455,3 +455,35 @@ def test_negative_ray_start_epsilon_keeps_hits_just_behind_the_start():
     for cls in ("finished", "active", "stopped", "dead"):
         assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
         assert torch.equal(out[cls], ref[cls]), cls
+
+
+def test_non_finite_ray_gradient_poisons_the_same_entries_as_in_the_oracle():
+    """optimizer.py:226-229 zeroes non-finite entries of the SUMMED parameter gradient: one ray
+    with a NaN gradient must therefore poison every parameter it touches (and only those) -- the
+    reverse sweep lets NaN through its sums instead of dropping the ray.  A NaN weight on one
+    finished ray's error term stands in for a degenerate ray."""
+    from tensorflowraytrace_amd import ops
+    scene = scene_util.lens_scene(600, k_front=3, k_back=3)
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, torch.float64)
+    out = ops.trace3d(src, fv, sc, max_passes=4)
+    fin, ids = out["finished"], out["finished_id"].long()
+    assert fin.shape[1] > 400
+    weight = torch.ones(600, dtype=torch.float64)
+    weight[ids[37].item()] = float("nan")
+    loss = (weight.to(fin.device)[ids] * (fin[4] ** 2 + fin[5] ** 2)).sum()
+    g_f, g_b = torch.autograd.grad(loss, [p_f, p_b])
+
+    system, (q_f, q_b), _ = oracle_util.lens_oracle(scene)
+    ref = tracer.ray_trace(system, oracle_util.source_dict(scene["rays"], scene["wavelength"]),
+                           max_iterations=4, inherit=("wavelength", "ray_id"))
+    rf = ref["finished"]
+    r_loss = (weight[rf["ray_id"].long()] * (rf["y_end"] ** 2 + rf["z_end"] ** 2)).sum()
+    r_f, r_b = torch.autograd.grad(r_loss, [q_f, q_b])
+    for g, r in ((g_f.cpu(), r_f), (g_b.cpu(), r_b)):
+        bad = ~torch.isfinite(r)
+        assert 0 < int(bad.sum()) <= 6                         # the vertices of the faces that ray hit
+        assert torch.equal(~torch.isfinite(g), bad)
+        assert float((g[~bad] - r[~bad]).abs().max()) <= 1e-8 * float(r[~bad].abs().max())
+    # the optimiser's processing then zeroes exactly those entries (tfrt_sgd_process)
+    done = ops.sgd_process(g_f, 1.0, 1e30)
+    assert bool(torch.isfinite(done).all()) and bool((done.cpu()[~torch.isfinite(r_f)] == 0).all())
