@@ -12,9 +12,13 @@ Synthetic, deterministic inputs (golden-spiral source points).
 Metric: ray-surface intersection tests/s (fwd+bwd), tests = sum over passes of
 N_active(pass) x M_merged (counted by the kernels).  With N GPUs the source rays are sharded
 contiguously over the ranks and the per-step parameter gradients are summed with one RCCL
-all-reduce.  Default is weak scaling: every GPU traces 1M rays of a global source of N x 1M
-(value = tests of all ranks / max-over-ranks time); the line also carries `strong_scaling`, the
-N=1 workload itself split over the ranks (`--scaling strong` makes that the headline).
+all-reduce.  Default is STRONG scaling (BASELINE configs[3]: the same 1M rays split over the
+ranks; value = tests of all ranks / max-over-ranks time); `--scaling weak` gives every GPU 1M rays
+and is also reported as a side field.
+
+The step runs as the fused launch sequence of tensorflowraytrace_amd/fused_step.py (error function
+stated as a GoalError, captured in a HIP graph); `--step-mode generic` times the same step with the
+error function as arbitrary torch code instead.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rays R] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -35,6 +39,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+VALU_SIMDS = 1024          # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9
+CYCLES_PER_WAVE_OP = 2.0   # MI355X_MICROARCH.md: v_fma_f32 (wave64) throughput, SIMD-32
 PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak (6290 measured copy)
 FLOPS_PER_TEST = 45        # SURVEY.md section 8d algorithmic cost model (Moeller-Trumbore)
 BYTES_PER_RAY_FWD = 64     # 32 B read + 32 B written per active ray per pass
@@ -90,17 +97,25 @@ def build_scene(n_rays, k_front, k_back, ray_dtype, accelerate="auto"):
     return eng, system, [front.parameters, back.parameters]
 
 
-def error_function(engine):
-    """Image-forming error of dev/hexalens.py:154-168 (inner goal, magnification 1)."""
-    fin = engine.finished_rays
-    out = torch.stack([fin["y_end"], fin["z_end"]], dim=1).double()
-    goal = -fin["object_coords"][:, 1:]
-    return (out - goal) ** 2
+def goal(src):
+    """Image-forming goal of dev/hexalens.py:154-157 (inner goal, magnification 1): the image
+    point of a ray's object point, one row per source ray."""
+    return -src["object_coords"][:, 1:]
+
+
+def make_error_function():
+    """error = squared_difference(stack(finished y_end, z_end), goal) (dev/hexalens.py:144-168),
+    stated as a GoalError so the optimiser can run the step as one fixed launch sequence; it is
+    also an ordinary error_function(engine) (``--generic-step`` times that path)."""
+    import tfrt.optimizer as optimizer
+    return optimizer.GoalError(("y_end", "z_end"), goal)
 
 
 def cpu_baseline(seconds_budget=20.0):
     """The reference algorithm restated (oracle: dense (M,N) float64 torch ops, forward +
-    autograd) on the host cores, on a bounded sample of the same scene."""
+    autograd) on the host cores, on a bounded sample of the same scene: consecutive 256-ray chunks
+    of the source (each chunk a forward + backward of its own: the gradient is a sum over rays,
+    and autograd keeps ~100 dense (10574 x chunk) float64 temporaries alive per chunk)."""
     import scene_util
     import oracle_util
     from oracle import tracer
@@ -110,32 +125,56 @@ def cpu_baseline(seconds_budget=20.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, 16))  # a one-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
-    n = 256
-    scene = scene_util.lens_scene(n, k_front=41, k_back=9)
-    t0 = time.time()
+    # 256-ray chunks: a dense (10574 x 256) float64 temporary is 21.6 MB, below glibc's 32 MB mmap
+    # threshold ceiling, so freed temporaries are reused instead of being unmapped and
+    # page-faulted in again on every one of the ~125 dense ops (4-20x slower at 512 rays)
+    chunk, warm_chunks = 256, 2
+    scene = scene_util.lens_scene(65_536, k_front=41, k_back=9)
     tests = 0
-    reps = 0
-    while True:
+    rays_done = 0
+    t0 = None
+    k = 0
+    while (k + 1) * chunk <= scene["rays"].shape[1]:
+        if k == warm_chunks:
+            t0 = time.time()          # the first chunks pay first-touch page faults: not timed
+        lo, hi = k * chunk, (k + 1) * chunk
+        k += 1
         system, (p_f, p_b), _ = oracle_util.lens_oracle(scene)
-        ref = tracer.ray_trace(system, oracle_util.source_dict(scene["rays"], scene["wavelength"]),
-                               max_iterations=3, inherit=("wavelength", "ray_id"), chunk=256)
+        ref = tracer.ray_trace(
+            system, oracle_util.source_dict(scene["rays"][:, lo:hi], scene["wavelength"][lo:hi]),
+            max_iterations=3, inherit=("wavelength", "ray_id"), chunk=chunk)
         fin = ref["finished"]
-        goal = torch.tensor(scene["goal"], dtype=torch.float64)[fin["ray_id"].long()]
+        goal = torch.tensor(scene["goal"][lo:hi], dtype=torch.float64)[fin["ray_id"].long()]
         err = ((fin["y_end"] - goal[:, 0]) ** 2 + (fin["z_end"] - goal[:, 1]) ** 2).sum()
         torch.autograd.grad(err, [p_f, p_b])
+        if t0 is None:
+            continue
         m = system.merged["xp"].shape[0]
-        n_act = n + sum(int(h["x_start"].shape[0]) for h in [ref["active"]] if h)
+        n_act = chunk + (int(ref["active"]["x_start"].shape[0]) if ref["active"] else 0)
         tests += n_act * m
-        reps += 1
+        rays_done += chunk
         if time.time() - t0 > seconds_budget:
             break
     dt = time.time() - t0
     return {
         "value": tests / dt, "unit": "tests/s", "cores": cores, "kind": "port",
-        "sample": f"{reps} x (fwd + autograd) of the oracle (torch-CPU float64, dense (M,N) "
-                  f"temporaries, 256-ray chunks) on {n} rays x 10574 faces, 3 passes; "
-                  f"{dt:.1f} s wall",
+        "sample": f"{rays_done} consecutive source rays (of a 65,536-ray instance of the same "
+                  f"scene) x 10574 faces, 3 passes, forward + autograd of the oracle (torch-CPU "
+                  f"float64, dense (M,N) temporaries) in {chunk}-ray chunks after {warm_chunks} "
+                  f"untimed warm-up chunks; {dt:.1f} s wall",
     }
+
+
+def _source_hash():
+    """Hash of the kernel sources: profiles/*.json record it, so PMC-derived numbers are only
+    reported for the kernels they were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "tensorflowraytrace_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -144,24 +183,27 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=1_000_000,
-                    help="rays per GPU (weak scaling) or in total (strong scaling)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: every GPU traces --rays rays of a global source of rays x N; "
-                         "strong: --rays rays are split over the GPUs")
+                    help="rays in total (strong scaling) or per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong: --rays rays are split over the GPUs (BASELINE configs[3]); "
+                         "weak: every GPU traces --rays rays of a global source of rays x N")
     ap.add_argument("--k-front", type=int, default=41)
     ap.add_argument("--k-back", type=int, default=9)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--step-mode", choices=["graph", "fused", "generic"], default="graph",
+                    help="graph: fused launch sequence replayed from a HIP graph (default); fused: "
+                         "the same sequence launched eagerly; generic: error function as arbitrary "
+                         "torch code through autograd (reads the ray counts back every step)")
     ap.add_argument("--trace-mode", choices=["auto", "all-pairs", "group", "sort"], default="auto",
                     help="how ray-face pairs are culled before the exact float64 test (results "
                          "are identical in every mode): all-pairs = float32 bounding-sphere "
                          "filter on every pair; group = two/three-level sphere hierarchy over "
                          "k-d face clusters; sort = clusters + Morton-sorted rays; auto = the "
                          "engine's default (group)")
-    ap.add_argument("--accelerate", action="store_true", help="alias of --trace-mode sort")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
-                    help="skip the separately reported legs that time the other trace modes")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+                    help="skip the separately reported legs (all-pairs mode, float64 state, ...)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -176,10 +218,6 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device((local % torch.cuda.device_count()) if world > 1 else 0)
     tfa.set_device(f"cuda:{torch.cuda.current_device()}")
-    ray_dtype = torch.float32 if args.dtype == "f32" else torch.float64
-
-    if args.accelerate:
-        args.trace_mode = "sort"
     lib = _lib.lib()
 
     def barrier():
@@ -188,32 +226,42 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed_leg(global_rays, trace_mode, profile):
+    def timed_leg(global_rays, trace_mode, step_mode, dtype, profile=False):
         """Build the scene with `global_rays` source rays (each rank traces its contiguous
-        shard), run warmup + exactly `steps` optimiser steps between barriers and return
-        (max-over-ranks seconds, tests summed over ranks, engine, faces, mode, launch ms)."""
+        shard), run warmup + exactly `steps` optimiser steps between barriers.  Returns a dict:
+        seconds (max over ranks), tests (sum over ranks), per-launch ms of the dominant kernel
+        (only with `profile`, which needs eagerly launched kernels), pass counts, faces, mode."""
+        ray_dtype = torch.float32 if dtype == "f32" else torch.float64
         eng, system, params = build_scene(global_rays, args.k_front, args.k_back, ray_dtype,
                                           accelerate=trace_mode)
-        opt = optimizer.SGD_Optimizer(eng, params, error_function, trace_depth=3,
-                                      learning_rate=1e-6, grad_clip=1e-3)
+        opt = optimizer.SGD_Optimizer(
+            eng, params, make_error_function(), trace_depth=3, learning_rate=1e-6, grad_clip=1e-3,
+            fused=False if step_mode == "generic" else "auto",
+            graph="auto" if step_mode == "graph" else False)
         opt.suppress_warnings = True
         for _ in range(args.warmup):
             opt.single_step(None)
+        fs = opt._fused_step
         barrier()
         if profile:
             lib.tfrt_profile_enable(1)
+        tests0 = int(fs.tests_total.item()) if fs is not None else 0
         tests_local = 0
+        barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             opt.single_step(None)
-            tests_local += eng.last_trace["n_tests"]
+            if fs is None:
+                tests_local += eng.last_trace["n_tests"]
         barrier()
         dt = time.perf_counter() - t0
+        if fs is not None:
+            tests_local = int(fs.tests_total.item()) - tests0
         kernel_ms = []
         if profile:
             import ctypes
-            buf = (ctypes.c_float * 4096)()
-            nrec = lib.tfrt_profile_read(buf, 4096)
+            buf = (ctypes.c_float * 8192)()
+            nrec = lib.tfrt_profile_read(buf, 8192)
             lib.tfrt_profile_enable(0)
             kernel_ms = [buf[i] for i in range(max(nrec, 0))]
         tests_total = float(tests_local)
@@ -224,68 +272,106 @@ def main():
             tsum = stats[1:].clone()
             torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
             dt, tests_total = float(tmax.item()), float(tsum.item())
-        return dt, tests_total, eng, int(system._merged_face_verts.shape[0]), \
-            eng._trace_mode(system), kernel_ms
-
-    # weak scaling (default): every GPU traces `--rays` rays, the global source has rays x N;
-    # strong: the same `--rays` rays are split over the GPUs
-    global_rays = args.rays * world if args.scaling == "weak" else args.rays
-    dt, tests_total, eng, M, mode, kernel_ms = timed_leg(global_rays, args.trace_mode, True)
-    counts = eng.last_trace["counts"]
-    del eng
-    strong = None
-    if world > 1 and args.scaling == "weak" and not args.no_extra_legs:
-        # separately reported (never `value`): the N=1 workload itself split over the ranks
+        out = dict(dt=dt, tests=tests_total, kernel_ms=kernel_ms,
+                   counts=eng.last_trace["counts"], M=int(system._merged_face_verts.shape[0]),
+                   mode=eng._trace_mode(system),
+                   graph_replays=fs.graph_replays if fs is not None else 0,
+                   capture_error=repr(fs.capture_error) if fs is not None and fs.capture_error
+                   else None)
+        del eng, system, params, opt
         torch.cuda.empty_cache()
-        dts, tests_s, eng_s, _, _, _ = timed_leg(args.rays, args.trace_mode, False)
-        del eng_s
-        strong = {"global_rays": args.rays, "ms_per_step": dts / args.steps * 1e3,
-                  "tests_per_s": tests_s / dts,
-                  "note": "the N=1 workload split over the ranks; the step is host-bound below "
-                          "~250k rays per rank (DESIGN.md section 6)"}
+        return out
+
+    per_rank = args.scaling == "weak"
+    global_rays = args.rays * world if per_rank else args.rays
+    main_leg = timed_leg(global_rays, args.trace_mode, args.step_mode, args.dtype)
+    side = {}
+    if world > 1 and not args.no_extra_legs:
+        # the other scaling convention, separately reported (never `value`)
+        other_rays = args.rays if per_rank else args.rays * world
+        leg = timed_leg(other_rays, args.trace_mode, args.step_mode, args.dtype)
+        side["weak_scaling" if not per_rank else "strong_scaling"] = {
+            "global_rays": other_rays, "ms_per_step": leg["dt"] / args.steps * 1e3,
+            "tests_per_s": leg["tests"] / leg["dt"]}
+    # per-launch time of the dominant kernel, HIP events on the launch stream: needs eagerly
+    # launched kernels (events cannot sit inside a replayed graph), so the same step is run
+    # `steps` more times as the eager fused sequence -- same kernels, same launches, same data
+    prof_leg = None
+    if world == 1:
+        prof_leg = timed_leg(global_rays, args.trace_mode,
+                             "generic" if args.step_mode == "generic" else "fused", args.dtype,
+                             profile=True)
 
     if rank != 0:
         return
 
+    M, mode, counts = main_leg["M"], main_leg["mode"], main_leg["counts"]
     n_active = [int(c[:4].sum()) for c in counts]          # rays entering each pass (rank 0)
-    launches = len(kernel_ms)
-    avg_ms = float(np.mean(kernel_ms)) if launches else float("nan")
-    tests_per_launch = float(np.mean([n * M for n in n_active])) if n_active else 0.0
-    alg_flops = tests_per_launch * FLOPS_PER_TEST
-    alg_bytes = float(np.mean(n_active)) * BYTES_PER_RAY_FWD + M * BYTES_PER_FACE
-    achieved_tf = alg_flops / (avg_ms * 1e-3) / 1e12 if launches else float("nan")
     kernel_name = {"all-pairs": "tfrt::k_intersect3d", "group": "tfrt::k_intersect_group",
                    "sort": "tfrt::k_intersect_cull"}[mode]
-    executed = {"all-pairs": 8.75, "group": 0.71, "sort": None}[mode]
-    roofline = {
-        "kernel": kernel_name,
-        "bound": "valu",
-        "achieved": achieved_tf, "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved_tf / PEAK_VALU_TFLOPS,
-        "avg_launch_ms": avg_ms, "launches_timed": launches,
-        "tests_per_launch": tests_per_launch,
-        "model": "SURVEY.md 8d: 45 flop per ray-face pair (Moeller-Trumbore) x pairs decided per "
-                 "launch / launch time.  The kernel decides pairs through conservative float32 "
-                 "bounding-sphere tests (a hierarchy over face clusters in the default mode) and "
-                 "runs the exact float64 test on the survivors only, so this algorithmic rate "
-                 "exceeds the VALU peak; executed_valu_ops_per_test and valu_issue_utilisation "
-                 "(PMC, profiles/) describe the executed work",
-        "executed_valu_ops_per_test": executed,
-        "valu_issue_utilisation": {"all-pairs": 0.84, "group": 0.54, "sort": None}[mode],
-        "hbm_achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else float("nan"),
-        "hbm_frac": (alg_bytes / (avg_ms * 1e-3) / 1e9) / PEAK_HBM_GBPS if launches else float("nan"),
-        "traffic": None,
-    }
-    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
-    # of the same kernel on the same workload, committed under profiles/
-    tpath = os.path.join(ROOT, "profiles", {"all-pairs": "r01_traffic.json",
-                                             "group": "r01_traffic_group.json"}.get(mode, "none"))
-    if (os.path.exists(tpath) and args.rays == 1_000_000 and args.gpus == 1
-            and args.k_front == 41):
-        tj = json.load(open(tpath))
-        roofline["traffic"] = (tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0
-        roofline["traffic_unit"] = "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, uncorrected)"
-        roofline["traffic_source"] = os.path.relpath(tpath, ROOT)
+    roofline = {"kernel": kernel_name, "bound": "valu"}
+    if prof_leg is not None and prof_leg["kernel_ms"]:
+        P = len(n_active)
+        ms = np.asarray(prof_leg["kernel_ms"], dtype=np.float64)
+        ms = ms[:len(ms) // P * P].reshape(-1, P)
+        per_pass_ms = ms.mean(axis=0)
+        avg_ms = float(ms.mean())
+        tests_per_launch = float(np.mean([n * M for n in n_active]))
+        alg_bytes = float(np.mean(n_active)) * BYTES_PER_RAY_FWD + M * BYTES_PER_FACE
+        roofline.update({
+            "avg_launch_ms": avg_ms, "per_pass_launch_ms": [float(x) for x in per_pass_ms],
+            "launches_timed": int(ms.size),
+            "timed_by": "HIP events on the launch stream (tfrt_profile_*), eager fused sequence "
+                        "run after the timed region with the same steps",
+            "tests_per_launch": tests_per_launch,
+            # SURVEY.md 8d cost model, kept as a separately named field: pairs DECIDED x 45 flop.
+            # The kernel decides pairs through conservative sphere tests, so this is not a
+            # utilisation of anything (it exceeds the VALU peak)
+            "algorithmic_tflops": tests_per_launch * FLOPS_PER_TEST / (avg_ms * 1e-3) / 1e12,
+            "hbm": {
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9,
+                "peak_GBps": PEAK_HBM_GBPS,
+                "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            },
+        })
+        # executed work: VALU wave-instructions per launch from separate rocprofv3 --pmc passes of
+        # the same kernel on the same workload (profiles/, scratch/collect_profiles.sh), combined
+        # with the launch time measured live above
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % mode.replace("-", "_"))
+        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
+        same_workload = (args.rays == 1_000_000 and args.gpus == 1 and args.k_front == 41
+                         and args.k_back == 9 and args.dtype == "f32")
+        if pmc is not None and same_workload and pmc.get("source_hash") == _source_hash():
+            valu = float(np.mean([p["SQ_INSTS_VALU"] for p in pmc["passes"]]))
+            issue_rate = valu / (avg_ms * 1e-3)                     # wave-instructions / s
+            peak = VALU_SIMDS * CLOCK_HZ / CYCLES_PER_WAVE_OP
+            fetch = float(np.mean([p["FETCH_SIZE_KB"] for p in pmc["passes"]])) * 1024.0
+            write = float(np.mean([p["WRITE_SIZE_KB"] for p in pmc["passes"]])) * 1024.0
+            traffic = 2.0 * fetch + write       # guide: FETCH_SIZE counts half of wide reads
+            roofline.update({
+                "achieved": issue_rate, "peak": peak, "unit": "VALU wave-instructions/s",
+                "frac": issue_rate / peak,
+                "peak_model": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 op "
+                              "(MI355X_MICROARCH.md, v_fma_f32 row)",
+                "valu_wave_instructions_per_launch": valu,
+                "executed_valu_lane_ops_per_test": valu * 64.0 / tests_per_launch,
+                "wait_fraction_of_wave_cycles": float(np.mean(
+                    [p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"] for p in pmc["passes"]])),
+                "traffic": traffic,
+                "traffic_unit": "HBM-side bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE "
+                                "(gfx950 correction of the guide for wide reads)",
+                "pmc_source": os.path.relpath(pmc_path, ROOT),
+            })
+            roofline["hbm"]["traffic_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS
+        else:
+            roofline.update({
+                "achieved": None, "peak": None, "unit": "VALU wave-instructions/s", "frac": None,
+                "traffic": None,
+                "pmc_note": "no PMC profile of this kernel source / workload under profiles/ "
+                            "(regenerate with scratch/collect_profiles.sh); counter-derived "
+                            "fields withheld"})
+    dt, tests_total = main_leg["dt"], main_leg["tests"]
     line = {
         "metric": "ray-surface intersection tests/sec (fwd+bwd)",
         "value": tests_total / dt,
@@ -308,38 +394,40 @@ def main():
             "trace_mode": {"all-pairs": "all-pairs float32 sphere filter",
                            "group": "sphere hierarchy over k-d face clusters (default)",
                            "sort": "face clusters + Morton-sorted rays"}[mode],
+            "step_mode": {"graph": "fused launch sequence (GoalError), HIP-graph replay",
+                          "fused": "fused launch sequence (GoalError), eager launches",
+                          "generic": "error function as torch code through autograd"}[
+                              args.step_mode],
+            "graph_replays": main_leg["graph_replays"],
             "parallelism": f"rays sharded over {args.gpus} GPU(s), 1 RCCL all-reduce/step",
         },
+        "value_note": "tests = ray-face pairs DECIDED (sum over passes of N_active x M, counted "
+                      "by the kernels); the hierarchy decides most pairs without executing a "
+                      "per-pair test -- ms_per_step is the comparable number, and "
+                      "other_legs.all_pairs is the same step with every pair executed",
         "roofline": roofline,
     }
-    if strong is not None:
-        line["strong_scaling"] = strong
+    if main_leg["capture_error"]:
+        line["config"]["graph_capture_error"] = main_leg["capture_error"]
+    line.update(side)
     if world == 1 and not args.no_extra_legs:
-        # separately reported legs (never `value`): the same step in the other trace modes.
-        # Results are bit-identical in every mode; pairs = N_active x M as in `value`.
+        # separately reported legs (never `value`); results are identical in every trace mode
         legs = {}
-        for other in ("all-pairs", "group", "sort"):
-            if other == mode:
-                continue
-            torch.cuda.empty_cache()
-            eng2, system2, params2 = build_scene(args.rays, args.k_front, args.k_back, ray_dtype,
-                                                 accelerate=other)
-            opt2 = optimizer.SGD_Optimizer(eng2, params2, error_function, trace_depth=3,
-                                           learning_rate=1e-6, grad_clip=1e-3)
-            opt2.suppress_warnings = True
-            for _ in range(args.warmup):
-                opt2.single_step(None)
-            torch.cuda.synchronize()
-            pairs = 0
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                opt2.single_step(None)
-                pairs += eng2.last_trace["n_tests"]
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            legs[other] = {"ms_per_step": dt2 / args.steps * 1e3, "tests_per_s": pairs / dt2}
-            del eng2, system2, params2, opt2
-        line["other_trace_modes"] = legs
+        if mode != "all-pairs":
+            leg = timed_leg(args.rays, "all-pairs", args.step_mode, args.dtype)
+            legs["all_pairs"] = {"ms_per_step": leg["dt"] / args.steps * 1e3,
+                                 "tests_per_s": leg["tests"] / leg["dt"],
+                                 "note": "every ray-face pair goes through the float32 sphere test"}
+        other_dt = "f64" if args.dtype == "f32" else "f32"
+        leg = timed_leg(args.rays, args.trace_mode, args.step_mode, other_dt)
+        legs[other_dt + "_ray_state"] = {"ms_per_step": leg["dt"] / args.steps * 1e3,
+                                         "tests_per_s": leg["tests"] / leg["dt"]}
+        if args.step_mode != "generic":
+            leg = timed_leg(args.rays, args.trace_mode, "generic", args.dtype)
+            legs["generic_step"] = {"ms_per_step": leg["dt"] / args.steps * 1e3,
+                                    "tests_per_s": leg["tests"] / leg["dt"],
+                                    "note": "same error function as arbitrary torch code"}
+        line["other_legs"] = legs
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
     print(json.dumps(line))

@@ -359,7 +359,7 @@ class FusedStep:
         """One optimiser step.  Returns the error tensor {sum, n_terms, mean} (device)."""
         opt = self.opt
         dev = opt.parameters[0].device
-        world = tdist.world_size() if tdist.is_distributed() else 1
+        world = 2 if tdist.is_distributed() else 1      # > 1: the collective splits the sequence
         if getattr(self, "_hyper", None) is None:
             self._hyper = _HyperTable(len(opt.parameters), dev)
             self._hyper_apply = _HyperTable(len(opt.parameters), dev)

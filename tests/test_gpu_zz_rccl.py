@@ -30,13 +30,13 @@ def test_sharded_step_through_rccl_with_one_rank(monkeypatch):
 
     def run(steps):
         eng, system, params = bench.build_scene(60_000, 9, 5, torch.float32)
-        opt = optimizer.SGD_Optimizer(eng, params, bench.error_function, trace_depth=3,
+        opt = optimizer.SGD_Optimizer(eng, params, bench.make_error_function(), trace_depth=3,
                                       learning_rate=1e-5, grad_clip=1e-3)
         opt.suppress_warnings = True
         errs = [float(opt.single_step(None)) for _ in range(steps)]
         return errs, [p.detach().clone() for p in params]
 
-    plain_e, plain_p = run(4)
+    plain_e, plain_p = run(8)      # 3 eager steps, capture, then HIP-graph replays
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", str(_free_port()))
     try:
@@ -45,7 +45,7 @@ def test_sharded_step_through_rccl_with_one_rank(monkeypatch):
         pytest.skip(f"RCCL process group could not be created here: {exc}")
     try:
         monkeypatch.setattr(tdist, "is_distributed", lambda: True)     # force the N > 1 path
-        dist_e, dist_p = run(4)
+        dist_e, dist_p = run(8)        # two graphs with the RCCL all-reduce between them
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
