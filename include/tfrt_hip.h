@@ -75,11 +75,17 @@ const char* tfrt_strerror(int code);
 int tfrt_build_faces_forward(const double* vertices, int64_t n_vertices, const int32_t* faces,
                              int64_t n_faces, double* face_verts, double* norm, void* stream);
 
-/* grad_vertices (V,3) is ACCUMULATED into (caller zeroes).  grad_norm and update_mask may be
- * NULL.  update_mask (F,3) u8: 0 = stop_gradient for that corner. */
+/* grad_norm and update_mask may be NULL.  update_mask (F,3) u8: 0 = stop_gradient for that
+ * corner.  corner_start (V+1) / corner_list (3F) i32, both or neither: the face corners f*3+c
+ * sorted by the vertex they reference (corner_list[corner_start[v] .. corner_start[v+1]) are
+ * vertex v's).  With them the reverse is a gather -- one lane per vertex sums its corners in
+ * list order: no atomics, grad_vertices (V,3) is OVERWRITTEN and the result is bit-identical
+ * from run to run.  Without them (NULL) it scatters with float64 atomics and ACCUMULATES into
+ * grad_vertices (caller zeroes). */
 int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_norm,
                               const double* face_verts, const int32_t* faces,
                               const uint8_t* update_mask, int64_t n_faces, int64_t n_vertices,
+                              const int32_t* corner_start, const int32_t* corner_list,
                               double* grad_vertices, void* stream);
 
 /* Parametric surface: parameters -> per-face data in one launch.
@@ -89,15 +95,18 @@ int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_
  * (product and sum stay separate roundings).
  *
  *   zero_points, vectors  (V,3) f64 row-major;  parameters (V,) f64
- * The reverse ACCUMULATES into grad_parameters (V,) (caller zeroes): per face corner that
- * update_mask lets through, dot(grad of that corner, vectors[vertex]). */
+ * The reverse sums, per face corner that update_mask lets through, dot(grad of that corner,
+ * vectors[vertex]) into grad_parameters (V,): as a gather when corner_start / corner_list are
+ * given (see tfrt_build_faces_backward: overwritten, deterministic), else with atomics
+ * (ACCUMULATED, caller zeroes). */
 int tfrt_param_faces_forward(const double* zero_points, const double* vectors,
                              const double* parameters, int64_t n_vertices, const int32_t* faces,
                              int64_t n_faces, double* face_verts, double* norm, void* stream);
 int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_norm,
                               const double* face_verts, const int32_t* faces,
                               const uint8_t* update_mask, const double* vectors, int64_t n_faces,
-                              int64_t n_vertices, double* grad_parameters, void* stream);
+                              int64_t n_vertices, const int32_t* corner_start,
+                              const int32_t* corner_list, double* grad_parameters, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser step, parameter side (SGD_Optimizer.process_gradient / single_step,
@@ -160,6 +169,14 @@ typedef struct tfrt_scene3d {
    * line touches (the default fast path); 1 = rays are additionally visited in a sorted,
    * spatially coherent order and whole wavefronts skip untouched clusters. */
   int32_t sort_rays;
+  /* Reverse sweep only.  0 (default): the 9 face-gradient terms of every ray are summed with
+   * float64 atomics (LDS windows, then global): fastest, but float64 addition is not
+   * associative, so the last bits of a face's sum depend on the arrival order and differ from
+   * run to run.  1: ordered mode -- per pass the terms are scaled by a power of two taken from
+   * their largest magnitude, rounded to 64-bit integers and summed with integer atomics (exact,
+   * hence order-independent), then converted back: bit-identical results on every run, at a
+   * resolution of 2^-40 of the pass's largest term. */
+  int32_t deterministic;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in
@@ -230,7 +247,8 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
  *
  *   finished_rays  6 x capacity ray block written by tfrt_trace3d_forward (state dtype)
  *   finished_id    (capacity) source-ray index per finished row (tfrt_ray_out.ray_id)
- *   n_finished     device pointer to the number of finished rows: counts + 8*max_passes + 1
+ *   counts         the device-side counters of that trace (TFRT_COUNTS_LEN(max_passes) int32):
+ *                  the number of finished rows and the trace's test count are read from its tail
  *   fields[c]      row of the ray block (0..5 = x_start..z_end) compared with goal column c
  *   goal           n_fields x goal_stride f64, goal[c * goal_stride + source_ray]
  *   grad_finished  6 x capacity f64: rows fields[c] receive 2 * (output - goal) for the
@@ -238,15 +256,18 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
  *                  (zero them once: tfrt_trace3d_backward reads finished rows only)
  *   error_out      3 f64: {sum of the error terms, number of terms, sum / max(terms, 1)}; the
  *                  sum is formed in a fixed order (bit-identical from run to run)
- *   workspace      tfrt_goal_error3d_workspace_bytes(capacity) bytes, zero-filled before the
- *                  first call; a call leaves it ready for the next one
+ *   zero_buffer    optional: zero_count f64 cleared by the same launch (the (M,9) face-gradient
+ *                  block the reverse sweep accumulates into), or NULL / 0
+ *   tests_total    optional device int64: incremented by the trace's ray-face test count
+ *   workspace      tfrt_goal_error3d_workspace_bytes(capacity) bytes of scratch
  */
 size_t tfrt_goal_error3d_workspace_bytes(int64_t capacity);
 int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
-                      int32_t state_dtype, const int32_t* n_finished, const int32_t* fields,
-                      int32_t n_fields, const double* goal, int64_t goal_stride,
-                      double* grad_finished, double* error_out, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      int32_t state_dtype, const int32_t* counts, int32_t max_passes,
+                      const int32_t* fields, int32_t n_fields, const double* goal,
+                      int64_t goal_stride, double* grad_finished, double* error_out,
+                      double* zero_buffer, int64_t zero_count, int64_t* tests_total,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Benchmark instrumentation (the only global state in the library; not used by the product
  * path).  While enabled, every launch of the dominant kernel (k_intersect3d) made by

@@ -1,0 +1,11 @@
+"""Builds tuning variants of the library into scratch/variants/ (not shipped).  Usage:
+build_variants.py NAME=flags ...   e.g.  w5="-DTFRT_GROUP_WAVES=5 -DTFRT_GROUP_LIST_CAP=640" """
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from tensorflowraytrace_amd import _build
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants")
+os.makedirs(out, exist_ok=True)
+for spec in sys.argv[1:]:
+    name, flags = spec.split("=", 1)
+    path = _build.build(extra_flags=tuple(flags.split()), lib_path=os.path.join(out, f"lib_{name}.so"), tag="_" + name)
+    print(name, "->", path, flush=True)

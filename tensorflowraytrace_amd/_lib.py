@@ -29,6 +29,7 @@ class Scene3D(ctypes.Structure):
         ("n_table", c_vp), ("n_table_stride", c_i64), ("n_materials", c_i32),
         ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
         ("face_grad_mask", c_vp), ("cluster_order", c_vp), ("sort_rays", c_i32),
+        ("deterministic", c_i32),
     ]
 
 
@@ -58,10 +59,11 @@ SIGNATURES = {
     "tfrt_profile_enable": (c_i32, [c_i32]),
     "tfrt_profile_read": (c_i32, [c_vp, c_i32]),
     "tfrt_build_faces_forward": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
-    "tfrt_build_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "tfrt_build_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp,
+                                          c_vp, c_vp]),
     "tfrt_param_faces_forward": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tfrt_param_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
-                                          c_vp]),
+                                          c_vp, c_vp, c_vp]),
     "tfrt_line_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_f64,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_line_triangle_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
@@ -79,8 +81,8 @@ SIGNATURES = {
         c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32,
         c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_goal_error3d_workspace_bytes": (c_sz, [c_i64]),
-    "tfrt_goal_error3d": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp,
-                                  c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_goal_error3d": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64,
+                                  c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_intersect3d_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "tfrt_intersect3d": (c_i32, [
         c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,

@@ -16,8 +16,8 @@
 // k_goal_error: one lane per finished-ray slot (the number of finished rays is read from the
 // device-side counters of the trace).  Writes d(sum error)/d(field) = 2 (output - goal) into the
 // matching rows of the (6 x capacity) float64 seed block tfrt_trace3d_backward consumes, and the
-// error sum in a FIXED summation order (per-workgroup partial sums, combined by the workgroup that
-// finishes last), so two runs give bit-identical errors.  HBM-bound: 4-8 B x n_fields read + 8 B x
+// error sum in a FIXED summation order (per-workgroup partial sums, combined by k_goal_finish), so
+// two runs give bit-identical errors.  HBM-bound: 4-8 B x n_fields read + 8 B x
 // n_fields written per finished ray.
 #include "tfrt_common.h"
 
@@ -33,13 +33,14 @@ __global__ __launch_bounds__(BLOCK) void k_goal_error(
     const T* __restrict__ fin, int64_t cap, const int32_t* __restrict__ fin_id,
     const int32_t* __restrict__ n_ptr, GoalFields gf, const double* __restrict__ goal,
     int64_t goal_stride, double* __restrict__ g_fin, double* __restrict__ partial,
-    unsigned int* __restrict__ ticket, double* __restrict__ err_out) {
+    double* __restrict__ zero_buf, int64_t zero_n) {
   // the reference's squared_difference and reduce_sum are separate ops: no contraction
 #pragma clang fp contract(off)
   __shared__ double wsum[WAVES];
-  __shared__ int is_last;
   const int n = *n_ptr;
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  // (optional) clear the buffer the reverse sweep accumulates into: saves the caller a fill launch
+  for (int64_t k = i; k < zero_n; k += (int64_t)gridDim.x * BLOCK) zero_buf[k] = 0.0;
   double acc = 0.0;
   if (i < n) {
     const int64_t id = fin_id[i];
@@ -59,31 +60,37 @@ __global__ __launch_bounds__(BLOCK) void k_goal_error(
     double s = 0.0;
     for (int w = 0; w < WAVES; ++w) s += wsum[w];
     partial[blockIdx.x] = s;
-    __threadfence();
-    const unsigned int t = atomicAdd(ticket, 1u);
-    is_last = (t == gridDim.x - 1) ? 1 : 0;
   }
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();
-  // the last workgroup sums the partials: lane t takes t, t + BLOCK, ... in order, then the same
-  // butterfly / wave-order combination as above -- independent of which workgroup came last
+}
+
+// Second stage (one workgroup): the partial sums in a fixed order.  A separate launch rather than
+// "the workgroup that finishes last": that needs a device-scope release fence per workgroup, and
+// with per-XCD L2s every such fence writes the XCD's dirty lines (the seed rows just stored) back
+// -- 117 us at 1M rays against ~10 us for the two launches.
+__global__ __launch_bounds__(BLOCK) void k_goal_finish(const double* __restrict__ partial,
+                                                       int n_partial,
+                                                       const int32_t* __restrict__ n_ptr,
+                                                       int n_fields, double* __restrict__ err_out,
+                                                       const int32_t* __restrict__ tests_lo_hi,
+                                                       long long* __restrict__ tests_total) {
+#pragma clang fp contract(off)
+  __shared__ double wsum[WAVES];
   double s = 0.0;
-  for (unsigned int b = threadIdx.x; b < gridDim.x; b += BLOCK)
-    s += partial[b];
+  for (int b = threadIdx.x; b < n_partial; b += BLOCK) s += partial[b];
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-  __syncthreads();
   if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int w = 0; w < WAVES; ++w) tot += wsum[w];
+    const double terms = (double)(*n_ptr) * (double)n_fields;
     err_out[0] = tot;
-    const double terms = (double)n * (double)gf.n;
     err_out[1] = terms;
     err_out[2] = tot / (terms > 1.0 ? terms : 1.0);  // reduce_mean of optimizer.py:257
-    *ticket = 0u;  // ready for the next call
+    if (tests_total != nullptr && tests_lo_hi != nullptr)
+      *tests_total += (long long)((unsigned long long)(uint32_t)tests_lo_hi[0] |
+                                  ((unsigned long long)(uint32_t)tests_lo_hi[1] << 32));
   }
 }
 
@@ -95,17 +102,18 @@ extern "C" {
 
 size_t tfrt_goal_error3d_workspace_bytes(int64_t capacity) {
   if (capacity < 0) return 0;
-  return align_up(sizeof(unsigned int)) + align_up((size_t)cdiv(capacity > 0 ? capacity : 1, BLOCK) *
-                                                   sizeof(double));
+  return align_up((size_t)cdiv(capacity > 0 ? capacity : 1, BLOCK) * sizeof(double));
 }
 
 int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
-                      int32_t state_dtype, const int32_t* n_finished, const int32_t* fields,
-                      int32_t n_fields, const double* goal, int64_t goal_stride,
-                      double* grad_finished, double* error_out, void* workspace,
-                      size_t workspace_bytes, void* stream) {
-  if (capacity < 0 || n_fields < 1 || n_fields > 6 || !fields || !n_finished || !error_out ||
-      !workspace || workspace_bytes < tfrt_goal_error3d_workspace_bytes(capacity))
+                      int32_t state_dtype, const int32_t* counts, int32_t max_passes,
+                      const int32_t* fields, int32_t n_fields, const double* goal,
+                      int64_t goal_stride, double* grad_finished, double* error_out,
+                      double* zero_buffer, int64_t zero_count, int64_t* tests_total,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (capacity < 0 || n_fields < 1 || n_fields > 6 || !fields || !counts || max_passes < 0 ||
+      !error_out || !workspace || workspace_bytes < tfrt_goal_error3d_workspace_bytes(capacity) ||
+      zero_count < 0 || (zero_count > 0 && !zero_buffer))
     return TFRT_E_BADARG;
   if (capacity > 0 && (!finished_rays || !finished_id || !goal || !grad_finished))
     return TFRT_E_BADARG;
@@ -115,15 +123,16 @@ int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t
     gf.row[c] = c < n_fields ? fields[c] : 0;
     if (gf.row[c] < 0 || gf.row[c] > 5) return TFRT_E_BADARG;
   }
-  unsigned int* ticket = static_cast<unsigned int*>(workspace);
-  double* partial =
-      reinterpret_cast<double*>(static_cast<char*>(workspace) + align_up(sizeof(unsigned int)));
-  const dim3 grid(cdiv(capacity > 0 ? capacity : 1, BLOCK));
+  // trailing counters of the trace: {total_active, total_finished, ..., n_tests_lo, n_tests_hi}
+  const int32_t* tail = counts + (size_t)max_passes * TFRT_COUNTS_PER_PASS;
+  const int32_t* n_finished = tail + 1;
+  double* partial = static_cast<double*>(workspace);
+  const int nblk = cdiv(capacity > 0 ? capacity : 1, BLOCK);
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define TFRT_GOAL(T)                                                                           \
-  hipLaunchKernelGGL((k_goal_error<T>), grid, dim3(BLOCK), 0, st,                              \
+  hipLaunchKernelGGL((k_goal_error<T>), dim3(nblk), dim3(BLOCK), 0, st,                        \
                      static_cast<const T*>(finished_rays), capacity, finished_id, n_finished,  \
-                     gf, goal, goal_stride, grad_finished, partial, ticket, error_out)
+                     gf, goal, goal_stride, grad_finished, partial, zero_buffer, zero_count)
   if (state_dtype == TFRT_F32) {
     TFRT_GOAL(float);
   } else if (state_dtype == TFRT_F64) {
@@ -134,6 +143,8 @@ int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t
     return TFRT_E_BADARG;
   }
 #undef TFRT_GOAL
+  hipLaunchKernelGGL(k_goal_finish, dim3(1), dim3(BLOCK), 0, st, partial, nblk, n_finished,
+                     n_fields, error_out, tail + 4, reinterpret_cast<long long*>(tests_total));
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 

@@ -162,6 +162,51 @@ __global__ __launch_bounds__(BLOCK) void k_param_faces_bwd(
   }
 }
 
+// Gather forms of the two reverse kernels: one lane per VERTEX walks the face corners that
+// reference it (corner_start / corner_list: the corners f*3+c sorted by vertex, built once per
+// mesh topology) and sums their gradients in that fixed order.  No atomics, no zero-filled
+// output, and the same bits on every run (a float64 atomic sum depends on arrival order).
+__global__ __launch_bounds__(BLOCK) void k_build_faces_bwd_gather(
+    const double* __restrict__ g_fverts, const double* __restrict__ g_norm,
+    const double* __restrict__ fverts, const uint8_t* __restrict__ mask,
+    const int32_t* __restrict__ corner_start, const int32_t* __restrict__ corner_list, int64_t V,
+    double* __restrict__ g_vertices) {
+  const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (v >= V) return;
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int q = corner_start[v]; q < corner_start[v + 1]; ++q) {
+    const int fc = corner_list[q], f = fc / 3, c = fc - 3 * f;
+    if (mask != nullptr && mask[fc] == 0) continue;
+    double g[9];
+    face_grad(g_fverts, g_norm, fverts, f, g);
+    acc[0] += g[3 * c];
+    acc[1] += g[3 * c + 1];
+    acc[2] += g[3 * c + 2];
+  }
+  g_vertices[3 * v] = acc[0];
+  g_vertices[3 * v + 1] = acc[1];
+  g_vertices[3 * v + 2] = acc[2];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_param_faces_bwd_gather(
+    const double* __restrict__ g_fverts, const double* __restrict__ g_norm,
+    const double* __restrict__ fverts, const uint8_t* __restrict__ mask,
+    const double* __restrict__ vectors, const int32_t* __restrict__ corner_start,
+    const int32_t* __restrict__ corner_list, int64_t V, double* __restrict__ g_params) {
+  const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (v >= V) return;
+  double acc = 0.0;
+  for (int q = corner_start[v]; q < corner_start[v + 1]; ++q) {
+    const int fc = corner_list[q], f = fc / 3, c = fc - 3 * f;
+    if (mask != nullptr && mask[fc] == 0) continue;
+    double g[9];
+    face_grad(g_fverts, g_norm, fverts, f, g);
+    acc += g[3 * c] * vectors[3 * v] + g[3 * c + 1] * vectors[3 * v + 1] +
+           g[3 * c + 2] * vectors[3 * v + 2];
+  }
+  g_params[v] = acc;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_snell3d(int64_t n, const double* xs, const double* ys,
                                                    const double* zs, const double* xe,
                                                    const double* ye, const double* ze,
@@ -243,12 +288,19 @@ int tfrt_build_faces_forward(const double* vertices, int64_t n_vertices, const i
 int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_norm,
                               const double* face_verts, const int32_t* faces,
                               const uint8_t* update_mask, int64_t n_faces, int64_t n_vertices,
+                              const int32_t* corner_start, const int32_t* corner_list,
                               double* grad_vertices, void* stream) {
   if (n_faces < 0 || n_vertices < 0) return TFRT_E_BADARG;
   if (n_faces == 0) return 0;
   if (!faces || !grad_vertices || (!grad_face_verts && !grad_norm) ||
-      (grad_norm && !face_verts))
+      (grad_norm && !face_verts) || ((corner_start == nullptr) != (corner_list == nullptr)))
     return TFRT_E_BADARG;
+  if (corner_start != nullptr) {
+    hipLaunchKernelGGL(k_build_faces_bwd_gather, dim3(cdiv(n_vertices, BLOCK)), dim3(BLOCK), 0,
+                       static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
+                       update_mask, corner_start, corner_list, n_vertices, grad_vertices);
+    return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+  }
   hipLaunchKernelGGL(k_build_faces_bwd, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
                      static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
                      faces, update_mask, n_faces, n_vertices, grad_vertices);
@@ -271,12 +323,20 @@ int tfrt_param_faces_forward(const double* zero_points, const double* vectors,
 int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_norm,
                               const double* face_verts, const int32_t* faces,
                               const uint8_t* update_mask, const double* vectors, int64_t n_faces,
-                              int64_t n_vertices, double* grad_parameters, void* stream) {
+                              int64_t n_vertices, const int32_t* corner_start,
+                              const int32_t* corner_list, double* grad_parameters, void* stream) {
   if (n_faces < 0 || n_vertices < 0) return TFRT_E_BADARG;
   if (n_faces == 0) return 0;
   if (!faces || !vectors || !grad_parameters || (!grad_face_verts && !grad_norm) ||
-      (grad_norm && !face_verts))
+      (grad_norm && !face_verts) || ((corner_start == nullptr) != (corner_list == nullptr)))
     return TFRT_E_BADARG;
+  if (corner_start != nullptr) {
+    hipLaunchKernelGGL(k_param_faces_bwd_gather, dim3(cdiv(n_vertices, BLOCK)), dim3(BLOCK), 0,
+                       static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
+                       update_mask, vectors, corner_start, corner_list, n_vertices,
+                       grad_parameters);
+    return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+  }
   hipLaunchKernelGGL(k_param_faces_bwd, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
                      static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
                      faces, update_mask, vectors, n_faces, n_vertices, grad_parameters);

@@ -59,8 +59,16 @@ constexpr int ERR_CAPACITY = 1;
 // c0 = mean of the face corner P0 over (a sample of) the faces: origin of the filter's
 // coordinate frame (keeps |c| small so the float32 rounding margin stays far below the sphere
 // radii).  Any point near the mesh serves, so at most ~2048 evenly spaced faces are read.
+// (Also does k_init's work -- the trace's counters -- so a trace with faces needs one set-up
+// launch instead of two.)
 __global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fverts, int M,
-                                                 double* __restrict__ c0) {
+                                                 double* __restrict__ c0, int32_t* nrays0, int n,
+                                                 int32_t* tail8, unsigned int* scan_ticket) {
+  if (nrays0 != nullptr) {
+    if (threadIdx.x == 0) *nrays0 = n;
+    if (threadIdx.x < 8) tail8[threadIdx.x] = 0;
+    if (threadIdx.x == 0 && scan_ticket != nullptr) *scan_ticket = 0u;
+  }
   __shared__ double red[3][1024];
   const int step = M > 2048 ? M / 2048 : 1;
   const int ns = M > 0 ? (M + step - 1) / step : 0;  // samples j * step, j < ns
@@ -933,8 +941,13 @@ __device__ __forceinline__ int cat_to_cls(int cat) {
   return cat == CAT_OPTICAL ? CLS_ACTIVE : (cat == CAT_TARGET ? CLS_FINISHED : CLS_STOPPED);
 }
 
+#ifdef TFRT_GROUP_WAVES
+#define TFRT_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_GROUP_WAVES, TFRT_GROUP_WAVES)))
+#else
+#define TFRT_GROUP_ATTR
+#endif
 template <typename T, int R>
-__global__ __launch_bounds__(BLOCK) void k_intersect_group(
+__global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
     const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
@@ -946,7 +959,10 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
     int32_t* __restrict__ blockcnt) {
   constexpr int RW = 64 * R;      // rays per wave
-  constexpr int GT = 256;         // cluster spheres per LDS tile
+#ifndef TFRT_GROUP_TILE
+#define TFRT_GROUP_TILE 256
+#endif
+  constexpr int GT = TFRT_GROUP_TILE;   // cluster spheres per LDS tile
   const int n = *n_ptr;
   const int base = blockIdx.x * (BLOCK * R);
   if (base >= n) return;  // block-uniform
@@ -958,10 +974,13 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   // cluster spheres of the current tile; one float4 of padding after every supercluster's 8 so
   // that lanes working on different superclusters read from different LDS banks
   __shared__ float4 tile[GT + GT / SUPER];
-  __shared__ float4 stile[GT / SUPER];       // their superclusters' spheres
   // candidate list of the wave: (tile-local cluster << 8 | ray slot), 16 bits because it is
   // always drained before the tile changes (LDS footprint decides the waves in flight)
-  constexpr int LIST_CAP = 1024;
+#ifndef TFRT_GROUP_LIST_CAP
+#define TFRT_GROUP_LIST_CAP 1024
+#endif
+  constexpr int LIST_CAP = TFRT_GROUP_LIST_CAP;   // > 64 * SUPER: one batch of 64 pairs must fit
+  static_assert(LIST_CAP > 64 * SUPER, "candidate list too small for one batch");
   __shared__ uint16_t clist[WAVES][LIST_CAP];
   // (tile-local supercluster << 8 | ray slot) pairs waiting for their cluster tests
   __shared__ uint16_t rlist[WAVES][128];
@@ -977,7 +996,20 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   __shared__ uint32_t pairs[WAVES][PAIRS];   // member slot << 8 | ray slot (member slot < 2^24)
   __shared__ uint8_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
   __shared__ int32_t x_face[WAVES][128];
-  __shared__ T ray_l[WAVES][6][RW];          // the wave's rays (state dtype) for the decisions
+  // The wave's rays for the screen / decision stages, kept in LDS.  (-DTFRT_GROUP_RAYS_GLOBAL
+  // re-reads them from the ray block instead and, with a shorter candidate list, frees enough LDS
+  // for a fifth workgroup per CU; measured at 1M rays: 5 waves per SIMD 236 us against 230 us for
+  // 4 -- the kernel is not short of waves in flight -- and 6 waves, which spill, 276 us.)
+#ifndef TFRT_GROUP_RAYS_GLOBAL
+  __shared__ T ray_l[WAVES][6][RW];
+#define TFRT_RAYV(q, slot) static_cast<double>(ray_l[wave][q][slot])
+#else
+  auto ray_at = [&](int slot) -> int64_t {
+    const int i = base + (slot >> 6) * BLOCK + wave * 64 + (slot & 63);
+    return i < n ? i : 0;
+  };
+#define TFRT_RAYV(q, slot) ldd(rays, (int64_t)(q) * stride + ray_at(slot))
+#endif
   __shared__ int32_t skip_l[WAVES][RW];      // face each ray starts on (-1: none)
 
   const double cx = c0[0], cy = c0[1], cz = c0[2];
@@ -993,8 +1025,10 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     {
       const int slot = r * 64 + lane;
       const int ii = i < n ? i : 0;
+#ifndef TFRT_GROUP_RAYS_GLOBAL
 #pragma unroll
       for (int q = 0; q < 6; ++q) ray_l[wave][q][slot] = rays[q * stride + ii];
+#endif
       skip_l[wave][slot] = (last_tri != nullptr && i < n) ? last_tri[ii] : -1;
     }
     if (i < n) {
@@ -1023,6 +1057,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
   // exact list so that the expensive float64 stage always runs on full wavefronts.
   const float es_f = (float)eps_size, er_f = (float)eps_start;
   int xn = 0;  // entries waiting in x_slot / x_face (wave-uniform)
+  int pn = 0;  // entries waiting in pairs[] (wave-uniform)
+  bool draining = false, drained = false;  // after the last tile: one final flush empties both
   auto screen = [&](const int nb) {
     bool keep = false;
     int j = -1, slot = 0;
@@ -1037,8 +1073,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       double s[3], e[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        s[q] = static_cast<double>(ray_l[wave][q][slot]);
-        e[q] = static_cast<double>(ray_l[wave][3 + q][slot]);
+        s[q] = TFRT_RAYV(q, slot);
+        e[q] = TFRT_RAYV(3 + q, slot);
       }
       // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t scales
       // with their magnitudes, not with |t|
@@ -1074,8 +1110,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       double s[3], e[3], P[9];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        s[q] = static_cast<double>(ray_l[wave][q][slot]);
-        e[q] = static_cast<double>(ray_l[wave][3 + q][slot]);
+        s[q] = TFRT_RAYV(q, slot);
+        e[q] = TFRT_RAYV(3 + q, slot);
       }
       const double* fp = fverts + 9 * (int64_t)j;
 #pragma unroll
@@ -1114,9 +1150,14 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     //    flight).  Member hits become (ray, face) pairs; while 64 are waiting -- and once more
     //    at the end -- they are decided, one per lane.  (One call site each for decide() and
     //    flush(): the float64 test is big and copies of it only bloat the kernel.)
-    int pn = 0;  // entries waiting in pairs[] (wave-uniform)
-    for (int q0 = 0; q0 < total; q0 += 4 * MU) {
-      {
+    // (pairs and screen survivors carry (member, ray) / (face, ray): they outlive the tile, so
+    // partial batches wait for the next flush and only the last one -- `draining`, after the
+    // last tile -- empties them.  Draining at every flush ran the screen and the ~350-instruction
+    // float64 decision on a mostly empty wavefront three or four extra times per wave.)
+    const int nsteps = (total + 4 * MU - 1) / (4 * MU);
+    for (int st = 0; st < nsteps + (draining ? 1 : 0); ++st) {
+      const int q0 = st * 4 * MU;
+      if (st < nsteps) {
         float4 sp[MU];
         int slot[MU], memb[MU];
 #pragma unroll
@@ -1148,7 +1189,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
           TFRT_STAT(3, __popcll(hm));
         }
       }
-      const bool last = q0 + 4 * MU >= total;
+      const bool last = draining && st == nsteps;
       while (pn >= 64 || (last && (pn > 0 || xn > 0))) {
         const int nb = min(pn, 64);
         wave_fence();
@@ -1183,7 +1224,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     ln = 0;
   };
 
-  static_assert(GT / SUPER == 32, "one 32-bit supercluster mask per ray and tile");
+  static_assert(GT / SUPER <= 32 && GT % SUPER == 0, "one 32-bit supercluster mask per ray and tile");
   static_assert(SUPER == 8, "8-lane groups test the 8 clusters of a supercluster");
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
   unsigned touched[R];  // per ray: superclusters of the current tile its line touches
@@ -1199,8 +1240,10 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
     bool pending = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) pending = pending || __any(touched[r] != 0u);
-    if (ln > LIST_CAP - 64 * SUPER || (!pending && rn == 0 && ln > 0)) {
+    if (ln > LIST_CAP - 64 * SUPER || (!pending && rn == 0 && ln > 0) ||
+        (draining && !drained && !pending && rn == 0)) {
       flush();
+      drained = draining;
     } else if (rn >= 64 || (!pending && rn > 0)) {
       const int nb = min(rn, 64);
       // One waiting (ray, supercluster) pair per lane: its 8 cluster spheres in turn, hits
@@ -1223,9 +1266,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
         // inside the 64 * 2^-24 (|c| + r) the spheres are inflated by.
         const float ux = fa.y * fb.z - fa.z * fb.y, uy = fa.z * fb.x - fa.x * fb.z,
                     uz = fa.x * fb.y - fa.y * fb.x;
-        const float sx = (float)(static_cast<double>(ray_l[wave][0][sl]) - cx),
-                    sy = (float)(static_cast<double>(ray_l[wave][1][sl]) - cy),
-                    sz = (float)(static_cast<double>(ray_l[wave][2][sl]) - cz);
+        const float sx = (float)(TFRT_RAYV(0, sl) - cx), sy = (float)(TFRT_RAYV(1, sl) - cy),
+                    sz = (float)(TFRT_RAYV(2, sl) - cz);
         const float t_off = fmaf(-sx, ux, fmaf(-sy, uy, -sz * uz)) +
                             (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
         // (first pass of a trace -- no ray starts on a face yet: sources normally sit outside
@@ -1287,19 +1329,26 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_group(
       }
       wave_fence();
     } else {
+      if (draining) break;  // (the final flush has run)
       t0 += GT;
-      if (t0 >= c_hi) break;
+      if (t0 >= c_hi) {
+        draining = true;
+        continue;
+      }
       const int nt = min(GT, c_hi - t0);
       const int ns = (nt + SUPER - 1) / SUPER;
       __syncthreads();
       for (int k = tid; k < ns * SUPER; k += BLOCK)
         tile[k + (k >> 3)] = (k < nt) ? clsphere[t0 + k] : never;
-      if (tid < ns) stile[tid] = susphere[t0 / SUPER + tid];
       __syncthreads();
-      // level 0: which superclusters of the tile does each ray's line touch
+      // level 0: which superclusters of the tile does each ray's line touch.  The supercluster
+      // spheres are wave-uniform data: read straight from global memory with a uniform index
+      // (scalar loads into SGPRs, four spheres per round) -- no LDS staging, no LDS reads
       TFRT_STAT(0, (long long)ns * __popcll(__ballot(base + tid < n)));
+      const float4* __restrict__ su = susphere + t0 / SUPER;
+#pragma unroll 4
       for (int k = 0; k < ns; ++k) {
-        const float4 sp = stile[k];  // same address in every lane: LDS broadcast
+        const float4 sp = su[k];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
@@ -1769,6 +1818,88 @@ __global__ __launch_bounds__(1024) void k_face_accumulate(
   }
 }
 
+// ---- ordered (deterministic) accumulation: tfrt_scene3d.deterministic
+// float64 sums depend on the order of the adds; integer sums do not.  Per pass: the largest
+// finite |term| of the stash fixes a power-of-two scale, every term becomes round(term * scale)
+// in 64 bits (|.| <= 2^40, so 2^22 rays per face cannot overflow), integer atomics sum them, and
+// k_fixed_finish adds the converted sums to g_fverts in face order.  Non-finite terms poison
+// their slot (NaN), as a float sum would.
+constexpr int FIXED_BITS = 40;
+
+__global__ __launch_bounds__(BLOCK) void k_stash_absmax(const int32_t* __restrict__ n_ptr,
+                                                        const int32_t* __restrict__ stash_face,
+                                                        const double* __restrict__ stash_g,
+                                                        unsigned long long* __restrict__ maxbits) {
+  const int n = *n_ptr;
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  double m = 0.0;
+  if (i < n && stash_face[i] >= 0) {
+    const double* g = stash_g + 9 * (int64_t)i;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+      const double a = fabs(g[c]);
+      if (a > m && a < INFINITY) m = a;  // (NaN compares false)
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) m = fmax(m, __shfl_xor(m, d, 64));
+  // non-negative doubles order like their bit patterns
+  if (lane_id() == 0 && m > 0.0) atomicMax(maxbits, (unsigned long long)__double_as_longlong(m));
+}
+
+__device__ __forceinline__ double fixed_scale(unsigned long long maxbits) {
+  if (maxbits == 0ull) return 0.0;
+  int e;
+  (void)frexp(__longlong_as_double((long long)maxbits), &e);  // max = f * 2^e, f in [0.5, 1)
+  return ldexp(1.0, FIXED_BITS - e);                            // |term| * scale < 2^40
+}
+
+__global__ __launch_bounds__(BLOCK) void k_face_accumulate_fixed(
+    const int32_t* __restrict__ n_ptr, const int32_t* __restrict__ stash_face,
+    const double* __restrict__ stash_g, const unsigned long long* __restrict__ maxbits,
+    unsigned long long* __restrict__ acc, uint8_t* __restrict__ flag) {
+  const int n = *n_ptr;
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int f = stash_face[i];
+  if (f < 0) return;
+  const double scale = fixed_scale(*maxbits);
+  const double* g = stash_g + 9 * (int64_t)i;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) {
+    const double x = g[c];
+    if (!(fabs(x) < INFINITY)) {
+      flag[9 * (int64_t)f + c] = 1;  // NaN / Inf: the slot's sum is not a number
+    } else {
+      const long long q = llrint(x * scale);
+      if (q != 0) atomicAdd(acc + 9 * (int64_t)f + c, (unsigned long long)q);  // two's complement
+    }
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fixed_finish(int64_t m9,
+                                                        const unsigned long long* __restrict__ max_this,
+                                                        unsigned long long* __restrict__ max_next,
+                                                        unsigned long long* __restrict__ acc,
+                                                        uint8_t* __restrict__ flag,
+                                                        double* __restrict__ g_fverts) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const double scale = fixed_scale(*max_this);
+  if (i < m9) {
+    const long long q = (long long)acc[i];
+    if (flag[i] != 0) {
+      g_fverts[i] = __builtin_nan("");
+    } else if (q != 0) {
+      g_fverts[i] += (double)q / scale;
+    }
+    acc[i] = 0ull;
+    flag[i] = 0;
+  }
+  // the other slot of the two-entry scale buffer is the next pass's: clear it here (this pass's
+  // is still being read by the other workgroups of this launch)
+  if (i == 0) *max_next = 0ull;
+}
+
 // Reverse of one ray slot of one pass.  Writes the gradient w.r.t. the slot's input ray to
 // g_out and returns the face whose gradient gP must be accumulated (-1: none).
 template <typename T>
@@ -1966,7 +2097,8 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
   size_t csphere, cface, clsphere, susphere, crec, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
-  size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, total;
+  size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, fix_acc, fix_flag,
+      fix_max, total;
 };
 
 static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& pl) {
@@ -2011,6 +2143,9 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.rec_cls = take((size_t)P * n);
   L.gbuf = take((size_t)2 * 6 * n * sizeof(double));
   L.stash_g = take((size_t)9 * n * sizeof(double));
+  L.fix_acc = take((size_t)9 * m * sizeof(unsigned long long));  // ordered accumulation
+  L.fix_flag = take((size_t)9 * m);
+  L.fix_max = take(2 * sizeof(unsigned long long));
   L.total = o;
   return L;
 }
@@ -2139,7 +2274,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* tail = counts + (size_t)P * TFRT_COUNTS_PER_PASS;
   const size_t n = N > 0 ? N : 1;
 
-  hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail, ticket);
+  if (M <= 0) hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail, ticket);
   Accel3 ac;
   // (the grouped kernel packs member slot and ray slot into 32 bits: member slots < 2^24)
   ac.order = (M >= 4 * CLUSTER && M < (1 << 24) - CLUSTER) ? sc->cluster_order : nullptr;
@@ -2157,7 +2292,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   ac.sort_bytes = lay.sort_bytes;
   int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
   if (M > 0) {
-    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0);
+    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0, nrays, (int)N,
+                       tail, ticket);
     if (ac.order != nullptr) {
       const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
       if (ac.sort_rays) {
@@ -2261,7 +2397,13 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // small ray counts) k_backward3d adds straight into g_fverts with float64 atomics -- faces are
   // then so many that they see little contention.
   const int windows = cdiv(M > 0 ? M : 1, FACE_WINDOW);
-  const bool stash = M > 0 && N >= 16384 && windows <= 32 && !coherent;
+  const bool ordered = sc->deterministic != 0 && M > 0 && g_fverts != nullptr;
+  const bool stash = ordered || (M > 0 && N >= 16384 && windows <= 32 && !coherent);
+  unsigned long long* fix_acc = reinterpret_cast<unsigned long long*>(ws + lay.fix_acc);
+  uint8_t* fix_flag = reinterpret_cast<uint8_t*>(ws + lay.fix_flag);
+  unsigned long long* fix_max = reinterpret_cast<unsigned long long*>(ws + lay.fix_max);
+  if (ordered)  // (fix_acc, fix_flag and fix_max are adjacent: one clear)
+    (void)hipMemsetAsync(fix_acc, 0, lay.total - lay.fix_acc, st);
   double* stash_g = reinterpret_cast<double*>(ws + lay.stash_g);
   int32_t* stash_face = vals_in;
   // ray slots per accumulate block, measured at 1M rays x 11 windows (us for the three passes,
@@ -2284,11 +2426,22 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
                        cap_dead, g_out, out_stride, g_fverts,
-                       coherent ? rperm_all + (size_t)p * n : nullptr,
+                       (coherent && !ordered) ? rperm_all + (size_t)p * n : nullptr,
                        stash ? stash_g : nullptr, stash ? stash_face : nullptr);
-    if (stash)
+    if (ordered) {
+      // two-entry scale buffer, alternating per pass (each pass's conversion clears the other)
+      unsigned long long* mx = fix_max + ((P - 1 - p) & 1);
+      hipLaunchKernelGGL(k_stash_absmax, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, stash_face,
+                         stash_g, mx);
+      hipLaunchKernelGGL(k_face_accumulate_fixed, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p,
+                         stash_face, stash_g, mx, fix_acc, fix_flag);
+      hipLaunchKernelGGL(k_fixed_finish, dim3(cdiv((int64_t)M * 9, BLOCK)), dim3(BLOCK), 0, st,
+                         (int64_t)M * 9, mx, fix_max + (((P - 1 - p) & 1) ^ 1), fix_acc, fix_flag,
+                         g_fverts);
+    } else if (stash) {
       hipLaunchKernelGGL(k_face_accumulate, dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
                          nrays + p, stash_face, stash_g, acc_chunk, M, g_fverts);
+    }
   }
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
@@ -2407,10 +2560,12 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
   int32_t* part_i = reinterpret_cast<int32_t*>(ws + o);
   o += align_up((size_t)pl.chunks * n * sizeof(int32_t));
   float* prep = reinterpret_cast<float*>(ws + o);
-  hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nptr, (int)n_rays, nptr + 8,
-                     (unsigned int*)nullptr);
+  if (M <= 0)
+    hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nptr, (int)n_rays, nptr + 8,
+                       (unsigned int*)nullptr);
   if (M > 0) {
-    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, face_verts, M, c0);
+    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, face_verts, M, c0, nptr, (int)n_rays,
+                       nptr + 8, (unsigned int*)nullptr);
     hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, face_verts, M, c0,
                        size_epsilion, sphere);
   }

@@ -222,44 +222,59 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
   for (int i = 0; i < 9; ++i) gP[i] = 0.0;
 
   if (has_child) {
-    const double clen = sqrt(dot3(C, C));
-    const double N[3] = {C[0] / clen, C[1] / clen, C[2] / clen};
-    const Snell3 f = snell3d(s, h, N, n_in, n_out);
+    // Forward quantities recomputed for the reverse step.  They need not reproduce the forward
+    // pass bit for bit (the gradient tolerance is 1e-8, not the last bit), so the unit vectors
+    // come from one reciprocal each instead of the forward's nine quotients, n = C / |C| skips
+    // the forward's second normalisation of an already-unit vector, and only the index ratio
+    // that is used is formed: 5 float64 divisions and 3 square roots instead of 14 and 5
+    // (a float64 division is ~30 instructions; the kernel is bound by float64 VALU issue).
+    const double inv_c = 1.0 / sqrt(dot3(C, C));
+    const double n[3] = {C[0] * inv_c, C[1] * inv_c, C[2] * inv_c};
+    const double r[3] = {h[0] - s[0], h[1] - s[1], h[2] - s[2]};
+    const double rsq = dot3(r, r);
+    const bool clamped = rsq < 1e-12;               // l2_normalize's max(sum x^2, 1e-12)
+    const double inv_r = clamped ? 1e6 : 1.0 / sqrt(rsq);
+    const double u[3] = {r[0] * inv_r, r[1] * inv_r, r[2] * inv_r};
+    const double nu = dot3(n, u);
+    const bool in_safe = n_in != 0.0, out_safe = n_out != 0.0;
+    const double nis = in_safe ? n_in : 1.0, nos = out_safe ? n_out : 1.0;
+    const bool internal = nu > 0.0;
+    const double eta = internal ? (out_safe ? nis / nos : 0.0) : (in_safe ? nos / nis : 0.0);
+    const double nu_eta = eta * nu;
+    const double k = 1.0 - eta * eta + nu_eta * nu_eta;
+    const bool reflect = (k < 0.0) || (n_in == 0.0);
     double wb[3], ub[3], nb[3];
     for (int i = 0; i < 3; ++i) {
       hb[i] += g_ce[i];
       wb[i] = L * g_ce[i];
     }
     double nub;
-    if (f.reflect) {
-      nub = -2.0 * dot3(wb, f.n);
+    if (reflect) {
+      nub = -2.0 * dot3(wb, n);
       for (int i = 0; i < 3; ++i) {
         ub[i] = wb[i];
-        nb[i] = -2.0 * f.nu * wb[i];
+        nb[i] = -2.0 * nu * wb[i];
       }
     } else {
-      const double sg = (f.nu > 0.0) ? 1.0 : ((f.nu < 0.0) ? -1.0 : 0.0);
-      const double rk = sqrt(f.k);
-      const double alpha = sg * rk - f.eta * f.nu;
-      const double ab = dot3(wb, f.n);
-      nub = ab * (sg * f.eta * f.eta * f.nu / rk - f.eta);
+      const double sg = (nu > 0.0) ? 1.0 : ((nu < 0.0) ? -1.0 : 0.0);
+      const double rk = sqrt(k);
+      const double alpha = sg * rk - nu_eta;
+      const double ab = dot3(wb, n);
+      nub = ab * (sg * eta * nu_eta / rk - eta);
       for (int i = 0; i < 3; ++i) {
         nb[i] = alpha * wb[i];
-        ub[i] = f.eta * wb[i];
+        ub[i] = eta * wb[i];
       }
     }
     for (int i = 0; i < 3; ++i) {
-      nb[i] += nub * f.u[i];
-      ub[i] += nub * f.n[i];
+      nb[i] += nub * u[i];
+      ub[i] += nub * n[i];
     }
     // u = l2_normalize(h - s)
-    const double r[3] = {h[0] - s[0], h[1] - s[1], h[2] - s[2]};
-    const double rsq = dot3(r, r);
-    if (rsq >= 1e-12) {
-      const double inv = 1.0 / sqrt(rsq);
-      const double uu = dot3(f.u, ub);
+    if (!clamped) {
+      const double uu = dot3(u, ub);
       for (int i = 0; i < 3; ++i) {
-        const double rb = (ub[i] - f.u[i] * uu) * inv;
+        const double rb = (ub[i] - u[i] * uu) * inv_r;
         hb[i] += rb;
         sb[i] -= rb;
       }
@@ -270,9 +285,9 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
       }
     }
     // n = l2_normalize(N), N = C/|C|  ->  dC = (nb - n (n.nb)) / |C|   (|N| = 1)
-    const double nn = dot3(f.n, nb);
+    const double nn = dot3(n, nb);
     double Cb[3];
-    for (int i = 0; i < 3; ++i) Cb[i] = (nb[i] - f.n[i] * nn) / clen;
+    for (int i = 0; i < 3; ++i) Cb[i] = (nb[i] - n[i] * nn) * inv_c;
     // C = E1 x E2
     double E1b[3], E2b[3];
     cross3(E2, Cb, E1b);
@@ -295,7 +310,7 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
   // t = num / den, num = (P0 - s).C, den = d.C
   const double den = dot3(d, C);
   const double numb = tb / den;
-  const double denb = -tb * t / den;
+  const double denb = -numb * t;
   double Cb[3];
   for (int i = 0; i < 3; ++i) {
     gP[i] += numb * C[i];

@@ -359,7 +359,8 @@ class OpticalSystem3D(OpticalSystemBase):
                 mat_out=col("mat_out", torch.int32), n_in=col("n_in", torch.float64),
                 n_out=col("n_out", torch.float64), face_grad_mask=gmask), held)
 
-    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False):
+    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False,
+                   deterministic=False):
         s = self._scene_cache[1]
         order = None
         if cluster:
@@ -375,10 +376,12 @@ class OpticalSystem3D(OpticalSystemBase):
             order = cached[1]
         kw = dict(intersect_epsilion=self.intersect_epsilion, size_epsilion=self.size_epsilion,
                   ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"],
-                  cluster_order=order, sort_rays=bool(sort_rays and order is not None))
+                  cluster_order=order, sort_rays=bool(sort_rays and order is not None),
+                  deterministic=bool(deterministic))
         # the argument object (and the ctypes struct it caches) only depends on tensors that stay
         # the same from step to step; the face tensor is passed separately to every trace
         memo_key = (id(s), id(n_table), bool(index_mode), bool(ghost), id(order), kw["sort_rays"],
+                    kw["deterministic"],
                     self.intersect_epsilion, self.size_epsilion, self.ray_start_epsilion)
         memo = getattr(self, "_scene_args_memo", None)
         if memo is not None and memo[0] == memo_key:
@@ -548,7 +551,7 @@ class OpticalEngine:
                  compile_dead_rays=False, compile_finished_rays=True, compile_active_rays=True,
                  dead_ray_length=None, compile_geometry_specific_result=False,
                  new_ray_length=1.0, simple_ray_inheritance={"wavelength"}, ray_dtype=None,
-                 ray_shard="auto", accelerate="auto"):
+                 ray_shard="auto", accelerate="auto", deterministic=False):
         if dimension not in (2, 3):
             raise ValueError(f"RayEngine: dimension must be 2 or 3, but was given {dimension}.")
         self._dimension = dimension
@@ -577,6 +580,10 @@ class OpticalEngine:
         if accelerate not in (False, True, None, "all-pairs", "group", "sort", "auto"):
             raise ValueError(f"OpticalEngine: unknown accelerate mode {accelerate!r}")
         self.accelerate = accelerate
+        # True: the reverse sweep sums face gradients in an order-independent way (scaled 64-bit
+        # integers): gradients are bit-identical from run to run (tfrt_scene3d.deterministic);
+        # default False: float64 atomics, whose last bits depend on the arrival order.
+        self.deterministic = bool(deterministic)
         # When True, ray_trace() does not wait for the per-class ray counts: it cuts the output
         # sets with the counts of the previous trace of the same shape and leaves the check to
         # verify_trace() (SGD_Optimizer does this; a wrong guess only costs a re-evaluation of
@@ -812,7 +819,7 @@ class OpticalEngine:
         mode = self._trace_mode(system)
         if self.dimension == 3:
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
-                                      sort_rays=mode == "sort")
+                                      sort_rays=mode == "sort", deterministic=self.deterministic)
         else:
             scene = system.scene_args(n_table, index_mode, ghost)
         fv = None

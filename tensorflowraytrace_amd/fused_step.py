@@ -182,8 +182,9 @@ class FusedStep:
             else:
                 aux[name + "_id"] = aux[name + "_face"] = None
                 outs[name] = ops._ray_out(None, None, None)
-        aux["unfinished"] = torch.empty((6, capN), dtype=block.dtype, device=dev)
-        aux["unfinished_id"] = ints.take(capN)
+        # the rays still active after the last pass are not copied out by a fused step
+        aux["unfinished"] = torch.empty((6, 0), dtype=block.dtype, device=dev)
+        aux["unfinished_id"] = torch.empty(0, dtype=torch.int32, device=dev)
         gws = L.tfrt_goal_error3d_workspace_bytes(capN)
         st = dict(
             sig=sig, N=N, M=M, P=P, dt=dt, flags=flags, capN=capN, full=full, aux=aux, outs=outs,
@@ -231,20 +232,20 @@ class FusedStep:
             ops._p(block), block.shape[1], st["N"], ctypes.byref(sc), float(eng.new_ray_length),
             float(eng.dead_ray_length or 0.0), P, dt, flags, ctypes.byref(o["finished"]),
             ctypes.byref(o["active"]), ctypes.byref(o["stopped"]), ctypes.byref(o["dead"]),
-            ops._p(st["aux"]["unfinished"]), ops._p(st["aux"]["unfinished_id"]),
+            None, None,      # (the rays still active after the last pass are not copied out)
             ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream), "tfrt_trace3d_forward")
         fin = st["full"]["finished"]
-        n_fin_ptr = ctypes.c_void_p(st["counts"].data_ptr() + 4 * (P * _lib.COUNTS_PER_PASS + 1))
+        need_back = bool(fv.requires_grad and st["M"] > 0)
+        # error + gradient seed; the same launch clears the face-gradient block the reverse sweep
+        # accumulates into and adds the trace's test count to the running total
         check(L.tfrt_goal_error3d(
-            ops._p(fin), st["capN"], ops._p(st["aux"]["finished_id"]), dt, n_fin_ptr,
+            ops._p(fin), st["capN"], ops._p(st["aux"]["finished_id"]), dt, ops._p(st["counts"]), P,
             st["fields"], len(erf.rows), ops._p(goal), goal.shape[1], ops._p(st["g_fin"]),
-            ops._p(st["err"]), ops._p(st["goal_ws"]), st["gws"], stream), "tfrt_goal_error3d")
-        # running total of ray-face tests (uint64 split over two int32 counters), for reporting
-        tail = st["counts"][P * _lib.COUNTS_PER_PASS + 4:P * _lib.COUNTS_PER_PASS + 6]
-        self.tests_total.add_(tail.view(torch.int64))
+            ops._p(st["err"]), ops._p(st["g_fv"]) if need_back else None,
+            st["g_fv"].numel() if need_back else 0, ops._p(self.tests_total),
+            ops._p(st["goal_ws"]), st["gws"], stream), "tfrt_goal_error3d")
         grads = [None] * len(opt.parameters)
-        if fv.requires_grad and st["M"] > 0:
-            st["g_fv"].zero_()
+        if need_back:
             check(L.tfrt_trace3d_backward(
                 ops._p(block), block.shape[1], st["N"], ctypes.byref(sc),
                 float(eng.new_ray_length), float(eng.dead_ray_length or 0.0), P, dt,

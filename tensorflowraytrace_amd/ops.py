@@ -54,6 +54,28 @@ def _c(t, dtype=None):
 
 # ------------------------------------------------------------------------- build_faces
 
+_corner_cache = {}
+
+
+def vertex_corners(faces, n_vertices):
+    """(corner_start (V+1) i32, corner_list (3F) i32): the face corners ``f*3+c`` sorted by the
+    vertex they reference, for the gather form of the reverse kernels (deterministic, no
+    atomics).  Built once per face tensor (mesh topology) and cached with it."""
+    key = (faces.data_ptr(), tuple(faces.shape), int(n_vertices), faces._version)
+    hit = _corner_cache.get(key)
+    if hit is not None and hit[0] is faces:
+        return hit[1], hit[2]
+    flat = faces.reshape(-1).long()
+    order = torch.argsort(flat, stable=True)
+    counts = torch.bincount(flat, minlength=int(n_vertices))[:int(n_vertices)]
+    start = torch.zeros(int(n_vertices) + 1, dtype=torch.int32, device=faces.device)
+    start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    if len(_corner_cache) > 256:
+        _corner_cache.clear()
+    _corner_cache[key] = (faces, start.contiguous(), order.to(torch.int32).contiguous())
+    return _corner_cache[key][1], _corner_cache[key][2]
+
+
 class _BuildFaces(torch.autograd.Function):
     """vertices (V,3) f64 -> face_verts (F,9) f64, norm (F,3) f64.
 
@@ -72,19 +94,22 @@ class _BuildFaces(torch.autograd.Function):
             "tfrt_build_faces_forward")
         ctx.save_for_backward(fv, faces, update_mask)
         ctx.n_vertices = vertices.shape[0]
+        if vertices.requires_grad and F > 0:
+            ctx.corners = vertex_corners(faces, vertices.shape[0])   # (outside any graph capture)
         return fv, norm
 
     @staticmethod
     def backward(ctx, g_fv, g_norm):
         fv, faces, update_mask = ctx.saved_tensors
-        gv = torch.zeros((ctx.n_vertices, 3), dtype=torch.float64, device=fv.device)
         g_fv = _c(g_fv, torch.float64)
         g_norm = _c(g_norm, torch.float64)
-        if g_fv is None and g_norm is None:
-            return gv, None, None
+        if (g_fv is None and g_norm is None) or faces.shape[0] == 0:
+            return torch.zeros((ctx.n_vertices, 3), dtype=torch.float64, device=fv.device), None, None
+        start, lst = ctx.corners
+        gv = torch.empty((ctx.n_vertices, 3), dtype=torch.float64, device=fv.device)
         check(_lib.lib().tfrt_build_faces_backward(
             _p(g_fv), _p(g_norm), _p(fv), _p(faces), _p(update_mask), faces.shape[0],
-            ctx.n_vertices, _p(gv), _stream(fv)), "tfrt_build_faces_backward")
+            ctx.n_vertices, _p(start), _p(lst), _p(gv), _stream(fv)), "tfrt_build_faces_backward")
         return gv, None, None
 
 
@@ -115,20 +140,24 @@ class _ParamFaces(torch.autograd.Function):
             _stream(parameters)), "tfrt_param_faces_forward")
         ctx.save_for_backward(fv, faces, update_mask, vectors)
         ctx.shape = parameters.shape
+        if F > 0:
+            ctx.corners = vertex_corners(faces, V)
         ctx.set_materialize_grads(False)
         return fv, norm
 
     @staticmethod
     def backward(ctx, g_fv, g_norm):
         fv, faces, update_mask, vectors = ctx.saved_tensors
-        gp = torch.zeros(ctx.shape, dtype=torch.float64, device=fv.device)
         g_fv = _c(g_fv, torch.float64)
         g_norm = _c(g_norm, torch.float64)
-        if g_fv is not None or g_norm is not None:
-            check(_lib.lib().tfrt_param_faces_backward(
-                _p(g_fv), _p(g_norm), _p(fv), _p(faces), _p(update_mask), _p(vectors),
-                faces.shape[0], vectors.shape[0], _p(gp), _stream(fv)),
-                "tfrt_param_faces_backward")
+        if (g_fv is None and g_norm is None) or faces.shape[0] == 0:
+            return torch.zeros(ctx.shape, dtype=torch.float64, device=fv.device), None, None, None, None
+        start, lst = ctx.corners
+        gp = torch.empty(ctx.shape, dtype=torch.float64, device=fv.device)
+        check(_lib.lib().tfrt_param_faces_backward(
+            _p(g_fv), _p(g_norm), _p(fv), _p(faces), _p(update_mask), _p(vectors),
+            faces.shape[0], vectors.shape[0], _p(start), _p(lst), _p(gp), _stream(fv)),
+            "tfrt_param_faces_backward")
         return gp, None, None, None, None
 
 
@@ -289,7 +318,7 @@ class Scene3DArgs:
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
                  ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None,
-                 sort_rays=False):
+                 sort_rays=False, deterministic=False):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -300,6 +329,7 @@ class Scene3DArgs:
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
         self.sort_rays = bool(sort_rays)                       # + Morton-sorted rays
+        self.deterministic = bool(deterministic)               # ordered reverse-sweep sums
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -331,6 +361,7 @@ class Scene3DArgs:
             raise TfrtError("cluster_order must be a permutation of the M face indices")
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
         sc.sort_rays = 1 if self.sort_rays else 0
+        sc.deterministic = 1 if self.deterministic else 0
         self._struct_cache = (M, sc)
         return sc
 

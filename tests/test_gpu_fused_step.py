@@ -144,18 +144,26 @@ def test_goal_error_kernel_sum_is_reproducible_and_matches_torch():
     fin = torch.randn((6, cap), dtype=torch.float32, device=dev, generator=g)
     ids = torch.randint(0, n_src, (cap,), dtype=torch.int32, device=dev, generator=g)
     goal = torch.randn((2, n_src), dtype=torch.float64, device=dev, generator=g)
-    n_fin = torch.tensor([n], dtype=torch.int32, device=dev)
+    P = 3
+    counts = torch.zeros(8 * (P + 1), dtype=torch.int32, device=dev)
+    counts[8 * P + 1] = n                               # total_finished
+    counts[8 * P + 4], counts[8 * P + 5] = 123456, 2    # n_tests = 2 * 2^32 + 123456
     fields = (ctypes.c_int32 * 6)(4, 5, 0, 0, 0, 0)
     wsb = L.tfrt_goal_error3d_workspace_bytes(cap)
-    ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    tests_total = torch.zeros(1, dtype=torch.int64, device=dev)
     outs = []
     for _ in range(3):
         g_fin = torch.zeros((6, cap), dtype=torch.float64, device=dev)
         err = torch.zeros(3, dtype=torch.float64, device=dev)
-        _lib.check(L.tfrt_goal_error3d(ops._p(fin), cap, ops._p(ids), _lib.F32, ops._p(n_fin), fields,
-                                       2, ops._p(goal), n_src, ops._p(g_fin), ops._p(err), ops._p(ws),
-                                       wsb, ops._stream(fin)), "tfrt_goal_error3d")
+        junk = torch.ones(12345, dtype=torch.float64, device=dev)
+        _lib.check(L.tfrt_goal_error3d(ops._p(fin), cap, ops._p(ids), _lib.F32, ops._p(counts), P,
+                                       fields, 2, ops._p(goal), n_src, ops._p(g_fin), ops._p(err),
+                                       ops._p(junk), 12000, ops._p(tests_total), ops._p(ws), wsb,
+                                       ops._stream(fin)), "tfrt_goal_error3d")
         outs.append((g_fin, err.cpu()))
+        assert not bool(junk[:12000].any()) and bool((junk[12000:] == 1).all())
+    assert int(tests_total.item()) == 3 * (2 * 2 ** 32 + 123456)
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[1][1], outs[2][1])
     r = fin[4:6, :n].double() - goal[:, ids[:n].long()]
     want = (r ** 2).sum()
@@ -164,4 +172,3 @@ def test_goal_error_kernel_sum_is_reproducible_and_matches_torch():
     assert float(err[1]) == 2 * n and abs(float(err[2]) - float(want) / (2 * n)) <= 1e-15
     assert torch.equal(g_fin[4:6, :n], 2.0 * r)
     assert not bool(g_fin[:4].any()) and not bool(g_fin[4:6, n:].any())
-    assert not bool(ws[:4].any())                        # the ticket is left ready for the next call
