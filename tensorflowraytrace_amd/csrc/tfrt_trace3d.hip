@@ -1346,6 +1346,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       // (scalar loads into SGPRs, four spheres per round) -- no LDS staging, no LDS reads
       TFRT_STAT(0, (long long)ns * __popcll(__ballot(base + tid < n)));
       const float4* __restrict__ su = susphere + t0 / SUPER;
+      // (a "wholly behind the ray's start" test here, as at level 1, was measured and does not
+      // pay: +4 instructions on each of the 83 supercluster tests for ~2 pairs saved per ray)
 #pragma unroll 4
       for (int k = 0; k < ns; ++k) {
         const float4 sp = su[k];
