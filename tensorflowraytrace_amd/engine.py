@@ -627,15 +627,29 @@ class OpticalEngine:
         self.operations = operations
 
     def _reaction(self):
-        """(index_mode, ghost) of the fused reaction declared by the operations."""
+        """(index_mode, ghost) of the fused reaction declared by the operations.  With custom
+        operations only (their ``main`` makes the new rays, see ``_custom_ops``) the projection
+        still runs in the kernels, as a ghost pass whose own children are discarded."""
         for o in self._operations:
             if getattr(o, "ghost", False) and o.active:
                 return False, True
             if isinstance(o, op.StandardReaction) and o.active:
                 return o.refractive_index_type == "index", False
+        if self._custom_ops():
+            return False, True
         raise RuntimeError(
-            "OpticalEngine: no active reaction operation (StandardReaction / GhostThrough); "
-            "the fused HIP trace implements those reactions only")
+            "OpticalEngine: no active reaction operation (StandardReaction / GhostThrough, or an "
+            "operation with its own main())")
+
+    def _custom_ops(self):
+        """Active operations that bring their own ``main`` (operation.py:25-160): run in Python
+        after every projection, like the reference does for all operations."""
+        return [o for o in self._operations
+                if o.active and not getattr(o, "fused", False)
+                and type(o).main is not op.RayOperation.main]
+
+    def _fused_op(self):
+        return next((o for o in self._operations if getattr(o, "fused", False) and o.active), None)
 
     def update(self):
         if self._optical_system is not None:
@@ -871,6 +885,16 @@ class OpticalEngine:
         src = self._source_set()
         if not src:
             return
+        if self._custom_ops():
+            # operations with their own main(): the reference's pass loop (engine.py:2311-2330),
+            # one projection launch sequence + the operations' Python code per pass
+            rays = {k: src[k] for k in src.keys()}
+            for _ in range(int(max_iterations)):
+                rays = self.single_pass(rays)
+                if not bool(rays):
+                    break
+            self._unfinished_rays = rays if bool(rays) else {}
+            return
         predicted = None
         sig = (src["x_start"].shape[0], int(max_iterations), self._flags())
         if self.speculative_counts and self._predicted is not None and self._predicted[0] == sig:
@@ -1010,10 +1034,23 @@ class OpticalEngine:
         for o in self._operations:
             o.preprocess(self, result)
         new_ray_dict = {}
-        if new:
+        reaction = self._fused_op()
+        if new and reaction is not None:
             valid = torch.ones(new["x_start"].shape[0], dtype=torch.bool, device=new["x_start"].device)
-            reaction = next(o for o in self._operations if getattr(o, "fused", False))
             new_ray_dict[reaction] = {"active": {"rays": new, "valid": valid}}
+        # operations with their own main() (engine.py:2228-2234) + simple inheritance for the ray
+        # sets they return (engine.py:2236-2281; the fused reaction's children already carry theirs)
+        for o in self._custom_ops():
+            op_result = o.main(self, result)
+            if bool(op_result):
+                for entry_type, entry in op_result.items():
+                    source_set = result["rays"].get(entry_type)
+                    if source_set is None:
+                        continue
+                    for sig in self.simple_ray_inheritance:
+                        if sig in source_set:
+                            entry["rays"][sig] = source_set[sig]
+                new_ray_dict[o] = op_result
         for o in self._operations:
             o.postprocess(self, result, new_ray_dict)
         out_list = []

@@ -7,6 +7,11 @@ pass kernel, so an operation object mainly *declares* what the engine must do: t
 sets the engine unions (engine.py:1308-1316) and, for ``StandardReaction``, the refractive
 index mode.  ``annotate`` / ``preprocess`` / ``postprocess`` hooks are still honoured by
 ``OpticalEngine.single_pass``.
+
+A user operation that overrides ``main`` (the reference's plug-in point for new reactions) is
+run the reference's way: ``ray_trace`` then loops over ``single_pass`` in Python, the projection
+(intersection, classification, boundary-data gather) still runs in the kernels, and ``main``
+receives the same ``proj_result`` dict and returns ``{"active": {"rays": {...}, "valid": mask}}``.
 """
 import torch
 

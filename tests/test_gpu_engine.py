@@ -290,3 +290,95 @@ def test_stops_and_technical_intersections_through_the_engine():
     assert res["stop"]["norm"].shape == (n_stopped, 3)
     np.testing.assert_allclose(res["stop"]["norm"].detach().abs().cpu().numpy()[:, 0], 1.0, atol=1e-12)
     assert "target" not in res or res["target"]["xp"].shape[0] == 0   # nothing reaches it in pass 1
+
+
+def test_custom_operation_main_runs_the_reference_pass_loop():
+    """A user reaction written against the plug-in API (operation.py:25-160: ``main(engine,
+    proj_result)`` returns ``{"active": {"rays", "valid"}}``): a mirror implemented in torch on
+    the projection result.  The engine then runs the reference's Python pass loop
+    (engine.py:2193-2330) around the fused projection.  Result = the oracle's StandardReaction on
+    the same scene with a reflective material (n_in = 0 mirrors, geometry.py:745-747)."""
+    import tfrt.boundaries as boundaries
+    import tfrt.engine as engine
+    import tfrt.mesh_tools as mt
+    import tfrt.operation as operation
+    import tfrt.sources as sources
+
+    class Mirror(operation.RayOperation):
+        calls = 0
+
+        @property
+        def optical_signature(self):
+            return set()
+
+        def main(self, eng, proj):
+            Mirror.calls += 1
+            act = proj["rays"].get("active")
+            if act is None or act["x_start"].shape[0] == 0:
+                return {}
+            s = torch.stack([act["x_start"], act["y_start"], act["z_start"]], 1).double()
+            h = torch.stack([act["x_end"], act["y_end"], act["z_end"]], 1).double()
+            n = proj["optical"]["norm"]
+            u = (h - s) / torch.linalg.norm(h - s, dim=1, keepdim=True)
+            w = u - 2.0 * (u * n).sum(1, keepdim=True) * n
+            e = h + eng.new_ray_length * w
+            rays = {"x_start": h[:, 0], "y_start": h[:, 1], "z_start": h[:, 2],
+                    "x_end": e[:, 0], "y_end": e[:, 1], "z_end": e[:, 2]}
+            return {"active": {"rays": rays,
+                               "valid": torch.ones(h.shape[0], dtype=torch.bool, device=h.device)}}
+
+    # a tilted mirror facet field (hex mesh, bumpy) in front of a target wall the light returns to
+    zp = mt.hexagonal_mesh(1.0, 3)
+    zp.rotate_y(90)
+    zp.rotate_x(90)
+    r2 = zp.points[:, 1] ** 2 + zp.points[:, 2] ** 2
+    mirror = boundaries.ParametricTriangleBoundary(
+        zp, boundaries.FromVectorVG((1, 0, 0)), initial_parameters=0.2 * r2)
+    target = boundaries.ManualTriangleBoundary(
+        mesh=mt.plane(center=(-4, 0, 0), direction=(1, 0, 0), i_size=30, j_size=30))
+    rng = np.random.default_rng(2)
+    n = 700
+    src = sources.ManualSource(3)
+    y0, z0 = rng.uniform(-0.6, 0.6, n), rng.uniform(-0.6, 0.6, n)
+    src["x_start"], src["y_start"], src["z_start"] = np.full(n, -2.0), y0, z0
+    src["x_end"], src["y_end"], src["z_end"] = np.full(n, -1.0), y0 + 0.02, z0 - 0.01
+    src["wavelength"] = np.full(n, 600.0)
+    src["tag"] = np.arange(n, dtype=np.float64)
+    system = engine.OpticalSystem3D()
+    system.optical = [mirror]
+    system.targets = [target]
+    system.sources = [src]
+    system.update()
+    eng = engine.OpticalEngine(3, [Mirror()], ray_dtype=torch.float64,
+                               simple_ray_inheritance={"tag"})
+    eng.optical_system = system
+    eng.ray_trace(4)
+    assert Mirror.calls >= 2                               # the operation's Python code did run
+    fin = eng.finished_rays
+    assert fin["x_start"].shape[0] > 600
+
+    opt = tracer.faces_from_vertices(mirror.vertices.detach().cpu(), mirror.faces[:, 1:])
+    nf = opt["xp"].shape[0]
+    opt["mat_in"] = torch.zeros(nf, dtype=torch.int64)      # material 0 = reflective (n = 0)
+    opt["mat_out"] = torch.zeros(nf, dtype=torch.int64)
+    tgt = tracer.faces_from_vertices(target.vertices.detach().cpu(), target.faces[:, 1:])
+    osys = tracer.System(3, materials=[tracer.MATERIALS["reflective"]], optical=opt, target=tgt)
+    osrc = {k: v.detach().cpu().double() for k, v in system._amalgamated_sources.items()}
+    ref = tracer.ray_trace(osys, osrc, max_iterations=4, inherit=("wavelength", "tag"))
+    rf = ref["finished"]
+    assert fin["x_start"].shape[0] == rf["x_start"].shape[0]
+    for f in ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end", "tag"):
+        np.testing.assert_allclose(fin[f].detach().cpu().numpy(), rf[f].numpy(), rtol=0, atol=1e-9,
+                                   err_msg=f)
+    # differentiable through the Python reaction: d(spot size)/d(mirror parameters) vs the oracle
+    loss = (fin["y_end"] ** 2 + fin["z_end"] ** 2).sum()
+    (g,) = torch.autograd.grad(loss, [mirror.parameters])
+    q = mirror.parameters.detach().cpu().clone().requires_grad_(True)
+    verts = mirror._zero_points.detach().cpu() + q.reshape(-1, 1) * mirror._vectors.detach().cpu()
+    opt2 = tracer.faces_from_vertices(verts, mirror.faces[:, 1:])
+    opt2["mat_in"], opt2["mat_out"] = opt["mat_in"], opt["mat_out"]
+    osys2 = tracer.System(3, materials=[tracer.MATERIALS["reflective"]], optical=opt2, target=tgt)
+    rf2 = tracer.ray_trace(osys2, osrc, max_iterations=4, inherit=("wavelength", "tag"))["finished"]
+    (r,) = torch.autograd.grad((rf2["y_end"] ** 2 + rf2["z_end"] ** 2).sum(), [q])
+    rel = float((g.cpu() - r).abs().max() / r.abs().max())
+    assert rel < 1e-8, f"gradient rel err {rel:.2e}"
