@@ -162,30 +162,43 @@ __global__ __launch_bounds__(BLOCK) void k_param_faces_bwd(
   }
 }
 
-// Gather forms of the two reverse kernels: one lane per VERTEX walks the face corners that
+// Gather forms of the two reverse kernels: a lane group per VERTEX walks the face corners that
 // reference it (corner_start / corner_list: the corners f*3+c sorted by vertex, built once per
 // mesh topology) and sums their gradients in that fixed order.  No atomics, no zero-filled
 // output, and the same bits on every run (a float64 atomic sum depends on arrival order).
+// (8 lanes per vertex: lane j takes the vertex's corners j, j + 8, ... and the eight partial sums
+// are combined by a fixed xor butterfly -- a vertex has ~6 corners, one lane per vertex left the
+// chip at 21 workgroups for a 5,167-vertex surface.)
+constexpr int GATHER_LANES = 8;
+
 __global__ __launch_bounds__(BLOCK) void k_build_faces_bwd_gather(
     const double* __restrict__ g_fverts, const double* __restrict__ g_norm,
     const double* __restrict__ fverts, const uint8_t* __restrict__ mask,
     const int32_t* __restrict__ corner_start, const int32_t* __restrict__ corner_list, int64_t V,
     double* __restrict__ g_vertices) {
-  const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (v >= V) return;
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t v = t / GATHER_LANES;
+  const int sub = (int)(t % GATHER_LANES);
   double acc[3] = {0.0, 0.0, 0.0};
-  for (int q = corner_start[v]; q < corner_start[v + 1]; ++q) {
-    const int fc = corner_list[q], f = fc / 3, c = fc - 3 * f;
-    if (mask != nullptr && mask[fc] == 0) continue;
-    double g[9];
-    face_grad(g_fverts, g_norm, fverts, f, g);
-    acc[0] += g[3 * c];
-    acc[1] += g[3 * c + 1];
-    acc[2] += g[3 * c + 2];
+  if (v < V) {
+    for (int q = corner_start[v] + sub; q < corner_start[v + 1]; q += GATHER_LANES) {
+      const int fc = corner_list[q], f = fc / 3, c = fc - 3 * f;
+      if (mask != nullptr && mask[fc] == 0) continue;
+      double g[9];
+      face_grad(g_fverts, g_norm, fverts, f, g);
+      acc[0] += g[3 * c];
+      acc[1] += g[3 * c + 1];
+      acc[2] += g[3 * c + 2];
+    }
   }
-  g_vertices[3 * v] = acc[0];
-  g_vertices[3 * v + 1] = acc[1];
-  g_vertices[3 * v + 2] = acc[2];
+#pragma unroll
+  for (int d = GATHER_LANES / 2; d > 0; d >>= 1)
+    for (int k = 0; k < 3; ++k) acc[k] += __shfl_xor(acc[k], d, 64);
+  if (v < V && sub == 0) {
+    g_vertices[3 * v] = acc[0];
+    g_vertices[3 * v + 1] = acc[1];
+    g_vertices[3 * v + 2] = acc[2];
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_param_faces_bwd_gather(
@@ -193,18 +206,23 @@ __global__ __launch_bounds__(BLOCK) void k_param_faces_bwd_gather(
     const double* __restrict__ fverts, const uint8_t* __restrict__ mask,
     const double* __restrict__ vectors, const int32_t* __restrict__ corner_start,
     const int32_t* __restrict__ corner_list, int64_t V, double* __restrict__ g_params) {
-  const int64_t v = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (v >= V) return;
+  const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t v = t / GATHER_LANES;
+  const int sub = (int)(t % GATHER_LANES);
   double acc = 0.0;
-  for (int q = corner_start[v]; q < corner_start[v + 1]; ++q) {
-    const int fc = corner_list[q], f = fc / 3, c = fc - 3 * f;
-    if (mask != nullptr && mask[fc] == 0) continue;
-    double g[9];
-    face_grad(g_fverts, g_norm, fverts, f, g);
-    acc += g[3 * c] * vectors[3 * v] + g[3 * c + 1] * vectors[3 * v + 1] +
-           g[3 * c + 2] * vectors[3 * v + 2];
+  if (v < V) {
+    for (int q = corner_start[v] + sub; q < corner_start[v + 1]; q += GATHER_LANES) {
+      const int fc = corner_list[q], f = fc / 3, c = fc - 3 * f;
+      if (mask != nullptr && mask[fc] == 0) continue;
+      double g[9];
+      face_grad(g_fverts, g_norm, fverts, f, g);
+      acc += g[3 * c] * vectors[3 * v] + g[3 * c + 1] * vectors[3 * v + 1] +
+             g[3 * c + 2] * vectors[3 * v + 2];
+    }
   }
-  g_params[v] = acc;
+#pragma unroll
+  for (int d = GATHER_LANES / 2; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (v < V && sub == 0) g_params[v] = acc;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_snell3d(int64_t n, const double* xs, const double* ys,
@@ -296,7 +314,8 @@ int tfrt_build_faces_backward(const double* grad_face_verts, const double* grad_
       (grad_norm && !face_verts) || ((corner_start == nullptr) != (corner_list == nullptr)))
     return TFRT_E_BADARG;
   if (corner_start != nullptr) {
-    hipLaunchKernelGGL(k_build_faces_bwd_gather, dim3(cdiv(n_vertices, BLOCK)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL(k_build_faces_bwd_gather, dim3(cdiv(n_vertices * GATHER_LANES, BLOCK)),
+                       dim3(BLOCK), 0,
                        static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
                        update_mask, corner_start, corner_list, n_vertices, grad_vertices);
     return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
@@ -331,7 +350,8 @@ int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_
       (grad_norm && !face_verts) || ((corner_start == nullptr) != (corner_list == nullptr)))
     return TFRT_E_BADARG;
   if (corner_start != nullptr) {
-    hipLaunchKernelGGL(k_param_faces_bwd_gather, dim3(cdiv(n_vertices, BLOCK)), dim3(BLOCK), 0,
+    hipLaunchKernelGGL(k_param_faces_bwd_gather, dim3(cdiv(n_vertices * GATHER_LANES, BLOCK)),
+                       dim3(BLOCK), 0,
                        static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
                        update_mask, vectors, corner_start, corner_list, n_vertices,
                        grad_parameters);

@@ -61,42 +61,46 @@ constexpr int ERR_CAPACITY = 1;
 // radii).  Any point near the mesh serves, so at most ~2048 evenly spaced faces are read.
 // (Also does k_init's work -- the trace's counters -- so a trace with faces needs one set-up
 // launch instead of two.)
-__global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fverts, int M,
-                                                 double* __restrict__ c0, int32_t* nrays0, int n,
-                                                 int32_t* tail8, unsigned int* scan_ticket) {
+__global__ __launch_bounds__(BLOCK) void k_center(const double* __restrict__ fverts, int M,
+                                                  double* __restrict__ c0, int32_t* nrays0, int n,
+                                                  int32_t* tail8, unsigned int* scan_ticket,
+                                                  int want_scale) {
   if (nrays0 != nullptr) {
     if (threadIdx.x == 0) *nrays0 = n;
     if (threadIdx.x < 8) tail8[threadIdx.x] = 0;
     if (threadIdx.x == 0 && scan_ticket != nullptr) *scan_ticket = 0u;
   }
-  __shared__ double red[3][1024];
+  __shared__ double red[WAVES][3];
+  __shared__ double ctr[3];
   const int step = M > 2048 ? M / 2048 : 1;
   const int ns = M > 0 ? (M + step - 1) / step : 0;  // samples j * step, j < ns
+  const int wave = threadIdx.x >> 6;
   double a[3] = {0, 0, 0};
-  for (int j = threadIdx.x; j < ns; j += 1024) {
+  for (int j = threadIdx.x; j < ns; j += BLOCK) {
     const double* P = fverts + 9 * (int64_t)j * step;
     a[0] += P[0];
     a[1] += P[1];
     a[2] += P[2];
   }
-  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = a[k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1)
+    for (int k = 0; k < 3; ++k) a[k] += __shfl_xor(a[k], d, 64);
+  if (lane_id() == 0)
+    for (int k = 0; k < 3; ++k) red[wave][k] = a[k];
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s)
-      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
-    __syncthreads();
-  }
-  __shared__ double ctr[3];
   if (threadIdx.x < 3) {
-    ctr[threadIdx.x] = (ns > 0) ? red[threadIdx.x][0] / ns : 0.0;
+    double sum = 0.0;
+    for (int w = 0; w < WAVES; ++w) sum += red[w][threadIdx.x];
+    ctr[threadIdx.x] = (ns > 0) ? sum / ns : 0.0;
     c0[threadIdx.x] = ctr[threadIdx.x];
   }
+  if (!want_scale) return;  // (block-uniform)
   __syncthreads();
   // c0[3] = length scale for the ray sort keys of the sorted-ray mode: twice the RMS distance
   // of the sampled faces from c0 (robust against a few huge faces such as a distant target
   // plane; rays passing farther out simply clamp to the border cell)
   double acc = 0.0;
-  for (int j = threadIdx.x; j < ns; j += 1024) {
+  for (int j = threadIdx.x; j < ns; j += BLOCK) {
     const double* P = fverts + 9 * (int64_t)j * step;
     double d2 = 0.0;
     for (int k = 0; k < 3; ++k) {
@@ -105,13 +109,15 @@ __global__ __launch_bounds__(1024) void k_center(const double* __restrict__ fver
     }
     acc += d2;
   }
-  red[0][threadIdx.x] = acc;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane_id() == 0) red[wave][0] = acc;
   __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) red[0][threadIdx.x] += red[0][threadIdx.x + s];
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    double sum = 0.0;
+    for (int w = 0; w < WAVES; ++w) sum += red[w][0];
+    c0[3] = 2.0 * sqrt(sum / (ns > 0 ? ns : 1));
   }
-  if (threadIdx.x == 0) c0[3] = 2.0 * sqrt(red[0][0] / (ns > 0 ? ns : 1));
 }
 
 // Smallest enclosing sphere of a triangle, inflated so that the float32 filter is
@@ -2294,8 +2300,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   ac.sort_bytes = lay.sort_bytes;
   int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
   if (M > 0) {
-    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, sc->face_verts, M, c0, nrays, (int)N,
-                       tail, ticket);
+    hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays, (int)N,
+                       tail, ticket, (ac.order != nullptr && ac.sort_rays) ? 1 : 0);
     if (ac.order != nullptr) {
       const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
       if (ac.sort_rays) {
@@ -2566,8 +2572,8 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
     hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nptr, (int)n_rays, nptr + 8,
                        (unsigned int*)nullptr);
   if (M > 0) {
-    hipLaunchKernelGGL(k_center, dim3(1), dim3(1024), 0, st, face_verts, M, c0, nptr, (int)n_rays,
-                       nptr + 8, (unsigned int*)nullptr);
+    hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, face_verts, M, c0, nptr, (int)n_rays,
+                       nptr + 8, (unsigned int*)nullptr, 0);
     hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, face_verts, M, c0,
                        size_epsilion, sphere);
   }

@@ -14,6 +14,7 @@ construction, so the step is plain ``p -= 0.01 * processed_grad``.  That is the 
 Nesterov rule the constructor presumably intended.
 """
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -29,7 +30,7 @@ class DeferredScalar:
     comparing, arithmetic) instead of inside ``single_step``: a blocking read there would drain
     the GPU queue once per step and leave the device idle while the host prepares the next
     trace."""
-    __slots__ = ("_tensor", "_value")
+    __slots__ = ("_tensor", "_value", "__weakref__")
 
     def __init__(self, tensor):
         self._tensor = tensor.detach()
@@ -151,6 +152,7 @@ class SGD_Optimizer:
         self.fused = fused
         self.graph = graph
         self._fused_step = None
+        self._pending_error = None
 
     @property
     def momentum(self):
@@ -340,10 +342,17 @@ class SGD_Optimizer:
         if self.fused in ("auto", True) and FusedStep.eligible(self, args, kwargs):
             if self._fused_step is None:
                 self._fused_step = FusedStep(self, graph=self.graph)
+            # the step writes its error into a buffer the next step overwrites: an error value
+            # nobody has read yet is copied out just before that (and only then: no copy launch
+            # per step when the caller drops or reads the value right away)
+            prev = self._pending_error() if self._pending_error is not None else None
+            if prev is not None and prev._value is None and prev._tensor is not None:
+                prev._tensor = prev._tensor.clone()
             err3 = self._fused_step.step(accumulators, lr_scale)   # {sum, n_terms, mean}, device
             self.iterations += 1
             self.last_error_terms = err3[1]
-            err = DeferredScalar(err3[2].clone())
+            err = DeferredScalar(err3[2])
+            self._pending_error = weakref.ref(err)
             if verbose:
                 print(f"step {self.iterations} error: {err}")
             return err
