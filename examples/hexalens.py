@@ -35,7 +35,7 @@ import tfrt.sources as sources                # noqa: E402
 
 
 def build(ray_count=20000, lens_res_scale=0.12, source_distance=10.0, magnification=1.0,
-          object_size=0.2, lens_aperature=1.0, random_rays=True):
+          object_size=0.2, lens_aperature=1.0, random_rays=True, generic_step=False):
     circle = distributions.RandomUniformCircle if random_rays else distributions.StaticUniformCircle
     start_points = circle(ray_count, object_size)
     distributions.BasePointTransformation(start_points, translation=(-source_distance, 0, 0))
@@ -74,11 +74,19 @@ def build(ray_count=20000, lens_res_scale=0.12, source_distance=10.0, magnificat
     trace_engine.optical_system = system
     trace_engine.validate_system()
 
-    def error_function(eng):
+    def torch_error_function(eng):
+        """dev/hexalens.py:144-168 (inner goal) as the reference writes it: arbitrary code on the
+        finished rays (the generic step: reads the ray counts back, autograd through torch ops)."""
         fin = eng.finished_rays
         output = torch.stack([fin["y_end"], fin["z_end"]], dim=1).double()
         goal = fin["object_coords"][:, 1:] * -magnification
         return (output - goal) ** 2
+
+    # the same error stated as a GoalError: squared_difference(stack(finished[fields]), goal) with the
+    # goal a function of inherited source fields -- the optimiser then runs the step as one fixed
+    # launch sequence replayed from a HIP graph (tensorflowraytrace_amd/fused_step.py)
+    error_function = torch_error_function if generic_step else optimizer.GoalError(
+        ("y_end", "z_end"), lambda src: src["object_coords"][:, 1:] * -magnification)
 
     smoother = mt.mesh_smoothing_tool(zero_points, [300, 50, 20, 10, 5])
     return dict(engine=trace_engine, system=system, lens=lens, error_function=error_function,
@@ -115,8 +123,8 @@ def save_meshes(lens, directory):
 
 
 def run(ray_count=20000, steps=30, lens_res_scale=0.12, verbose=True, history_file=None,
-        resume_from=None):
-    s = build(ray_count, lens_res_scale)
+        resume_from=None, generic_step=False):
+    s = build(ray_count, lens_res_scale, generic_step=generic_step)
     parameter_history = []
     if resume_from:
         parameter_history = load_parameters(s["lens"], s["system"], resume_from)
@@ -160,8 +168,11 @@ if __name__ == "__main__":
     ap.add_argument("--history", default=None, help="write the parameter history (pickle) here")
     ap.add_argument("--resume", default=None, help="start from the last record of this history")
     ap.add_argument("--stl-dir", default=None, help="write both optimised surfaces as STL here")
+    ap.add_argument("--generic-step", action="store_true",
+                    help="error function as torch code (the reference's form) instead of a GoalError")
     a = ap.parse_args()
-    errs, state = run(a.rays, a.steps, a.edge, history_file=a.history, resume_from=a.resume)
+    errs, state = run(a.rays, a.steps, a.edge, history_file=a.history, resume_from=a.resume,
+                      generic_step=a.generic_step)
     if a.stl_dir:
         save_meshes(state["lens"], a.stl_dir)
     print(f"mean squared image error: first {errs[0]:.6g} -> last {errs[-1]:.6g}")
