@@ -304,3 +304,58 @@ def test_bounding_circle_filter_never_loses_a_hit_on_random_soups(seed, n_seg, n
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()))
         hit += n_ref if cls != "dead" else 0
     assert hit > 0.2 * n_rays
+
+
+def test_config1_at_its_stated_size_against_the_oracle():
+    """BASELINE configs[0] as SURVEY.md 8 sizes it: 1,000 beam points x 1 wavelength against one
+    acrylic arc, one single_pass through the public API; every active / dead ray and every child
+    against the oracle's single pass (float64 state: 1e-9; classes identical)."""
+    import tfrt.boundaries as boundaries
+    import tfrt.distributions as distributions
+    import tfrt.engine as eng
+    import tfrt.materials as materials
+    import tfrt.operation as op
+    import tfrt.sources as sources
+
+    arc = boundaries.ManualArcBoundary()
+    arc["x_center"], arc["y_center"] = np.array([5.0]), np.array([0.0])
+    arc["angle_start"], arc["angle_end"] = np.array([3 * PI / 4]), np.array([5 * PI / 4])
+    arc["radius"] = np.array([5.0])
+    eng.annotation_helper(arc, "mat_in", 1, "x_center", dtype=torch.int64)
+    eng.annotation_helper(arc, "mat_out", 0, "x_center", dtype=torch.int64)
+    beam = distributions.StaticUniformBeam(-4.0, 4.0, 1000)       # wider than the arc: some rays miss
+    angles = distributions.StaticUniformAngularDistribution(0, 0, 1)
+    source = sources.AngularSource(2, (-1.0, 0.0), 0.0, angles, beam, [680.0])
+    system = eng.OpticalSystem2D()
+    system.optical_arcs = [arc]
+    system.sources = [source]
+    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
+    engine = eng.OpticalEngine(2, [op.StandardReaction()], compile_dead_rays=True,
+                               dead_ray_length=10, ray_dtype=torch.float64)
+    engine.optical_system = system
+    system.update()
+    engine.validate_system()
+    src = system._amalgamated_sources
+    assert src["x_start"].shape[0] == 1000
+    new = engine.single_pass(dict(src))
+    res = engine.last_projection_result
+
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    osys = tracer.System(
+        2, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"]],
+        optical_arcs=dict(x_center=t([5.0]), y_center=t([0.0]), angle_start=t([3 * PI / 4]),
+                          angle_end=t([5 * PI / 4]), radius=t([5.0]),
+                          mat_in=torch.ones(1, dtype=torch.int64),
+                          mat_out=torch.zeros(1, dtype=torch.int64)))
+    osrc = {k: src[k].detach().cpu().double() for k in ("x_start", "y_start", "x_end", "y_end", "wavelength")}
+    history = {"active": [], "finished": [], "stopped": [], "dead": []}
+    child, _ = tracer.single_pass(osys, osrc, history,
+                                  flags=dict(compile_dead_rays=True, dead_ray_length=10))
+    n_act = history["active"][0]["x_start"].shape[0]
+    assert 300 < n_act < 1000 and history["dead"][0]["x_start"].shape[0] == 1000 - n_act
+    for name, got, want in (("active", res["rays"]["active"], history["active"][0]),
+                            ("dead", res["rays"]["dead"], history["dead"][0]), ("child", new, child)):
+        assert got["x_start"].shape[0] == want["x_start"].shape[0], name
+        for f in ("x_start", "y_start", "x_end", "y_end"):
+            np.testing.assert_allclose(got[f].detach().cpu().numpy(), want[f].numpy(), rtol=0,
+                                       atol=1e-9, err_msg=f"{name}.{f}")
