@@ -1,0 +1,149 @@
+"""
+tests/golden/reference_geometry.npz holds the outputs of the reference's OWN tfrt/geometry.py
+source (executed in the build container under the minimal TensorFlow stand-in of tests/tf_shim,
+see tests/golden/make_reference_golden.py) on seeded random inputs: raw_line_intersect,
+raw_line_triangle_intersect, raw_line_circle_intersect, angle_in_interval, snells_law_2D,
+snells_law_3D (tfrt/geometry.py:96-802).
+
+* the oracle restatement reproduces every output BIT FOR BIT (same formulas, same order, same
+  masking, same arithmetic): a transcription error in oracle/geom.py would show here;
+* on the GPU the HIP entry points reproduce the algebraic outputs (line x line, line x triangle,
+  Snell 3-D) bit for bit and the outputs that go through atan2 / sin / cos / asin (device libm vs
+  host libm) to 1e-12; valid masks identical.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geom
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_geometry.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLD)
+
+
+def _t(a, dev="cpu"):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+
+
+def test_oracle_reproduces_the_reference_source_bit_for_bit(g):
+    eps = 1e-10
+    x, y, valid, u, v = geom.raw_line_intersect(*[_t(r) for r in g["li"]], eps)
+    assert np.array_equal(valid.numpy(), g["li_valid"]) and 0 < (~g["li_valid"]).sum() < 300
+    assert np.array_equal(torch.stack([x, y, u, v]).numpy(), g["li_out"])
+    res = geom.raw_line_triangle_intersect(*[_t(r) for r in g["tri_rays"]], *[_t(r) for r in g["tri"]], eps)
+    assert np.array_equal(res[3].numpy(), g["tri_valid"])
+    assert np.array_equal(torch.stack([res[0], res[1], res[2], res[4], res[5], res[6]]).numpy(), g["tri_out"])
+    plus, minus = geom.raw_line_circle_intersect(*[_t(r) for r in g["circ_lines"]],
+                                                 *[_t(r) for r in g["circ"]], eps)
+    for name, root in (("plus", plus), ("minus", minus)):
+        assert np.array_equal(root["valid"].numpy(), g[f"circ_{name}_valid"]), name
+        got = torch.stack([root["x"], root["y"], root["u"], root["v"]]).numpy()
+        assert np.array_equal(got, g[f"circ_{name}"]), name
+    assert 0 < g["circ_plus_valid"].sum() < g["circ_plus_valid"].size       # hits and misses
+    assert np.array_equal(geom.angle_in_interval(*[_t(r) for r in g["ang"]]).numpy(), g["ang_out"])
+    L = float(g["new_ray_length"])
+    o2 = geom.snells_law_2D(*[_t(r) for r in g["sn2_rays"]], _t(g["sn2_norm"]), _t(g["sn_n"][0]),
+                            _t(g["sn_n"][1]), L)
+    assert np.array_equal(torch.stack(list(o2)).numpy(), g["sn2_out"])
+    o3 = geom.snells_law_3D(*[_t(r) for r in g["sn3_rays"]], _t(g["sn3_norm"]), _t(g["sn_n"][0]),
+                            _t(g["sn_n"][1]), L)
+    assert np.array_equal(torch.stack(list(o3)).numpy(), g["sn3_out"])
+
+
+@pytest.mark.gpu
+def test_hip_geometry_reproduces_the_reference_source(g):
+    from tensorflowraytrace_amd import ops
+    dev = "cuda:0"
+    t = lambda a: _t(a, dev)
+    eps = 1e-10
+    x, y, valid, u, v = ops.line_intersect([t(r) for r in g["li"][:4]], [t(r) for r in g["li"][4:]],
+                                           eps, grid=False)
+    assert np.array_equal(valid.cpu().numpy(), g["li_valid"])
+    assert np.array_equal(torch.stack([x, y, u, v]).cpu().numpy(), g["li_out"])
+    x, y, z, valid, ru, tu, tv = ops.line_triangle_intersect(
+        [t(r) for r in g["tri_rays"]], [t(r) for r in g["tri"]], eps, grid=False)
+    assert np.array_equal(valid.cpu().numpy(), g["tri_valid"])
+    assert np.array_equal(torch.stack([x, y, z, ru, tu, tv]).cpu().numpy(), g["tri_out"])
+    plus, minus = ops.line_circle_intersect([t(r) for r in g["circ_lines"]], [t(r) for r in g["circ"]],
+                                            eps, grid=False)
+    for name, root in (("plus", plus), ("minus", minus)):
+        assert np.array_equal(root["valid"].cpu().numpy(), g[f"circ_{name}_valid"]), name
+        got = torch.stack([root["x"], root["y"], root["u"], root["v"]]).cpu().numpy()
+        np.testing.assert_allclose(got, g[f"circ_{name}"], rtol=0, atol=1e-12, err_msg=name)
+    L = float(g["new_ray_length"])
+    s3 = g["sn3_rays"]
+    out = ops.snell3d(*[t(s3[i]) for i in range(6)], t(g["sn3_norm"]), t(g["sn_n"][0]),
+                      t(g["sn_n"][1]), L).cpu().numpy()
+    assert np.array_equal(out, g["sn3_out"])
+    s2 = g["sn2_rays"]
+    out = ops.snell2d(*[t(s2[i]) for i in range(4)], t(g["sn2_norm"]), t(g["sn_n"][0]),
+                      t(g["sn_n"][1]), L).cpu().numpy()
+    np.testing.assert_allclose(out, g["sn2_out"], rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# tests/golden/reference_trace3d.npz: a 4-pass 3-D trace of the lens scene (1,200 rays x 246 faces)
+# and its parameter gradients, produced by the reference's own engine / operation / materials /
+# geometry modules executed under tests/tf_shim (tests/golden/make_reference_trace_golden.py)
+
+TRACE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_trace3d.npz")
+NAMES = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
+
+
+def test_oracle_trace_reproduces_the_reference_engine_bit_for_bit():
+    import oracle_util
+    from oracle import tracer
+    g = np.load(TRACE)
+    scene = {k: g[k] for k in g.files}
+    system, (p_f, p_b), _ = oracle_util.lens_oracle(scene)
+    ref = tracer.ray_trace(system, oracle_util.source_dict(g["rays"], g["wavelength"]),
+                           max_iterations=int(g["passes"]), inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    for cls in ("finished", "active"):
+        assert np.array_equal(ref[cls]["ray_id"].numpy().astype(np.int64), g[cls + "_id"]), cls
+        assert np.array_equal(oracle_util.block(ref[cls]), g[cls]), cls      # every bit
+    assert g["dead"].shape[1] == 0 and (not ref["dead"] or ref["dead"]["x_start"].shape[0] == 0)
+    fin = ref["finished"]
+    goal = torch.tensor(g["goal"])[fin["ray_id"].long()]
+    loss = ((fin["y_end"] - goal[:, 0]) ** 2 + (fin["z_end"] - goal[:, 1]) ** 2).sum()
+    assert float(loss.detach()) == float(g["loss"])
+    g_f, g_b = torch.autograd.grad(loss, [p_f, p_b])
+    for got, want in ((g_f.numpy(), g["grad_front"]), (g_b.numpy(), g["grad_back"])):
+        assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 0.0), (torch.float32, 1e-5)])
+def test_hip_trace_reproduces_the_reference_engine(dtype, tol):
+    """float64 ray state: classes, order and every coordinate of the finished and active sets equal
+    the reference engine's output bit for bit; gradients to 1e-8.  float32 state: 1e-5."""
+    from tensorflowraytrace_amd import ops, _lib
+    from test_gpu_trace3d import _gpu_scene
+    g = np.load(TRACE)
+    scene = {k: g[k] for k in g.files}
+    for cluster in ("group", False):
+        src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster=cluster)
+        flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+        out = ops.trace3d(src, fv, sc, max_passes=int(g["passes"]), flags=flags)
+        assert out["dead"].shape[1] == 0 and out["stopped"].shape[1] == 0
+        for cls in ("finished", "active"):
+            assert np.array_equal(out[cls + "_id"].cpu().numpy().astype(np.int64), g[cls + "_id"]), cls
+            got = out[cls].detach().cpu().double().numpy()
+            if tol == 0.0:
+                assert np.array_equal(got, g[cls]), (cls, cluster)
+            else:
+                assert np.abs(got - g[cls]).max() / max(1.0, np.abs(g[cls]).max()) <= tol
+        fin = out["finished"]
+        goal = torch.tensor(g["goal"], device=fin.device)[out["finished_id"].long()]
+        loss = ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
+        g_f, g_b = torch.autograd.grad(loss, [p_f, p_b])
+        gtol = 1e-8 if tol == 0.0 else tol
+        assert abs(float(loss.detach()) - float(g["loss"])) <= max(gtol, 1e-12) * float(g["loss"])
+        for got, want in ((g_f.cpu().numpy(), g["grad_front"]), (g_b.cpu().numpy(), g["grad_back"])):
+            assert np.abs(got - want).max() <= gtol * np.abs(want).max()

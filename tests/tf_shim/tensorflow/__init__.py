@@ -1,0 +1,286 @@
+"""
+TEST-ONLY stand-in for the handful of TensorFlow names that tfrt/geometry.py uses, on torch-CPU
+float64 tensors, so that the reference's OWN source file can be executed in the build container
+(where TensorFlow is not installed) by tests/golden/make_reference_golden.py.  Never imported by
+the product package, the GPU tests or bench.py; it does not travel anywhere that matters (the
+reference does not exist on the GPU box).
+
+Every op is one correctly rounded float64 operation, like TensorFlow's CPU kernels (Eigen): in
+particular ``sqrt`` is numpy's IEEE square root, not torch's (see oracle/geom.py).  Only eager
+semantics are provided: ``tf.function`` returns the undecorated function.
+"""
+import builtins as _builtins
+import contextlib
+
+import numpy as np
+import torch
+
+float64 = torch.float64
+float32 = torch.float32
+int64 = torch.int64
+int32 = torch.int32
+bool = torch.bool  # noqa: A001
+
+
+class TensorSpec:
+    def __init__(self, shape=None, dtype=None, name=None):
+        self.shape, self.dtype, self.name = shape, dtype, name
+
+
+def function(func=None, input_signature=None, **_):
+    if func is None:
+        return lambda f: f
+    return func
+
+
+@contextlib.contextmanager
+def name_scope(_name):
+    yield
+
+
+def _t(x):
+    if isinstance(x, torch.Tensor):
+        return x
+    if isinstance(x, (_builtins.bool, np.bool_)):
+        return torch.tensor(_builtins.bool(x))
+    return torch.as_tensor(x, dtype=torch.float64)
+
+
+def constant(x, dtype=None, name=None):
+    return torch.as_tensor(x, dtype=dtype or torch.float64)
+
+
+def cast(x, dtype, name=None):
+    return _t(x).to(dtype)
+
+
+def meshgrid(*args, indexing="xy", name=None):
+    return list(torch.meshgrid(*[_t(a) for a in args], indexing=indexing))
+
+
+def where(cond, x=None, y=None, name=None):
+    x, y = _t(x), _t(y)
+    return torch.where(cond, x, y)
+
+
+def ones_like(x, dtype=None, name=None):
+    return torch.ones_like(_t(x), dtype=dtype)
+
+
+def zeros_like(x, dtype=None, name=None):
+    return torch.zeros_like(_t(x), dtype=dtype)
+
+
+def broadcast_to(x, shape, name=None):
+    return torch.broadcast_to(_t(x), tuple(int(s) for s in shape))
+
+
+def reshape(x, shape, name=None):
+    return torch.reshape(_t(x), tuple(shape))
+
+
+def shape(x, out_type=torch.int32, name=None):
+    return torch.tensor(tuple(_t(x).shape), dtype=torch.int64)
+
+
+def stack(xs, axis=0, name=None):
+    return torch.stack([_t(x) for x in xs], dim=axis)
+
+
+def unstack(x, num=None, axis=0, name=None):
+    return list(torch.unbind(_t(x), dim=axis))
+
+
+def reduce_sum(x, axis=None, keepdims=False, name=None):
+    return torch.sum(_t(x)) if axis is None else torch.sum(_t(x), dim=axis, keepdim=keepdims)
+
+
+def abs(x, name=None):  # noqa: A001
+    return torch.abs(_t(x))
+
+
+def sign(x, name=None):
+    return torch.sign(_t(x))
+
+
+class _Sqrt(torch.autograd.Function):
+    """Correctly rounded float64 square root (numpy) with the usual derivative."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.from_numpy(np.sqrt(x.detach().contiguous().numpy()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return g / (2 * y)
+
+
+def sqrt(x, name=None):
+    return _Sqrt.apply(_t(x))
+
+
+def sin(x, name=None):
+    return torch.sin(_t(x))
+
+
+def cos(x, name=None):
+    return torch.cos(_t(x))
+
+
+def asin(x, name=None):
+    return torch.asin(_t(x))
+
+
+def atan2(y, x, name=None):
+    return torch.atan2(_t(y), _t(x))
+
+
+def less(a, b, name=None):
+    return _t(a) < _t(b)
+
+
+def less_equal(a, b, name=None):
+    return _t(a) <= _t(b)
+
+
+def greater(a, b, name=None):
+    return _t(a) > _t(b)
+
+
+def greater_equal(a, b, name=None):
+    return _t(a) >= _t(b)
+
+
+def equal(a, b, name=None):
+    return _t(a) == _t(b)
+
+
+def not_equal(a, b, name=None):
+    return _t(a) != _t(b)
+
+
+def logical_and(a, b, name=None):
+    return torch.logical_and(a, b)
+
+
+def logical_or(a, b, name=None):
+    return torch.logical_or(a, b)
+
+
+def logical_not(a, name=None):
+    return torch.logical_not(a)
+
+
+class _Math:
+    @staticmethod
+    def mod(x, y, name=None):
+        return torch.remainder(_t(x), _t(y))          # tf.math.mod is floor-mod
+
+    floormod = mod
+
+    @staticmethod
+    def l2_normalize(x, axis=None, epsilon=1e-12, name=None):
+        x = _t(x)
+        sq = torch.sum(x * x, dim=axis, keepdim=True)
+        return x * torch.rsqrt(torch.clamp(sq, min=epsilon))   # torch.rsqrt is IEEE 1/sqrt here
+
+    is_finite = staticmethod(lambda x: torch.isfinite(_t(x)))
+    squared_difference = staticmethod(lambda a, b: (_t(a) - _t(b)) ** 2)
+
+
+math = _Math()
+
+
+# ------------------------------------------------------------------- used by tfrt/engine.py,
+# tfrt/operation.py, tfrt/materials.py (tests/golden/make_reference_trace_golden.py)
+
+DType = torch.dtype
+dtype = torch.dtype
+
+
+class TensorShape(tuple):
+    pass
+
+
+def concat(values, axis=0, name=None):
+    return torch.cat([_t(v) for v in values], dim=axis)
+
+
+def zeros(shape, dtype=torch.float32, name=None):
+    return torch.zeros(tuple(shape), dtype=dtype)
+
+
+def ones(shape, dtype=torch.float32, name=None):
+    return torch.ones(tuple(shape), dtype=dtype)
+
+
+def fill(dims, value, name=None):
+    return torch.full(tuple(int(d) for d in dims), float(value), dtype=torch.float64)
+
+
+def range(start, limit=None, delta=1, dtype=None, name=None):  # noqa: A001
+    if limit is None:
+        start, limit = 0, start
+    return torch.arange(int(start), int(limit), int(delta), dtype=dtype or torch.int64)
+
+
+def transpose(a, perm=None, name=None):
+    a = _t(a)
+    return a.t() if perm is None else a.permute(*perm)
+
+
+def gather(params, indices, axis=0, name=None):
+    assert axis == 0
+    return _t(params)[_t(indices).to(torch.int64)]
+
+
+def gather_nd(params, indices, name=None):
+    idx = _t(indices).to(torch.int64)
+    return _t(params)[tuple(idx[..., k] for k in builtins_range(idx.shape[-1]))]
+
+
+def boolean_mask(tensor, mask, axis=None, name=None):
+    return _t(tensor)[mask]                    # keeps the order (stable), like tf.boolean_mask
+
+
+def argmin(input, axis=None, output_type=torch.int64, name=None):  # noqa: A002
+    # tf.argmin returns the FIRST index of the minimum; torch.argmin does not promise that on
+    # ties, so spell it out: min value, then the first position that attains it
+    x = _t(input)
+    m = torch.min(x, dim=axis, keepdim=True).values
+    n = x.shape[axis]
+    pos = torch.arange(n, dtype=torch.int64).reshape([-1 if k == axis else 1 for k in builtins_range(x.dim())])
+    first = torch.where(x == m, pos, torch.full_like(pos, n)).min(dim=axis).values
+    return first.to(output_type)
+
+
+def reduce_max(x, axis=None, keepdims=False, name=None):
+    return torch.max(_t(x)) if axis is None else torch.max(_t(x), dim=axis, keepdim=keepdims).values
+
+
+def reduce_min(x, axis=None, keepdims=False, name=None):
+    return torch.min(_t(x)) if axis is None else torch.min(_t(x), dim=axis, keepdim=keepdims).values
+
+
+def reduce_any(x, axis=None, keepdims=False, name=None):
+    return torch.any(x) if axis is None else torch.any(x, dim=axis, keepdim=keepdims)
+
+
+def reduce_prod(x, axis=None, name=None):
+    return torch.prod(_t(x)) if axis is None else torch.prod(_t(x), dim=axis)
+
+
+def expand_dims(x, axis, name=None):
+    return torch.unsqueeze(_t(x), axis)
+
+
+def squeeze(x, axis=None, name=None):
+    return torch.squeeze(_t(x)) if axis is None else torch.squeeze(_t(x), axis)
+
+
+import builtins as _builtins  # noqa: E402
+
+builtins_range = _builtins.range
