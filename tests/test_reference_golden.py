@@ -147,3 +147,74 @@ def test_hip_trace_reproduces_the_reference_engine(dtype, tol):
         assert abs(float(loss.detach()) - float(g["loss"])) <= max(gtol, 1e-12) * float(g["loss"])
         for got, want in ((g_f.cpu().numpy(), g["grad_front"]), (g_b.cpu().numpy(), g["grad_back"])):
             assert np.abs(got - want).max() <= gtol * np.abs(want).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# tests/golden/reference_trace2d.npz: 4-pass 2-D traces (arcs only / segments only / both) by the
+# reference's own OpticalSystem2D + OpticalEngine (tests/golden/make_reference_trace2d_golden.py)
+
+TRACE2D = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_trace2d.npz")
+GEO2 = ("x_start", "y_start", "x_end", "y_end")
+
+
+def _sets_2d(g, tag):
+    sets = {}
+    for key in g.files:
+        if key.startswith(tag + "__"):
+            _, name, field = key.split("__")
+            v = g[key]
+            sets.setdefault(name, {})[field] = torch.tensor(v)
+    return sets
+
+
+def _oracle_2d(g, tag, bug_compatible=False):
+    from oracle import tracer
+    sets = _sets_2d(g, tag)
+    osys = tracer.System(2, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"],
+                                       tracer.MATERIALS["reflective"]], **sets)
+    rays, wl = g[tag + "_rays"], g[tag + "_wl"]
+    src = {n: torch.tensor(rays[i]) for i, n in enumerate(GEO2)}
+    src["wavelength"] = torch.tensor(wl)
+    src["ray_id"] = torch.arange(rays.shape[1], dtype=torch.float64)
+    return tracer.ray_trace(osys, src, max_iterations=4, inherit=("wavelength", "ray_id"),
+                            flags=dict(compile_dead_rays=True, compile_stopped_rays=True),
+                            bug_compatible=bug_compatible), sets
+
+
+@pytest.mark.parametrize("tag", ["arc", "seg", "both"])
+def test_oracle_2d_trace_reproduces_the_reference_engine_bit_for_bit(tag):
+    """Unmixed scenes: plain oracle.  The mixed scene: the reference pairs the reacting rays
+    [segment hits, arc hits] with boundary data ordered [arc, segment] (engine.py:1958-1965); the
+    oracle reproduces that output exactly with ``bug_compatible=True``."""
+    import oracle_util
+    g = np.load(TRACE2D)
+    ref, _ = _oracle_2d(g, tag, bug_compatible=(tag == "both"))
+    for cls in ("finished", "active", "stopped", "dead"):
+        want = g[f"{tag}_{cls}"]
+        got = oracle_util.block(ref[cls], dim=2) if ref[cls] else np.zeros((4, 0))
+        assert got.shape == want.shape, (tag, cls)
+        if want.size:
+            assert np.array_equal(ref[cls]["ray_id"].numpy().astype(np.int64), g[f"{tag}_{cls}_id"])
+            assert np.array_equal(got, want), (tag, cls)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["arc", "seg"])
+def test_hip_2d_trace_reproduces_the_reference_engine(tag):
+    """float64 ray state: same rays in the same classes and order; coordinates to 1e-9 (atan2 /
+    sin / cos / asin come from the device's libm)."""
+    from tensorflowraytrace_amd import ops, _lib
+    import test_gpu_trace2d as t2
+    g = np.load(TRACE2D)
+    sets = _sets_2d(g, tag)
+    scene, _, _ = t2._gpu_scene(sets, g[tag + "_wl"])
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src = torch.tensor(g[tag + "_rays"], dtype=torch.float64, device="cuda:0")
+    out = ops.trace2d(src, scene, max_passes=4, flags=flags)
+    for cls in ("finished", "active", "stopped", "dead"):
+        want = g[f"{tag}_{cls}"]
+        assert out[cls].shape[1] == want.shape[1], (tag, cls)
+        if want.size:
+            assert np.array_equal(out[cls + "_id"].cpu().numpy().astype(np.int64), g[f"{tag}_{cls}_id"])
+            np.testing.assert_allclose(out[cls].detach().cpu().numpy(), want, rtol=0, atol=1e-9,
+                                       err_msg=f"{tag}.{cls}")

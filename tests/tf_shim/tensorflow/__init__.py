@@ -43,6 +43,8 @@ def _t(x):
         return x
     if isinstance(x, (_builtins.bool, np.bool_)):
         return torch.tensor(_builtins.bool(x))
+    if isinstance(x, np.ndarray) and x.dtype.kind in "biu":
+        return torch.as_tensor(x)              # masks and indices keep their type
     return torch.as_tensor(x, dtype=torch.float64)
 
 
@@ -284,3 +286,148 @@ def squeeze(x, axis=None, name=None):
 import builtins as _builtins  # noqa: E402
 
 builtins_range = _builtins.range
+
+
+# ------------------------------------------------------------------- used by tfrt/sources.py,
+# tfrt/distributions.py, tfrt/boundaries.py (tests/golden/make_reference_host_golden.py)
+
+string = str
+
+
+def rank(x, name=None):
+    return _t(x).dim()
+
+
+def convert_to_tensor(x, dtype=None, name=None):
+    t = _t(x)
+    return t if dtype is None else t.to(dtype)
+
+
+def linspace(start, stop, num, name=None, axis=0):
+    return torch.linspace(float(start), float(stop), int(num), dtype=torch.float64)
+
+
+def acos(x, name=None):
+    return torch.acos(_t(x))
+
+
+def norm(x, ord="euclidean", axis=None, keepdims=False, name=None):  # noqa: A002
+    x = _t(x)
+    sq = torch.sum(x * x) if axis is None else torch.sum(x * x, dim=axis, keepdim=keepdims)
+    return sqrt(sq)
+
+
+def reduce_mean(x, axis=None, keepdims=False, name=None):
+    return torch.mean(_t(x)) if axis is None else torch.mean(_t(x), dim=axis, keepdim=keepdims)
+
+
+def pad(tensor, paddings, mode="CONSTANT", constant_values=0, name=None):
+    t = _t(tensor)
+    p = torch.as_tensor(paddings).to(torch.int64).reshape(-1, 2).tolist()
+    flat = []
+    for before, after in reversed(p):
+        flat += [int(before), int(after)]
+    return torch.nn.functional.pad(t, flat, value=constant_values)
+
+
+def repeat(input, repeats, axis=None, name=None):  # noqa: A002
+    return torch.repeat_interleave(_t(input), torch.as_tensor(repeats), dim=axis)
+
+
+def stop_gradient(x, name=None):
+    return _t(x).detach()
+
+
+def clip_by_value(t, clip_value_min, clip_value_max, name=None):
+    return torch.clamp(_t(t), min=float(clip_value_min), max=float(clip_value_max))
+
+
+def Variable(initial_value, dtype=None, trainable=True, validate_shape=True, name=None):
+    t = _t(initial_value).detach().clone()
+    if dtype is not None:
+        t = t.to(dtype)
+    t.requires_grad_(_builtins.bool(trainable) and t.is_floating_point())
+
+    def assign(value, t=t):
+        with torch.no_grad():
+            t.copy_(_t(value))
+        return t
+
+    def assign_add(value, t=t):
+        with torch.no_grad():
+            t.add_(_t(value))
+        return t
+
+    def assign_sub(value, t=t):
+        with torch.no_grad():
+            t.sub_(_t(value))
+        return t
+
+    t.assign, t.assign_add, t.assign_sub = assign, assign_add, assign_sub
+    return t
+
+
+class _Linalg:
+    @staticmethod
+    def normalize(tensor, ord="euclidean", axis=None, name=None):  # noqa: A002
+        x = _t(tensor)
+        n = sqrt(torch.sum(x * x, dim=axis, keepdim=True))
+        return x / n, n
+
+    @staticmethod
+    def cross(a, b, name=None):
+        a, b = _t(a), _t(b)
+        return torch.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1],
+                            a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                            a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], dim=-1)
+
+
+linalg = _Linalg()
+
+
+class _Errors:
+    class InvalidArgumentError(Exception):
+        pass
+
+
+errors = _Errors()
+
+
+class _Debugging:
+    @staticmethod
+    def _ok(*a, **k):
+        return None
+
+    assert_integer = assert_greater = assert_greater_equal = assert_less = _ok
+    assert_less_equal = assert_positive = assert_equal = _ok
+
+
+debugging = _Debugging()
+
+
+class _Random:
+    @staticmethod
+    def uniform(shape, minval=0, maxval=None, dtype=torch.float64, seed=None, name=None):
+        maxval = 1.0 if maxval is None else maxval
+        return torch.rand(tuple(int(s) for s in shape), dtype=dtype) * (maxval - minval) + minval
+
+    @staticmethod
+    def normal(shape, mean=0.0, stddev=1.0, dtype=torch.float64, seed=None, name=None):
+        return torch.randn(tuple(int(s) for s in shape), dtype=dtype) * stddev + mean
+
+
+random = _Random()
+_Math.floormod = staticmethod(lambda x, y, name=None: torch.remainder(_t(x), _t(y)))
+
+
+# tf tensors hand out .numpy() whether or not a tape watches them; torch refuses for tensors that
+# require grad.  The reference calls .numpy() on such tensors (boundaries.py:932), so inside the
+# generator processes -- the only ones that import this stand-in -- numpy() detaches first.
+_torch_numpy = torch.Tensor.numpy
+
+
+def _numpy_like_tf(self, *args, **kwargs):
+    return _torch_numpy(self.detach().cpu(), *args, **kwargs)
+
+
+torch.Tensor.numpy = _numpy_like_tf
