@@ -637,8 +637,19 @@ class TriangleBoundaryBase(BoundaryBase):
 
     def update_from_mesh(self):
         if self._mesh is not None:
+            # a static mesh is uploaded and turned into faces once: update() runs every optimiser
+            # step, and a host->device copy per step is slow and cannot sit in a captured launch
+            # graph.  The host arrays are compared, so editing mesh.points in place is seen.
+            pts = np.asarray(self._mesh.points)
+            fcs = np.asarray(self._mesh.faces)
+            seen = self.__dict__.get("_mesh_seen")
+            if (seen is not None and self._face_verts is not None and seen[0].shape == pts.shape
+                    and seen[1].shape == fcs.shape and np.array_equal(seen[0], pts)
+                    and np.array_equal(seen[1], fcs)):
+                return
             self.update_vertices_from_mesh()
             self.update_fields_from_vertices()
+            self.__dict__["_mesh_seen"] = (pts.copy(), fcs.copy())
 
     def update_mesh_from_vertices(self):
         if self._vertices is not None and self._mesh is not None:

@@ -375,12 +375,7 @@ class FusedStep:
             return self._replay()
         if (want_graph and self._eager_steps >= self.graph_warmup and self._stable(sig)
                 and not self.untapped):
-            try:
-                return self._capture(sig, accumulators, world)
-            except Exception as e:  # capture is an optimisation: fall back to the eager sequence
-                self.capture_error = e
-                self._graphs = None
-                torch.cuda.synchronize()
+            return self._capture(sig, accumulators, world)   # (runs this step, then tries to capture)
         self._eager(accumulators, world)
         self._eager_steps += 1
         self._last_sig = sig
@@ -427,16 +422,25 @@ class FusedStep:
             err_now = self._err_view.clone()
         cur.wait_stream(side)
         self._last_sig = sig
-        torch.cuda.synchronize(dev)
-        pool = torch.cuda.graph_pool_handle()
-        ga = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, pool=pool, stream=side):
-            grads = self._sequence(accumulators, world)
-        gb = None
-        if world > 1:
-            gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb, pool=pool, stream=side):
-                self._after_reduce(grads, accumulators)
-        self._graphs = (sig, ga, gb, grads)
+        self._eager_steps += 1
+        # the step itself is done; capturing is an optimisation of the following ones: anything in
+        # update() that a capture does not allow (a host->device copy, a blocking read) turns it
+        # off for this optimizer and the steps go on eagerly
+        try:
+            torch.cuda.synchronize(dev)
+            pool = torch.cuda.graph_pool_handle()
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga, pool=pool, stream=side):
+                grads = self._sequence(accumulators, world)
+            gb = None
+            if world > 1:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=pool, stream=side):
+                    self._after_reduce(grads, accumulators)
+            self._graphs = (sig, ga, gb, grads)
+        except Exception as e:
+            self.capture_error = e
+            self._graphs = None
+            torch.cuda.synchronize(dev)
         self._republish()
         return err_now

@@ -431,3 +431,64 @@ def _numpy_like_tf(self, *args, **kwargs):
 
 
 torch.Tensor.numpy = _numpy_like_tf
+
+
+# ------------------------------------------------------------------- used by tfrt/optimizer.py
+# (tests/golden/make_reference_optimizer_golden.py)
+
+def matmul(a, b, name=None):
+    return torch.matmul(_t(a), _t(b))
+
+
+class GradientTape:
+    """tape.gradient(target, sources) = torch.autograd.grad of sum(target): TensorFlow sums a
+    non-scalar target the same way; unconnected sources come back as None."""
+
+    def __init__(self, persistent=False, watch_accessed_variables=True):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def watch(self, _tensor):
+        pass
+
+    def gradient(self, target, sources):
+        single = isinstance(sources, torch.Tensor)
+        srcs = [sources] if single else list(sources)
+        t = _t(target)
+        if not t.requires_grad:
+            out = [None] * len(srcs)
+        else:
+            out = list(torch.autograd.grad(t.sum(), srcs, allow_unused=True, retain_graph=True))
+        return out[0] if single else out
+
+
+class _SGD:
+    """Keras OptimizerV2 SGD as tfrt/optimizer.py uses it: built with the defaults (learning rate
+    0.01, momentum 0.0) and ``nesterov=True``; the momentum branch is chosen at CONSTRUCTION
+    (``self._momentum = momentum > 0``), so assigning ``opt.momentum`` afterwards, which is all the
+    reference does (optimizer.py:128-132), leaves the update at ``var -= learning_rate * grad``."""
+
+    def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False, name="SGD", **kwargs):
+        self.learning_rate = learning_rate
+        self.momentum = momentum
+        self.nesterov = nesterov
+        self._use_momentum = momentum > 0
+
+    def apply_gradients(self, grads_and_vars, name=None):
+        assert not self._use_momentum
+        with torch.no_grad():
+            for g, v in grads_and_vars:
+                if g is not None:
+                    v.sub_(self.learning_rate * _t(g))
+
+
+class _Optimizers:
+    SGD = _SGD
+
+
+optimizers = _Optimizers()
