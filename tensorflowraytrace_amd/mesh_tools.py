@@ -166,7 +166,7 @@ def hexagonal_mesh(radius=1.0, step_count=10):
                 o0 = ring_index(r, t * r + m)
                 o1 = ring_index(r, t * r + m + 1)
                 i0 = ring_index(r - 1, t * (r - 1) + m)
-                faces.append((3, o0, o1, i0))
+                faces.append((3, o1, i0, o0))      # (the reference's corner order: third, second, first)
                 if m < r - 1:
                     i1 = ring_index(r - 1, t * (r - 1) + m + 1)
                     faces.append((3, i0, o1, i1))
@@ -260,7 +260,7 @@ def circular_mesh(radius, target_edge_size, starting_radius=0, theta_start=0, th
             for m in range(e_out):
                 o_a, o_b = outer(t * e_out + m), outer(t * e_out + m + 1)
                 i_a = inner(t * e_in + min(m, e_in))
-                faces.append((3, o_a, o_b, i_a))
+                faces.append((3, o_b, i_a, o_a))      # (the reference's corner order)
                 if m < e_in:
                     faces.append((3, i_a, o_b, inner(t * e_in + m + 1)))
     return PolyData(np.array(points), np.array(faces, dtype=np.int64).reshape(-1))
