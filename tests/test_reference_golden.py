@@ -218,3 +218,80 @@ def test_hip_2d_trace_reproduces_the_reference_engine(tag):
             assert np.array_equal(out[cls + "_id"].cpu().numpy().astype(np.int64), g[f"{tag}_{cls}_id"])
             np.testing.assert_allclose(out[cls].detach().cpu().numpy(), want, rtol=0, atol=1e-9,
                                        err_msg=f"{tag}.{cls}")
+
+
+# ---------------------------------------------------------------------------------------------
+# tests/golden/reference_soup3d.npz: 3-pass traces of adversarial triangle soups (coplanar ties,
+# grazing rays, stops, targets, mirrors, 6 materials) by the reference's own engine, all five ray
+# classes, with and without dead_ray_length (tests/golden/make_reference_soup_golden.py)
+
+SOUP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_soup3d.npz")
+CLASSES = ("finished", "active", "dead", "stopped", "unfinished")
+
+
+def _soup_case(g, seed):
+    n = torch.tensor(g["n_material"])
+    mat_in, mat_out = torch.tensor(g[f"s{seed}__mat_in"]), torch.tensor(g[f"s{seed}__mat_out"])
+    return dict(P=torch.tensor(g[f"s{seed}__P"]), cat=torch.tensor(g[f"s{seed}__cat"]),
+                n_in=n[mat_in], n_out=n[mat_out], rays=torch.tensor(g[f"s{seed}__rays"]),
+                L=float(g[f"s{seed}__L"]), dead=float(g[f"s{seed}__dead_ray_length"]))
+
+
+@pytest.mark.parametrize("tag", ["plain", "deadlen"])
+def test_oracle_reproduces_the_reference_engine_on_adversarial_soups(tag):
+    from oracle import tracer
+    g = np.load(SOUP)
+    for seed in g["seeds"]:
+        sc = _soup_case(g, seed)
+
+        def sub(mask):
+            verts = sc["P"][mask].reshape(-1, 3)
+            d = tracer.faces_from_vertices(verts, torch.arange(verts.shape[0]).reshape(-1, 3))
+            d["n_in"], d["n_out"] = sc["n_in"][mask], sc["n_out"][mask]
+            return d
+        cat = sc["cat"]
+        system = tracer.System(3, optical=sub(cat == 0), stop=sub(cat == 1), target=sub(cat == 2))
+        src = {n: sc["rays"][i] for i, n in enumerate(NAMES)}
+        src["ray_id"] = torch.arange(sc["rays"].shape[1], dtype=torch.float64)
+        ref = tracer.ray_trace(system, src, max_iterations=int(g["passes"]), inherit=("ray_id",),
+                               index_type="value", new_ray_length=sc["L"],
+                               flags=dict(compile_dead_rays=True, compile_stopped_rays=True,
+                                          dead_ray_length=sc["dead"] if tag == "deadlen" else None))
+        for cls in CLASSES:
+            want, want_id = g[f"s{seed}__{tag}__{cls}"], g[f"s{seed}__{tag}__{cls}_id"]
+            rs = ref.get(cls) or {}
+            n = rs["x_start"].shape[0] if "x_start" in rs else 0
+            assert n == want.shape[1], (seed, cls)
+            if n:
+                assert np.array_equal(rs["ray_id"].numpy().astype(np.int64), want_id), (seed, cls)
+                got = torch.stack([rs[k] for k in NAMES]).numpy()
+                assert np.array_equal(got, want), (seed, cls)                 # every bit
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["plain", "deadlen"])
+def test_hip_reproduces_the_reference_engine_on_adversarial_soups(tag):
+    """float64 ray state, hierarchy and all-pairs modes: every class holds the reference engine's
+    rays, in its order, with every coordinate bit equal (coplanar ties, stops, dead rays cut to
+    dead_ray_length, rays still travelling after the last pass)."""
+    from tensorflowraytrace_amd import ops, _lib
+    g = np.load(SOUP)
+    dev = "cuda:0"
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    for seed in g["seeds"]:
+        sc = _soup_case(g, seed)
+        fv = sc["P"].to(dev)
+        for clustered in (True, False):
+            args = ops.Scene3DArgs(fv, sc["cat"].int().to(dev), n_in=sc["n_in"].to(dev),
+                                   n_out=sc["n_out"].to(dev),
+                                   cluster_order=ops.cluster_order(fv) if clustered else None)
+            out = ops.trace3d(sc["rays"].to(dev), fv, args, max_passes=int(g["passes"]), flags=flags,
+                              new_ray_length=sc["L"],
+                              dead_ray_length=sc["dead"] if tag == "deadlen" else None)
+            for cls in CLASSES:
+                want, want_id = g[f"s{seed}__{tag}__{cls}"], g[f"s{seed}__{tag}__{cls}_id"]
+                got = out[cls].cpu().numpy()
+                assert got.shape[1] == want.shape[1], (seed, cls, clustered)
+                assert np.array_equal(out[cls + "_id"].cpu().numpy().astype(np.int64), want_id), \
+                    (seed, cls, clustered)
+                assert np.array_equal(got, want), (seed, cls, clustered)
