@@ -1576,6 +1576,18 @@ __device__ __forceinline__ bool emit(const tfrt_ray_out& o, int64_t slot, const 
   return true;
 }
 
+// k_react3d's own scan (launches of <= SELF_SCAN_MAX_BLOCKS ray blocks: one launch less per pass)
+constexpr int SELF_SCAN_MAX_BLOCKS = 1024;
+struct SelfScan {
+  const int32_t* blockcnt = nullptr;     // per-block class histograms; nullptr: a scan kernel ran
+  const int32_t* prev_counts = nullptr;  // counts row of the previous pass (nullptr: first pass)
+  int32_t* counts_row = nullptr;         // counts row of this pass (written by the last block)
+  int32_t* totals = nullptr;             // running class totals of the trace
+  int32_t* n_next = nullptr;             // ray count of the next pass
+  unsigned long long* n_tests = nullptr;
+  int M = 0;
+};
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_react3d(
     const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
@@ -1587,15 +1599,31 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
     int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_tri_out,
     int32_t* __restrict__ rec_slot, tfrt_ray_out fin, tfrt_ray_out act, tfrt_ray_out stp,
     tfrt_ray_out dead, int32_t* __restrict__ err, float* __restrict__ prep_next, int64_t pstride,
-    const double* __restrict__ c0) {
+    const double* __restrict__ c0, SelfScan ss) {
   const int n = *n_ptr;
   const int base = blockIdx.x * BLOCK;
+  // Self-scan mode (few ray blocks): no scan launch ran.  Every block sums the class histograms
+  // of the blocks before it itself, and the last one closes the pass like k_scan3d_one does.
+  const bool self = ss.blockcnt != nullptr;
+  int before[4] = {0, 0, 0, 0};  // rays of each class emitted by earlier passes
+  if (self && ss.prev_counts != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) before[c] = ss.prev_counts[4 + c] + ss.prev_counts[c];
+  }
+  if (self && n == 0 && blockIdx.x == 0) {  // nothing left to trace: the pass is empty
+    if (threadIdx.x < 4) {
+      ss.counts_row[threadIdx.x] = 0;
+      ss.counts_row[4 + threadIdx.x] = before[threadIdx.x];
+    }
+    if (threadIdx.x == 0) *ss.n_next = 0;
+  }
   if (base >= n) return;
   const int i = base + threadIdx.x;
   const int cls = (i < n) ? (int)rec_cls[i] : -1;
 
   // stable rank of this ray inside its class within the block
   __shared__ int wc[WAVES][4];
+  __shared__ int wpre[WAVES][4];
   const int wave = threadIdx.x >> 6;
   int rank = 0;
 #pragma unroll
@@ -1604,13 +1632,49 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
     if (cls == c) rank = rank_below(m);
     if (lane_id() == 0) wc[wave][c] = __popcll(m);
   }
+  if (self) {
+    int loc[4] = {0, 0, 0, 0};
+    const int4* __restrict__ rows = reinterpret_cast<const int4*>(ss.blockcnt);
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += BLOCK) {
+      const int4 v = rows[b];
+      loc[0] += v.x;
+      loc[1] += v.y;
+      loc[2] += v.z;
+      loc[3] += v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) loc[c] += __shfl_xor(loc[c], d, 64);
+      if (lane_id() == 0) wpre[wave][c] = loc[c];
+    }
+  }
   __syncthreads();
+  if (self && blockIdx.x == (unsigned)((n - 1) / BLOCK) && threadIdx.x < 4) {
+    const int c = threadIdx.x;
+    int total = 0;
+    for (int w = 0; w < WAVES; ++w) total += wpre[w][c] + wc[w][c];
+    ss.counts_row[c] = total;
+    ss.counts_row[4 + c] = before[c];
+    ss.totals[c] = before[c] + total;
+    if (c == CLS_ACTIVE) *ss.n_next = total;
+    if (c == 1) *ss.n_tests += (unsigned long long)n * (unsigned long long)ss.M;
+  }
   if (i >= n) return;
   for (int w = 0; w < wave; ++w) rank += wc[w][cls];
-  // within this pass: offset inside the scan workgroup's 1024 blocks + that workgroup's base
-  const int slot = blockoff[blockIdx.x * 4 + cls] +
-                   (rowbase != nullptr ? rowbase[(blockIdx.x >> 10) * 4 + cls] : 0) + rank;
-  const int64_t gslot = (int64_t)pass_counts[4 + cls] + slot;  // within the whole trace
+  int slot;
+  int64_t gslot;
+  if (self) {
+    int off = 0;
+    for (int w = 0; w < WAVES; ++w) off += wpre[w][cls];
+    slot = off + rank;
+    gslot = (int64_t)before[cls] + slot;
+  } else {
+    // within this pass: offset inside the scan workgroup's 1024 blocks + that workgroup's base
+    slot = blockoff[blockIdx.x * 4 + cls] +
+           (rowbase != nullptr ? rowbase[(blockIdx.x >> 10) * 4 + cls] : 0) + rank;
+    gslot = (int64_t)pass_counts[4 + cls] + slot;  // within the whole trace
+  }
 
   double s[3], e[3];
   load_ray3(rays_in, stride_in, i, s, e);
@@ -1779,43 +1843,49 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
 constexpr int FACE_WINDOW = 1024;
 
 __global__ __launch_bounds__(1024) void k_face_accumulate(
-    const int32_t* __restrict__ n_ptr, const int32_t* __restrict__ stash_face,
-    const double* __restrict__ stash_g, int chunk, int M, double* __restrict__ g_fverts) {
+    const int32_t* __restrict__ nrays, int passes, int64_t pass_stride,
+    const int32_t* __restrict__ stash_face, const double* __restrict__ stash_g, int chunk, int M,
+    double* __restrict__ g_fverts) {
   __shared__ double acc[FACE_WINDOW * 9];
-  const int n = *n_ptr;
   const int lo = blockIdx.x * chunk;
-  if (lo >= n) return;  // block-uniform
-  const int hi = min(n, lo + chunk);
+  if (lo >= nrays[0]) return;  // block-uniform (the ray count never grows from pass to pass)
   const int w0 = blockIdx.y * FACE_WINDOW;
   const int w1 = min(M, w0 + FACE_WINDOW);
   for (int k = threadIdx.x; k < FACE_WINDOW * 9; k += 1024) acc[k] = 0.0;
   __syncthreads();
-  // The block is a chain of dependent round trips (face -> 9 terms -> LDS add): fetch the
-  // faces of four slots first, then the terms of those that fall into the window, then add.
-  constexpr int U = 4;
-  for (int base = lo + threadIdx.x; base < hi; base += 1024 * U) {
-    int t[U];
+  // All passes of the sweep in one launch: the window is cleared and flushed once per block
+  // instead of once per block and pass (the flush is 9,216 global float64 atomics).
+  for (int p = 0; p < passes; ++p) {
+    const int hi = min(nrays[p], lo + chunk);
+    const int32_t* __restrict__ face = stash_face + (int64_t)p * pass_stride;
+    const double* __restrict__ terms = stash_g + 9 * (int64_t)p * pass_stride;
+    // The block is a chain of dependent round trips (face -> 9 terms -> LDS add): fetch the
+    // faces of four slots first, then the terms of those that fall into the window, then add.
+    constexpr int U = 4;
+    for (int base = lo + threadIdx.x; base < hi; base += 1024 * U) {
+      int t[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + u * 1024;
-      t[u] = i < hi ? stash_face[i] : -1;
-    }
-    double g[U][9];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t[u] >= w0 && t[u] < w1) {
-        const double* src = stash_g + 9 * (int64_t)(base + u * 1024);
-#pragma unroll
-        for (int c = 0; c < 9; ++c) g[u][c] = src[c];
+      for (int u = 0; u < U; ++u) {
+        const int i = base + u * 1024;
+        t[u] = i < hi ? face[i] : -1;
       }
-    }
+      double g[U][9];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t[u] >= w0 && t[u] < w1) {
-        double* a = acc + 9 * (t[u] - w0);
+      for (int u = 0; u < U; ++u) {
+        if (t[u] >= w0 && t[u] < w1) {
+          const double* src = terms + 9 * (int64_t)(base + u * 1024);
 #pragma unroll
-        for (int c = 0; c < 9; ++c)
-          if (g[u][c] != 0.0) unsafeAtomicAdd(a + c, g[u][c]);
+          for (int c = 0; c < 9; ++c) g[u][c] = src[c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (t[u] >= w0 && t[u] < w1) {
+          double* a = acc + 9 * (t[u] - w0);
+#pragma unroll
+          for (int c = 0; c < 9; ++c)
+            if (g[u][c] != 0.0) unsafeAtomicAdd(a + c, g[u][c]);
+        }
       }
     }
   }
@@ -2105,8 +2175,8 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
   size_t csphere, cface, clsphere, susphere, crec, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
-  size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, fix_acc, fix_flag,
-      fix_max, total;
+  size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
+      fix_flag, fix_max, total;
 };
 
 static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& pl) {
@@ -2150,7 +2220,8 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.rec_t = take((size_t)P * n * sizeof(double));
   L.rec_cls = take((size_t)P * n);
   L.gbuf = take((size_t)2 * 6 * n * sizeof(double));
-  L.stash_g = take((size_t)9 * n * sizeof(double));
+  L.stash_g = take((size_t)(P > 0 ? P : 1) * 9 * n * sizeof(double));   // per pass: summed in one launch
+  L.stash_face = take((size_t)(P > 0 ? P : 1) * n * sizeof(int32_t));
   L.fix_acc = take((size_t)9 * m * sizeof(unsigned long long));  // ordered accumulation
   L.fix_flag = take((size_t)9 * m);
   L.fix_max = take(2 * sizeof(unsigned long long));
@@ -2345,7 +2416,16 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                          part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
                          rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt);
     const bool grid_scan = pl.nblk >= SCAN_GRID_MIN_ROWS;
-    if (grid_scan)
+    SelfScan ss;
+    if (pl.nblk <= SELF_SCAN_MAX_BLOCKS) {
+      ss.blockcnt = blockcnt;
+      ss.prev_counts = p > 0 ? counts + (size_t)(p - 1) * TFRT_COUNTS_PER_PASS : nullptr;
+      ss.counts_row = counts + (size_t)p * TFRT_COUNTS_PER_PASS;
+      ss.totals = tail;
+      ss.n_next = nrays + p + 1;
+      ss.n_tests = reinterpret_cast<unsigned long long*>(tail + 4);
+      ss.M = M;
+    } else if (grid_scan)
       hipLaunchKernelGGL(k_scan3d, dim3(cdiv(pl.nblk, 1024)), dim3(1024), 0, st, nrays + p,
                          blockcnt, blockoff, rowtot, rowbase, ticket,
                          counts + (size_t)p * TFRT_COUNTS_PER_PASS, tail, nrays + p + 1,
@@ -2363,7 +2443,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                        rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
                        stp ? *stp : none, dead ? *dead : none, tail + 6,
                        (p + 1 < P && !(ac.order != nullptr && ac.sort_rays)) ? prep : nullptr,
-                       (int64_t)n, c0);
+                       (int64_t)n, c0, ss);
   }
   if (unfinished != nullptr && P > 0) {
     hipLaunchKernelGGL((k_copy_rays<T>), dim3(pl.nblk), dim3(BLOCK), 0, st,
@@ -2395,7 +2475,6 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   const uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
   double* gbuf = reinterpret_cast<double*>(ws + lay.gbuf);
   int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
-  int32_t* vals_in = reinterpret_cast<int32_t*>(ws + lay.vals_in);
   // the sorted-ray forward left its Morton ray order in rperm: neighbouring lanes then mostly hit
   // the same few faces and k_backward3d sums their face gradients across the wave
   const bool coherent = sc->cluster_order != nullptr && sc->sort_rays != 0 && M >= 4 * CLUSTER;
@@ -2412,8 +2491,8 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   unsigned long long* fix_max = reinterpret_cast<unsigned long long*>(ws + lay.fix_max);
   if (ordered)  // (fix_acc, fix_flag and fix_max are adjacent: one clear)
     (void)hipMemsetAsync(fix_acc, 0, lay.total - lay.fix_acc, st);
-  double* stash_g = reinterpret_cast<double*>(ws + lay.stash_g);
-  int32_t* stash_face = vals_in;
+  double* stash_g_all = reinterpret_cast<double*>(ws + lay.stash_g);
+  int32_t* stash_face_all = reinterpret_cast<int32_t*>(ws + lay.stash_face);
   // ray slots per accumulate block, measured at 1M rays x 11 windows (us for the three passes,
   // target pass first): 2048 -> 37/50/54, 4096 -> 21/33/38, 8192 -> 15/37/34, 16384 -> 12/49/36.
   // Every block zeroes and flushes its window, so big chunks win while the blocks still fill
@@ -2428,6 +2507,8 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     const double* g_child = (p == P - 1) ? nullptr : gbuf + (size_t)((p + 1) & 1) * 6 * n;
     double* g_out = (p == 0 && g_src != nullptr) ? g_src : gbuf + (size_t)(p & 1) * 6 * n;
     const int64_t out_stride = (p == 0 && g_src != nullptr) ? N : (int64_t)n;
+    double* stash_g = stash_g_all + (size_t)p * 9 * n;
+    int32_t* stash_face = stash_face_all + (size_t)p * n;
     hipLaunchKernelGGL((k_backward3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
                        idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
                        rec_cls + (size_t)p * n, rec_slot + (size_t)p * n,
@@ -2446,11 +2527,11 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
       hipLaunchKernelGGL(k_fixed_finish, dim3(cdiv((int64_t)M * 9, BLOCK)), dim3(BLOCK), 0, st,
                          (int64_t)M * 9, mx, fix_max + (((P - 1 - p) & 1) ^ 1), fix_acc, fix_flag,
                          g_fverts);
-    } else if (stash) {
-      hipLaunchKernelGGL(k_face_accumulate, dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
-                         nrays + p, stash_face, stash_g, acc_chunk, M, g_fverts);
     }
   }
+  if (stash && !ordered && P > 0)
+    hipLaunchKernelGGL(k_face_accumulate, dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
+                       nrays, P, (int64_t)n, stash_face_all, stash_g_all, acc_chunk, M, g_fverts);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 
