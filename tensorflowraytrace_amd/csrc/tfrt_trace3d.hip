@@ -1161,21 +1161,25 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     // last tile -- empties them.  Draining at every flush ran the screen and the ~350-instruction
     // float64 decision on a mostly empty wavefront three or four extra times per wave.)
     const int nsteps = (total + 4 * MU - 1) / (4 * MU);
+    // Whole steps only: the list is padded with a harmless entry -- the tile's first cluster
+    // against ray slot 0; one more candidate is always allowed -- so that the loads below need
+    // no bounds test (compare, exec juggling and default values were a fifth of a step).
+    static_assert(LIST_CAP % (4 * MU) == 0 && 4 * MU <= 64, "padding stays inside the list");
+    if (total + lane < nsteps * 4 * MU) clist[wave][total + lane] = 0;
+    wave_fence();
     for (int st = 0; st < nsteps + (draining ? 1 : 0); ++st) {
       const int q0 = st * 4 * MU;
       if (st < nsteps) {
         float4 sp[MU];
-        int slot[MU], memb[MU];
+        int slot[MU];
+        unsigned memb[MU];
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
           const int q = q0 + 4 * u + (lane >> 4);
-          sp[u] = make_float4(0.f, 0.f, 0.f, -1.f);  // never hit
-          slot[u] = 0;
-          memb[u] = 0;
-          if (q < total) {
-            const int v = list[q];
-            slot[u] = v & 255;
-            memb[u] = (t0 + (v >> 8)) * CLUSTER + (lane & (CLUSTER - 1));
+          {
+            const unsigned v = list[q];
+            slot[u] = (int)(v & 255u);
+            memb[u] = ((unsigned)t0 + (v >> 8)) * CLUSTER + (unsigned)(lane & (CLUSTER - 1));
             sp[u] = csphere[memb[u]];
           }
         }
@@ -1190,7 +1194,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
           if (hm == 0x5A5A5A5A5A5A5A5Aull) rn = -1;  // timing experiment only: no decisions
           continue;
 #endif
-          if (hit) pairs[wave][pn + rank_below(hm)] = ((uint32_t)memb[u] << 8) | (uint32_t)slot[u];
+          if (hit) pairs[wave][pn + rank_below(hm)] = (memb[u] << 8) | (uint32_t)slot[u];
           pn += __popcll(hm);
           TFRT_STAT(3, __popcll(hm));
         }
