@@ -91,7 +91,10 @@ __global__ __launch_bounds__(BLOCK) void k_center(const double* __restrict__ fve
   if (threadIdx.x < 3) {
     double sum = 0.0;
     for (int w = 0; w < WAVES; ++w) sum += red[w][threadIdx.x];
-    ctr[threadIdx.x] = (ns > 0) ? sum / ns : 0.0;
+    // rounded to float32: (float)(s - c0) is then a plain float subtraction for float32 ray
+    // state (k_intersect_group forms it for every candidate pair), same value, no conversions
+    const float cf = (ns > 0) ? (float)(sum / ns) : 0.f;
+    ctr[threadIdx.x] = (cf - cf == 0.f) ? (double)cf : 0.0;  // (inf / NaN: the origin serves)
     c0[threadIdx.x] = ctr[threadIdx.x];
   }
   if (!want_scale) return;  // (block-uniform)
@@ -947,6 +950,14 @@ __device__ __forceinline__ int cat_to_cls(int cat) {
   return cat == CAT_OPTICAL ? CLS_ACTIVE : (cat == CAT_TARGET ? CLS_FINISHED : CLS_STOPPED);
 }
 
+// acc = 2 acc + (q <= w), w wave-uniform (a scalar register): v_cmp + v_addc.  (NaN q: 0.)
+__device__ __forceinline__ void shift_in_le(unsigned& acc, const float q, const float w) {
+  __asm__ volatile("v_cmp_ge_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                   : "+v"(acc)
+                   : "v"(q), "s"(w)
+                   : "vcc");
+}
+
 #ifdef TFRT_GROUP_WAVES
 #define TFRT_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_GROUP_WAVES, TFRT_GROUP_WAVES)))
 #else
@@ -1019,6 +1030,12 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   __shared__ int32_t skip_l[WAVES][RW];      // face each ray starts on (-1: none)
 
   const double cx = c0[0], cy = c0[1], cz = c0[2];
+  const float cxf = (float)cx, cyf = (float)cy, czf = (float)cz;  // exact: k_center rounds c0
+  // (s - c0) in float32 of a start coordinate read from the ray state
+  auto rel_c0 = [](const double v, const double c, const float cf) -> float {
+    if constexpr (sizeof(T) <= 4) return (float)v - cf;  // v is a float32 / float16 value
+    else return (float)(v - c);
+  };
   float ax[R], ay[R], az[R], bx[R], by[R], bz[R], nsa[R], nsb[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -1084,7 +1101,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       }
       // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t scales
       // with their magnitudes, not with |t|
-      const float sx = (float)(s[0] - cx), sy = (float)(s[1] - cy), sz = (float)(s[2] - cz);
+      const float sx = rel_c0(s[0], cx, cxf), sy = rel_c0(s[1], cy, cyf), sz = rel_c0(s[2], cz, czf);
       const float tx = sx - r0.x, ty = sy - r0.y, tz = sz - r0.z;
       const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(sx) + fabsf(sy) + fabsf(sz) +
                            fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z);
@@ -1276,8 +1293,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
         // inside the 64 * 2^-24 (|c| + r) the spheres are inflated by.
         const float ux = fa.y * fb.z - fa.z * fb.y, uy = fa.z * fb.x - fa.x * fb.z,
                     uz = fa.x * fb.y - fa.y * fb.x;
-        const float sx = (float)(TFRT_RAYV(0, sl) - cx), sy = (float)(TFRT_RAYV(1, sl) - cy),
-                    sz = (float)(TFRT_RAYV(2, sl) - cz);
+        const float sx = rel_c0(TFRT_RAYV(0, sl), cx, cxf), sy = rel_c0(TFRT_RAYV(1, sl), cy, cyf),
+                    sz = rel_c0(TFRT_RAYV(2, sl), cz, czf);
         const float t_off = fmaf(-sx, ux, fmaf(-sy, uy, -sz * uz)) +
                             (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
         // (first pass of a trace -- no ray starts on a face yet: sources normally sit outside
@@ -1358,16 +1375,25 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       const float4* __restrict__ su = susphere + t0 / SUPER;
       // (a "wholly behind the ray's start" test here, as at level 1, was measured and does not
       // pay: +4 instructions on each of the 83 supercluster tests for ~2 pairs saved per ray)
-#pragma unroll 4
-      for (int k = 0; k < ns; ++k) {
-        const float4 sp = su[k];
+      // (descending, the result of each test shifted in at bit 0: compare + add-with-carry, two
+      // instructions where `touched |= bit << k` took four; bit k still stands for supercluster k)
+      auto level0 = [&](const float4 sp) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
           const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-          touched[r] |= (fmaf(pa, pa, pb * pb) <= sp.w ? 1u : 0u) << k;
+          shift_in_le(touched[r], fmaf(pa, pa, pb * pb), sp.w);
         }
+      };
+      int k = ns - 1;
+      for (; k >= 3; k -= 4) {  // four scalar loads in flight
+        const float4 s0 = su[k], s1 = su[k - 1], s2 = su[k - 2], s3 = su[k - 3];
+        level0(s0);
+        level0(s1);
+        level0(s2);
+        level0(s3);
       }
+      for (; k >= 0; --k) level0(su[k]);
     }
   }
 
