@@ -42,8 +42,11 @@ __device__ __forceinline__ void store_ray3(T* rays, int64_t stride, int64_t i, c
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 
 // number of set bits of `mask` strictly below this lane
+// (v_mbcnt_lo + v_mbcnt_hi: the hardware's masked bit count below the lane, two instructions;
+// `popc(mask & lanes_below)` compiles to four)
 __device__ __forceinline__ int rank_below(unsigned long long mask) {
-  return __popcll(mask & ((1ull << lane_id()) - 1ull));
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
 inline int cdiv(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }

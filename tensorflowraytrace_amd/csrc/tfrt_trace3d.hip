@@ -1001,8 +1001,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   __shared__ uint16_t clist[WAVES][LIST_CAP];
   // (tile-local supercluster << 8 | ray slot) pairs waiting for their cluster tests
   __shared__ uint16_t rlist[WAVES][128];
-  __shared__ float4 prep_a[WAVES][RW];       // (a, -s.a) of the wave's rays
-  __shared__ float4 prep_b[WAVES][RW];       // (b, -s.b)
+  // (a, -s.a) and (b, -s.b) of the wave's rays, interleaved: one address serves both reads
+  __shared__ float4 prep_ab[WAVES][2 * RW];
   __shared__ unsigned long long best_k[WAVES][RW];
   __shared__ int32_t best_i[WAVES][RW];
 #ifndef TFRT_MEMBER_UNROLL
@@ -1065,8 +1065,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       nsb[r] = prep[7 * pstride + i];
     }
     const int slot = r * 64 + lane;
-    prep_a[wave][slot] = make_float4(ax[r], ay[r], az[r], nsa[r]);
-    prep_b[wave][slot] = make_float4(bx[r], by[r], bz[r], nsb[r]);
+    prep_ab[wave][2 * slot] = make_float4(ax[r], ay[r], az[r], nsa[r]);
+    prep_ab[wave][2 * slot + 1] = make_float4(bx[r], by[r], bz[r], nsb[r]);
     best_k[wave][slot] = dkey(INFINITY);
     best_i[wave][slot] = -1;
   }
@@ -1202,7 +1202,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
         }
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
-          const float4 fa = prep_a[wave][slot[u]], fb = prep_b[wave][slot[u]];
+          const float4 fa = prep_ab[wave][2 * slot[u]], fb = prep_ab[wave][2 * slot[u] + 1];
           const float pa = fmaf(sp[u].x, fa.x, fmaf(sp[u].y, fa.y, fmaf(sp[u].z, fa.z, fa.w)));
           const float pb = fmaf(sp[u].x, fb.x, fmaf(sp[u].y, fb.y, fmaf(sp[u].z, fb.z, fb.w)));
           const bool hit = fmaf(pa, pa, pb * pb) <= sp[u].w;
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
         const int v = rlist[wave][lane];
         cl0 = (v >> 8) * SUPER;
         sl = v & 255;
-        const float4 fa = prep_a[wave][sl], fb = prep_b[wave][sl];
+        const float4 fa = prep_ab[wave][2 * sl], fb = prep_ab[wave][2 * sl + 1];
         const float4* row = &tile[cl0 + (cl0 >> 3)];
         // The sphere tests are line tests; a cluster wholly behind the ray's start cannot hold
         // a valid hit (ray_u > 0) either.  Rays that leave a surface see half of the clusters
