@@ -33,9 +33,9 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
 }
 
 template <int MODE>
-double run(const char* name, double flop_per_op) {
+double run(const char* name, double flop_per_op, int waves_per_simd = 8) {
   float* d; hipMalloc(&d, 4);
-  const int iters = 2000, blocks = 256 * 8;
+  const int iters = 2000, blocks = 256 * waves_per_simd;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, d, 10, 1.0f);
   hipDeviceSynchronize();
@@ -58,5 +58,11 @@ int main() {
   run<3>("v_min_f32", 1);
   run<4>("v_mul_f32", 1);
   run<5>("v_dot2c_f32_f16", 4);
+  // the same FMA stream with fewer waves per SIMD (256 blocks of 4 waves = 1 wave per SIMD)
+  for (int w : {1, 2, 3, 4, 5, 6}) {
+    char name[64];
+    snprintf(name, sizeof name, "v_fma_f32, %d waves/SIMD", w);
+    run<0>(name, 2, w);
+  }
   return 0;
 }

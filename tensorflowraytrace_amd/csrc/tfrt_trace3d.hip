@@ -1187,33 +1187,41 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     for (int st = 0; st < nsteps + (draining ? 1 : 0); ++st) {
       const int q0 = st * 4 * MU;
       if (st < nsteps) {
-        float4 sp[MU];
-        int slot[MU];
-        unsigned memb[MU];
+        // 4 * MU candidates per step: 8 lanes take one (ray, cluster) and two members each (the
+        // list entry, the ray's filter state and the address are then shared by two tests)
+        static_assert(MU % 2 == 0 && CLUSTER == 16, "two members per lane, eight lanes per cluster");
+        constexpr int MH = MU / 2;
+        float4 spa[MH], spb[MH];
+        int slot[MH];
+        unsigned memb[MH];
 #pragma unroll
-        for (int u = 0; u < MU; ++u) {
-          const int q = q0 + 4 * u + (lane >> 4);
-          {
-            const unsigned v = list[q];
-            slot[u] = (int)(v & 255u);
-            memb[u] = ((unsigned)t0 + (v >> 8)) * CLUSTER + (unsigned)(lane & (CLUSTER - 1));
-            sp[u] = csphere[memb[u]];
-          }
+        for (int u = 0; u < MH; ++u) {
+          const int q = q0 + 8 * u + (lane >> 3);
+          const unsigned v = list[q];
+          slot[u] = (int)(v & 255u);
+          memb[u] = ((unsigned)t0 + (v >> 8)) * CLUSTER + 2u * (unsigned)(lane & 7);
+          spa[u] = csphere[memb[u]];
+          spb[u] = csphere[memb[u] + 1];
         }
 #pragma unroll
-        for (int u = 0; u < MU; ++u) {
+        for (int u = 0; u < MH; ++u) {
           const float4 fa = prep_ab[wave][2 * slot[u]], fb = prep_ab[wave][2 * slot[u] + 1];
-          const float pa = fmaf(sp[u].x, fa.x, fmaf(sp[u].y, fa.y, fmaf(sp[u].z, fa.z, fa.w)));
-          const float pb = fmaf(sp[u].x, fb.x, fmaf(sp[u].y, fb.y, fmaf(sp[u].z, fb.z, fb.w)));
-          const bool hit = fmaf(pa, pa, pb * pb) <= sp[u].w;
-          const unsigned long long hm = __ballot(hit);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float4 sp = h == 0 ? spa[u] : spb[u];
+            const float pa = fmaf(sp.x, fa.x, fmaf(sp.y, fa.y, fmaf(sp.z, fa.z, fa.w)));
+            const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
+            const bool hit = fmaf(pa, pa, pb * pb) <= sp.w;
+            const unsigned long long hm = __ballot(hit);
 #if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 2
-          if (hm == 0x5A5A5A5A5A5A5A5Aull) rn = -1;  // timing experiment only: no decisions
-          continue;
+            if (hm == 0x5A5A5A5A5A5A5A5Aull) rn = -1;  // timing experiment only: no decisions
+            continue;
 #endif
-          if (hit) pairs[wave][pn + rank_below(hm)] = (memb[u] << 8) | (uint32_t)slot[u];
-          pn += __popcll(hm);
-          TFRT_STAT(3, __popcll(hm));
+            if (hit)
+              pairs[wave][pn + rank_below(hm)] = ((memb[u] + (unsigned)h) << 8) | (uint32_t)slot[u];
+            pn += __popcll(hm);
+            TFRT_STAT(3, __popcll(hm));
+          }
         }
       }
       const bool last = draining && st == nsteps;
