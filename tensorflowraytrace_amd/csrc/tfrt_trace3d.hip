@@ -2204,7 +2204,11 @@ static Plan3 make_plan(int64_t N, int64_t M) {
     if (r == 1 || r == 2 || r == 4) p.gR = r;
   }
   p.g_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.gR);
-  int gtarget = 2048;
+  // One cluster chunk (classification then happens in the kernel's epilogue: one launch less per
+  // pass) from a few dozen ray blocks on; measured on the 10,574-face scene, optimiser step with
+  // 1 chunk / 2048-workgroup target: 15k rays 0.255 / 0.261 ms, 60k 0.255 / 0.263, 125k 0.263 /
+  // 0.263, 250k 0.307 / 0.333.  Only tiny launches spread the scene over more workgroups.
+  int gtarget = 64;
   if (const char* env = getenv("TFRT_GROUP_TARGET_BLOCKS")) gtarget = atoi(env) > 0 ? atoi(env) : gtarget;
   int gch = cdiv(gtarget, p.g_blocks);
   const int gmax = cdiv(n_clusters, 64);       // at least 64 clusters (1024 faces) per chunk
