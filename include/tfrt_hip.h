@@ -130,6 +130,14 @@ int tfrt_sgd_process(const void* grad, void* processed, void* param, int64_t n, 
 int tfrt_sgd_process_dev(const void* grad, void* processed, void* param, int64_t n, int32_t dtype,
                          const double* hyper, void* stream);
 
+/* tfrt_sgd_process_dev for up to 8 float64 tensors in ONE launch (the per-parameter loop of
+ * optimizer.py:223-247, 316): host arrays of n_tensors device pointers (`processed` / `param`
+ * and their entries may be NULL as above) and element counts; `hyper` holds {scale, clip,
+ * sgd_learning_rate} per tensor, 3 * n_tensors float64 on the device. */
+int tfrt_sgd_process_multi(int32_t n_tensors, const void* const* grad, void* const* processed,
+                           void* const* param, const int64_t* n, const double* hyper,
+                           void* stream);
+
 /* y = A x, A in CSR form (int64 indices, f64 values): the accumulator (optimizer.py:250-255)
  * and smoother (optimizer.py:277-282) products for the sparse matrices the mesh tools
  * produce (mesh_tools.py:221-421).  x and y must not alias. */

@@ -72,6 +72,7 @@ SIGNATURES = {
                                            c_f64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_sgd_process": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f64, c_f64, c_f64, c_vp]),
     "tfrt_sgd_process_dev": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "tfrt_sgd_process_multi": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_csr_matvec": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tfrt_trace3d_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
     "tfrt_trace3d_forward": (c_i32, [

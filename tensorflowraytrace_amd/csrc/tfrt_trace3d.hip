@@ -416,11 +416,43 @@ __global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
 // Both sphere levels of the grouped filter in one launch (each is a latency-bound ~12 us
 // kernel on its own and neither reads the other's output): blocks [0, n_super) walk one
 // supercluster ball each with their first 128 threads, the rest do 16 clusters each.
+//
+// The launch also does k_center's work (one set-up launch per trace instead of two): every block
+// derives the frame origin itself -- the mean of P0 over 64 evenly spaced faces, one wave, the
+// same arithmetic in every block, rounded to float32 like k_center's -- and block 0 publishes it
+// for the kernels that follow and clears the trace's counters.
 __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
-    const double* __restrict__ c0, double size_eps, int n_clusters, int n_super,
+    double* __restrict__ c0_out, double size_eps, int n_clusters, int n_super,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
-    float4* __restrict__ crec, float4* __restrict__ susphere) {
+    float4* __restrict__ crec, float4* __restrict__ susphere, int32_t* nrays0, int n,
+    int32_t* tail8, unsigned int* scan_ticket) {
+  __shared__ double c0[3];
+  if (threadIdx.x < 64) {
+    const int step = M > 64 ? M / 64 : 1;
+    const int ns = (M + step - 1) / step < 64 ? (M + step - 1) / step : 64;
+    double a[3] = {0.0, 0.0, 0.0};
+    if ((int)threadIdx.x < ns) {
+      const double* P = fverts + 9 * (int64_t)threadIdx.x * step;
+      a[0] = P[0];
+      a[1] = P[1];
+      a[2] = P[2];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+      for (int k = 0; k < 3; ++k) a[k] += __shfl_xor(a[k], d, 64);
+    if (threadIdx.x < 3) {
+      const float cf = (ns > 0) ? (float)(a[threadIdx.x] / ns) : 0.f;
+      c0[threadIdx.x] = (cf - cf == 0.f) ? (double)cf : 0.0;  // (inf / NaN: the origin serves)
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 3) c0_out[threadIdx.x] = c0[threadIdx.x];
+    if (threadIdx.x == 0) *nrays0 = n;
+    if (threadIdx.x < 8) tail8[threadIdx.x] = 0;
+    if (threadIdx.x == 0 && scan_ticket != nullptr) *scan_ticket = 0u;
+  }
   if ((int)blockIdx.x < n_super) {
     if (threadIdx.x >= SUPER * CLUSTER) return;  // (whole waves: 128 is a multiple of 64)
     super_spheres_block(blockIdx.x, fverts, M, order, c0, size_eps, susphere);
@@ -1092,6 +1124,13 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       const float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
                    r2 = crec[3 * (int64_t)memb + 2];
       j = cface[memb];
+#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 7
+      {  // sensitivity: the screen's gathers twice (another record)
+        const int64_t m2 = (memb + 1024) % ((int64_t)n_clusters * CLUSTER);
+        const float4 q0 = crec[3 * m2], q1 = crec[3 * m2 + 1], q2 = crec[3 * m2 + 2];
+        if (q0.x + q1.x + q2.x == 1.2345e-30f) j = cface[m2];
+      }
+#endif
       const double best = dkey_inv(best_k[wave][slot]);
       double s[3], e[3];
 #pragma unroll
@@ -1139,6 +1178,14 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       const double* fp = fverts + 9 * (int64_t)j;
 #pragma unroll
       for (int q = 0; q < 9; ++q) P[q] = fp[q];
+#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 8
+      {  // sensitivity: the decision's gathers twice (another face)
+        const double* fq = fverts + 9 * (int64_t)((j + 1000) % (n_clusters * CLUSTER / 2));
+        double acc = 0.0;
+        for (int q = 0; q < 9; ++q) acc += fq[q];
+        if (acc == 1.2345e-300) P[0] = acc;
+      }
+#endif
       const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
       if (h.valid) {
         have = true;
@@ -1208,6 +1255,15 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
           memb[u] = ((unsigned)t0 + (v >> 8)) * CLUSTER + (unsigned)ML * (unsigned)(lane % LPC);
 #pragma unroll
           for (int h = 0; h < ML; ++h) sp[u][h] = csphere[memb[u] + h];
+#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 5
+          // sensitivity experiments (tuning builds only): one class of work issued twice
+#pragma unroll
+          for (int h = 0; h < ML; ++h) sp[u][h].w += csphere[(memb[u] + h) ^ 1u].w * 0.f;  // same lines
+#elif defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 6
+#pragma unroll
+          for (int h = 0; h < ML; ++h)
+            sp[u][h].w += csphere[(memb[u] + h + 4096u) % (unsigned)(n_clusters * CLUSTER)].w * 0.f;
+#endif
         }
 #pragma unroll
         for (int u = 0; u < MH; ++u) {
@@ -1408,6 +1464,24 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
         level0(s3);
       }
       for (; k >= 0; --k) level0(su[k]);
+#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 9
+      {  // sensitivity: level 0 twice (into a second mask that is merged at the end)
+        unsigned again[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) again[r] = 0u;
+        for (int k2 = ns - 1; k2 >= 0; --k2) {
+          const float4 sp = su[k2];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
+            const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
+            shift_in_le(again[r], fmaf(pa, pa, pb * pb), sp.w);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) touched[r] |= again[r];
+      }
+#endif
     }
   }
 
@@ -2419,8 +2493,9 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   ac.sort_bytes = lay.sort_bytes;
   int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
   if (M > 0) {
-    hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays, (int)N,
-                       tail, ticket, (ac.order != nullptr && ac.sort_rays) ? 1 : 0);
+    if (!(ac.order != nullptr && !ac.sort_rays))  // (the hierarchy kernel does this itself)
+      hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
+                         (int)N, tail, ticket, (ac.order != nullptr && ac.sort_rays) ? 1 : 0);
     if (ac.order != nullptr) {
       const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
       if (ac.sort_rays) {
@@ -2431,7 +2506,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
         const int n_super = cdiv(ac.n_clusters, SUPER);
         hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
                            sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
-                           n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere);
+                           n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
+                           (int)N, tail, ticket);
       }
     } else {
       hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,

@@ -39,6 +39,33 @@ __global__ __launch_bounds__(BLOCK) void k_sgd_process(const T* __restrict__ gra
   if (param != nullptr) param[i] = param[i] - sgd_lr * g;
 }
 
+// The same for up to SGD_BATCH tensors in one launch (an optimiser with several parameter
+// tensors -- the two surfaces of a lens -- otherwise pays one ~4 us launch each per step).
+constexpr int SGD_BATCH = 8;
+struct SgdBatch {
+  const double* grad[SGD_BATCH];
+  double* processed[SGD_BATCH];
+  double* param[SGD_BATCH];
+  int64_t n[SGD_BATCH];
+  int32_t first_block[SGD_BATCH + 1];
+  int32_t count;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_sgd_process_multi(SgdBatch b,
+                                                             const double* __restrict__ hyper) {
+  int k = 0;
+  while (k + 1 < b.count && (int)blockIdx.x >= b.first_block[k + 1]) ++k;  // block-uniform
+  const int64_t i = (int64_t)((int)blockIdx.x - b.first_block[k]) * BLOCK + threadIdx.x;
+  if (i >= b.n[k]) return;
+  const double scale = hyper[3 * k], clip = hyper[3 * k + 1], sgd_lr = hyper[3 * k + 2];
+  double g = b.grad[k][i];
+  g = isfinite(g) ? g : 0.0;
+  g = g * scale;
+  g = g < -clip ? -clip : (g > clip ? clip : g);
+  if (b.processed[k] != nullptr) b.processed[k][i] = g;
+  if (b.param[k] != nullptr) b.param[k][i] = b.param[k][i] - sgd_lr * g;
+}
+
 // one wave per row; lanes stride over the row's non-zeros, butterfly-sum at the end
 __global__ __launch_bounds__(BLOCK) void k_csr_matvec(const int64_t* __restrict__ crow,
                                                       const int64_t* __restrict__ col,
@@ -92,6 +119,31 @@ int tfrt_sgd_process_dev(const void* grad, void* processed, void* param, int64_t
   if (n < 0 || (n > 0 && !grad) || !hyper || (dtype != TFRT_F32 && dtype != TFRT_F64))
     return TFRT_E_BADARG;
   return sgd_process_launch(grad, processed, param, n, dtype, 0.0, 0.0, 0.0, hyper, stream);
+}
+
+int tfrt_sgd_process_multi(int32_t n_tensors, const void* const* grad, void* const* processed,
+                           void* const* param, const int64_t* n, const double* hyper,
+                           void* stream) {
+  if (n_tensors < 0 || n_tensors > SGD_BATCH || (n_tensors > 0 && (!grad || !n || !hyper)))
+    return TFRT_E_BADARG;
+  SgdBatch b;
+  int blocks = 0;
+  for (int k = 0; k < SGD_BATCH; ++k) {
+    const bool on = k < n_tensors;
+    if (on && (n[k] < 0 || (n[k] > 0 && !grad[k]))) return TFRT_E_BADARG;
+    b.grad[k] = on ? static_cast<const double*>(grad[k]) : nullptr;
+    b.processed[k] = (on && processed) ? static_cast<double*>(processed[k]) : nullptr;
+    b.param[k] = (on && param) ? static_cast<double*>(param[k]) : nullptr;
+    b.n[k] = on ? n[k] : 0;
+    b.first_block[k] = blocks;
+    if (on) blocks += cdiv(n[k], BLOCK);
+  }
+  b.first_block[SGD_BATCH] = blocks;
+  b.count = n_tensors;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(k_sgd_process_multi, dim3(blocks), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), b, hyper);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 
 int tfrt_csr_matvec(const int64_t* crow_indices, const int64_t* col_indices, const double* values,

@@ -283,6 +283,20 @@ class FusedStep:
         the step-dependent scalars read from the device table."""
         opt = self.opt
         L = _lib.lib()
+        k = len(grads)
+        if 1 < k <= 8 and all(a is None for a in accumulators) and \
+                len({ops._stream(p).value for p in opt.parameters}) == 1:
+            # plain SGD on every parameter tensor: one launch for all of them (the device table
+            # holds the three scalars of parameter i at offset 3 i)
+            gp = (ctypes.c_void_p * k)(*[g.data_ptr() for g in grads])
+            pp = (ctypes.c_void_p * k)(*[p.data_ptr() for p in opt.parameters])
+            nn = (ctypes.c_int64 * k)(*[g.numel() for g in grads])
+            with torch.no_grad():
+                check(L.tfrt_sgd_process_multi(k, gp, None, pp, nn,
+                                               ctypes.c_void_p(self._hyper.dev.data_ptr()),
+                                               ops._stream(opt.parameters[0])),
+                      "tfrt_sgd_process_multi")
+            return
         for i, (g, p) in enumerate(zip(grads, opt.parameters)):
             hyper = ctypes.c_void_p(self._hyper.dev.data_ptr() + 24 * i)
             stream = ops._stream(p)
