@@ -34,6 +34,43 @@ def test_sgd_process_matches_eager_ops(dtype, n):
     assert torch.equal(p2, want_p)
 
 
+def test_sgd_process_multi_equals_the_per_tensor_launches():
+    """tfrt_sgd_process_multi through ctypes: several parameter tensors in one launch, scalars from
+    a device table with one row per tensor; bit-identical to tfrt_sgd_process on each."""
+    import ctypes
+    from tensorflowraytrace_amd import _lib, ops
+    L = _lib.lib()
+    sizes = [5167, 271, 1, 0, 100_003]
+    gen = torch.Generator().manual_seed(5)
+    grads, params, want_p, want_g = [], [], [], []
+    rows = []
+    for k, n in enumerate(sizes):
+        g = torch.randn(n, generator=gen, dtype=torch.float64) * 3e-3
+        if n > 10:
+            g[1], g[5], g[7], g[9] = float("nan"), float("inf"), float("-inf"), 1e30
+        p = torch.randn(n, generator=gen, dtype=torch.float64)
+        scale, clip, lr = 0.37 + 0.1 * k, 1e-3 * (k + 1), 0.01 / (k + 1)
+        rows.append([scale, clip, lr])
+        grads.append(g.cuda())
+        params.append(p.cuda())
+        pg = _ref_process(grads[-1], scale, clip)
+        want_g.append(pg)
+        want_p.append(params[-1] - torch.as_tensor(lr, dtype=torch.float64).cuda() * pg)
+    hyper = torch.tensor(rows, dtype=torch.float64).cuda()
+    k = len(sizes)
+    processed = [torch.full_like(g, 7.0) for g in grads]
+    arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() if t.numel() else None for t in ts])
+    nn = (ctypes.c_int64 * k)(*sizes)
+    _lib.check(L.tfrt_sgd_process_multi(k, arr(grads), arr(processed), arr(params), nn,
+                                        ops._p(hyper), ops._stream(hyper)), "tfrt_sgd_process_multi")
+    for i in range(k):
+        assert torch.equal(processed[i], want_g[i]), i
+        assert torch.equal(params[i], want_p[i]), i
+    # more tensors than one launch takes, and a missing table
+    assert L.tfrt_sgd_process_multi(9, arr(grads), None, None, nn, ops._p(hyper), None) == -1
+    assert L.tfrt_sgd_process_multi(k, arr(grads), None, None, nn, None, None) == -1
+
+
 def test_sgd_process_rejects_bad_arguments():
     from tensorflowraytrace_amd import ops
     from tensorflowraytrace_amd._lib import TfrtError
