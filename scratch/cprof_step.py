@@ -4,7 +4,7 @@ import torch, bench
 import tfrt.optimizer as optimizer
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 125_000
 eng, system, params = bench.build_scene(N, 41, 9, torch.float32)
-opt = optimizer.SGD_Optimizer(eng, params, bench.error_function, trace_depth=3, learning_rate=1e-6, grad_clip=1e-3)
+opt = optimizer.SGD_Optimizer(eng, params, bench.make_error_function(), trace_depth=3, learning_rate=1e-6, grad_clip=1e-3, fused=False)
 opt.suppress_warnings = True
 for _ in range(5): opt.single_step(None)
 torch.cuda.synchronize()

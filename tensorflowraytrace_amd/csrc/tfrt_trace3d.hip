@@ -1852,14 +1852,29 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
 
 // -------------------------------------------------------------------------- backward
 
-__device__ __forceinline__ void add6(const double* g, int64_t cap, int64_t slot, double a[3],
+template <typename G>
+__device__ __forceinline__ void add6(const G* g, int64_t cap, int64_t slot, double a[3],
                                      double b[3]) {
   if (g == nullptr) return;
   for (int k = 0; k < 3; ++k) {
-    a[k] += g[k * cap + slot];
-    b[k] += g[(3 + k) * cap + slot];
+    a[k] += static_cast<double>(g[k * cap + slot]);
+    b[k] += static_cast<double>(g[(3 + k) * cap + slot]);
   }
 }
+
+// Storage type of the reverse sweep's own intermediates (the ray gradients handed from pass to
+// pass and the per-ray face-gradient terms): float32 next to float32 / float16 ray state --
+// the forward's hit points carry 2^-24 relative rounding there already -- float64 next to float64
+// state.  All arithmetic and every sum stay float64.  (96 + 72 B per ray and pass halved: the
+// sweep is bound by its memory traffic.)
+template <typename T>
+struct SweepStore {
+  using type = float;
+};
+template <>
+struct SweepStore<double> {
+  using type = double;
+};
 
 template <typename T>
 __device__ __forceinline__ int backward_ray(
@@ -1867,10 +1882,12 @@ __device__ __forceinline__ int backward_ray(
     const int32_t* __restrict__ rec_tri, const double* __restrict__ rec_t,
     const uint8_t* __restrict__ rec_cls, const int32_t* __restrict__ rec_slot,
     const int32_t* __restrict__ pass_counts, const tfrt_scene3d& sc, double L, double dead_len,
-    const double* __restrict__ g_child, int64_t child_stride, const double* __restrict__ g_fin,
-    int64_t cap_fin, const double* __restrict__ g_act, int64_t cap_act,
-    const double* __restrict__ g_stp, int64_t cap_stp, const double* __restrict__ g_dead,
-    int64_t cap_dead, double* __restrict__ g_out, int64_t out_stride, double gP[9]);
+    const typename SweepStore<T>::type* __restrict__ g_child, int64_t child_stride,
+    const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
+    int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
+    const double* __restrict__ g_dead, int64_t cap_dead,
+    typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
+    int64_t out_stride, double gP[9]);
 
 // (106 VGPRs = 4 waves per SIMD; the kernel is bound by float64 VALU issue -- ~2,000 executed
 // instructions per ray, 28 of them divisions -- and forcing 5 or 6 waves with
@@ -1881,13 +1898,14 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
     const double* __restrict__ rec_t, const uint8_t* __restrict__ rec_cls,
     const int32_t* __restrict__ rec_slot, const int32_t* __restrict__ pass_counts,
-    tfrt_scene3d sc, double L, double dead_len, const double* __restrict__ g_child,
-    int64_t child_stride, const double* __restrict__ g_fin, int64_t cap_fin,
-    const double* __restrict__ g_act, int64_t cap_act, const double* __restrict__ g_stp,
-    int64_t cap_stp, const double* __restrict__ g_dead, int64_t cap_dead,
-    double* __restrict__ g_out, int64_t out_stride, double* __restrict__ g_fverts,
-    const int32_t* __restrict__ rperm, double* __restrict__ stash_g,
-    int32_t* __restrict__ stash_face) {
+    tfrt_scene3d sc, double L, double dead_len,
+    const typename SweepStore<T>::type* __restrict__ g_child, int64_t child_stride,
+    const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
+    int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
+    const double* __restrict__ g_dead, int64_t cap_dead,
+    typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
+    int64_t out_stride, double* __restrict__ g_fverts, const int32_t* __restrict__ rperm,
+    typename SweepStore<T>::type* __restrict__ stash_g, int32_t* __restrict__ stash_face) {
   const int n = *n_ptr;
   const int q0 = blockIdx.x * BLOCK + threadIdx.x;
   if (rperm != nullptr) {
@@ -1900,7 +1918,8 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     if (live)
       tri = backward_ray<T>(i, rays_in, stride_in, ray_id_in, rec_tri, rec_t, rec_cls, rec_slot,
                             pass_counts, sc, L, dead_len, g_child, child_stride, g_fin, cap_fin,
-                            g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead, g_out, out_stride, gP);
+                            g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead, g_out, g_src_out, out_stride,
+                            gP);
     unsigned long long todo = __ballot(tri >= 0);
     int guard = 0;
     while (todo != 0ull && guard++ < 64) {
@@ -1925,14 +1944,15 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
   const int tri = backward_ray<T>(i, rays_in, stride_in, ray_id_in, rec_tri, rec_t, rec_cls,
                                   rec_slot, pass_counts, sc, L, dead_len, g_child, child_stride,
                                   g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead,
-                                  g_out, out_stride, gP);
+                                  g_out, g_src_out, out_stride, gP);
   if (stash_face != nullptr) {
     // face gradients are summed by k_face_accumulate: leave this ray's 9 terms and its face
     stash_face[i] = tri;
     if (tri >= 0) {
-      double* o = stash_g + 9 * (int64_t)i;
+      using S = typename SweepStore<T>::type;
+      S* o = stash_g + 9 * (int64_t)i;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) o[c] = gP[c];
+      for (int c = 0; c < 9; ++c) o[c] = static_cast<S>(gP[c]);
     }
     return;
   }
@@ -1960,9 +1980,10 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
 // with LDS atomics, and the window is flushed once per block.
 constexpr int FACE_WINDOW = 1024;
 
+template <typename S>
 __global__ __launch_bounds__(1024) void k_face_accumulate(
     const int32_t* __restrict__ nrays, int passes, int64_t pass_stride,
-    const int32_t* __restrict__ stash_face, const double* __restrict__ stash_g, int chunk, int M,
+    const int32_t* __restrict__ stash_face, const S* __restrict__ stash_g, int chunk, int M,
     double* __restrict__ g_fverts) {
   __shared__ double acc[FACE_WINDOW * 9];
   const int lo = blockIdx.x * chunk;
@@ -1976,7 +1997,7 @@ __global__ __launch_bounds__(1024) void k_face_accumulate(
   for (int p = 0; p < passes; ++p) {
     const int hi = min(nrays[p], lo + chunk);
     const int32_t* __restrict__ face = stash_face + (int64_t)p * pass_stride;
-    const double* __restrict__ terms = stash_g + 9 * (int64_t)p * pass_stride;
+    const S* __restrict__ terms = stash_g + 9 * (int64_t)p * pass_stride;
     // The block is a chain of dependent round trips (face -> 9 terms -> LDS add): fetch the
     // faces of four slots first, then the terms of those that fall into the window, then add.
     constexpr int U = 4;
@@ -1991,9 +2012,9 @@ __global__ __launch_bounds__(1024) void k_face_accumulate(
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         if (t[u] >= w0 && t[u] < w1) {
-          const double* src = terms + 9 * (int64_t)(base + u * 1024);
+          const S* src = terms + 9 * (int64_t)(base + u * 1024);
 #pragma unroll
-          for (int c = 0; c < 9; ++c) g[u][c] = src[c];
+          for (int c = 0; c < 9; ++c) g[u][c] = static_cast<double>(src[c]);
         }
       }
 #pragma unroll
@@ -2022,18 +2043,19 @@ __global__ __launch_bounds__(1024) void k_face_accumulate(
 // their slot (NaN), as a float sum would.
 constexpr int FIXED_BITS = 40;
 
+template <typename S>
 __global__ __launch_bounds__(BLOCK) void k_stash_absmax(const int32_t* __restrict__ n_ptr,
                                                         const int32_t* __restrict__ stash_face,
-                                                        const double* __restrict__ stash_g,
+                                                        const S* __restrict__ stash_g,
                                                         unsigned long long* __restrict__ maxbits) {
   const int n = *n_ptr;
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   double m = 0.0;
   if (i < n && stash_face[i] >= 0) {
-    const double* g = stash_g + 9 * (int64_t)i;
+    const S* g = stash_g + 9 * (int64_t)i;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-      const double a = fabs(g[c]);
+      const double a = fabs(static_cast<double>(g[c]));
       if (a > m && a < INFINITY) m = a;  // (NaN compares false)
     }
   }
@@ -2050,9 +2072,10 @@ __device__ __forceinline__ double fixed_scale(unsigned long long maxbits) {
   return ldexp(1.0, FIXED_BITS - e);                            // |term| * scale < 2^40
 }
 
+template <typename S>
 __global__ __launch_bounds__(BLOCK) void k_face_accumulate_fixed(
     const int32_t* __restrict__ n_ptr, const int32_t* __restrict__ stash_face,
-    const double* __restrict__ stash_g, const unsigned long long* __restrict__ maxbits,
+    const S* __restrict__ stash_g, const unsigned long long* __restrict__ maxbits,
     unsigned long long* __restrict__ acc, uint8_t* __restrict__ flag) {
   const int n = *n_ptr;
   const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -2060,10 +2083,10 @@ __global__ __launch_bounds__(BLOCK) void k_face_accumulate_fixed(
   const int f = stash_face[i];
   if (f < 0) return;
   const double scale = fixed_scale(*maxbits);
-  const double* g = stash_g + 9 * (int64_t)i;
+  const S* g = stash_g + 9 * (int64_t)i;
 #pragma unroll
   for (int c = 0; c < 9; ++c) {
-    const double x = g[c];
+    const double x = static_cast<double>(g[c]);
     if (!(fabs(x) < INFINITY)) {
       flag[9 * (int64_t)f + c] = 1;  // NaN / Inf: the slot's sum is not a number
     } else {
@@ -2104,10 +2127,12 @@ __device__ __forceinline__ int backward_ray(
     const int32_t* __restrict__ rec_tri, const double* __restrict__ rec_t,
     const uint8_t* __restrict__ rec_cls, const int32_t* __restrict__ rec_slot,
     const int32_t* __restrict__ pass_counts, const tfrt_scene3d& sc, double L, double dead_len,
-    const double* __restrict__ g_child, int64_t child_stride, const double* __restrict__ g_fin,
-    int64_t cap_fin, const double* __restrict__ g_act, int64_t cap_act,
-    const double* __restrict__ g_stp, int64_t cap_stp, const double* __restrict__ g_dead,
-    int64_t cap_dead, double* __restrict__ g_out, int64_t out_stride, double gP[9]) {
+    const typename SweepStore<T>::type* __restrict__ g_child, int64_t child_stride,
+    const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
+    int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
+    const double* __restrict__ g_dead, int64_t cap_dead,
+    typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
+    int64_t out_stride, double gP[9]) {
   int face_out = -1;
   const int cls = rec_cls[i];
   const int slot = rec_slot[i];
@@ -2153,9 +2178,18 @@ __device__ __forceinline__ int backward_ray(
       if (sc.face_grad_mask == nullptr || sc.face_grad_mask[tri] != 0) face_out = tri;
     }
   }
-  for (int k = 0; k < 3; ++k) {
-    g_out[k * out_stride + i] = gs[k];
-    g_out[(3 + k) * out_stride + i] = ge[k];
+  // (first pass: to the caller's source-ray gradient, or nowhere when nobody asked for it)
+  if (g_out != nullptr) {
+    using G = typename SweepStore<T>::type;
+    for (int k = 0; k < 3; ++k) {
+      g_out[k * out_stride + i] = static_cast<G>(gs[k]);
+      g_out[(3 + k) * out_stride + i] = static_cast<G>(ge[k]);
+    }
+  } else if (g_src_out != nullptr) {
+    for (int k = 0; k < 3; ++k) {
+      g_src_out[k * out_stride + i] = gs[k];
+      g_src_out[(3 + k) * out_stride + i] = ge[k];
+    }
   }
   return face_out;
 }
@@ -2597,7 +2631,8 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   const int32_t* rec_slot = reinterpret_cast<int32_t*>(ws + lay.rec_slot);
   const double* rec_t = reinterpret_cast<double*>(ws + lay.rec_t);
   const uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
-  double* gbuf = reinterpret_cast<double*>(ws + lay.gbuf);
+  using G = typename SweepStore<T>::type;  // (the regions are sized for float64)
+  G* gbuf = reinterpret_cast<G*>(ws + lay.gbuf);
   int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
   // the sorted-ray forward left its Morton ray order in rperm: neighbouring lanes then mostly hit
   // the same few faces and k_backward3d sums their face gradients across the wave
@@ -2615,7 +2650,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   unsigned long long* fix_max = reinterpret_cast<unsigned long long*>(ws + lay.fix_max);
   if (ordered)  // (fix_acc, fix_flag and fix_max are adjacent: one clear)
     (void)hipMemsetAsync(fix_acc, 0, lay.total - lay.fix_acc, st);
-  double* stash_g_all = reinterpret_cast<double*>(ws + lay.stash_g);
+  G* stash_g_all = reinterpret_cast<G*>(ws + lay.stash_g);
   int32_t* stash_face_all = reinterpret_cast<int32_t*>(ws + lay.stash_face);
   // ray slots per accumulate block, measured at 1M rays x 11 windows (us for the three passes,
   // target pass first): 2048 -> 37/50/54, 4096 -> 21/33/38, 8192 -> 15/37/34, 16384 -> 12/49/36.
@@ -2630,25 +2665,27 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
     const int64_t sin = p == 0 ? src_stride : (int64_t)n;
     const int32_t* idin = p == 0 ? nullptr : rayid + (size_t)(p - 1) * n;
-    const double* g_child = (p == P - 1) ? nullptr : gbuf + (size_t)((p + 1) & 1) * 6 * n;
-    double* g_out = (p == 0 && g_src != nullptr) ? g_src : gbuf + (size_t)(p & 1) * 6 * n;
-    const int64_t out_stride = (p == 0 && g_src != nullptr) ? N : (int64_t)n;
-    double* stash_g = stash_g_all + (size_t)p * 9 * n;
+    const G* g_child = (p == P - 1) ? nullptr : gbuf + (size_t)((p + 1) & 1) * 6 * n;
+    // (the first pass's ray gradient goes to the caller's g_src, or nowhere)
+    G* g_out = p == 0 ? nullptr : gbuf + (size_t)(p & 1) * 6 * n;
+    double* g_src_out = p == 0 ? g_src : nullptr;
+    const int64_t out_stride = p == 0 ? N : (int64_t)n;
+    G* stash_g = stash_g_all + (size_t)p * 9 * n;
     int32_t* stash_face = stash_face_all + (size_t)p * n;
     hipLaunchKernelGGL((k_backward3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
                        idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
                        rec_cls + (size_t)p * n, rec_slot + (size_t)p * n,
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
-                       cap_dead, g_out, out_stride, g_fverts,
+                       cap_dead, g_out, g_src_out, out_stride, g_fverts,
                        (coherent && !ordered) ? rperm_all + (size_t)p * n : nullptr,
                        stash ? stash_g : nullptr, stash ? stash_face : nullptr);
     if (ordered) {
       // two-entry scale buffer, alternating per pass (each pass's conversion clears the other)
       unsigned long long* mx = fix_max + ((P - 1 - p) & 1);
-      hipLaunchKernelGGL(k_stash_absmax, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, stash_face,
+      hipLaunchKernelGGL((k_stash_absmax<G>), dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, stash_face,
                          stash_g, mx);
-      hipLaunchKernelGGL(k_face_accumulate_fixed, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p,
+      hipLaunchKernelGGL((k_face_accumulate_fixed<G>), dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p,
                          stash_face, stash_g, mx, fix_acc, fix_flag);
       hipLaunchKernelGGL(k_fixed_finish, dim3(cdiv((int64_t)M * 9, BLOCK)), dim3(BLOCK), 0, st,
                          (int64_t)M * 9, mx, fix_max + (((P - 1 - p) & 1) ^ 1), fix_acc, fix_flag,
@@ -2656,7 +2693,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     }
   }
   if (stash && !ordered && P > 0)
-    hipLaunchKernelGGL(k_face_accumulate, dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
+    hipLaunchKernelGGL((k_face_accumulate<G>), dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
                        nrays, P, (int64_t)n, stash_face_all, stash_g_all, acc_chunk, M, g_fverts);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
