@@ -1121,9 +1121,15 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       const uint32_t pr = pairs[wave][lane];
       slot = (int)(pr & 255u);
       const int memb = (int)(pr >> 8);
-      const float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
-                   r2 = crec[3 * (int64_t)memb + 2];
+      float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
+             r2 = crec[3 * (int64_t)memb + 2];
       j = cface[memb];
+      // All four gathers are in flight before anything is decided: left to itself the compiler
+      // sinks the record's loads behind the face-index and skip tests and the first early-out of
+      // the screen -- three dependent round trips per batch instead of one.
+      __asm__ volatile(""
+                       : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z),
+                         "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(j));
 #if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 7
       {  // sensitivity: the screen's gathers twice (another record)
         const int64_t m2 = (memb + 1024) % ((int64_t)n_clusters * CLUSTER);
