@@ -990,8 +990,19 @@ __device__ __forceinline__ void shift_in_le(unsigned& acc, const float q, const 
                    : "vcc");
 }
 
-#ifdef TFRT_GROUP_WAVES
-#define TFRT_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_GROUP_WAVES, TFRT_GROUP_WAVES)))
+// Five workgroups per CU (30.8 KB of LDS each: no copy of the rays in LDS, a 640-entry candidate
+// list) and five waves per SIMD (94 VGPRs, no spills).  Measured at 1M rays, optimiser step: with the
+// 7,100-instruction kernel of the round's first half 5 waves were no faster than 4 (236 vs 230 us per
+// launch); after the instruction trimming, with the screen / decision stages' gather latency a
+// larger share of a wave's life, 0.809 ms against 0.826.  (-DTFRT_GROUP_WAVES=0 -DTFRT_GROUP_RAYS_LDS
+// -DTFRT_GROUP_LIST_CAP=1024 is the four-wave configuration.)
+#ifndef TFRT_GROUP_WAVES
+#define TFRT_GROUP_WAVES 5
+#endif
+#if TFRT_GROUP_WAVES > 0
+// (only the shipped one-ray-per-lane instantiation: 2 or 4 rays per lane need more LDS than that)
+#define TFRT_GROUP_ATTR \
+  __attribute__((amdgpu_waves_per_eu(R == 1 ? TFRT_GROUP_WAVES : 1, R == 1 ? TFRT_GROUP_WAVES : 8)))
 #else
 #define TFRT_GROUP_ATTR
 #endif
@@ -1026,7 +1037,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   // candidate list of the wave: (tile-local cluster << 8 | ray slot), 16 bits because it is
   // always drained before the tile changes (LDS footprint decides the waves in flight)
 #ifndef TFRT_GROUP_LIST_CAP
-#define TFRT_GROUP_LIST_CAP 1024
+#define TFRT_GROUP_LIST_CAP 640
 #endif
   constexpr int LIST_CAP = TFRT_GROUP_LIST_CAP;   // > 64 * SUPER: one batch of 64 pairs must fit
   static_assert(LIST_CAP > 64 * SUPER, "candidate list too small for one batch");
@@ -1045,11 +1056,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   __shared__ uint32_t pairs[WAVES][PAIRS];   // member slot << 8 | ray slot (member slot < 2^24)
   __shared__ uint8_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
   __shared__ int32_t x_face[WAVES][128];
-  // The wave's rays for the screen / decision stages, kept in LDS.  (-DTFRT_GROUP_RAYS_GLOBAL
-  // re-reads them from the ray block instead and, with a shorter candidate list, frees enough LDS
-  // for a fifth workgroup per CU; measured at 1M rays: 5 waves per SIMD 236 us against 230 us for
-  // 4 -- the kernel is not short of waves in flight -- and 6 waves, which spill, 276 us.)
-#ifndef TFRT_GROUP_RAYS_GLOBAL
+  // The wave's rays for the screen / decision stages are re-read from the ray block (gathers of
+  // 4-8 bytes per coordinate; -DTFRT_GROUP_RAYS_LDS keeps a copy in LDS instead, 6-12 KB that
+  // cost the fifth workgroup per CU).  (6 waves per SIMD spill: 276 us against 230.)
+#ifdef TFRT_GROUP_RAYS_LDS
   __shared__ T ray_l[WAVES][6][RW];
 #define TFRT_RAYV(q, slot) static_cast<double>(ray_l[wave][q][slot])
 #else
@@ -1080,7 +1090,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     {
       const int slot = r * 64 + lane;
       const int ii = i < n ? i : 0;
-#ifndef TFRT_GROUP_RAYS_GLOBAL
+#ifdef TFRT_GROUP_RAYS_LDS
 #pragma unroll
       for (int q = 0; q < 6; ++q) ray_l[wave][q][slot] = rays[q * stride + ii];
 #endif
