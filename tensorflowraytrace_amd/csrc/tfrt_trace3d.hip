@@ -1711,7 +1711,7 @@ __device__ __forceinline__ bool emit(const tfrt_ray_out& o, int64_t slot, const 
 }
 
 // k_react3d's own scan (launches of <= SELF_SCAN_MAX_BLOCKS ray blocks: one launch less per pass)
-constexpr int SELF_SCAN_MAX_BLOCKS = 1024;
+constexpr int SELF_SCAN_MAX_BLOCKS = 4096;
 struct SelfScan {
   const int32_t* blockcnt = nullptr;     // per-block class histograms; nullptr: a scan kernel ran
   const int32_t* prev_counts = nullptr;  // counts row of the previous pass (nullptr: first pass)
