@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
 #endif
       skip_l[wave][slot] = (last_tri != nullptr && i < n) ? last_tri[ii] : -1;
     }
-    if (i < n) {
+    if (i < n && prep != nullptr) {
       ax[r] = prep[i];
       ay[r] = prep[pstride + i];
       az[r] = prep[2 * pstride + i];
@@ -1105,6 +1105,22 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       bz[r] = prep[5 * pstride + i];
       nsa[r] = prep[6 * pstride + i];
       nsb[r] = prep[7 * pstride + i];
+    } else if (i < n) {
+      // first pass of a trace: nobody has written the filter state of these rays yet.  Forming
+      // it here (k_rayprep's arithmetic, ~60 float64 instructions) saves that kernel's launch,
+      // its 32 B per ray written and the same 32 B read back
+      double s[3], e[3], u[3], scv[3];
+      load_ray3(rays, stride, i, s, e);
+      float o[8];
+      ray_filter_state(s, e, c0, o, u, scv);
+      ax[r] = o[0];
+      ay[r] = o[1];
+      az[r] = o[2];
+      bx[r] = o[3];
+      by[r] = o[4];
+      bz[r] = o[5];
+      nsa[r] = o[6];
+      nsb[r] = o[7];
     }
     const int slot = r * 64 + lane;
     prep_ab[wave][2 * slot] = make_float4(ax[r], ay[r], az[r], nsa[r]);
@@ -2435,7 +2451,9 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
   if (grouped && pl.g_chunks == 1 && classify != nullptr && classify->rec_cls != nullptr)
     fz = *classify;
   if (classified != nullptr) *classified = fz.rec_cls != nullptr;
-  if (!prep_ready || clustered)  // (sorted-ray mode also needs the sort keys)
+  // (the grouped kernel forms the filter state of a trace's first pass itself: prep = nullptr)
+  const bool prep_inline = grouped && !prep_ready;
+  if ((!prep_ready && !prep_inline) || clustered)  // (sorted-ray mode also needs the sort keys)
     hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
                        prep, pstride, clustered ? ac->keys_in : nullptr,
                        clustered ? ac->vals_in : nullptr, n_cap);
@@ -2464,7 +2482,8 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
   else if (grouped)                                                                            \
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
                        n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec,     \
-                       ac->cface, fverts, c0, prep, pstride, ac->n_clusters,                   \
+                       ac->cface, fverts, c0, prep_inline ? nullptr : prep, pstride,           \
+                       ac->n_clusters,                                                         \
                        pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride,           \
                        fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt);            \
   else                                                                                         \
