@@ -1079,6 +1079,33 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     else return (float)(v - c);
   };
   float ax[R], ay[R], az[R], bx[R], by[R], bz[R], nsa[R], nsb[R];
+  // float32 / float16 ray state, one ray per lane: every lane keeps its own ray in registers and
+  // the screen / decision stages fetch a pair's ray from the lane that owns it (ds_bpermute)
+  // instead of gathering six coordinates from the ray block
+  constexpr bool RAY_SHUFFLE = (R == 1) && sizeof(T) <= 4;
+  float own_ray[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if constexpr (RAY_SHUFFLE) {
+    const int i0 = base + tid;
+    const int ii = i0 < n ? i0 : 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<float>(rays[q * stride + ii]);
+  }
+  // (all lanes active: a lane that is masked off would hand out zeros)
+  auto ray_of = [&](const int slot, double s[3], double e[3]) {
+    if constexpr (RAY_SHUFFLE) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        s[q] = static_cast<double>(__shfl(own_ray[q], slot, 64));
+        e[q] = static_cast<double>(__shfl(own_ray[3 + q], slot, 64));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        s[q] = TFRT_RAYV(q, slot);
+        e[q] = TFRT_RAYV(3 + q, slot);
+      }
+    }
+  };
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int i = base + r * BLOCK + tid;
@@ -1142,10 +1169,12 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   bool draining = false, drained = false;  // after the last tile: one final flush empties both
   auto screen = [&](const int nb) {
     bool keep = false;
-    int j = -1, slot = 0;
+    int j = -1;
+    const uint32_t pr = lane < nb ? pairs[wave][lane] : 0u;
+    const int slot = (int)(pr & 255u);
+    double s[3], e[3];
+    ray_of(slot, s, e);
     if (lane < nb) {
-      const uint32_t pr = pairs[wave][lane];
-      slot = (int)(pr & 255u);
       const int memb = (int)(pr >> 8);
       float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
              r2 = crec[3 * (int64_t)memb + 2];
@@ -1164,12 +1193,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       }
 #endif
       const double best = dkey_inv(best_k[wave][slot]);
-      double s[3], e[3];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        s[q] = TFRT_RAYV(q, slot);
-        e[q] = TFRT_RAYV(3 + q, slot);
-      }
       // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t scales
       // with their magnitudes, not with |t|
       const float sx = rel_c0(s[0], cx, cxf), sy = rel_c0(s[1], cy, cyf), sz = rel_c0(s[2], cz, czf);
@@ -1196,17 +1219,14 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   auto decide = [&](const int nb) {
     bool have = false;
     unsigned long long key = 0, old = 0;
-    int j = -1, slot = 0;
+    int j = -1;
+    const int slot = lane < nb ? (int)x_slot[wave][lane] : 0;
+    double s[3], e[3];
+    ray_of(slot, s, e);
     if (lane < nb) {
-      slot = x_slot[wave][lane];
       j = x_face[wave][lane];
       old = best_k[wave][slot];
-      double s[3], e[3], P[9];
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        s[q] = TFRT_RAYV(q, slot);
-        e[q] = TFRT_RAYV(3 + q, slot);
-      }
+      double P[9];
       const double* fp = fverts + 9 * (int64_t)j;
 #pragma unroll
       for (int q = 0; q < 9; ++q) P[q] = fp[q];
@@ -1380,11 +1400,14 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       // round (ballot + rank).  (8 lanes per pair with one append per step cost ~345
       // instructions per 64 pairs, this ~160.)
       unsigned hits = 0u;
-      int cl0 = 0, sl = 0;
+      const int v = lane < nb ? (int)rlist[wave][lane] : 0;
+      const int cl0 = (v >> 8) * SUPER, sl = v & 255;
+      double l1s[3] = {0.0, 0.0, 0.0};
+      if (last_tri != nullptr && eps_start >= 0.0) {  // (wave-uniform: only the behind test needs it)
+        double l1e[3];
+        ray_of(sl, l1s, l1e);
+      }
       if (lane < nb) {
-        const int v = rlist[wave][lane];
-        cl0 = (v >> 8) * SUPER;
-        sl = v & 255;
         const float4 fa = prep_ab[wave][2 * sl], fb = prep_ab[wave][2 * sl + 1];
         const float4* row = &tile[cl0 + (cl0 >> 3)];
         // The sphere tests are line tests; a cluster wholly behind the ray's start cannot hold
@@ -1395,8 +1418,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
         // inside the 64 * 2^-24 (|c| + r) the spheres are inflated by.
         const float ux = fa.y * fb.z - fa.z * fb.y, uy = fa.z * fb.x - fa.x * fb.z,
                     uz = fa.x * fb.y - fa.y * fb.x;
-        const float sx = rel_c0(TFRT_RAYV(0, sl), cx, cxf), sy = rel_c0(TFRT_RAYV(1, sl), cy, cyf),
-                    sz = rel_c0(TFRT_RAYV(2, sl), cz, czf);
+        const float sx = rel_c0(l1s[0], cx, cxf), sy = rel_c0(l1s[1], cy, cyf),
+                    sz = rel_c0(l1s[2], cz, czf);
         const float t_off = fmaf(-sx, ux, fmaf(-sy, uy, -sz * uz)) +
                             (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
         // (first pass of a trace -- no ray starts on a face yet: sources normally sit outside
