@@ -35,6 +35,7 @@
 // gradients of the rays are summed in LDS face windows (k_face_accumulate).
 #include <vector>
 
+#include <type_traits>
 #include "tfrt_common.h"
 
 namespace tfrt {
@@ -1082,13 +1083,14 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   // float32 / float16 ray state, one ray per lane: every lane keeps its own ray in registers and
   // the screen / decision stages fetch a pair's ray from the lane that owns it (ds_bpermute)
   // instead of gathering six coordinates from the ray block
-  constexpr bool RAY_SHUFFLE = (R == 1) && sizeof(T) <= 4;
-  float own_ray[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr bool RAY_SHUFFLE = (R == 1);
+  using RT = std::conditional_t<sizeof(T) <= 4, float, double>;  // (exact for every ray state)
+  RT own_ray[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (RAY_SHUFFLE) {
     const int i0 = base + tid;
     const int ii = i0 < n ? i0 : 0;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<float>(rays[q * stride + ii]);
+    for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<RT>(rays[q * stride + ii]);
   }
   // (all lanes active: a lane that is masked off would hand out zeros)
   auto ray_of = [&](const int slot, double s[3], double e[3]) {
