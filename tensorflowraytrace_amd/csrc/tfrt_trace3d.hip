@@ -248,7 +248,9 @@ __device__ __forceinline__ void cluster_spheres_block(
     cface[k] = f;
     csphere[k] = f >= 0 ? pack_sphere(ctr, rad) : make_float4(0.f, 0.f, 0.f, -1.f);
     if (crec != nullptr) {  // float32 record for the screen: P0 - c0, P1 - P0, P2 - P0
-      crec[3 * (int64_t)k] = make_float4((float)V[0][0], (float)V[0][1], (float)V[0][2], 0.f);
+      // (.w of the first entry carries the face index: the screen needs no second gather for it)
+      crec[3 * (int64_t)k] =
+          make_float4((float)V[0][0], (float)V[0][1], (float)V[0][2], __int_as_float(f));
       crec[3 * (int64_t)k + 1] = make_float4((float)(V[1][0] - V[0][0]), (float)(V[1][1] - V[0][1]),
                                              (float)(V[1][2] - V[0][2]), 0.f);
       crec[3 * (int64_t)k + 2] = make_float4((float)(V[2][0] - V[0][0]), (float)(V[2][1] - V[0][1]),
@@ -1180,13 +1182,13 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       const int memb = (int)(pr >> 8);
       float4 r0 = crec[3 * (int64_t)memb], r1 = crec[3 * (int64_t)memb + 1],
              r2 = crec[3 * (int64_t)memb + 2];
-      j = cface[memb];
-      // All four gathers are in flight before anything is decided: left to itself the compiler
+      // All three gathers are in flight before anything is decided: left to itself the compiler
       // sinks the record's loads behind the face-index and skip tests and the first early-out of
       // the screen -- three dependent round trips per batch instead of one.
       __asm__ volatile(""
-                       : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r1.x), "+v"(r1.y), "+v"(r1.z),
-                         "+v"(r2.x), "+v"(r2.y), "+v"(r2.z), "+v"(j));
+                       : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y),
+                         "+v"(r1.z), "+v"(r2.x), "+v"(r2.y), "+v"(r2.z));
+      j = __float_as_int(r0.w);
 #if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 7
       {  // sensitivity: the screen's gathers twice (another record)
         const int64_t m2 = (memb + 1024) % ((int64_t)n_clusters * CLUSTER);
