@@ -384,6 +384,10 @@ def main():
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": args.dtype + " ray state, f32 filter + f64 decisions",
+        "dtype_note": "every hit/miss and nearest-face decision, hit point, Snell step and the reverse "
+                      "sweep's arithmetic and sums are float64; the ray state between passes and the "
+                      "reverse sweep's per-ray intermediates are STORED in " + args.dtype +
+                      " (other_legs.f64_ray_state: everything float64)",
         "data": "synthetic",
         "config": {
             "workload": "cfg4: 1M-ray aperture source x 2-surface parametric hex lens "
