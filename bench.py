@@ -177,7 +177,28 @@ def _source_hash():
     return h.hexdigest()[:16]
 
 
-def main():
+def spawn_ranks(n, argv):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: start N fresh worker
+    processes (one rank per GPU) BEFORE this process touches a GPU, relay their output (rank 0
+    prints the JSON line) and return the launcher's exit status.  Workers never re-exec."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+MIN_TIMED_SECONDS = 0.2
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -204,7 +225,11 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the separately reported legs (all-pairs mode, float64 state, ...)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under torchrun: one process cannot stand for N ranks
+        raise SystemExit(spawn_ranks(args.gpus, argv))
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the tfrt hot path has no CPU fallback")
@@ -214,8 +239,11 @@ def main():
     import tfrt.optimizer as optimizer
 
     rank, world, local = tdist.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        world = torch.distributed.get_world_size()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {world} rank(s) are running (WORLD_SIZE)")
+    backend = torch.distributed.get_backend() if tdist.is_distributed() else None
     torch.cuda.set_device((local % torch.cuda.device_count()) if world > 1 else 0)
     tfa.set_device(f"cuda:{torch.cuda.current_device()}")
     lib = _lib.lib()
@@ -237,11 +265,23 @@ def main():
         opt = optimizer.SGD_Optimizer(
             eng, params, make_error_function(), trace_depth=3, learning_rate=1e-6, grad_clip=1e-3,
             fused=False if step_mode == "generic" else "auto",
-            graph="auto" if step_mode == "graph" else False)
+            graph="auto" if step_mode == "graph" else False,
+            speculative=step_mode == "generic")   # (the bench's error function is pure)
         opt.suppress_warnings = True
         for _ in range(args.warmup):
             opt.single_step(None)
         fs = opt._fused_step
+        barrier()
+        # at least MIN_TIMED_SECONDS inside the timed region: the requested step count is raised
+        # when K steps would be shorter (every rank takes the same count: max over ranks)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            opt.single_step(None)
+        torch.cuda.synchronize()
+        est = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device="cuda")
+        if world > 1:
+            torch.distributed.all_reduce(est, op=torch.distributed.ReduceOp.MIN)
+        steps = max(args.steps, int(np.ceil(MIN_TIMED_SECONDS / max(float(est.item()), 1e-6))))
         barrier()
         if profile:
             lib.tfrt_profile_enable(1)
@@ -249,7 +289,7 @@ def main():
         tests_local = 0
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             opt.single_step(None)
             if fs is None:
                 tests_local += eng.last_trace["n_tests"]
@@ -272,7 +312,7 @@ def main():
             tsum = stats[1:].clone()
             torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
             dt, tests_total = float(tmax.item()), float(tsum.item())
-        out = dict(dt=dt, tests=tests_total, kernel_ms=kernel_ms,
+        out = dict(dt=dt, steps=steps, tests=tests_total, kernel_ms=kernel_ms,
                    counts=eng.last_trace["counts"], M=int(system._merged_face_verts.shape[0]),
                    mode=eng._trace_mode(system),
                    graph_replays=fs.graph_replays if fs is not None else 0,
@@ -291,7 +331,7 @@ def main():
         other_rays = args.rays if per_rank else args.rays * world
         leg = timed_leg(other_rays, args.trace_mode, args.step_mode, args.dtype)
         side["weak_scaling" if not per_rank else "strong_scaling"] = {
-            "global_rays": other_rays, "ms_per_step": leg["dt"] / args.steps * 1e3,
+            "global_rays": other_rays, "ms_per_step": leg["dt"] / leg["steps"] * 1e3,
             "tests_per_s": leg["tests"] / leg["dt"]}
     # per-launch time of the dominant kernel, HIP events on the launch stream: needs eagerly
     # launched kernels (events cannot sit inside a replayed graph), so the same step is run
@@ -376,10 +416,11 @@ def main():
         "metric": "ray-surface intersection tests/sec (fwd+bwd)",
         "value": tests_total / dt,
         "unit": "tests/s",
-        "n_gpus": args.gpus,
-        "steps": args.steps,
+        "n_gpus": world,
+        "steps": main_leg["steps"],
+        "steps_requested": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": dt / main_leg["steps"] * 1e3,
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
@@ -403,7 +444,10 @@ def main():
                           "generic": "error function as torch code through autograd"}[
                               args.step_mode],
             "graph_replays": main_leg["graph_replays"],
-            "parallelism": f"rays sharded over {args.gpus} GPU(s), 1 RCCL all-reduce/step",
+            "ranks": world, "backend": backend,
+            "parallelism": (f"rays sharded over {world} ranks (one per GPU), 1 {backend} "
+                            f"all-reduce of the parameter gradients per step")
+            if tdist.is_distributed() else "single GPU, no collective",
         },
         "value_note": "tests = ray-face pairs DECIDED (sum over passes of N_active x M, counted "
                       "by the kernels); the hierarchy decides most pairs without executing a "
@@ -419,16 +463,16 @@ def main():
         legs = {}
         if mode != "all-pairs":
             leg = timed_leg(args.rays, "all-pairs", args.step_mode, args.dtype)
-            legs["all_pairs"] = {"ms_per_step": leg["dt"] / args.steps * 1e3,
+            legs["all_pairs"] = {"ms_per_step": leg["dt"] / leg["steps"] * 1e3,
                                  "tests_per_s": leg["tests"] / leg["dt"],
                                  "note": "every ray-face pair goes through the float32 sphere test"}
         other_dt = "f64" if args.dtype == "f32" else "f32"
         leg = timed_leg(args.rays, args.trace_mode, args.step_mode, other_dt)
-        legs[other_dt + "_ray_state"] = {"ms_per_step": leg["dt"] / args.steps * 1e3,
+        legs[other_dt + "_ray_state"] = {"ms_per_step": leg["dt"] / leg["steps"] * 1e3,
                                          "tests_per_s": leg["tests"] / leg["dt"]}
         if args.step_mode != "generic":
             leg = timed_leg(args.rays, args.trace_mode, "generic", args.dtype)
-            legs["generic_step"] = {"ms_per_step": leg["dt"] / args.steps * 1e3,
+            legs["generic_step"] = {"ms_per_step": leg["dt"] / leg["steps"] * 1e3,
                                     "tests_per_s": leg["tests"] / leg["dt"],
                                     "note": "same error function as arbitrary torch code"}
         line["other_legs"] = legs

@@ -41,6 +41,27 @@ def amalgamate(stuff, signature=None):
     return {f: torch.cat([s[f] for s in items], 0) for f in signature}
 
 
+_tap_log = None     # id(parameter) -> [aliases] while a collect_taps() block is open
+
+
+class collect_taps:
+    """``with collect_taps() as log: system.update()`` -- ``log[id(p)]`` lists the aliases through
+    which the update read parameter ``p`` (a parameter may feed several boundaries).  Nothing is
+    kept anywhere once the block is closed: no list grows with the number of updates and the
+    parameter tensors stay plain leaves (``copy.deepcopy`` works)."""
+
+    def __enter__(self):
+        global _tap_log
+        self._outer = _tap_log
+        _tap_log = {}
+        return _tap_log
+
+    def __exit__(self, *exc):
+        global _tap_log
+        _tap_log = self._outer
+        return False
+
+
 def tap(parameters):
     """A fresh non-leaf alias of a parameter tensor, through which ``update()`` reads it.
 
@@ -49,15 +70,12 @@ def tap(parameters):
     autograd graph of the parameter does and remembers the stream it was created on; a backward
     pass inside a HIP-graph capture (fused_step.FusedStep) that reaches an accumulator of another
     stream forks the capture onto that stream (the legacy stream, typically) and the runtime then
-    crashes ending the capture.  The aliases of the current update are listed on the tensor as
-    ``_tfrt_taps`` (a parameter may feed several boundaries)."""
+    crashes ending the capture.  The aliases are recorded only inside a ``collect_taps()`` block."""
     if not (isinstance(parameters, torch.Tensor) and parameters.requires_grad):
         return parameters
     alias = parameters.view_as(parameters)
-    taps = parameters.__dict__.get("_tfrt_taps")
-    if taps is None:
-        taps = parameters.__dict__["_tfrt_taps"] = []
-    taps.append(alias)
+    if _tap_log is not None:
+        _tap_log.setdefault(id(parameters), []).append(alias)
     return alias
 
 

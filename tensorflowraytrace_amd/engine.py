@@ -359,6 +359,19 @@ class OpticalSystem3D(OpticalSystemBase):
                 mat_out=col("mat_out", torch.int32), n_in=col("n_in", torch.float64),
                 n_out=col("n_out", torch.float64), face_grad_mask=gmask), held)
 
+    def scene_signature(self):
+        """What a captured launch sequence has baked in about the scene besides the face tensor:
+        which boundaries (identity), their material columns (identity + version), the epsilons
+        and the material list.  Cheap (no tensor work): checked before every graph replay."""
+        sig = []
+        for name in ("_optical", "_stop", "_target"):
+            for b in getattr(self, name):
+                sig.append((id(b),) + tuple(
+                    (id(b[f]), b[f]._version) for f in ("mat_in", "mat_out", "n_in", "n_out")
+                    if f in b))
+        return (tuple(sig), self.intersect_epsilion, self.size_epsilion,
+                self.ray_start_epsilion, tuple(id(m) for m in self.materials))
+
     def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False,
                    deterministic=False):
         s = self._scene_cache[1]

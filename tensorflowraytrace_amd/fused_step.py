@@ -65,6 +65,8 @@ class GoalError:
             raise ValueError(f"GoalError: fields must be taken from {_GEO3}, got {fields!r}")
         if goal is None:
             raise ValueError("GoalError: a goal (callable or tensor) is required")
+        if len(set(self.fields)) != len(self.fields):
+            raise ValueError(f"GoalError: duplicate fields in {fields!r}")
         self.rows = [_GEO3.index(f) for f in self.fields]
         self.goal = goal
         self._cache = None
@@ -140,6 +142,7 @@ class FusedStep:
         self.graph_replays = 0
         self.capture_error = None
         self.untapped = False             # a parameter reached the faces without boundaries.tap
+        self._tap_checks = 0              # eager steps that compared leaf and alias gradients
 
     # ------------------------------------------------------------------------ eligibility
     @staticmethod
@@ -162,7 +165,9 @@ class FusedStep:
     def _buffers(self, block, fv, P, flags, dt):
         """Persistent outputs / tape / seeds of the trace for this (N, M, P, dtype, flags)."""
         N, M = block.shape[1], fv.shape[0]
-        sig = (N, M, P, dt, flags, str(block.device))
+        # (the error function's rows are baked into `fields` and into which rows of g_fin are
+        # ever written: another GoalError gets fresh, zeroed buffers)
+        sig = (N, M, P, dt, flags, str(block.device), tuple(self.opt.error_function.rows))
         st = self._state
         if st is not None and st["sig"] == sig:
             return st
@@ -209,9 +214,9 @@ class FusedStep:
         opt, eng = self.opt, self.opt.engine
         system = eng.optical_system
         eng.clear_ray_history()
-        for p in opt.parameters:
-            p.__dict__["_tfrt_taps"] = []
-        system.update()
+        from . import boundaries
+        with boundaries.collect_taps() as tap_log:
+            system.update()
         src = eng._source_set()
         if not src:
             raise RuntimeError("FusedStep: the optical system has no source rays")
@@ -252,22 +257,42 @@ class FusedStep:
                 ops._p(st["g_fin"]), st["capN"], None, 0, None, 0, None, 0, ops._p(st["g_fv"]),
                 None, ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream),
                 "tfrt_trace3d_backward")
-            # differentiate w.r.t. the aliases update() read the parameters through (see
-            # boundaries.tap), not w.r.t. the leaves; a parameter nobody tapped falls back to the
-            # leaf, which is correct but must not be captured in a graph
+            # Inside a graph capture: differentiate w.r.t. the aliases update() read the parameters
+            # through (see boundaries.tap), never w.r.t. the leaves.  Outside a capture the leaf is
+            # differentiated too -- its gradient is the total whatever route update() took -- and
+            # the first eager steps compare the two: a parameter that reaches the faces (partly)
+            # without an alias (a custom _update reading the leaf) must never be captured.
+            capturing = torch.cuda.is_current_stream_capturing()
             inputs, owner = [], []
             for i, p in enumerate(opt.parameters):
-                taps = p.__dict__.get("_tfrt_taps") or [p]
-                if taps[0] is p:
+                taps = tap_log.get(id(p), [])
+                if not taps:
                     self.untapped = True
-                inputs.extend(taps)
-                owner.extend([i] * len(taps))
+                if capturing and taps:
+                    inputs.extend(taps)
+                    owner.extend([i] * len(taps))
+                else:
+                    inputs.extend(taps + [p])
+                    owner.extend([i] * len(taps) + [-1 - i])
             with torch.autograd.set_multithreading_enabled(False):
                 got = torch.autograd.grad([fv], inputs, grad_outputs=[st["g_fv"]],
                                           allow_unused=True)
+            total = {}
             for i, g in zip(owner, got):
-                if g is not None:
+                if g is None:
+                    continue
+                if i < 0:
+                    total[-1 - i] = g
+                else:
                     grads[i] = g if grads[i] is None else grads[i] + g
+            for i, g in total.items():
+                if (not self.untapped and self._tap_checks < self.graph_warmup
+                        and not (grads[i] is not None and
+                                 torch.allclose(grads[i], g, rtol=1e-12, atol=0.0, equal_nan=True))):
+                    self.untapped = True      # (one host read per parameter, first steps only)
+                grads[i] = g
+            if not capturing:
+                self._tap_checks += 1
         self._publish_lazily(st, src, P, flags)
         return grads, st["err"]
 
@@ -368,7 +393,8 @@ class FusedStep:
         return (tuple(id(a) for a in accumulators), tuple(p.data_ptr() for p in opt.parameters),
                 tuple(id(src[f]) for f in _GEO3) if src else (), int(opt.trace_depth),
                 eng._flags(), eng.new_ray_length, eng.dead_ray_length, eng._trace_mode(),
-                id(opt.error_function.goal), opt.error_function.fields, tdist.world_size())
+                id(opt.error_function), id(opt.error_function.goal), opt.error_function.fields,
+                tdist.world_size(), eng.optical_system.scene_signature(), bool(eng.deterministic))
 
     def step(self, accumulators, lr_scale):
         """One optimiser step.  Returns the error tensor {sum, n_terms, mean} (device)."""

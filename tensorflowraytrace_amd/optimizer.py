@@ -115,7 +115,7 @@ class DeferredScalar:
 class SGD_Optimizer:
     def __init__(self, engine, parameters, error_function, trace_depth, momentum=0.0,
                  learning_rate=1.0, individual_lr=None, grad_clip="default", clip_mode="common",
-                 clip_scale=10.0, sgd_learning_rate=0.01, apply_momentum=False, speculative=True,
+                 clip_scale=10.0, sgd_learning_rate=0.01, apply_momentum=False, speculative=False,
                  fused="auto", graph="auto"):
         self.engine = engine
         if type(parameters) is list or type(parameters) is tuple:
@@ -126,8 +126,11 @@ class SGD_Optimizer:
         self.trace_depth = trace_depth
         self.sgd_learning_rate = sgd_learning_rate
         self.apply_momentum = apply_momentum
-        # overlap host and device: do not block on the per-class ray counts of the trace, guess
-        # them from the previous step and verify after the gradient has been enqueued
+        # ``speculative=True`` (opt-in) overlaps host and device on the generic path: the per-class
+        # ray counts of the trace are guessed from the previous step and verified after the
+        # gradient has been enqueued.  On a wrong guess the error function has ALREADY run once on
+        # ray sets cut with the stale counts (rows beyond the true count are uninitialised) and is
+        # run again -- only for pure error functions; the default reads the counts first.
         self.speculative = speculative
         self.speculation_misses = 0
         # start pessimistic: the first steps read the ray counts (blocking) and speculation
