@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFRT_VERSION 100 /* 0.1.0 */
+#define TFRT_VERSION 101 /* 0.1.0 */
 
 #define TFRT_F32 0
 #define TFRT_F64 1
@@ -386,6 +386,12 @@ typedef struct tfrt_scene2d {
   int64_t n_table_stride;
   int32_t n_materials;
   double intersect_epsilion, size_epsilion, ray_start_epsilion;
+  /* Reverse sweep only.  0 (default, the reference): the gradient of a totally reflected ray
+   * is NaN -- geometry.py:640-646 evaluates asin(theta2) with |theta2| > 1 in the unselected
+   * branch of tf.where, and 0 * (d asin) = NaN flows into every boundary entry the ray touched
+   * up to the reflecting one; tfrt_sgd_process zeroes such entries (optimizer.py:226-229).
+   * 1: the reflect branch's own finite gradient (new_angle = norm + theta1 + pi) instead. */
+  int32_t finite_tir_gradient;
 } tfrt_scene2d;
 
 /* OpticalSystem2D._segment_intersection, tfrt/engine.py:688-749 (rays: 4 x stride block). */

@@ -225,8 +225,16 @@ def angle_in_interval(angle, start, end):
 
 # ---------------------------------------------------------------------------- Snell
 
-def snells_law_2D(x_start, y_start, x_end, y_end, norm, n_in, n_out, new_ray_length):
-    """geometry.py:565-653 (angle form)."""
+def snells_law_2D(x_start, y_start, x_end, y_end, norm, n_in, n_out, new_ray_length,
+                  finite_tir_gradient=False):
+    """geometry.py:565-653 (angle form).
+
+    As in the reference, ``asin(theta2)`` is evaluated for every ray and is NaN in the
+    unselected branch of a totally reflected one (geometry.py:640-646): the forward value is the
+    reflect branch, but the GRADIENT of such a ray is NaN (0 * NaN in asin's derivative) and
+    poisons every boundary entry the ray touched; optimizer.py:226-229 zeroes those entries.
+    ``finite_tir_gradient=True`` (not the reference; the product's opt-in) feeds asin a safe
+    value there, which leaves the reflect branch's own finite gradient."""
     x_start, y_start, x_end, y_end = (_t(v) for v in (x_start, y_start, x_end, y_end))
     norm, n_in, n_out = _t(norm), _t(n_in), _t(n_out)
     norm = torch.remainder(norm, 2 * PI)
@@ -257,10 +265,8 @@ def snells_law_2D(x_start, y_start, x_end, y_end, norm, n_in, n_out, new_ray_len
 
     theta2 = n * torch.sin(theta1)
     ok = torch.logical_and(torch.abs(theta2) <= 1.0, n != 0.0)
-    # asin of an out-of-range value is NaN in the unselected branch; clamp it the way a
-    # "safe value" would so autograd stays finite (forward value is unaffected).
-    safe_theta2 = torch.where(ok, theta2, zero)
-    new_angle = torch.where(ok, norm - torch.asin(safe_theta2), norm + theta1 + PI)
+    asin_arg = torch.where(ok, theta2, zero) if finite_tir_gradient else theta2
+    new_angle = torch.where(ok, norm - torch.asin(asin_arg), norm + theta1 + PI)
 
     xs = x_end
     ys = y_end

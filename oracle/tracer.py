@@ -413,7 +413,7 @@ def _project_2d(system, rays, flags, history, bug_compatible):
     return result
 
 
-def _react(system, proj, new_ray_length, index_type):
+def _react(system, proj, new_ray_length, index_type, finite_tir_gradient=False):
     """operation.py:255-307 StandardReaction.main."""
     rays = proj["rays"].get("active")
     if not rays or rays["x_start"].shape[0] == 0:
@@ -433,7 +433,8 @@ def _react(system, proj, new_ray_length, index_type):
     if system.dimension == 2:
         new["x_start"], new["y_start"], new["x_end"], new["y_end"] = geom.snells_law_2D(
             rays["x_start"], rays["y_start"], rays["x_end"], rays["y_end"],
-            proj["optical"]["norm"], n_in, n_out, new_ray_length)
+            proj["optical"]["norm"], n_in, n_out, new_ray_length,
+            finite_tir_gradient=finite_tir_gradient)
     else:
         (new["x_start"], new["y_start"], new["z_start"],
          new["x_end"], new["y_end"], new["z_end"]) = geom.snells_law_3D(
@@ -450,7 +451,8 @@ DEFAULT_FLAGS = dict(
 
 
 def single_pass(system, rays, history, flags=None, new_ray_length=1.0,
-                inherit=("wavelength",), index_type="index", chunk=2048, bug_compatible=False):
+                inherit=("wavelength",), index_type="index", chunk=2048, bug_compatible=False,
+                finite_tir_gradient=False):
     """engine.py:2193-2302 with one StandardReaction operation.  Returns the new ray set
     (``{}`` when nothing reacted) and the projection result."""
     fl = dict(DEFAULT_FLAGS)
@@ -460,7 +462,7 @@ def single_pass(system, rays, history, flags=None, new_ray_length=1.0,
         proj = _project_3d(system, rays, fl, history, chunk)
     else:
         proj = _project_2d(system, rays, fl, history, bug_compatible)
-    new = _react(system, proj, new_ray_length, index_type)
+    new = _react(system, proj, new_ray_length, index_type, finite_tir_gradient)
     if new is None:
         return {}, proj
     for field in inherit:

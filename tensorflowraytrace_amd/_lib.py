@@ -42,6 +42,7 @@ class Scene2D(ctypes.Structure):
         ("arc_n_in", c_vp), ("arc_n_out", c_vp), ("n_arcs", c_i64),
         ("n_table", c_vp), ("n_table_stride", c_i64), ("n_materials", c_i32),
         ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
+        ("finite_tir_gradient", c_i32),
     ]
 
 

@@ -610,7 +610,8 @@ __global__ __launch_bounds__(BLOCK) void k_backward2d(
       double n_in = 1.0, n_out = 1.0, gp[5];
       if (has_child) prim_indices(sc, prim, rid, &n_in, &n_out);
       const double* pp = is_arc ? sc.arc + (int64_t)(prim - Ms) * 5 : sc.seg + (int64_t)prim * 4;
-      adjoint2d(s, e, pp, is_arc, rec_u[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gp);
+      adjoint2d(s, e, pp, is_arc, rec_u[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gp,
+                sc.finite_tir_gradient != 0);
       if (is_arc) {
         if (g_arc != nullptr)
           for (int q = 0; q < 5; ++q)

@@ -116,10 +116,15 @@ TFRT_HD double segment_norm(const double seg[4]) {
 // (prim = {A, B}) or an arc (prim = {c, a1, a2, r}); outputs (s, h) for finished / stopped /
 // history, child (h, h + L (cos t, sin t)) with t = snells_law_2D(s, h, norm, n_in, n_out).
 //   g_s, g_h, g_ce as in adjoint3d.  gprim: 4 (segment) or 5 (arc) gradients.
+// Total internal reflection: the reference evaluates asin(theta2), |theta2| > 1, in the branch
+// tf.where does not select (geometry.py:640-646); that branch's gradient is 0 * d asin = NaN,
+// whatever the upstream gradient (zero included), so theta1 -- i.e. the norm angle and the ray
+// angle -- receive NaN and with them the boundary entries and the parent ray.  Reproduced unless
+// finite_tir (tfrt_scene2d.finite_tir_gradient): then the reflect branch's own gradient.
 TFRT_HD void adjoint2d(const double s[2], const double e[2], const double* prim, bool is_arc,
                        double u, bool has_child, double n_in, double n_out, double L,
                        const double g_s[2], const double g_h[2], const double g_ce[2],
-                       double gs[2], double ge[2], double gprim[5]) {
+                       double gs[2], double ge[2], double gprim[5], bool finite_tir = false) {
   const double d[2] = {e[0] - s[0], e[1] - s[1]};
   const double h[2] = {s[0] + u * d[0], s[1] + u * d[1]};
   double hb[2] = {g_h[0], g_h[1]};
@@ -159,7 +164,9 @@ TFRT_HD void adjoint2d(const double s[2], const double e[2], const double* prim,
       const double k = n * cos(th1e) / sqrt(1.0 - th2 * th2);
       normb = newb * (1.0 - k);
       rab = newb * k;
-    } else {
+    } else if (fabs(th2) > 1.0 && !finite_tir) {
+      normb = rab = __builtin_nan("");
+    } else {  // (mirror, n == 0: theta2 = 0 and asin's unselected gradient is a plain 0)
       normb = newb * 2.0;
       rab = -newb;
     }

@@ -523,10 +523,11 @@ class OpticalSystem2D(OpticalSystemBase):
         self._merged_arcs = self._merge_kind(
             "arcs", ("x_center", "y_center", "angle_start", "angle_end", "radius"))
 
-    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False):
+    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False,
+                   finite_tir_gradient=False):
         return ops.Scene2DArgs(self._merged_segments, self._merged_arcs, n_table, index_mode,
                                ghost, self.intersect_epsilion, self.size_epsilion,
-                               self.ray_start_epsilion)
+                               self.ray_start_epsilion, finite_tir_gradient=finite_tir_gradient)
 
     @staticmethod
     def _segment_intersection(rx1, ry1, rx2, ry2, sx1, sy1, sx2, sy2, intersect_epsilion,
@@ -564,7 +565,8 @@ class OpticalEngine:
                  compile_dead_rays=False, compile_finished_rays=True, compile_active_rays=True,
                  dead_ray_length=None, compile_geometry_specific_result=False,
                  new_ray_length=1.0, simple_ray_inheritance={"wavelength"}, ray_dtype=None,
-                 ray_shard="auto", accelerate="auto", deterministic=False):
+                 ray_shard="auto", accelerate="auto", deterministic=False,
+                 finite_tir_gradient=False):
         if dimension not in (2, 3):
             raise ValueError(f"RayEngine: dimension must be 2 or 3, but was given {dimension}.")
         self._dimension = dimension
@@ -597,6 +599,11 @@ class OpticalEngine:
         # integers): gradients are bit-identical from run to run (tfrt_scene3d.deterministic);
         # default False: float64 atomics, whose last bits depend on the arrival order.
         self.deterministic = bool(deterministic)
+        # 2-D only.  False (default, the reference): a totally reflected ray has a NaN gradient
+        # (tf.asin in the unselected tf.where branch, geometry.py:640-646) which poisons every
+        # boundary entry it touched; SGD_Optimizer zeroes those (optimizer.py:226-229).  True:
+        # the reflect branch's finite gradient instead (tfrt_scene2d.finite_tir_gradient).
+        self.finite_tir_gradient = bool(finite_tir_gradient)
         # When True, ray_trace() does not wait for the per-class ray counts: it cuts the output
         # sets with the counts of the previous trace of the same shape and leaves the check to
         # verify_trace() (SGD_Optimizer does this; a wrong guess only costs a re-evaluation of
@@ -848,7 +855,8 @@ class OpticalEngine:
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       sort_rays=mode == "sort", deterministic=self.deterministic)
         else:
-            scene = system.scene_args(n_table, index_mode, ghost)
+            scene = system.scene_args(n_table, index_mode, ghost,
+                                      finite_tir_gradient=self.finite_tir_gradient)
         fv = None
         if self.dimension == 3:
             fv = system._merged_face_verts

@@ -767,8 +767,9 @@ class Scene2DArgs:
     ``cat`` int32, optional ``mat_in/mat_out/n_in/n_out``) or None."""
 
     def __init__(self, segments, arcs, n_table, index_mode, ghost, intersect_epsilion=1e-10,
-                 size_epsilion=1e-10, ray_start_epsilion=1e-10):
+                 size_epsilion=1e-10, ray_start_epsilion=1e-10, finite_tir_gradient=False):
         self.segments, self.arcs = segments, arcs
+        self.finite_tir_gradient = bool(finite_tir_gradient)
         self.n_table = _c(n_table, torch.float64)
         self.index_mode, self.ghost = index_mode, ghost
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
@@ -816,6 +817,7 @@ class Scene2DArgs:
         else:
             sc.n_table, sc.n_table_stride, sc.n_materials = None, 0, 0
         sc.intersect_epsilion, sc.size_epsilion, sc.ray_start_epsilion = self.eps
+        sc.finite_tir_gradient = 1 if self.finite_tir_gradient else 0
         return sc
 
 

@@ -11,6 +11,13 @@ engine.py:1149; the epsilon windows, engine.py:1130-1140) are delicate.  Every r
 engine can compile is stored: active, finished, dead (with dead_ray_length set on one run,
 engine.py:1962-1990), stopped, and the unfinished rays left after the last pass.
 
+Gradients ("plain" runs): d loss / d face vertices by torch.autograd over the reference's op
+sequence, loss = a scalar of the finished, active-history and stopped rays scaled by the scene's
+length scale (soup_loss below).  Mirrors (n_in = 0) and total internal reflection take the
+reflect branch of snells_law_3D (geometry.py:735-747), whose unselected sqrt sees a safe radicand:
+unlike the 2-D form these gradients are finite; what non-finite entries there are come from
+degenerate (grazing / parallel) pairs and are recorded as they are.
+
 The reference takes refractive indices through material indices (engine.py:1166-1197), so each
 face gets mat_in / mat_out into a list of six constant-index materials (among them index 0 =
 reflective, materials.py) instead of the stress test's per-face random indices.
@@ -68,11 +75,24 @@ def soup(seed):
                 rays=np.concatenate([s, e]), L=float(scale))
 
 
-def reference_trace(sc, dead_ray_length):
+def soup_loss(fin, act, stp, L):
+    """fin / act / stp: 6 x n blocks (or None).  Used by the tests as well."""
+    loss = 0.0
+    if fin is not None:
+        loss = loss + ((fin[3] / L) ** 2).sum() + 0.5 * (fin[4] * fin[2]).sum() / L ** 2
+    if act is not None:
+        loss = loss + 0.3 * act[5].sum() / L
+    if stp is not None:
+        loss = loss + 0.2 * stp[4].sum() / L
+    return loss
+
+
+def reference_trace(sc, dead_ray_length, grads=False):
     tt = lambda a: torch.tensor(np.asarray(a), dtype=F64)
+    P_all = tt(sc["P"]).requires_grad_(grads)
 
     def sub(mask, optical):
-        verts = tt(sc["P"][mask]).reshape(-1, 3)
+        verts = P_all[torch.tensor(mask)].reshape(-1, 3)
         fs = faces_from_vertices(verts, np.arange(verts.shape[0]).reshape(-1, 3))
         if optical:
             fs["mat_in"] = torch.tensor(sc["mat_in"][mask], dtype=torch.int64)
@@ -108,6 +128,11 @@ def reference_trace(sc, dead_ray_length):
             break
         travelling = result
     out = {}
+    if grads:
+        blk = lambda rs: torch.stack([rs[g] for g in GEO]) if bool(rs) else None
+        loss = soup_loss(blk(eng.finished_rays), blk(eng.active_rays), blk(eng.stopped_rays), sc["L"])
+        (g_P,) = torch.autograd.grad(loss, [P_all])
+        out["loss"], out["grad_P"] = np.float64(loss.item()), g_P.numpy()
     for cls, rs in (("finished", eng.finished_rays), ("active", eng.active_rays),
                     ("dead", eng.dead_rays), ("stopped", eng.stopped_rays),
                     ("unfinished", travelling)):
@@ -126,10 +151,14 @@ def main():
         for k, v in sc.items():
             out[f"s{seed}__{k}"] = np.asarray(v)
         for tag, dl in (("plain", None), ("deadlen", 2.5 * sc["L"])):
-            res = reference_trace(sc, dl)
+            res = reference_trace(sc, dl, grads=tag == "plain")
             for k, v in res.items():
                 out[f"s{seed}__{tag}__{k}"] = v
-            print(seed, tag, {k: v.shape[-1] for k, v in res.items() if not k.endswith("_id")})
+            print(seed, tag, {k: v.shape[-1] for k, v in res.items()
+                              if not k.endswith("_id") and k not in ("loss", "grad_P")},
+                  "" if "grad_P" not in res else
+                  f"grad_P: {int((~np.isfinite(res['grad_P'])).sum())} non-finite of "
+                  f"{res['grad_P'].size}, {int((res['grad_P'] != 0).any(axis=1).sum())} faces touched")
         out[f"s{seed}__dead_ray_length"] = np.float64(2.5 * sc["L"])
     np.savez_compressed(os.path.join(HERE, "reference_soup3d.npz"), **out)
 

@@ -116,12 +116,30 @@ def test_forward_2d(dtype, tol, kinds):
     assert seen >= 2
 
 
+def _same_grad(got, want, tol, what):
+    """Identical non-finite entries (a poisoned entry is poisoned on both sides); the finite ones
+    agree to `tol` of the largest finite reference entry."""
+    got, want = got.double().cpu(), want.double().cpu()
+    bad = ~torch.isfinite(want)
+    assert torch.equal(~torch.isfinite(got), bad), f"{what}: non-finite pattern differs"
+    if (~bad).any():
+        rel = (got[~bad] - want[~bad]).abs().max() / want[~bad].abs().max()
+        assert rel <= tol, f"{what} gradient rel err {rel:.2e}"
+    return int(bad.sum())
+
+
+@pytest.mark.parametrize("finite_tir", [False, True])
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-7), (torch.float32, 1e-5)])
-def test_backward_2d(dtype, tol):
+def test_backward_2d(dtype, tol, finite_tir):
+    """Gradients w.r.t. every segment and arc entry against oracle autograd.  The scene has arcs
+    of both radius signs, i.e. totally reflected rays: with the default policy (the reference's,
+    geometry.py:640-646) the entries those rays touched are NaN on both sides; with
+    finite_tir_gradient everything is finite."""
     from tensorflowraytrace_amd import ops
     rng = np.random.default_rng(5)
     sets, rays, wl = _scene(rng, 3000)
     scene, seg, arc = _gpu_scene(sets, wl, requires_grad=True)
+    scene.finite_tir_gradient = finite_tir
     src = torch.tensor(rays, dtype=dtype, device=DEV)
     out = ops.trace2d(src, scene, max_passes=4)
     loss = (out["finished"][2].double() ** 2).sum() + 0.3 * (out["active"][3].double()).sum()
@@ -130,7 +148,8 @@ def test_backward_2d(dtype, tol):
     osets = {k: {f: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v)
                  for f, v in s.items()} for k, s in sets.items()}
     ref = tracer.ray_trace(_oracle_system(osets), _src2(rays, wl, dtype == torch.float32),
-                           max_iterations=4, inherit=("wavelength", "ray_id"))
+                           max_iterations=4, inherit=("wavelength", "ray_id"),
+                           finite_tir_gradient=finite_tir)
     rloss = (ref["finished"]["x_end"] ** 2).sum() + 0.3 * ref["active"]["y_end"].sum()
     leaves = []
     for kind, geo in (("segments", ("x_start", "y_start", "x_end", "y_end")),
@@ -150,12 +169,10 @@ def test_backward_2d(dtype, tol):
     r_seg = torch.cat(segs)
     r_arc = torch.cat(arcs)
     assert abs(loss.item() - rloss.item()) <= 10 * tol * abs(rloss.item())
-    rel = (g_seg.cpu() - r_seg).abs().max() / r_seg.abs().max()
-    assert rel <= tol, f"segment gradient rel err {rel:.2e}"
-    ga = g_arc.cpu()[:, [0, 1, 4]]
-    rel = (ga - r_arc).abs().max() / r_arc.abs().max()
-    assert rel <= tol, f"arc gradient rel err {rel:.2e}"
+    poisoned = _same_grad(g_seg, r_seg, tol, "segment")
+    poisoned += _same_grad(g_arc[:, [0, 1, 4]], r_arc, tol, "arc")
     assert float(g_arc[:, 2:4].abs().max()) == 0.0
+    assert (poisoned == 0) == finite_tir, poisoned
 
 
 def test_seams_2d():

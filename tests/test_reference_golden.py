@@ -220,6 +220,149 @@ def test_hip_2d_trace_reproduces_the_reference_engine(tag):
                                        err_msg=f"{tag}.{cls}")
 
 
+# ---- 2-D gradients of the reference's own op sequence (dev/optimize_single_arc.py:31-47 pattern),
+# including the NaN pattern of totally reflected rays (geometry.py:640-646)
+
+GRAD2D_TAGS = ["arc", "seg", "grefr", "prism", "gtir"]
+FLOAT2D = {"segments": GEO2, "arcs": ("x_center", "y_center", "angle_start", "angle_end", "radius")}
+
+
+def _loss_2d(fin, act):
+    """The scalar of make_reference_trace2d_golden.loss_of (rows of a 4 x n block or a dict)."""
+    loss = 0.0
+    if fin is not None:
+        loss = loss + (fin[2] ** 2).sum() + 0.5 * (fin[3] * fin[0]).sum()
+    if act is not None:
+        loss = loss + 0.3 * act[3].sum()
+    return loss
+
+
+def _check_grad(got, want, tag, key, rtol):
+    """Same non-finite entries; finite ones to rtol of the field's largest finite magnitude."""
+    assert got.shape == want.shape, (tag, key)
+    nan = ~np.isfinite(want)
+    assert np.array_equal(~np.isfinite(got), nan), \
+        f"{tag}.{key}: non-finite pattern {~np.isfinite(got)} vs reference {nan}"
+    if (~nan).any():
+        scale = max(np.abs(want[~nan]).max(), 1e-300)
+        err = np.abs(got[~nan] - want[~nan]).max() / scale
+        assert err <= rtol, f"{tag}.{key}: rel err {err:.2e}"
+
+
+@pytest.mark.parametrize("tag", GRAD2D_TAGS)
+def test_oracle_2d_gradients_reproduce_the_reference_tape(tag):
+    """torch.autograd through the oracle == torch.autograd through the reference's own source
+    (the fixture), field by field, NaN for NaN: grefr / arc / seg have no total internal
+    reflection (all finite); prism and gtir do (the entries the reflected rays touched are NaN,
+    the others finite)."""
+    from oracle import tracer
+    g = np.load(TRACE2D)
+    sets = _sets_2d(g, tag)
+    leaves = []
+    for name, fields in sets.items():
+        for f in FLOAT2D[name.split("_")[1]]:
+            fields[f] = fields[f].clone().requires_grad_(True)
+            leaves.append((name, f, fields[f]))
+    osys = tracer.System(2, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"],
+                                       tracer.MATERIALS["reflective"]], **sets)
+    rays, wl = g[tag + "_rays"], g[tag + "_wl"]
+    src = {n: torch.tensor(rays[i]) for i, n in enumerate(GEO2)}
+    src["wavelength"] = torch.tensor(wl)
+    src["ray_id"] = torch.arange(rays.shape[1], dtype=torch.float64)
+    ref = tracer.ray_trace(osys, src, max_iterations=4, inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    blk = lambda r: [r[n] for n in GEO2] if r else None
+    loss = _loss_2d(blk(ref["finished"]), blk(ref["active"]))
+    assert loss.item() == float(g[tag + "_loss"])
+    got = torch.autograd.grad(loss, [t for _, _, t in leaves], allow_unused=True)
+    n_nan = 0
+    for (name, f, t), gr in zip(leaves, got):
+        want = g[f"{tag}_grad__{name}__{f}"]
+        have = np.zeros(t.shape) if gr is None else gr.numpy()
+        _check_grad(have, want, tag, f"{name}.{f}", 1e-12)
+        n_nan += int(np.isnan(want).sum())
+    assert (n_nan > 0) == (tag in ("prism", "gtir"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", GRAD2D_TAGS)
+def test_hip_2d_gradients_reproduce_the_reference_tape(tag):
+    """k_backward2d (float64 ray state) against the reference-source gradients: identical NaN
+    pattern (default policy = the reference's: a totally reflected ray poisons what it touched),
+    finite entries to 1e-8 of the field's largest gradient."""
+    from tensorflowraytrace_amd import ops
+    import test_gpu_trace2d as t2
+    g = np.load(TRACE2D)
+    sets = _sets_2d(g, tag)
+    scene, seg, arc = t2._gpu_scene(sets, g[tag + "_wl"], requires_grad=True)
+    src = torch.tensor(g[tag + "_rays"], dtype=torch.float64, device="cuda:0")
+    out = ops.trace2d(src, scene, max_passes=4)
+    fin = out["finished"].double() if out["finished"].shape[1] else None
+    act = out["active"].double() if out["active"].shape[1] else None
+    loss = _loss_2d(fin, act)
+    np.testing.assert_allclose(float(loss), float(g[tag + "_loss"]), rtol=1e-10)
+    for kind, geo, cols in ((seg, GEO2, range(4)), (arc, FLOAT2D["arcs"], range(5))):
+        if kind is None:
+            continue
+        (gr,) = torch.autograd.grad(loss, [kind["geo"]], retain_graph=True)
+        gr = gr.cpu().numpy()
+        suffix = "segments" if geo is GEO2 else "arcs"
+        row = 0
+        for cname in ("optical", "stop", "target"):        # merged order of _gpu_scene
+            name = f"{cname}_{suffix}"
+            if name not in sets:
+                continue
+            n = sets[name][geo[0]].shape[0]
+            for c in cols:
+                _check_grad(gr[row:row + n, c], g[f"{tag}_grad__{name}__{geo[c]}"], tag,
+                            f"{name}.{geo[c]}", 1e-8)
+            row += n
+        assert row == gr.shape[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["prism", "gtir"])
+def test_hip_2d_finite_tir_gradient_is_an_opt_in(tag):
+    """tfrt_scene2d.finite_tir_gradient = 1: the reflect branch's own gradient, no NaN; equals
+    the oracle asked for the same thing (oracle.geom.snells_law_2D(finite_tir_gradient=True))."""
+    from oracle import tracer
+    from tensorflowraytrace_amd import ops
+    import test_gpu_trace2d as t2
+    g = np.load(TRACE2D)
+    sets = _sets_2d(g, tag)
+    scene, seg, arc = t2._gpu_scene(sets, g[tag + "_wl"], requires_grad=True)
+    scene.finite_tir_gradient = True
+    src = torch.tensor(g[tag + "_rays"], dtype=torch.float64, device="cuda:0")
+    out = ops.trace2d(src, scene, max_passes=4)
+    loss = _loss_2d(out["finished"].double(), out["active"].double())
+    kind, geo = (seg, GEO2) if seg is not None else (arc, FLOAT2D["arcs"])
+    (gr,) = torch.autograd.grad(loss, [kind["geo"]])
+    gr = gr.cpu().numpy()
+    assert np.isfinite(gr).all()
+
+    osets = _sets_2d(g, tag)
+    name = "optical_segments" if seg is not None else "optical_arcs"
+    leaves = []
+    for f in geo:
+        osets[name][f] = osets[name][f].clone().requires_grad_(True)
+        leaves.append(osets[name][f])
+    osys = tracer.System(2, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"],
+                                       tracer.MATERIALS["reflective"]], **osets)
+    rays = g[tag + "_rays"]
+    osrc = {n: torch.tensor(rays[i]) for i, n in enumerate(GEO2)}
+    osrc["wavelength"] = torch.tensor(g[tag + "_wl"])
+    osrc["ray_id"] = torch.arange(rays.shape[1], dtype=torch.float64)
+    ref = tracer.ray_trace(osys, osrc, max_iterations=4, inherit=("wavelength", "ray_id"),
+                           finite_tir_gradient=True)
+    rloss = _loss_2d([ref["finished"][n] for n in GEO2], [ref["active"][n] for n in GEO2])
+    want = torch.autograd.grad(rloss, leaves, allow_unused=True)
+    n = leaves[0].shape[0]
+    for c, w in enumerate(want):
+        w = np.zeros(n) if w is None else w.numpy()
+        scale = max(np.abs(w).max(), 1e-300)
+        assert np.abs(gr[:n, c] - w).max() / scale <= 1e-8, (tag, geo[c])
+
+
 # ---------------------------------------------------------------------------------------------
 # tests/golden/reference_soup3d.npz: 3-pass traces of adversarial triangle soups (coplanar ties,
 # grazing rays, stops, targets, mirrors, 6 materials) by the reference's own engine, all five ray
@@ -227,6 +370,18 @@ def test_hip_2d_trace_reproduces_the_reference_engine(tag):
 
 SOUP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_soup3d.npz")
 CLASSES = ("finished", "active", "dead", "stopped", "unfinished")
+
+
+def _soup_loss(fin, act, stp, L):
+    """make_reference_soup_golden.soup_loss."""
+    loss = 0.0
+    if fin is not None and fin.shape[1]:
+        loss = loss + ((fin[3] / L) ** 2).sum() + 0.5 * (fin[4] * fin[2]).sum() / L ** 2
+    if act is not None and act.shape[1]:
+        loss = loss + 0.3 * act[5].sum() / L
+    if stp is not None and stp.shape[1]:
+        loss = loss + 0.2 * stp[4].sum() / L
+    return loss
 
 
 def _soup_case(g, seed):
@@ -252,6 +407,8 @@ def test_oracle_reproduces_the_reference_engine_on_adversarial_soups(tag):
             d["n_in"], d["n_out"] = sc["n_in"][mask], sc["n_out"][mask]
             return d
         cat = sc["cat"]
+        if tag == "plain":
+            sc["P"] = sc["P"].clone().requires_grad_(True)
         system = tracer.System(3, optical=sub(cat == 0), stop=sub(cat == 1), target=sub(cat == 2))
         src = {n: sc["rays"][i] for i, n in enumerate(NAMES)}
         src["ray_id"] = torch.arange(sc["rays"].shape[1], dtype=torch.float64)
@@ -266,8 +423,16 @@ def test_oracle_reproduces_the_reference_engine_on_adversarial_soups(tag):
             assert n == want.shape[1], (seed, cls)
             if n:
                 assert np.array_equal(rs["ray_id"].numpy().astype(np.int64), want_id), (seed, cls)
-                got = torch.stack([rs[k] for k in NAMES]).numpy()
+                got = torch.stack([rs[k] for k in NAMES]).detach().numpy()
                 assert np.array_equal(got, want), (seed, cls)                 # every bit
+        if tag == "plain":
+            # d loss / d face vertices: autograd over the oracle == autograd over the reference's
+            # own op sequence (mirrors and total internal reflection included)
+            blk = lambda rs: torch.stack([rs[k] for k in NAMES]) if rs else None
+            loss = _soup_loss(blk(ref["finished"]), blk(ref["active"]), blk(ref["stopped"]), sc["L"])
+            assert loss.item() == float(g[f"s{seed}__plain__loss"])
+            (gP,) = torch.autograd.grad(loss, [sc["P"]])
+            _check_grad(gP.numpy(), g[f"s{seed}__plain__grad_P"], f"soup {seed}", "P", 1e-11)
 
 
 @pytest.mark.gpu
@@ -282,18 +447,23 @@ def test_hip_reproduces_the_reference_engine_on_adversarial_soups(tag):
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
     for seed in g["seeds"]:
         sc = _soup_case(g, seed)
-        fv = sc["P"].to(dev)
+        fv = sc["P"].to(dev).requires_grad_(tag == "plain")
         for clustered in (True, False):
-            args = ops.Scene3DArgs(fv, sc["cat"].int().to(dev), n_in=sc["n_in"].to(dev),
+            args = ops.Scene3DArgs(fv.detach(), sc["cat"].int().to(dev), n_in=sc["n_in"].to(dev),
                                    n_out=sc["n_out"].to(dev),
-                                   cluster_order=ops.cluster_order(fv) if clustered else None)
+                                   cluster_order=ops.cluster_order(fv.detach()) if clustered else None)
             out = ops.trace3d(sc["rays"].to(dev), fv, args, max_passes=int(g["passes"]), flags=flags,
                               new_ray_length=sc["L"],
                               dead_ray_length=sc["dead"] if tag == "deadlen" else None)
             for cls in CLASSES:
                 want, want_id = g[f"s{seed}__{tag}__{cls}"], g[f"s{seed}__{tag}__{cls}_id"]
-                got = out[cls].cpu().numpy()
+                got = out[cls].detach().cpu().numpy()
                 assert got.shape[1] == want.shape[1], (seed, cls, clustered)
                 assert np.array_equal(out[cls + "_id"].cpu().numpy().astype(np.int64), want_id), \
                     (seed, cls, clustered)
                 assert np.array_equal(got, want), (seed, cls, clustered)
+            if tag == "plain":
+                # the reverse sweep against the reference-source gradient of the same scalar
+                loss = _soup_loss(out["finished"], out["active"], out["stopped"], sc["L"])
+                (gP,) = torch.autograd.grad(loss, [fv])
+                _check_grad(gP.cpu().numpy(), g[f"s{seed}__plain__grad_P"], f"soup {seed}", "P", 1e-8)
