@@ -77,8 +77,10 @@ def scene2d():
     src = {nme: t(rays[i]) for i, nme in enumerate(("x_start", "y_start", "x_end", "y_end"))}
     src["wavelength"] = t(wl)
     src["ray_id"] = torch.arange(n, dtype=torch.float64)
+    # (the finite form of the total-internal-reflection gradient: the reference's own is NaN for
+    # every arc of this scene, see oracle.geom.snells_law_2D and tests/golden/reference_trace2d.npz)
     ref = tracer.ray_trace(system, src, max_iterations=5, inherit=("wavelength", "ray_id"),
-                           flags=dict(compile_dead_rays=True))
+                           flags=dict(compile_dead_rays=True), finite_tir_gradient=True)
     loss = (ref["finished"]["y_end"] ** 2).sum() + 0.3 * ref["active"]["y_end"].sum()
     leaves = [oa["x_center"], oa["y_center"], oa["radius"]] + [os_[k] for k in ("x_start", "y_start", "x_end", "y_end")]
     grads = torch.autograd.grad(loss, leaves)

@@ -97,4 +97,17 @@ void hm_adjoint2d(int64_t n, const double* s, const double* e, const double* pri
                     ge + 2 * i, gprim + 5 * i);
   }
 }
+
+// the opt-in finite form of the total-internal-reflection gradient (tfrt_scene2d.finite_tir_gradient)
+void hm_adjoint2d_finite(int64_t n, const double* s, const double* e, const double* prim,
+                         int prim_stride, int is_arc, const double* u, const uint8_t* has_child,
+                         const double* n_in, const double* n_out, double L, const double* g_s,
+                         const double* g_h, const double* g_ce, double* gs, double* ge,
+                         double* gprim) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::adjoint2d(s + 2 * i, e + 2 * i, prim + prim_stride * i, is_arc != 0, u[i], has_child[i] != 0,
+                    n_in[i], n_out[i], L, g_s + 2 * i, g_h + 2 * i, g_ce + 2 * i, gs + 2 * i,
+                    ge + 2 * i, gprim + 5 * i, true);
+  }
+}
 }

@@ -92,6 +92,391 @@ def test_full_size_sample_against_the_oracle(full):
         system, oracle_util.source_dict(scene["rays"][:, pick], scene["wavelength"][pick], np.float32),
         max_iterations=PASSES, inherit=("wavelength", "ray_id"),
         flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    checked = 0
+    for cls in ("finished", "dead"):
+        if not ref[cls] or ref[cls]["ray_id"].shape[0] == 0:
+            continue
+        want_ids = pick[ref[cls]["ray_id"].numpy().astype(np.int64)]
+        ids = out[cls + "_id"].long().cpu().numpy()
+        where = np.full(N_FULL, -1, dtype=np.int64)          # row of every source ray in the class
+        where[ids] = np.arange(ids.shape[0])
+        pos = where[want_ids]
+        assert (pos >= 0).all(), f"{cls}: a sampled ray is in this class for the oracle only"
+        assert np.array_equal(ids[pos], want_ids), f"{cls}: sampled rays classified differently"
+        got = out[cls].detach()[:, torch.as_tensor(pos, device=out[cls].device)].cpu().double().numpy()
+        want = oracle_util.block(ref[cls])
+        rel = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+        assert rel <= 1e-5, f"{cls}: {rel:.2e}"
+        checked += want_ids.shape[0]
+    assert checked >= 250
+
+
+def _loss_and_grads(out, scene, params):
+    fin = out["finished"]
+    goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fin.device)[out["finished_id"].long()]
+    loss = ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
+    return loss, torch.autograd.grad(loss, params)
+
+
+def test_full_size_shards_add_up(full):
+    """Two contiguous halves of the ray set (what two ranks would trace) against the whole."""
+    from tensorflowraytrace_amd import ops
+    scene, out = full["scene"], full["out"]
+    loss, (g_f, g_b) = _loss_and_grads(out, scene, full["params"])
+    half = N_FULL // 2
+    parts, fin_rows, fin_ids = [], [], []
+    for lo, hi in ((0, half), (half, N_FULL)):
+        sub = dict(scene)
+        sub["rays"] = scene["rays"][:, lo:hi]
+        sub["wavelength"] = scene["wavelength"][lo:hi]
+        sub["goal"] = scene["goal"][lo:hi]
+        src, fv, sc, params = _gpu_scene(sub, torch.float32, cluster="group")
+        o = ops.trace3d(src, fv, sc, max_passes=PASSES, flags=full["flags"])
+        parts.append(_loss_and_grads(o, sub, params))
+        fin_rows.append(o["finished"])
+        fin_ids.append(o["finished_id"].long() + lo)
+    ids, rows = torch.cat(fin_ids), torch.cat(fin_rows, dim=1)
+    a, b = torch.argsort(ids), torch.argsort(out["finished_id"].long())    # (classes are per-pass blocks)
+    assert torch.equal(ids[a], out["finished_id"].long()[b])
+    assert torch.equal(rows[:, a], out["finished"][:, b])                   # same rays, bit for bit
+    total = parts[0][0] + parts[1][0]
+    assert abs(float((total - loss).detach())) <= 1e-12 * abs(float(loss.detach()))
+    for k, g in enumerate((g_f, g_b)):
+        s = parts[0][1][k] + parts[1][1][k]
+        assert float((s - g).abs().max()) <= 1e-11 * float(g.abs().max())
+
+
+def test_full_size_permutation_invariance(full):
+    from tensorflowraytrace_amd import ops
+    scene, out = full["scene"], full["out"]
+    perm = torch.randperm(N_FULL, generator=torch.Generator().manual_seed(3)).numpy()
+    sub = dict(scene)
+    sub["rays"] = scene["rays"][:, perm]
+    sub["wavelength"] = scene["wavelength"][perm]
+    src, fv, sc, _ = _gpu_scene(sub, torch.float32, cluster="group")
+    o = ops.trace3d(src, fv, sc, max_passes=PASSES, flags=full["flags"])
+    assert np.array_equal(o["counts"][:, :4], out["counts"][:, :4])
+    perm_t = torch.as_tensor(perm, device=o["finished_id"].device)
+    orig_ids = perm_t[o["finished_id"].long()]                  # source ids of the permuted run's rows
+    order = torch.argsort(orig_ids)
+    ref_order = torch.argsort(out["finished_id"].long())        # (classes are per-pass blocks)
+    assert torch.equal(orig_ids[order], out["finished_id"].long()[ref_order])
+    assert torch.equal(o["finished"].detach()[:, order], out["finished"].detach()[:, ref_order])
+    assert torch.equal(o["finished_face"][order], out["finished_face"][ref_order])
+
+
+# ------------------------------------------------------------------------------------------
+# 2-D at cfg5b's size: 4,000,000 rays x (256 segments + 64 arcs), 4 passes
+
+def _scene_5b(n_rays, seed=0):
+    import math
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    na = 64
+    xc = np.linspace(-16, 16, na)
+    xs = np.linspace(-18, 18, 256)
+    ys = 6.0 + 0.3 * np.sin(xs)
+    sets = {
+        "optical_arcs": dict(x_center=t(xc), y_center=t(np.full(na, 3.0)),
+                             angle_start=t(np.full(na, -math.pi + 0.3)), angle_end=t(np.full(na, -0.3)),
+                             radius=t(np.full(na, 0.6)), mat_in=torch.ones(na, dtype=torch.int64),
+                             mat_out=torch.zeros(na, dtype=torch.int64)),
+        "optical_segments": dict(x_start=t(xs[:-1]), y_start=t(ys[:-1]), x_end=t(xs[1:]), y_end=t(ys[1:]),
+                                 mat_in=torch.full((255,), 2, dtype=torch.int64),
+                                 mat_out=torch.zeros(255, dtype=torch.int64)),
+        "target_segments": dict(x_start=t([20.0]), y_start=t([-1.0]), x_end=t([20.0]), y_end=t([9.0])),
+    }
+    rng = np.random.default_rng(seed)
+    ang = rng.uniform(0.3 * math.pi, 0.7 * math.pi, n_rays)
+    x0 = rng.uniform(-15, 15, n_rays)
+    rays = np.stack([x0, np.zeros(n_rays), x0 + np.cos(ang), np.sin(ang)])
+    wl = np.full(n_rays, 550.0)
+    return sets, rays, wl
+
+
+def test_full_size_2d_conservation_sample_and_shards():
+    from tensorflowraytrace_amd import ops, _lib
+    import test_gpu_trace2d as t2
+    N, P = 4_000_000, 4
+    sets, rays, wl = _scene_5b(N)
+    scene, _, _ = t2._gpu_scene(sets, wl)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src = torch.tensor(rays, dtype=torch.float32, device="cuda:0")
+    out = ops.trace2d(src, scene, max_passes=P, flags=flags)
+    counts = out["counts"]
+    n_in = N
+    for p in range(P):
+        assert int(counts[p, :4].sum()) == n_in
+        n_in = int(counts[p, 0])
+    assert out["n_tests"] == int(counts[:, :4].sum()) * 320
+    assert out["unfinished"].shape[1] == n_in
+    assert out["dead"].shape[1] == int(counts[:, 3].sum()) > 3_000_000     # most rays leave the scene
+
+    # 256 sampled rays through the oracle: same class, same geometry (float32 state: 1e-5)
+    pick = np.sort(np.random.default_rng(5).choice(N, 256, replace=False))
+    ref = tracer.ray_trace(t2._oracle_system(sets), t2._src2(rays[:, pick], wl[pick], True),
+                           max_iterations=P, inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    checked = 0
+    for cls in ("finished", "dead"):
+        r = ref[cls]
+        if not r or r["ray_id"].shape[0] == 0:
+            continue
+        want_ids = pick[r["ray_id"].numpy().astype(np.int64)]
+        ids = out[cls + "_id"].long().cpu().numpy()
+        where = np.full(N, -1, dtype=np.int64)
+        where[ids] = np.arange(ids.shape[0])
+        pos = where[want_ids]
+        assert (pos >= 0).all(), cls
+        got = out[cls].detach()[:, torch.as_tensor(pos, device="cuda:0")].cpu().double().numpy()
+        want = oracle_util.block(r, dim=2)
+        assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) <= 1e-5, cls
+        checked += want_ids.shape[0]
+    assert checked >= 200
+
+    # halves of the ray set reproduce the whole, ray for ray
+    half = N // 2
+    ids_parts, rows_parts = [], []
+    for lo, hi in ((0, half), (half, N)):
+        sc_h, _, _ = t2._gpu_scene(sets, wl[lo:hi])
+        o = ops.trace2d(src[:, lo:hi].contiguous(), sc_h, max_passes=P, flags=flags)
+        ids_parts.append(o["dead_id"].long() + lo)
+        rows_parts.append(o["dead"].detach())
+    ids, rows = torch.cat(ids_parts), torch.cat(rows_parts, dim=1)
+    a, b = torch.argsort(ids), torch.argsort(out["dead_id"].long())
+    assert torch.equal(ids[a], out["dead_id"].long()[b])
+    assert torch.equal(rows[:, a], out["dead"].detach()[:, b])
+
+
+def test_3d_trace_beyond_8192_ray_blocks_matches_its_halves():
+    """From 8192 ray blocks (2.1M rays) on the per-pass offsets come from the grid scan
+    (k_scan3d, a ticket across workgroups) instead of the single-block one: 2.3M rays in one trace
+    against the same rays traced as two halves, which take the single-block path."""
+    from tensorflowraytrace_amd import ops, _lib
+    N = 2_300_000
+    scene = scene_util.lens_scene(N, k_front=6, k_back=5)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, _ = _gpu_scene(scene, torch.float32, cluster="group")
+    out = ops.trace3d(src, fv, sc, max_passes=4, flags=flags)
+    counts = out["counts"]
+    n_in = N
+    for p in range(4):
+        assert int(counts[p, :4].sum()) == n_in
+        n_in = int(counts[p, 0])
+    half = N // 2
+    parts = {c: ([], []) for c in ("finished", "dead", "active")}
+    for lo, hi in ((0, half), (half, N)):
+        sub = dict(scene)
+        sub["rays"] = scene["rays"][:, lo:hi]
+        sub["wavelength"] = scene["wavelength"][lo:hi]
+        s2, f2, c2, _ = _gpu_scene(sub, torch.float32, cluster="group")
+        o = ops.trace3d(s2, f2, c2, max_passes=4, flags=flags)
+        for c in parts:
+            parts[c][0].append(o[c + "_id"].long() + lo)
+            parts[c][1].append(o[c].detach())
+    for c in ("finished", "dead"):
+        ids, rows = torch.cat(parts[c][0]), torch.cat(parts[c][1], dim=1)
+        a, b = torch.argsort(ids), torch.argsort(out[c + "_id"].long())
+        assert torch.equal(ids[a], out[c + "_id"].long()[b]), c
+        assert torch.equal(rows[:, a], out[c].detach()[:, b]), c
+    assert out["active"].shape[1] == sum(x.shape[1] for x in parts["active"][1])
+
+
+# ------------------------------------------------------------------------------------------
+# cfg2 / cfg3 at their stated size: 100,000 rays x 974 faces (two H(9) surfaces + target), 5 passes
+
+def test_cfg2_cfg3_stated_size_sample_and_gradients():
+    """BASELINE configs[1] and [2] at full size: conservation, 512 sampled rays against the oracle
+    (float32 state, 1e-5), and the parameter gradients of the sampled rays alone against oracle
+    autograd (the gradient is a sum over rays, so the sample's gradient is checked exactly and
+    the full gradient through shard additivity)."""
+    from tensorflowraytrace_amd import ops, _lib
+    N, P = 100_000, 5
+    scene = scene_util.lens_scene(N, k_front=9, k_back=9)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, params = _gpu_scene(scene, torch.float32, cluster="group")
+    assert fv.shape[0] == 974
+    out = ops.trace3d(src, fv, sc, max_passes=P, flags=flags)
+    counts = out["counts"]
+    n_in = N
+    for p in range(P):
+        assert int(counts[p, :4].sum()) == n_in
+        n_in = int(counts[p, 0])
+    assert out["n_tests"] == int(counts[:, :4].sum()) * 974
+    assert out["finished"].shape[1] > 90_000
+    loss, g_full = _loss_and_grads(out, scene, params)
+
+    pick = np.sort(np.random.default_rng(23).choice(N, 512, replace=False))
+    sub = dict(scene)
+    sub["rays"], sub["wavelength"], sub["goal"] = (scene["rays"][:, pick], scene["wavelength"][pick],
+                                                   scene["goal"][pick])
+    system, (q_f, q_b), _ = oracle_util.lens_oracle(sub)
+    ref = tracer.ray_trace(system, oracle_util.source_dict(sub["rays"], sub["wavelength"], np.float32),
+                           max_iterations=P, inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    rf = ref["finished"]
+    want_ids = pick[rf["ray_id"].numpy().astype(np.int64)]
+    ids = out["finished_id"].long().cpu().numpy()
+    where = np.full(N, -1, dtype=np.int64)
+    where[ids] = np.arange(ids.shape[0])
+    pos = where[want_ids]
+    assert (pos >= 0).all() and want_ids.shape[0] > 450
+    got = out["finished"].detach()[:, torch.as_tensor(pos, device="cuda:0")].cpu().double().numpy()
+    want = oracle_util.block(rf)
+    assert np.abs(got - want).max() / max(1.0, np.abs(want).max()) <= 1e-5
+
+    # cfg3: gradients of the sampled rays alone, GPU vs oracle autograd (float32 state: 1e-5)
+    s_src, s_fv, s_sc, s_params = _gpu_scene(sub, torch.float32, cluster="group")
+    s_out = ops.trace3d(s_src, s_fv, s_sc, max_passes=P, flags=flags)
+    _, g_sample = _loss_and_grads(s_out, sub, s_params)
+    goal = torch.tensor(sub["goal"], dtype=torch.float64)[rf["ray_id"].long()]
+    r_loss = ((rf["y_end"] - goal[:, 0]) ** 2 + (rf["z_end"] - goal[:, 1]) ** 2).sum()
+    r_g = torch.autograd.grad(r_loss, [q_f, q_b])
+    for g, r in zip(g_sample, r_g):
+        rel = float((g.cpu() - r).abs().max() / r.abs().max())
+        assert rel <= 1e-5, f"sample gradient rel err {rel:.2e}"
+
+    # the full gradient is the sum over two shards (what ray sharding over GPUs relies on)
+    half = N // 2
+    g_sum = [torch.zeros_like(g) for g in g_full]
+    for lo, hi in ((0, half), (half, N)):
+        part = dict(scene)
+        part["rays"], part["wavelength"], part["goal"] = (scene["rays"][:, lo:hi],
+                                                          scene["wavelength"][lo:hi], scene["goal"][lo:hi])
+        p_src, p_fv, p_sc, p_params = _gpu_scene(part, torch.float32, cluster="group")
+        p_out = ops.trace3d(p_src, p_fv, p_sc, max_passes=P, flags=flags)
+        _, g_part = _loss_and_grads(p_out, part, p_params)
+        for acc, g in zip(g_sum, g_part):
+            acc += g
+    for s, g in zip(g_sum, g_full):
+        assert float((s - g).abs().max()) <= 1e-11 * float(g.abs().max())
+
+
+# ------------------------------------------------------------------------------------------
+# cfg5a (SURVEY.md section 8d): hex lens H(24) x 2 + ParametricCylindricalGuide(64, 64) + target,
+# 4,000,000 rays, 8 passes, through the public API; float32 vs float16 vs float64 ray state
+
+N_5A, PASSES_5A = 4_000_000, 8
+
+
+def _build_5a(ray_dtype, n_rays=N_5A, accelerate="auto", ray_shard=None, compile_all=True):
+    import tfrt.boundaries as boundaries
+    import tfrt.distributions as distributions
+    import tfrt.drawing as drawing
+    import tfrt.engine as engine
+    import tfrt.materials as materials
+    import tfrt.mesh_tools as mt
+    import tfrt.operation as operation
+    import tfrt.sources as sources
+
+    def surface(k, flip, sign, z):
+        zp = mt.hexagonal_mesh(0.45, k)                 # in the x-y plane
+        zp.points[:, 2] = z
+        r2 = (zp.points[:, 0] ** 2 + zp.points[:, 1] ** 2) / 0.45 ** 2
+        return boundaries.ParametricTriangleBoundary(
+            zp, boundaries.FromVectorVG((0, 0, 1)), flip_norm=flip,
+            initial_parameters=sign * (0.02 + 0.05 * (1 - r2)),
+            material_dict={"mat_in": 1, "mat_out": 0})
+
+    front, back = surface(24, True, -1.0, 0.3), surface(24, False, +1.0, 0.5)
+    guide = boundaries.ParametricCylindricalGuide(
+        (0, 0, 1.0), (0, 0, 7.0), 0.5, theta_res=64, z_res=64, initial_taper=(0.0, 0.15),
+        material_dict={"mat_in": 1, "mat_out": 0})
+    target = boundaries.ManualTriangleBoundary(
+        mesh=mt.plane(center=(0, 0, 6.9), direction=(0, 0, 1), i_size=3, j_size=3))
+    start = distributions.StaticUniformCircle(n_rays, 0.05)
+    end = distributions.StaticUniformCircle(n_rays, 0.42)
+    start.update()
+    end.update()
+    sp, ep = start.points, end.points
+    z0 = torch.full((n_rays,), -1.0, dtype=torch.float64, device=sp.device)
+    src = sources.ManualSource(3)
+    src["x_start"], src["y_start"], src["z_start"] = sp[:, 0], sp[:, 1], z0
+    src["x_end"], src["y_end"], src["z_end"] = ep[:, 0], ep[:, 1], z0 + 1.2
+    src["wavelength"] = torch.full((n_rays,), float(drawing.YELLOW), dtype=torch.float64,
+                                   device=sp.device)
+    system = engine.OpticalSystem3D()
+    system.optical = [front, back, guide]
+    system.targets = [target]
+    system.sources = [src]
+    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
+    system.update()
+    eng = engine.OpticalEngine(
+        3, [operation.StandardReaction()], ray_dtype=ray_dtype, accelerate=accelerate,
+        compile_dead_rays=compile_all, compile_stopped_rays=compile_all,
+        compile_active_rays=compile_all, simple_ray_inheritance={"wavelength"},
+        ray_shard=ray_shard)
+    eng.optical_system = system
+    return eng, system, (front, back, guide, target)
+
+
+@pytest.fixture(scope="module")
+def cfg5a():
+    eng, system, parts = _build_5a(torch.float32)
+    eng.ray_trace(PASSES_5A)
+    return dict(eng=eng, system=system, parts=parts, out=eng.last_trace)
+
+
+def test_cfg5a_conservation_and_order(cfg5a):
+    out, M = cfg5a["out"], int(cfg5a["system"]._merged_face_verts.shape[0])
+    assert M == 2 * 3456 + 64 * 64 * 2 + 2           # two H(24) surfaces, the guide's wall + caps, target
+    counts = out["counts"]
+    n_in = N_5A
+    for p in range(PASSES_5A):
+        assert int(counts[p, :4].sum()) == n_in
+        n_in = int(counts[p, 0])
+    assert out["n_tests"] == int(counts[:, :4].sum()) * M
+    assert out["finished"].shape[1] > 3_000_000      # the guide pipes most of the light to the target
+    assert np.count_nonzero(counts[:, 1]) >= 3       # after different numbers of bounces
+    for col, cls in ((1, "finished"), (3, "dead")):
+        ids = out[cls + "_id"].long()
+        base = 0
+        for p in range(PASSES_5A):
+            seg = ids[base:base + int(counts[p, col])]
+            assert bool((seg[1:] > seg[:-1]).all()), (cls, p)
+            base += int(counts[p, col])
+        assert base == ids.numel()
+    fin = out["finished"].detach()
+    assert bool(torch.isfinite(fin).all())
+    assert float((fin[5] - 6.9).abs().max()) < 1e-5  # finished rays end on the target plane z = 6.9
+
+
+def test_cfg5a_hierarchy_equals_all_pairs(cfg5a):
+    eng2, _, _ = _build_5a(torch.float32, accelerate="all-pairs")
+    eng2.ray_trace(PASSES_5A)
+    ref, out = eng2.last_trace, cfg5a["out"]
+    assert np.array_equal(out["counts"], ref["counts"]) and out["n_tests"] == ref["n_tests"]
+    for cls in ("finished", "active", "stopped", "dead"):
+        assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), cls
+        assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
+        assert torch.equal(out[cls].detach(), ref[cls].detach()), cls
+
+
+def _oracle_5a(parts):
+    front, back, guide, target = parts
+    cpu = lambda t: t.detach().cpu()
+    sets = []
+    for b in (front, back, guide):
+        f = tracer.faces_from_vertices(cpu(b.vertices), b.faces[:, 1:])
+        n = f["xp"].shape[0]
+        f["mat_in"] = torch.ones(n, dtype=torch.int64)
+        f["mat_out"] = torch.zeros(n, dtype=torch.int64)
+        sets.append(f)
+    tgt = tracer.faces_from_vertices(cpu(target.vertices), target.faces[:, 1:])
+    return tracer.System(3, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"]],
+                         optical=tracer.amalgamate(sets), target=tgt)
+
+
+def test_cfg5a_sample_against_the_oracle(cfg5a):
+    out, system = cfg5a["out"], cfg5a["system"]
+    pick = np.sort(np.random.default_rng(41).choice(N_5A, 256, replace=False))
+    src = system._amalgamated_sources
+    names = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
+    pick_t = torch.as_tensor(pick, device=src["x_start"].device)
+    rays = np.stack([src[n][pick_t].cpu().numpy() for n in names])
+    wl = src["wavelength"][pick_t].cpu().numpy()
+    ref = tracer.ray_trace(_oracle_5a(cfg5a["parts"]), oracle_util.source_dict(rays, wl, np.float32),
+                           max_iterations=PASSES_5A, inherit=("wavelength", "ray_id"),
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
     # Which sampled rays end differently on the device (float32 ray state: a child ray's start and
     # end are rounded to 2^-24 relative between passes) than in the float64 oracle?  Each one is
     # NAMED and must be explained: its oracle path has a hit within EDGE_MARGIN (barycentric

@@ -107,20 +107,38 @@ def test_segment_exact_and_adjoint2d(host_math):
     x, y, valid, u, v = geom.raw_line_intersect(st[:, 0], st[:, 1], et[:, 0], et[:, 1], pt[:, 0],
                                                 pt[:, 1], pt[:, 2], pt[:, 3], 1e-10)
     norm = torch.atan2(pt[:, 3] - pt[:, 1], pt[:, 2] - pt[:, 0]) + PI / 2
-    o = geom.snells_law_2D(st[:, 0], st[:, 1], x, y, norm, torch.tensor(n_in), torch.tensor(n_out), L)
+    # (the Snell step is applied to the rows that have a child only: in the reference's tape a row
+    # that goes through snells_law_2D gets asin's 0 * NaN under total internal reflection even
+    # when nothing downstream depends on it)
+    ci = torch.tensor(np.nonzero(child)[0])
     g = [rng.normal(size=(n, 2)) for _ in range(4)]
-    cm = torch.tensor(child.astype(np.float64))
     hT = torch.stack([x, y], 1)
-    loss = (st * torch.tensor(g[0])).sum() + (hT * torch.tensor(g[1])).sum() + (cm * (
-        o[0] * torch.tensor(g[2][:, 0]) + o[1] * torch.tensor(g[2][:, 1]) +
-        o[2] * torch.tensor(g[3][:, 0]) + o[3] * torch.tensor(g[3][:, 1]))).sum()
-    gr = torch.autograd.grad(loss, [st, et, pt])
+
+    def total(finite):
+        o = geom.snells_law_2D(st[ci, 0], st[ci, 1], x[ci], y[ci], norm[ci], torch.tensor(n_in)[ci],
+                               torch.tensor(n_out)[ci], L, finite_tir_gradient=finite)
+        g2, g3 = torch.tensor(g[2])[ci], torch.tensor(g[3])[ci]
+        return (st * torch.tensor(g[0])).sum() + (hT * torch.tensor(g[1])).sum() + (
+            o[0] * g2[:, 0] + o[1] * g2[:, 1] + o[2] * g3[:, 0] + o[3] * g3[:, 1]).sum()
+    gr = torch.autograd.grad(total(False), [st, et, pt], retain_graph=True)
     gs, ge, gp = np.zeros((n, 2)), np.zeros((n, 2)), np.zeros((n, 5))
     gh = g[1] + child[:, None] * g[2]
     uu = u.detach().numpy().copy()
     host_math.hm_adjoint2d(I(n), P(s), P(e), P(seg), ctypes.c_int(4), ctypes.c_int(0), P(uu),
                            P(child), P(n_in), P(n_out), D(L), P(g[0]), P(gh), P(g[3]), P(gs),
                            P(ge), P(gp))
+    # totally reflected rays: NaN on both sides (geometry.py:640-646: asin in the unselected branch)
+    bad = ~np.isfinite(gr[0].numpy()).all(axis=1)
+    assert 0 < bad.sum() < n // 4
+    for got, want in ((gs, gr[0].numpy()), (ge, gr[1].numpy()), (gp[:, :4], gr[2].numpy())):
+        assert np.array_equal(~np.isfinite(got).all(axis=1), bad)
+        assert np.isnan(got[bad]).all() and np.isnan(want[bad]).all()
+        assert _rel(got[~bad], want[~bad]) < 1e-10
+    # ... and the opt-in finite form (tfrt_scene2d.finite_tir_gradient) against the oracle's
+    gr = torch.autograd.grad(total(True), [st, et, pt])
+    host_math.hm_adjoint2d_finite(I(n), P(s), P(e), P(seg), ctypes.c_int(4), ctypes.c_int(0), P(uu),
+                                  P(child), P(n_in), P(n_out), D(L), P(g[0]), P(gh), P(g[3]), P(gs),
+                                  P(ge), P(gp))
     assert _rel(gs, gr[0].numpy()) < 1e-10 and _rel(ge, gr[1].numpy()) < 1e-10
     assert _rel(gp[:, :4], gr[2].numpy()) < 1e-10
 
