@@ -215,12 +215,11 @@ def main(argv=None):
                     help="graph: fused launch sequence replayed from a HIP graph (default); fused: "
                          "the same sequence launched eagerly; generic: error function as arbitrary "
                          "torch code through autograd (reads the ray counts back every step)")
-    ap.add_argument("--trace-mode", choices=["auto", "all-pairs", "group", "sort"], default="auto",
+    ap.add_argument("--trace-mode", choices=["auto", "all-pairs", "group"], default="auto",
                     help="how ray-face pairs are culled before the exact float64 test (results "
                          "are identical in every mode): all-pairs = float32 bounding-sphere "
-                         "filter on every pair; group = two/three-level sphere hierarchy over "
-                         "k-d face clusters; sort = clusters + Morton-sorted rays; auto = the "
-                         "engine's default (group)")
+                         "filter on every pair; group = sphere hierarchy over k-d face "
+                         "clusters; auto = the engine's default (group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the separately reported legs (all-pairs mode, float64 state, ...)")
@@ -347,8 +346,7 @@ def main(argv=None):
 
     M, mode, counts = main_leg["M"], main_leg["mode"], main_leg["counts"]
     n_active = [int(c[:4].sum()) for c in counts]          # rays entering each pass (rank 0)
-    kernel_name = {"all-pairs": "tfrt::k_intersect3d", "group": "tfrt::k_intersect_group",
-                   "sort": "tfrt::k_intersect_cull"}[mode]
+    kernel_name = {"all-pairs": "tfrt::k_intersect3d", "group": "tfrt::k_intersect_group"}[mode]
     roofline = {"kernel": kernel_name, "bound": "valu"}
     if prof_leg is not None and prof_leg["kernel_ms"]:
         P = len(n_active)
@@ -437,8 +435,7 @@ def main(argv=None):
             "rays_per_gpu": global_rays // world, "global_rays": global_rays, "faces": M,
             "trace_depth": 3,
             "trace_mode": {"all-pairs": "all-pairs float32 sphere filter",
-                           "group": "sphere hierarchy over k-d face clusters (default)",
-                           "sort": "face clusters + Morton-sorted rays"}[mode],
+                           "group": "sphere hierarchy over k-d face clusters (default)"}[mode],
             "step_mode": {"graph": "fused launch sequence (GoalError), HIP-graph replay",
                           "fused": "fused launch sequence (GoalError), eager launches",
                           "generic": "error function as torch code through autograd"}[

@@ -173,10 +173,7 @@ typedef struct tfrt_scene3d {
    * visits faces in clusters of 16 consecutive entries behind a bounding-sphere test (a
    * two-level conservative filter); results are identical to the all-pairs path (NULL). */
   const int32_t* cluster_order;
-  /* With cluster_order: 0 = rays stay in their natural order, each ray queues the clusters its
-   * line touches (the default fast path); 1 = rays are additionally visited in a sorted,
-   * spatially coherent order and whole wavefronts skip untouched clusters. */
-  int32_t sort_rays;
+  int32_t reserved0;  /* must be 0 */
   /* Reverse sweep only.  0 (default): the 9 face-gradient terms of every ray are summed with
    * float64 atomics (LDS windows, then global): fastest, but float64 addition is not
    * associative, so the last bits of a face's sum depend on the arrival order and differ from

@@ -1,9 +1,9 @@
-"""Builds tuning variants of the library into scratch/variants/ (not shipped).  Usage:
+"""Builds tuning variants of the library into scratch/variants_live/ (git-ignored, not shipped; it travels to the GPU box: delete it after use).  Usage:
 build_variants.py NAME=flags ...   e.g.  w5="-DTFRT_GROUP_WAVES=5 -DTFRT_GROUP_LIST_CAP=640" """
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from tensorflowraytrace_amd import _build
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants")
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants_live")
 os.makedirs(out, exist_ok=True)
 for spec in sys.argv[1:]:
     name, flags = spec.split("=", 1)

@@ -7,7 +7,7 @@ import tfrt.optimizer as optimizer
 t0 = time.time()
 # 1) bench scene, many steps at several sizes and modes
 for N, mode, dt in ((1_000_000, "auto", torch.float32), (333_333, "auto", torch.float32), (50_001, "all-pairs", torch.float32),
-                    (200_000, "sort", torch.float32), (120_000, "auto", torch.float64), (77_777, "auto", torch.float16)):
+                    (200_000, "group", torch.float32), (120_000, "auto", torch.float64), (77_777, "auto", torch.float16)):
     eng, system, params = bench.build_scene(N, 41, 9, dt, accelerate=mode)
     opt = optimizer.SGD_Optimizer(eng, params, bench.error_function, trace_depth=3, learning_rate=1e-5, grad_clip=1e-3)
     opt.suppress_warnings = True

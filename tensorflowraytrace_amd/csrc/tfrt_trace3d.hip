@@ -12,7 +12,7 @@
 //                  EXACTLY in float64 with the reference's own Cramer sums and epsilons
 //                  (trace_math.h exact_triangle), so hit/miss and nearest-hit decisions are the
 //                  float64 reference's decisions; the float32 stages only remove pairs that
-//                  cannot hit.  Three kernels share that scheme:
+//                  cannot hit.  Two kernels share that scheme:
 //        k_intersect_group  (default, scenes of >= 64 faces) sphere hierarchy over k-d face
 //                           clusters: 8-cluster superclusters -> 16-face clusters -> faces;
 //                           lanes queue the clusters their rays touch, the wave drains the
@@ -20,7 +20,6 @@
 //                           compacted full wavefronts).
 //        k_intersect3d      every pair through the sphere filter: grid (ray blocks, face
 //                           chunks), lane = R rays, spheres stream through an LDS tile.
-//        k_intersect_cull   clusters + rays visited in a sorted, coherent order.
 //   k_classify3d   min over chunks (lowest face index wins ties, like tf.argmin), boundary
 //                  catagory -> ray class, per-block class histogram.
 //   k_scan3d       one block: exclusive scan of the histograms -> stable output slots,
@@ -64,8 +63,7 @@ constexpr int ERR_CAPACITY = 1;
 // launch instead of two.)
 __global__ __launch_bounds__(BLOCK) void k_center(const double* __restrict__ fverts, int M,
                                                   double* __restrict__ c0, int32_t* nrays0, int n,
-                                                  int32_t* tail8, unsigned int* scan_ticket,
-                                                  int want_scale) {
+                                                  int32_t* tail8, unsigned int* scan_ticket) {
   if (nrays0 != nullptr) {
     if (threadIdx.x == 0) *nrays0 = n;
     if (threadIdx.x < 8) tail8[threadIdx.x] = 0;
@@ -97,30 +95,6 @@ __global__ __launch_bounds__(BLOCK) void k_center(const double* __restrict__ fve
     const float cf = (ns > 0) ? (float)(sum / ns) : 0.f;
     ctr[threadIdx.x] = (cf - cf == 0.f) ? (double)cf : 0.0;  // (inf / NaN: the origin serves)
     c0[threadIdx.x] = ctr[threadIdx.x];
-  }
-  if (!want_scale) return;  // (block-uniform)
-  __syncthreads();
-  // c0[3] = length scale for the ray sort keys of the sorted-ray mode: twice the RMS distance
-  // of the sampled faces from c0 (robust against a few huge faces such as a distant target
-  // plane; rays passing farther out simply clamp to the border cell)
-  double acc = 0.0;
-  for (int j = threadIdx.x; j < ns; j += BLOCK) {
-    const double* P = fverts + 9 * (int64_t)j * step;
-    double d2 = 0.0;
-    for (int k = 0; k < 3; ++k) {
-      const double d = P[k] - ctr[k];
-      d2 += d * d;
-    }
-    acc += d2;
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-  if (lane_id() == 0) red[wave][0] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double sum = 0.0;
-    for (int w = 0; w < WAVES; ++w) sum += red[w][0];
-    c0[3] = 2.0 * sqrt(sum / (ns > 0 ? ns : 1));
   }
 }
 
@@ -211,12 +185,10 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
 // ~20 % fewer rays per cluster.
 constexpr int CLUSTER = 16;
 
-// Funnel counters of k_intersect_group for tuning builds (-DTFRT_GROUP_STATS; never in the
-// shipped library): [0] level-0 tests, [1] (ray, supercluster) pairs, [2] queued clusters,
-// [3] member-sphere hits, [4] pairs past the float32 screen, [5] float64 decisions that hit.
-#ifdef TFRT_GROUP_STATS
-__device__ unsigned long long g_group_stats[8];
-#define TFRT_STAT(k, v) do { if (lane_id() == 0) atomicAdd(&g_group_stats[k], (unsigned long long)(v)); } while (0)
+// Funnel counters of k_intersect_group: tuning builds only (-DTFRT_TUNING, csrc/tfrt_tuning.h;
+// never in the shipped library).
+#ifdef TFRT_TUNING
+#include "tfrt_tuning.h"
 #else
 #define TFRT_STAT(k, v) do { } while (0)
 #endif
@@ -406,16 +378,6 @@ __device__ __forceinline__ void super_spheres_block(
   }
 }
 
-// The sorted-ray mode only needs the cluster level.
-__global__ __launch_bounds__(BLOCK) void k_cluster_spheres(
-    const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
-    const double* __restrict__ c0, double size_eps, int n_clusters,
-    float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
-    float4* __restrict__ crec) {
-  cluster_spheres_block(blockIdx.x, fverts, M, order, c0, size_eps, n_clusters, csphere, cface,
-                        clsphere, crec);
-}
-
 // Both sphere levels of the grouped filter in one launch (each is a latency-bound ~12 us
 // kernel on its own and neither reads the other's output): blocks [0, n_super) walk one
 // supercluster ball each with their first 128 threads, the rest do 16 clusters each.
@@ -506,45 +468,16 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, int64_t stride,
                                                    const int32_t* __restrict__ n_ptr,
                                                    const double* __restrict__ c0,
-                                                   float* __restrict__ prep, int64_t pstride,
-                                                   uint32_t* __restrict__ keys,
-                                                   int32_t* __restrict__ vals, int n_cap) {
+                                                   float* __restrict__ prep, int64_t pstride) {
   const int n = *n_ptr;
   const int i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) {
-    if (keys != nullptr && i < n_cap) {  // unused slots sort to the end
-      keys[i] = 0xFFFFFFFFu;
-      vals[i] = i;
-    }
-    return;
-  }
-  uint32_t key = 0x3FFFFFFFu;
+  if (i >= n) return;
   float o[8];
   double s[3], e[3], u[3], sc[3];
   load_ray3(rays, stride, i, s, e);
-  if (ray_filter_state(s, e, c0, o, u, sc) && keys != nullptr) {
-    // sort key: Morton code of the foot of the perpendicular from the mesh centre to the
-    // ray's line -- rays whose lines pass close to each other near the mesh sort together
-    const double su = dot3(sc, u);
-    const double inv_r = 1.0 / fmax(c0[3], 1e-300);
-    key = 0;
-    for (int k = 0; k < 3; ++k) {
-      double q = ((sc[k] - su * u[k]) * inv_r * 0.5 + 0.5) * 1023.0;
-      q = fmin(fmax(q, 0.0), 1023.0);
-      uint32_t v = (uint32_t)q;
-      v = (v | (v << 16)) & 0x030000FFu;
-      v = (v | (v << 8)) & 0x0300F00Fu;
-      v = (v | (v << 4)) & 0x030C30C3u;
-      v = (v | (v << 2)) & 0x09249249u;
-      key |= v << k;
-    }
-  }
+  ray_filter_state(s, e, c0, o, u, sc);
 #pragma unroll
   for (int k = 0; k < 8; ++k) prep[k * pstride + i] = o[k];
-  if (keys != nullptr) {
-    keys[i] = key;
-    vals[i] = i;
-  }
 }
 
 // ------------------------------------------------------------------- float32 screen
@@ -664,11 +597,6 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
   int cnt = 0;
   // exact float64 decision for every queued candidate of this lane
   auto flush = [&]() {
-#ifdef TFRT_ABLATE_FLUSH
-    if (cnt > 1000000) bt[0] = 0.0;  // timing experiment only: drop the float64 stage
-    cnt = 0;
-    return;
-#endif
     for (int k = 0; k < cnt; ++k) {
       const int v = cand[k * BLOCK + tid];
       const int j = v >> 2;
@@ -724,44 +652,6 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
     }
   };
 
-#if defined(TFRT_VARIANT_SGPR)
-  // spheres through the scalar cache: wave-uniform address -> s_load_dwordx4, operands in SGPRs
-  {
-    const int nfull = (f1 - f0) & ~3;
-    int j = f0;
-    for (; j < f0 + nfull; j += 4) {
-      const float4 s0 = sphere[j], s1 = sphere[j + 1], s2 = sphere[j + 2], s3 = sphere[j + 3];
-      test(s0, j);
-      test(s1, j + 1);
-      test(s2, j + 2);
-      test(s3, j + 3);
-      if (__any(cnt > KC - 4 * R)) flush();
-    }
-    for (; j < f1; ++j) {
-      test(sphere[j], j);
-      if (__any(cnt > KC - 4 * R)) flush();
-    }
-  }
-#elif defined(TFRT_VARIANT_PREFETCH)
-  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 is never true
-  for (int t0 = f0; t0 < f1; t0 += TILE) {
-    const int nt = min(TILE, f1 - t0);
-    const int nt4 = (nt + 3) & ~3;
-    __syncthreads();
-    for (int k = tid; k < nt4 + 4; k += BLOCK) tile[k] = (k < nt) ? sphere[t0 + k] : never;
-    __syncthreads();
-    float4 a0 = tile[0], a1 = tile[1], a2 = tile[2], a3 = tile[3];
-    for (int j = 0; j < nt4; j += 4) {
-      const float4 b0 = tile[j + 4], b1 = tile[j + 5], b2 = tile[j + 6], b3 = tile[j + 7];
-      test(a0, t0 + j);
-      test(a1, t0 + j + 1);
-      test(a2, t0 + j + 2);
-      test(a3, t0 + j + 3);
-      a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-      if (__any(cnt > KC - 4 * R)) flush();
-    }
-  }
-#else
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);  // |w|^2 <= -1 is never true
   for (int t0 = f0; t0 < f1; t0 += TILE) {
     const int nt = min(TILE, f1 - t0);
@@ -782,7 +672,6 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
       if (__any(cnt > KC - 4 * R)) flush();
     }
   }
-#endif
   flush();
 
 #pragma unroll
@@ -791,160 +680,6 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
     if (i < n) {
       part_t[blockIdx.y * part_stride + i] = bt[r];
       part_i[blockIdx.y * part_stride + i] = bi[r];
-    }
-  }
-}
-
-// ------------------------------------------------------------------ clustered intersect
-
-// Same decisions as k_intersect3d, fewer filter evaluations: rays are visited in the order of
-// `rperm` (sorted by a Morton key of their line, so the R*256 rays of a workgroup form a narrow
-// bundle) and faces in spatial clusters of CLUSTER.  A cluster's bounding sphere is tested
-// first; only when some lane of the wave touches it are its member spheres tested.  Every
-// ray-face pair the all-pairs kernel would hand to the float64 stage still reaches it (both
-// sphere levels are conservative), so results are identical; ties on ray_u are broken by the
-// lower face index explicitly because faces are no longer visited in index order.
-template <typename T, int R>
-__global__ __launch_bounds__(BLOCK) void k_intersect_cull(
-    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
-    const int32_t* __restrict__ last_tri, const int32_t* __restrict__ rperm,
-    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
-    const int32_t* __restrict__ cface, const double* __restrict__ fverts,
-    const float* __restrict__ prep, int64_t pstride, int n_clusters, double eps_int,
-    double eps_size, double eps_start, double* __restrict__ out_t, int32_t* __restrict__ out_i) {
-  const int n = *n_ptr;
-  const int base = blockIdx.x * (BLOCK * R);
-  if (base >= n) return;
-  const int tid = threadIdx.x;
-
-  __shared__ float4 tile[TILE + 8];
-  __shared__ int32_t cand[KC * BLOCK];
-
-  float ax[R], ay[R], az[R], bx[R], by[R], bz[R], nsa[R], nsb[R];
-  double bt[R];
-  int32_t bi[R], slot[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int q = base + r * BLOCK + tid;
-    bt[r] = INFINITY;
-    bi[r] = -1;
-    slot[r] = -1;
-    ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
-    nsa[r] = nsb[r] = __builtin_nanf("");  // never a candidate (see k_intersect3d)
-    if (q < n) {
-      const int i = rperm[q];
-      slot[r] = i;
-      ax[r] = prep[i];
-      ay[r] = prep[pstride + i];
-      az[r] = prep[2 * pstride + i];
-      bx[r] = prep[3 * pstride + i];
-      by[r] = prep[4 * pstride + i];
-      bz[r] = prep[5 * pstride + i];
-      nsa[r] = prep[6 * pstride + i];
-      nsb[r] = prep[7 * pstride + i];
-    }
-  }
-
-  int cnt = 0;
-  auto flush = [&]() {
-    for (int k = 0; k < cnt; ++k) {
-      const int v = cand[k * BLOCK + tid];
-      const int j = cface[v >> 2];
-      const int r = v & 3;
-      int i = -1;
-#pragma unroll
-      for (int rr = 0; rr < R; ++rr)
-        if (rr == r) i = slot[rr];
-      if (j < 0 || i < 0) continue;
-      if (last_tri != nullptr && last_tri[i] == j) continue;
-      double s[3], e[3], P[9];
-      load_ray3(rays, stride, i, s, e);
-      const double* fp = fverts + 9 * (int64_t)j;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) P[q] = fp[q];
-      double best = bt[0];
-#pragma unroll
-      for (int rr = 1; rr < R; ++rr)
-        if (rr == r) best = bt[rr];
-      if (!may_hit(s, e, P, eps_size, eps_start, best)) continue;
-      const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
-      if (h.valid) {
-#pragma unroll
-        for (int rr = 0; rr < R; ++rr) {
-          if (rr == r && (h.ray_u < bt[rr] || (h.ray_u == bt[rr] && j < bi[rr]))) {
-            bt[rr] = h.ray_u;
-            bi[rr] = j;
-          }
-        }
-      }
-    }
-    cnt = 0;
-  };
-
-  auto dist2 = [&](const float4 sp, float q[R]) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
-      const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-      q[r] = fmaf(pa, pa, pb * pb);
-    }
-    float qmin = q[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) qmin = fminf(qmin, q[r]);
-    return qmin;
-  };
-
-  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-  for (int t0 = 0; t0 < n_clusters; t0 += TILE) {
-    const int nt = min(TILE, n_clusters - t0);
-    const int nt4 = (nt + 3) & ~3;
-    __syncthreads();
-    for (int k = tid; k < nt4; k += BLOCK) tile[k] = (k < nt) ? clsphere[t0 + k] : never;
-    __syncthreads();
-    for (int j = 0; j < nt4; j += 4) {
-      float4 cs[4] = {tile[j], tile[j + 1], tile[j + 2], tile[j + 3]};
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float q[R];
-        const float qmin = dist2(cs[c], q);
-        if (__any(qmin <= cs[c].w)) {  // wave-uniform: some ray of this wave touches the cluster
-          const int k0 = (t0 + j + c) * CLUSTER;
-          // one coalesced load brings the cluster's 16 member spheres into lanes 0..15;
-          // each member is then broadcast to the wave with readlane (SGPR operands)
-          const float4 mine = csphere[k0 + (lane_id() & (CLUSTER - 1))];
-          for (int g = 0; g < CLUSTER; g += 4) {
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-              float4 sp;
-              sp.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), g + gg));
-              sp.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), g + gg));
-              sp.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), g + gg));
-              sp.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.w), g + gg));
-              float qq[R];
-              const float m = dist2(sp, qq);
-              if (m <= sp.w) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                  if (qq[r] <= sp.w) {
-                    cand[cnt * BLOCK + tid] = ((k0 + g + gg) << 2) | r;
-                    ++cnt;
-                  }
-                }
-              }
-            }
-            if (__any(cnt > KC - 4 * R)) flush();
-          }
-        }
-      }
-    }
-  }
-  flush();
-
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    if (slot[r] >= 0) {
-      out_t[slot[r]] = bt[r];
-      out_i[slot[r]] = bi[r];
     }
   }
 }
@@ -1189,13 +924,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
                        : "+v"(r0.x), "+v"(r0.y), "+v"(r0.z), "+v"(r0.w), "+v"(r1.x), "+v"(r1.y),
                          "+v"(r1.z), "+v"(r2.x), "+v"(r2.y), "+v"(r2.z));
       j = __float_as_int(r0.w);
-#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 7
-      {  // sensitivity: the screen's gathers twice (another record)
-        const int64_t m2 = (memb + 1024) % ((int64_t)n_clusters * CLUSTER);
-        const float4 q0 = crec[3 * m2], q1 = crec[3 * m2 + 1], q2 = crec[3 * m2 + 2];
-        if (q0.x + q1.x + q2.x == 1.2345e-30f) j = cface[m2];
-      }
-#endif
       const double best = dkey_inv(best_k[wave][slot]);
       // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t scales
       // with their magnitudes, not with |t|
@@ -1234,14 +962,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       const double* fp = fverts + 9 * (int64_t)j;
 #pragma unroll
       for (int q = 0; q < 9; ++q) P[q] = fp[q];
-#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 8
-      {  // sensitivity: the decision's gathers twice (another face)
-        const double* fq = fverts + 9 * (int64_t)((j + 1000) % (n_clusters * CLUSTER / 2));
-        double acc = 0.0;
-        for (int q = 0; q < 9; ++q) acc += fq[q];
-        if (acc == 1.2345e-300) P[0] = acc;
-      }
-#endif
       const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
       if (h.valid) {
         have = true;
@@ -1267,10 +987,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   auto flush = [&]() {
     const uint16_t* list = &clist[wave][0];
     const int total = ln;
-#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 1
-    ln = 0;  // timing experiment only: levels 0 and 1 alone
-    return;
-#endif
     // 2. member tests, 16 queued candidates per step: each 16-lane group takes four; their
     //    member spheres are fetched first (four independent coalesced 256-byte reads in
     //    flight).  Member hits become (ray, face) pairs; while 64 are waiting -- and once more
@@ -1311,15 +1027,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
           memb[u] = ((unsigned)t0 + (v >> 8)) * CLUSTER + (unsigned)ML * (unsigned)(lane % LPC);
 #pragma unroll
           for (int h = 0; h < ML; ++h) sp[u][h] = csphere[memb[u] + h];
-#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 5
-          // sensitivity experiments (tuning builds only): one class of work issued twice
-#pragma unroll
-          for (int h = 0; h < ML; ++h) sp[u][h].w += csphere[(memb[u] + h) ^ 1u].w * 0.f;  // same lines
-#elif defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 6
-#pragma unroll
-          for (int h = 0; h < ML; ++h)
-            sp[u][h].w += csphere[(memb[u] + h + 4096u) % (unsigned)(n_clusters * CLUSTER)].w * 0.f;
-#endif
         }
 #pragma unroll
         for (int u = 0; u < MH; ++u) {
@@ -1331,10 +1038,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
             const float pb = fmaf(m.x, fb.x, fmaf(m.y, fb.y, fmaf(m.z, fb.z, fb.w)));
             const bool hit = fmaf(pa, pa, pb * pb) <= m.w;
             const unsigned long long hm = __ballot(hit);
-#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 2
-            if (hm == 0x5A5A5A5A5A5A5A5Aull) rn = -1;  // timing experiment only: no decisions
-            continue;
-#endif
             if (hit)
               pairs[wave][pn + rank_below(hm)] = ((memb[u] + (unsigned)h) << 8) | (uint32_t)slot[u];
             pn += __popcll(hm);
@@ -1523,24 +1226,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
         level0(s3);
       }
       for (; k >= 0; --k) level0(su[k]);
-#if defined(TFRT_ABLATE_GROUP) && TFRT_ABLATE_GROUP == 9
-      {  // sensitivity: level 0 twice (into a second mask that is merged at the end)
-        unsigned again[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) again[r] = 0u;
-        for (int k2 = ns - 1; k2 >= 0; --k2) {
-          const float4 sp = su[k2];
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const float pa = fmaf(sp.x, ax[r], fmaf(sp.y, ay[r], fmaf(sp.z, az[r], nsa[r])));
-            const float pb = fmaf(sp.x, bx[r], fmaf(sp.y, by[r], fmaf(sp.z, bz[r], nsb[r])));
-            shift_in_le(again[r], fmaf(pa, pa, pb * pb), sp.w);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) touched[r] |= again[r];
-      }
-#endif
     }
   }
 
@@ -1963,40 +1648,10 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
     const double* __restrict__ g_dead, int64_t cap_dead,
     typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
-    int64_t out_stride, double* __restrict__ g_fverts, const int32_t* __restrict__ rperm,
+    int64_t out_stride, double* __restrict__ g_fverts,
     typename SweepStore<T>::type* __restrict__ stash_g, int32_t* __restrict__ stash_face) {
   const int n = *n_ptr;
   const int q0 = blockIdx.x * BLOCK + threadIdx.x;
-  if (rperm != nullptr) {
-    // sorted (coherent) order: neighbouring lanes mostly hit the same few faces, so face
-    // gradients are summed across the wave before touching memory
-    const bool live = q0 < n;
-    const int i = live ? rperm[q0] : 0;
-    double gP[9];
-    int tri = -1;
-    if (live)
-      tri = backward_ray<T>(i, rays_in, stride_in, ray_id_in, rec_tri, rec_t, rec_cls, rec_slot,
-                            pass_counts, sc, L, dead_len, g_child, child_stride, g_fin, cap_fin,
-                            g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead, g_out, g_src_out, out_stride,
-                            gP);
-    unsigned long long todo = __ballot(tri >= 0);
-    int guard = 0;
-    while (todo != 0ull && guard++ < 64) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int k = __shfl(tri, leader, 64);
-      const bool mine = tri == k;
-      const unsigned long long grp = __ballot(mine);
-#pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        double v = mine ? gP[c] : 0.0;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-        if ((int)lane_id() == leader && v != 0.0) unsafeAtomicAdd(g_fverts + 9 * (int64_t)k + c, v);
-      }
-      todo &= ~grp;
-    }
-    return;
-  }
   const int i = q0;
   if (i >= n) return;
   double gP[9];
@@ -2019,11 +1674,7 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     double* gp = g_fverts + 9 * (int64_t)tri;
 #pragma unroll
     for (int c = 0; c < 9; ++c) {
-#ifdef TFRT_ABLATE_BWD_ATOMICS
-      if (gP[c] == 12345.678) gp[c] = gP[c];  // timing experiment only: no accumulation
-#else
       if (gP[c] != 0.0) unsafeAtomicAdd(gp + c, gP[c]);
-#endif
     }
   }
 }
@@ -2322,33 +1973,21 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_seam(
 
 // ------------------------------------------------------------------- host-side plan
 
-size_t sort_pairs_temp_bytes(size_t n);
-int sort_pairs_u32_i32(void* tmp, size_t bytes, const uint32_t* keys_in, uint32_t* keys_out,
-                       const int32_t* vals_in, int32_t* vals_out, size_t n, int end_bit,
-                       hipStream_t st);
-
 struct Plan3 {
   int R, ray_blocks, chunks, chunk_faces, nblk;
   // grouped (two-level) kernel: rays per lane, grid and clusters per chunk
   int gR, g_blocks, g_chunks, g_chunk_clusters;
 };
 
-// device buffers of the clustered path for one pass (order == nullptr: all-pairs filter)
+// device buffers of the hierarchy for one trace (order == nullptr: all-pairs filter)
 struct Accel3 {
   const int32_t* order;
-  bool sort_rays;  // true: Morton-sorted rays + wave-level cluster test; false: grouped kernel
   int n_clusters;
   float4* csphere;
   int32_t* cface;
   float4* clsphere;
   float4* susphere;  // one per SUPER clusters
   float4* crec;      // 3 per member: float32 face record for the screen
-  uint32_t* keys_in;
-  uint32_t* keys_out;
-  int32_t* vals_in;
-  int32_t* rperm;  // sorted slot order of this pass (kept: the reverse sweep reuses it)
-  void* sort_tmp;
-  size_t sort_bytes;
 };
 
 static Plan3 make_plan(int64_t N, int64_t M) {
@@ -2395,7 +2034,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec, keys_in, keys_out, vals_in, rperm, sort_tmp, sort_bytes;
+  size_t csphere, cface, clsphere, susphere, crec;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -2427,12 +2066,6 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.clsphere = take(ncl * sizeof(float4));
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
-  L.keys_in = take(n * sizeof(uint32_t));
-  L.keys_out = take(n * sizeof(uint32_t));
-  L.vals_in = take(n * sizeof(int32_t));
-  L.rperm = take((size_t)(P > 0 ? P : 1) * n * sizeof(int32_t));
-  L.sort_bytes = sort_pairs_temp_bytes(n);
-  L.sort_tmp = take(L.sort_bytes);
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -2474,30 +2107,20 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                             const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
                             const double* fverts, const double* c0, float* prep, int64_t pstride,
                             int M, double ei, double es, double er, double* part_t,
-                            int32_t* part_i, int64_t part_stride, const Accel3* ac, int n_cap,
+                            int32_t* part_i, int64_t part_stride, const Accel3* ac,
                             bool prep_ready = false, const Classify3* classify = nullptr,
                             bool* classified = nullptr) {
-  const bool accel = ac != nullptr && ac->order != nullptr;
-  const bool clustered = accel && ac->sort_rays;
-  const bool grouped = accel && !ac->sort_rays;
+  const bool grouped = ac != nullptr && ac->order != nullptr;
   Classify3 fz;
   if (grouped && pl.g_chunks == 1 && classify != nullptr && classify->rec_cls != nullptr)
     fz = *classify;
   if (classified != nullptr) *classified = fz.rec_cls != nullptr;
   // (the grouped kernel forms the filter state of a trace's first pass itself: prep = nullptr)
   const bool prep_inline = grouped && !prep_ready;
-  if ((!prep_ready && !prep_inline) || clustered)  // (sorted-ray mode also needs the sort keys)
+  if (!prep_ready && !prep_inline)
     hipLaunchKernelGGL((k_rayprep<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rays, stride, n_ptr, c0,
-                       prep, pstride, clustered ? ac->keys_in : nullptr,
-                       clustered ? ac->vals_in : nullptr, n_cap);
-  if (clustered) {
-    if (sort_pairs_u32_i32(ac->sort_tmp, ac->sort_bytes, ac->keys_in, ac->keys_out, ac->vals_in,
-                           ac->rperm, (size_t)n_cap, 32, st) != 0)
-      return TFRT_E_LAUNCH;
-  }
-  const int Rc = 1;  // rays per lane in the clustered kernel
+                       prep, pstride);
   dim3 grid(pl.ray_blocks, pl.chunks);
-  if (clustered) grid = dim3(cdiv(n_cap > 0 ? n_cap : 1, BLOCK * Rc), 1);
   if (grouped) grid = dim3(pl.g_blocks, pl.g_chunks);
   ProfRec rec;
   if (g_prof_on) {
@@ -2508,11 +2131,7 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     (void)hipEventRecord(rec.a, st);
   }
 #define TFRT_LAUNCH_R(RR)                                                                      \
-  if (clustered)                                                                               \
-    hipLaunchKernelGGL((k_intersect_cull<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,      \
-                       n_ptr, last_tri, ac->rperm, ac->clsphere, ac->csphere, ac->cface,       \
-                       fverts, prep, pstride, ac->n_clusters, ei, es, er, part_t, part_i);     \
-  else if (grouped)                                                                            \
+  if (grouped)                                                                                 \
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
                        n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec,     \
                        ac->cface, fverts, c0, prep_inline ? nullptr : prep, pstride,           \
@@ -2523,7 +2142,7 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
                        part_t, part_i, part_stride)
-  const int Ruse = clustered ? 1 : (grouped ? pl.gR : pl.R);
+  const int Ruse = grouped ? pl.gR : pl.R;
   if (Ruse == 1) { TFRT_LAUNCH_R(1); }
   else if (Ruse == 4) { TFRT_LAUNCH_R(4); }
   else { TFRT_LAUNCH_R(2); }
@@ -2581,42 +2200,28 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   Accel3 ac;
   // (the grouped kernel packs member slot and ray slot into 32 bits: member slots < 2^24)
   ac.order = (M >= 4 * CLUSTER && M < (1 << 24) - CLUSTER) ? sc->cluster_order : nullptr;
-  ac.sort_rays = sc->sort_rays != 0;
   ac.n_clusters = cdiv(M > 0 ? M : 1, CLUSTER);
   ac.csphere = reinterpret_cast<float4*>(ws + lay.csphere);
   ac.cface = reinterpret_cast<int32_t*>(ws + lay.cface);
   ac.clsphere = reinterpret_cast<float4*>(ws + lay.clsphere);
   ac.susphere = reinterpret_cast<float4*>(ws + lay.susphere);
   ac.crec = reinterpret_cast<float4*>(ws + lay.crec);
-  ac.keys_in = reinterpret_cast<uint32_t*>(ws + lay.keys_in);
-  ac.keys_out = reinterpret_cast<uint32_t*>(ws + lay.keys_out);
-  ac.vals_in = reinterpret_cast<int32_t*>(ws + lay.vals_in);
-  ac.sort_tmp = ws + lay.sort_tmp;
-  ac.sort_bytes = lay.sort_bytes;
-  int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
   if (M > 0) {
-    if (!(ac.order != nullptr && !ac.sort_rays))  // (the hierarchy kernel does this itself)
-      hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
-                         (int)N, tail, ticket, (ac.order != nullptr && ac.sort_rays) ? 1 : 0);
-    if (ac.order != nullptr) {
+    if (ac.order != nullptr) {  // (the hierarchy kernel also does k_center's work)
       const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
-      if (ac.sort_rays) {
-        hipLaunchKernelGGL(k_cluster_spheres, dim3(cl_blocks), dim3(BLOCK), 0, st,
-                           sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
-                           ac.csphere, ac.cface, ac.clsphere, (float4*)nullptr);
-      } else {
-        const int n_super = cdiv(ac.n_clusters, SUPER);
-        hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
-                           sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
-                           n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
-                           (int)N, tail, ticket);
-      }
+      const int n_super = cdiv(ac.n_clusters, SUPER);
+      hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
+                         sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
+                         n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
+                         (int)N, tail, ticket);
     } else {
+      hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
+                         (int)N, tail, ticket);
       hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,
                          c0, sc->size_epsilion, sphere);
     }
   }
-  const int chunks_used = ac.order == nullptr ? pl.chunks : (ac.sort_rays ? 1 : pl.g_chunks);
+  const int chunks_used = ac.order == nullptr ? pl.chunks : pl.g_chunks;
   const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};
   for (int p = 0; p < P; ++p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
@@ -2624,7 +2229,6 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     const int32_t* idin = p == 0 ? nullptr : rayid + (size_t)(p - 1) * n;
     const int32_t* ltin = p == 0 ? nullptr : lasttri + (size_t)(p - 1) * n;
     T* rout = rays_ws + (size_t)p * 6 * n;
-    ac.rperm = rperm_all + (size_t)p * n;
     Classify3 fz;
     fz.catagory = sc->catagory;
     fz.rec_tri = rec_tri + (size_t)p * n;
@@ -2634,7 +2238,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     bool classified = false;
     if (launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, prep,
                             (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion,
-                            sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac, (int)N,
+                            sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac,
                             /*prep_ready=*/p > 0, &fz, &classified) != 0)
       return TFRT_E_LAUNCH;
     if (!classified)
@@ -2668,7 +2272,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                        (int64_t)n, rayid + (size_t)p * n, lasttri + (size_t)p * n,
                        rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
                        stp ? *stp : none, dead ? *dead : none, tail + 6,
-                       (p + 1 < P && !(ac.order != nullptr && ac.sort_rays)) ? prep : nullptr,
+                       (p + 1 < P) ? prep : nullptr,
                        (int64_t)n, c0, ss);
   }
   if (unfinished != nullptr && P > 0) {
@@ -2701,10 +2305,6 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   const uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
   using G = typename SweepStore<T>::type;  // (the regions are sized for float64)
   G* gbuf = reinterpret_cast<G*>(ws + lay.gbuf);
-  int32_t* rperm_all = reinterpret_cast<int32_t*>(ws + lay.rperm);
-  // the sorted-ray forward left its Morton ray order in rperm: neighbouring lanes then mostly hit
-  // the same few faces and k_backward3d sums their face gradients across the wave
-  const bool coherent = sc->cluster_order != nullptr && sc->sort_rays != 0 && M >= 4 * CLUSTER;
   const size_t n = N > 0 ? N : 1;
   // Windowed LDS accumulation of the face gradients (k_face_accumulate): every window block
   // scans its chunk's face ids, so it is used while the windows are few; beyond that (and for
@@ -2712,7 +2312,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // then so many that they see little contention.
   const int windows = cdiv(M > 0 ? M : 1, FACE_WINDOW);
   const bool ordered = sc->deterministic != 0 && M > 0 && g_fverts != nullptr;
-  const bool stash = ordered || (M > 0 && N >= 16384 && windows <= 32 && !coherent);
+  const bool stash = ordered || (M > 0 && N >= 16384 && windows <= 32);
   unsigned long long* fix_acc = reinterpret_cast<unsigned long long*>(ws + lay.fix_acc);
   uint8_t* fix_flag = reinterpret_cast<uint8_t*>(ws + lay.fix_flag);
   unsigned long long* fix_max = reinterpret_cast<unsigned long long*>(ws + lay.fix_max);
@@ -2746,7 +2346,6 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
                        cap_dead, g_out, g_src_out, out_stride, g_fverts,
-                       (coherent && !ordered) ? rperm_all + (size_t)p * n : nullptr,
                        stash ? stash_g : nullptr, stash ? stash_face : nullptr);
     if (ordered) {
       // two-entry scale buffer, alternating per pass (each pass's conversion clears the other)
@@ -2885,14 +2484,14 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
                        (unsigned int*)nullptr);
   if (M > 0) {
     hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, face_verts, M, c0, nptr, (int)n_rays,
-                       nptr + 8, (unsigned int*)nullptr, 0);
+                       nptr + 8, (unsigned int*)nullptr);
     hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, face_verts, M, c0,
                        size_epsilion, sphere);
   }
 #define TFRT_SEAM(TT)                                                                          \
   launch_intersect<TT>(pl, st, static_cast<const TT*>(rays), stride, nptr, nullptr, sphere,    \
                        face_verts, c0, prep, (int64_t)n, M, intersect_epsilion, size_epsilion, \
-                       ray_start_epsilion, part_t, part_i, (int64_t)n, nullptr, (int)n_rays);  \
+                       ray_start_epsilion, part_t, part_i, (int64_t)n, nullptr);               \
   hipLaunchKernelGGL((k_finalize_seam<TT>), dim3(pl.nblk), dim3(BLOCK), 0, st,                 \
                      static_cast<const TT*>(rays), stride, (int)n_rays, pl.chunks, part_t,     \
                      part_i, (int64_t)n, face_verts, M, intersect_epsilion, size_epsilion,     \
@@ -2932,13 +2531,8 @@ int tfrt_profile_read(float* ms, int32_t max_records) {
   return n;
 }
 
-#ifdef TFRT_GROUP_STATS
-// tuning builds only: read (and clear) the funnel counters of k_intersect_group
-int tfrt_debug_group_stats(unsigned long long* out8) {
-  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_group_stats), sizeof(zero)) != hipSuccess) return -1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_group_stats), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
-}
+#ifdef TFRT_TUNING
+TFRT_TUNING_EXPORTS
 #endif
 
 }  // extern "C"

@@ -372,8 +372,7 @@ class OpticalSystem3D(OpticalSystemBase):
         return (tuple(sig), self.intersect_epsilion, self.size_epsilion,
                 self.ray_start_epsilion, tuple(id(m) for m in self.materials))
 
-    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False,
-                   deterministic=False):
+    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, deterministic=False):
         s = self._scene_cache[1]
         order = None
         if cluster:
@@ -389,11 +388,10 @@ class OpticalSystem3D(OpticalSystemBase):
             order = cached[1]
         kw = dict(intersect_epsilion=self.intersect_epsilion, size_epsilion=self.size_epsilion,
                   ray_start_epsilion=self.ray_start_epsilion, face_grad_mask=s["face_grad_mask"],
-                  cluster_order=order, sort_rays=bool(sort_rays and order is not None),
-                  deterministic=bool(deterministic))
+                  cluster_order=order, deterministic=bool(deterministic))
         # the argument object (and the ctypes struct it caches) only depends on tensors that stay
         # the same from step to step; the face tensor is passed separately to every trace
-        memo_key = (id(s), id(n_table), bool(index_mode), bool(ghost), id(order), kw["sort_rays"],
+        memo_key = (id(s), id(n_table), bool(index_mode), bool(ghost), id(order),
                     kw["deterministic"],
                     self.intersect_epsilion, self.size_epsilion, self.ray_start_epsilion)
         memo = getattr(self, "_scene_args_memo", None)
@@ -523,8 +521,7 @@ class OpticalSystem2D(OpticalSystemBase):
         self._merged_arcs = self._merge_kind(
             "arcs", ("x_center", "y_center", "angle_start", "angle_end", "radius"))
 
-    def scene_args(self, n_table, index_mode, ghost=False, cluster=False, sort_rays=False,
-                   finite_tir_gradient=False):
+    def scene_args(self, n_table, index_mode, ghost=False, finite_tir_gradient=False):
         return ops.Scene2DArgs(self._merged_segments, self._merged_arcs, n_table, index_mode,
                                ghost, self.intersect_epsilion, self.size_epsilion,
                                self.ray_start_epsilion, finite_tir_gradient=finite_tir_gradient)
@@ -588,10 +585,11 @@ class OpticalEngine:
         # How a 3-D trace culls ray-face pairs before the exact float64 decision.  Every mode
         # gives identical results (all filters are conservative):
         #   False / "all-pairs": every pair goes through the float32 bounding-sphere filter;
-        #   "group": faces in spatial clusters of 16 behind a cluster bounding sphere, rays in
-        #            their natural order (two-level filter, ~16x fewer level-1 tests);
-        #   True / "sort": as "group" plus Morton-sorted rays, whole wavefronts skip clusters;
+        #   True / "group": sphere hierarchy over k-d face clusters (superclusters of 8 clusters of
+        #            16 faces), rays in their natural order;
         #   "auto" (default): "group" once the merged scene has >= 64 faces.
+        # ("sort" -- clusters + Morton-sorted rays -- was slower than "group" on every workload
+        # measured and is gone; the name is still accepted and means "group".)
         if accelerate not in (False, True, None, "all-pairs", "group", "sort", "auto"):
             raise ValueError(f"OpticalEngine: unknown accelerate mode {accelerate!r}")
         self.accelerate = accelerate
@@ -753,9 +751,7 @@ class OpticalEngine:
         a = self.accelerate
         if a in (False, None, "all-pairs") or self._dimension != 3:
             return "all-pairs"
-        if a in (True, "sort"):
-            return "sort"
-        if a == "group":
+        if a in (True, "sort", "group"):
             return "group"
         fv = getattr(system if system is not None else self._optical_system,
                      "_merged_face_verts", None)
@@ -853,7 +849,7 @@ class OpticalEngine:
         mode = self._trace_mode(system)
         if self.dimension == 3:
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
-                                      sort_rays=mode == "sort", deterministic=self.deterministic)
+                                      deterministic=self.deterministic)
         else:
             scene = system.scene_args(n_table, index_mode, ghost,
                                       finite_tir_gradient=self.finite_tir_gradient)

@@ -318,7 +318,7 @@ class Scene3DArgs:
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
                  ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None,
-                 sort_rays=False, deterministic=False):
+                 deterministic=False):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -328,7 +328,6 @@ class Scene3DArgs:
         self.n_table = _c(n_table, torch.float64)  # (n_materials, N)
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
-        self.sort_rays = bool(sort_rays)                       # + Morton-sorted rays
         self.deterministic = bool(deterministic)               # ordered reverse-sweep sums
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
@@ -360,7 +359,7 @@ class Scene3DArgs:
         if co is not None and co.numel() != M:
             raise TfrtError("cluster_order must be a permutation of the M face indices")
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
-        sc.sort_rays = 1 if self.sort_rays else 0
+        sc.reserved0 = 0
         sc.deterministic = 1 if self.deterministic else 0
         self._struct_cache = (M, sc)
         return sc

@@ -39,12 +39,12 @@ def _gpu_scene(scene, dtype, p_f=None, p_b=None, masks=(None, None), cluster=Fal
     n_table = torch.stack([tracer.MATERIALS["vacuum"](wl), tracer.MATERIALS["acrylic"](wl)]).to(dev)
     gmask = (cat == 0).to(torch.uint8)  # the target plane is a constant
     # cluster: False = all-pairs filter; True / "group" = two-level filter (k-d clusters);
-    # "group-morton" = same with a Morton face order; "sort" = clusters + sorted rays
+    # "group-morton" = same with a Morton face order
     order = None
     if cluster:
         order = ops.morton_order(fv) if cluster == "group-morton" else ops.cluster_order(fv)
     sc = ops.Scene3DArgs(fv, cat, mat_in=mat_in, mat_out=mat_out, n_table=n_table,
-                         face_grad_mask=gmask, cluster_order=order, sort_rays=cluster == "sort")
+                         face_grad_mask=gmask, cluster_order=order)
     src = tt(scene["rays"], dtype)
     return src, fv, sc, (p_f, p_b)
 
@@ -207,10 +207,10 @@ def test_empty_and_degenerate_inputs():
     assert out["finished"].shape[1] + out["dead"].shape[1] + out["unfinished"].shape[1] == 1
 
 
-@pytest.mark.parametrize("mode", ["group", "group-morton", "sort"])
+@pytest.mark.parametrize("mode", ["group", "group-morton"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-9), (torch.float32, 1e-5)])
 def test_clustered_path_matches_oracle_and_all_pairs(dtype, tol, mode):
-    """cluster_order given (two-level filter, with or without sorted rays): results identical
+    """cluster_order given (sphere hierarchy): results identical
     to the all-pairs filter, bit for bit."""
     from tensorflowraytrace_amd import ops, _lib
     scene = scene_util.lens_scene(5000, k_front=8, k_back=6)
@@ -259,10 +259,10 @@ def test_ties_go_to_the_lowest_face_index_in_every_trace_mode(n_rays):
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD
     single = ops.trace3d(src, fv.detach(), sc, max_passes=1, flags=flags)
     assert single["active"].shape[1] > 0.8 * n_rays
-    for mode in (False, "group", "sort"):
+    for mode in (False, "group"):
         order = ops.cluster_order(fv2) if mode else None
         sc2 = ops.Scene3DArgs(fv2, dup(sc.catagory), mat_in=dup(sc.mat_in), mat_out=dup(sc.mat_out),
-                              n_table=sc.n_table, cluster_order=order, sort_rays=mode == "sort")
+                              n_table=sc.n_table, cluster_order=order)
         o = ops.trace3d(src, fv2, sc2, max_passes=1, flags=flags)
         assert int(o["active_face"].max()) < M, mode
         for cls in ("active", "dead"):
@@ -297,8 +297,7 @@ def _soup_scene(seed, n_faces, n_rays, dev="cuda:0"):
         order = None
         if mode:
             order = ops.morton_order(fv) if mode == "group-morton" else ops.cluster_order(fv)
-        return ops.Scene3DArgs(fv, cat, n_in=n_in, n_out=n_out, cluster_order=order,
-                               sort_rays=mode == "sort")
+        return ops.Scene3DArgs(fv, cat, n_in=n_in, n_out=n_out, cluster_order=order)
     return rays, fv, scene
 
 
@@ -306,14 +305,14 @@ def _soup_scene(seed, n_faces, n_rays, dev="cuda:0"):
     (1, 64, 1), (2, 65, 63), (3, 100, 257), (4, 129, 5000), (5, 1000, 20000), (6, 4097, 3000),
     (7, 30000, 700)])
 def test_every_trace_mode_gives_the_all_pairs_result_on_random_soups(seed, n_faces, n_rays):
-    """The sphere hierarchy, the float32 screen and the sorted-ray path may only skip work that
+    """The sphere hierarchy, and the float32 screen may only skip work that
     cannot change the result: all outputs must equal the all-pairs filter's bit for bit."""
     from tensorflowraytrace_amd import ops, _lib
     rays, fv, scene = _soup_scene(seed, n_faces, n_rays)
     flags = (_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED)
     ref = ops.trace3d(rays, fv, scene(False), max_passes=4, flags=flags, dead_ray_length=2.0)
     assert ref["active"].shape[1] > 0 or n_rays < 10
-    for mode in ("group", "group-morton", "sort"):
+    for mode in ("group", "group-morton"):
         out = ops.trace3d(rays, fv, scene(mode), max_passes=4, flags=flags, dead_ray_length=2.0)
         assert np.array_equal(out["counts"], ref["counts"]), mode
         for cls in ("finished", "active", "stopped", "dead"):
@@ -394,7 +393,7 @@ def test_grouped_kernel_classifies_in_its_epilogue_when_it_runs_as_one_chunk(ray
         assert torch.equal(out[cls], ref[cls]), cls
 
 
-@pytest.mark.parametrize("mode", ["group", "sort"])
+@pytest.mark.parametrize("mode", ["group"])
 def test_empty_and_tiny_inputs_in_the_cluster_modes(mode):
     from tensorflowraytrace_amd import ops, _lib
     rays, fv, scene = _soup_scene(31, 200, 300)
@@ -424,7 +423,7 @@ def test_lanes_without_rays_never_queue_candidates():
     from tensorflowraytrace_amd import ops, _lib
     rays, fv, scene = _soup_scene(41, 200, 5)
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
-    for mode in (False, "group", "sort"):
+    for mode in (False, "group"):
         sc = scene(mode)
         sc.eps = (1e-10, 1e300, 1e-10)           # size_epsilion: every face becomes "all space"
         out = ops.trace3d(rays, fv, sc, max_passes=2, flags=flags)

@@ -402,8 +402,8 @@ def test_engine_trace_mode_selection():
 
     e3 = engine.OpticalEngine(3, [operation.StandardReaction()])
     assert e3._trace_mode(Sys(10)) == "all-pairs" and e3._trace_mode(Sys(64)) == "group"
-    for setting, want in ((False, "all-pairs"), ("all-pairs", "all-pairs"), (True, "sort"),
-                          ("sort", "sort"), ("group", "group")):
+    for setting, want in ((False, "all-pairs"), ("all-pairs", "all-pairs"), (True, "group"),
+                          ("sort", "group"), ("group", "group")):
         e = engine.OpticalEngine(3, [operation.StandardReaction()], accelerate=setting)
         assert e._trace_mode(Sys(5000)) == want
     e2 = engine.OpticalEngine(2, [operation.StandardReaction()], accelerate="group")
