@@ -182,6 +182,13 @@ typedef struct tfrt_scene3d {
    * hence order-independent), then converted back: bit-identical results on every run, at a
    * resolution of 2^-40 of the pass's largest term. */
   int32_t deterministic;
+  /* (n_rays) i32, optional, with cluster_order: a permutation of the source rays in which rays
+   * whose lines run close together are neighbours (e.g. a Hilbert-curve order of their aperture
+   * points).  The trace then visits rays in this order -- later passes visit the children of a
+   * wavefront's rays -- and a wavefront whose 64 rays form a narrow bundle walks the hierarchy
+   * ONCE for all of them (k_intersect_beam); other wavefronts take the per-ray walk.  Only the
+   * visiting order changes: every output (sets, order, hit faces, coordinates) is identical. */
+  const int32_t* ray_order;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in

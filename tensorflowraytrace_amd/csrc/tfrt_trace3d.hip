@@ -391,7 +391,9 @@ __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     double* __restrict__ c0_out, double size_eps, int n_clusters, int n_super,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
     float4* __restrict__ crec, float4* __restrict__ susphere, int32_t* nrays0, int n,
-    int32_t* tail8, unsigned int* scan_ticket) {
+    int32_t* tail8, unsigned int* scan_ticket, int32_t* __restrict__ hist0, int hist_len) {
+  // (visiting-order traces: the class histogram the first pass's intersect kernels add into)
+  for (int k = blockIdx.x * BLOCK + threadIdx.x; k < hist_len; k += gridDim.x * BLOCK) hist0[k] = 0;
   __shared__ double c0[3];
   if (threadIdx.x < 64) {
     const int step = M > 64 ? M / 64 : 1;
@@ -755,7 +757,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ blockcnt) {
+    int32_t* __restrict__ blockcnt, const int32_t* __restrict__ order, int nq,
+    const uint8_t* __restrict__ wave_done, int32_t* __restrict__ hist) {
   constexpr int RW = 64 * R;      // rays per wave
 #ifndef TFRT_GROUP_TILE
 #define TFRT_GROUP_TILE 256
@@ -763,9 +766,31 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   constexpr int GT = TFRT_GROUP_TILE;   // cluster spheres per LDS tile
   const int n = *n_ptr;
   const int base = blockIdx.x * (BLOCK * R);
-  if (base >= n) return;  // block-uniform
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+  // Visiting order (R == 1 only): slot q of the launch visits ray order[q] (-1: none), and only
+  // the wavefronts k_intersect_beam has left (wave_done == 0) are done here.  A wave with nothing
+  // to do still walks the tiles with its block (the staging barriers), without any tests.
+  const bool ordered = order != nullptr;
+  bool idle_wave = false;
+  if (ordered) {
+    if (base >= nq) return;  // block-uniform
+    const int w0 = base >> 6;
+    bool any_left = false;
+    for (int w = 0; w < WAVES; ++w) any_left = any_left || (((w0 + w) << 6) < nq && wave_done[w0 + w] == 0);
+    if (!any_left) return;   // block-uniform
+    idle_wave = !((((w0 + wave) << 6) < nq) && wave_done[w0 + wave] == 0);
+  } else if (base >= n) {
+    return;  // block-uniform
+  }
+  // ray visited by slot r * 64 + lane of this wave (-1: none)
+  auto ray_index = [&](const int r) -> int {
+    const int qq = base + r * BLOCK + tid;
+    if (!ordered) return qq < n ? qq : -1;
+    if (idle_wave || qq >= nq) return -1;
+    const int v = order[qq];
+    return v < n ? v : -1;
+  };
   const int c_lo = blockIdx.y * chunk_clusters;
   const int c_hi = min(n_clusters, c_lo + chunk_clusters);
 
@@ -801,7 +826,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   __shared__ T ray_l[WAVES][6][RW];
 #define TFRT_RAYV(q, slot) static_cast<double>(ray_l[wave][q][slot])
 #else
-  auto ray_at = [&](int slot) -> int64_t {
+  auto ray_at = [&](int slot) -> int64_t {  // (R > 1: natural order only)
     const int i = base + (slot >> 6) * BLOCK + wave * 64 + (slot & 63);
     return i < n ? i : 0;
   };
@@ -824,8 +849,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   using RT = std::conditional_t<sizeof(T) <= 4, float, double>;  // (exact for every ray state)
   RT own_ray[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (RAY_SHUFFLE) {
-    const int i0 = base + tid;
-    const int ii = i0 < n ? i0 : 0;
+    const int i0 = ray_index(0);
+    const int64_t ii = i0 >= 0 ? i0 : 0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<RT>(rays[q * stride + ii]);
   }
@@ -847,7 +872,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   };
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = base + r * BLOCK + tid;
+    const int i = ray_index(r);
     ax[r] = ay[r] = az[r] = bx[r] = by[r] = bz[r] = 0.f;
     // NaN, not +inf: a lane without a ray must never pass `d2 <= r2`, even for a face whose
     // inflated radius overflowed to +inf (size_eps = 1e300 does that); an inf here let ray-less
@@ -855,14 +880,14 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     nsa[r] = nsb[r] = __builtin_nanf("");
     {
       const int slot = r * 64 + lane;
-      const int ii = i < n ? i : 0;
+      const int64_t ii = i >= 0 ? i : 0;
 #ifdef TFRT_GROUP_RAYS_LDS
 #pragma unroll
       for (int q = 0; q < 6; ++q) ray_l[wave][q][slot] = rays[q * stride + ii];
 #endif
-      skip_l[wave][slot] = (last_tri != nullptr && i < n) ? last_tri[ii] : -1;
+      skip_l[wave][slot] = (last_tri != nullptr && i >= 0) ? last_tri[ii] : -1;
     }
-    if (i < n && prep != nullptr) {
+    if (i >= 0 && prep != nullptr) {
       ax[r] = prep[i];
       ay[r] = prep[pstride + i];
       az[r] = prep[2 * pstride + i];
@@ -871,7 +896,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       bz[r] = prep[5 * pstride + i];
       nsa[r] = prep[6 * pstride + i];
       nsb[r] = prep[7 * pstride + i];
-    } else if (i < n) {
+    } else if (i >= 0) {
       // first pass of a trace: nobody has written the filter state of these rays yet.  Forming
       // it here (k_rayprep's arithmetic, ~60 float64 instructions) saves that kernel's launch,
       // its 32 B per ray written and the same 32 B read back
@@ -1203,7 +1228,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       // level 0: which superclusters of the tile does each ray's line touch.  The supercluster
       // spheres are wave-uniform data: read straight from global memory with a uniform index
       // (scalar loads into SGPRs, four spheres per round) -- no LDS staging, no LDS reads
-      TFRT_STAT(0, (long long)ns * __popcll(__ballot(base + tid < n)));
+      TFRT_STAT(0, (long long)ns * __popcll(__ballot(ray_index(0) >= 0)));
       const float4* __restrict__ su = susphere + t0 / SUPER;
       // (a "wholly behind the ray's start" test here, as at level 1, was measured and does not
       // pay: +4 instructions on each of the 83 supercluster tests for ~2 pairs saved per ray)
@@ -1217,7 +1242,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
           shift_in_le(touched[r], fmaf(pa, pa, pb * pb), sp.w);
         }
       };
-      int k = ns - 1;
+      int k = idle_wave ? -1 : ns - 1;   // (wave-uniform)
       for (; k >= 3; k -= 4) {  // four scalar loads in flight
         const float4 s0 = su[k], s1 = su[k - 1], s2 = su[k - 2], s3 = su[k - 3];
         level0(s0);
@@ -1232,8 +1257,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   if (rec_cls == nullptr) {  // several cluster chunks: k_classify3d merges the partial results
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int i = base + r * BLOCK + tid;
-      if (i < n) {
+      const int i = ray_index(r);
+      if (i >= 0) {
         const int slot = r * 64 + lane;
         part_t[blockIdx.y * part_stride + i] = dkey_inv(best_k[wave][slot]);
         part_i[blockIdx.y * part_stride + i] = best_i[wave][slot];
@@ -1246,16 +1271,19 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   __shared__ int wc[WAVES][4];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int i = base + r * BLOCK + tid;
+    const int i = ray_index(r);
     int cls = -1;
-    if (i < n) {
+    if (i >= 0) {
       const int slot = r * 64 + lane;
       const int bi = best_i[wave][slot];
       cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
       rec_tri[i] = bi;
       rec_t[i] = dkey_inv(best_k[wave][slot]);
       rec_cls[i] = (uint8_t)cls;
+      // visiting order: the rays of a wave belong to many 256-slot blocks of the ray block
+      if (ordered) atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
     }
+    if (ordered) break;                // (R == 1; block-uniform)
     if (base + r * BLOCK >= n) break;  // block-uniform: no rays in this 256-ray slice
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1270,6 +1298,349 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------- coherent-wave intersect
+//
+// k_intersect_beam: the same decisions as k_intersect_group for wavefronts whose 64 rays form a
+// narrow bundle.  Rays are visited in a caller-supplied order (tfrt_scene3d.ray_order: a
+// permutation of the source rays that puts rays with neighbouring lines next to each other, e.g.
+// a Hilbert-curve order of their aperture points; later passes visit the children of a wave's
+// rays, wherever the stable compaction put them).  Then a wave shares ONE walk of the hierarchy:
+//
+//   bundle     axis (o, w) = mean start / mean direction of the wave's rays; every point of every
+//              ray's line at axial coordinate t lies within R0 + S |t| of the axis (R0, S: wave
+//              maxima of the lines' offsets and slopes).  A sphere (c, r) can contain a point of
+//              some line only if dist(c, axis) <= r + R0 + S (|t_c| + r)   [triangle inequality]
+//              -- and, from the second pass on, only if t_c + r >= min start coordinate (valid
+//              hits lie ahead of the starts).
+//   levels     LANE = NODE: 64 supercluster / cluster / member spheres per instruction against the
+//              bundle (no per-ray work at all), survivors compacted into the next level's list.
+//   faces      candidate faces (a dozen for a coherent wave) are taken one at a time, LANE = RAY:
+//              the face's float32 record is broadcast from the lane that fetched it (v_readlane:
+//              scalar operands, no per-pair gathers) into the float32 screen (may_hit_core);
+//              survivors queue for the exact float64 decision, one (ray, face) per lane, nearest
+//              hit per ray by 64-bit ds_min -- as in the grouped kernel.
+//
+// Every stage only removes pairs that cannot win (the bundle bounds are inflated well beyond
+// their float32 rounding), so results are bit-identical to k_intersect_group / k_intersect3d.
+// A wave whose rays do NOT form a narrow bundle (directions spread, or more than BEAM_CLIST
+// clusters / BEAM_FLIST faces touched) gives up early, leaves wave_done = 0, and the grouped
+// kernel -- launched behind this one over the same visiting order -- does that wave.
+constexpr int BEAM_SLIST = 64;    // touched superclusters a narrow bundle may have
+constexpr int BEAM_CLIST = 32;    // ... clusters
+constexpr int BEAM_FLIST = 192;   // ... candidate faces
+
+struct Beam {  // wave-uniform
+  float ox, oy, oz, wx, wy, wz, R0, S, tmin;
+};
+
+__device__ __forceinline__ bool beam_touch(const Beam& b, const float4 sp) {
+  // radius from the stored (inflated) r^2, rounded up; padding entries have w < 0: NaN, never true
+  const float r = __builtin_sqrtf(sp.w) * 1.000001f;
+  const float vx = sp.x - b.ox, vy = sp.y - b.oy, vz = sp.z - b.oz;
+  const float t = vx * b.wx + vy * b.wy + vz * b.wz;
+  const float v2 = vx * vx + vy * vy + vz * vz;
+  const float B = r + b.R0 + b.S * (fabsf(t) + r);
+  // (2e-6 v2: ten times the rounding error of v2 - t^2 and of a not exactly unit w)
+  return (v2 - t * t <= B * B + 2e-6f * v2) && !(t + r < b.tmin);
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float bcast_f(float v, int src_lane) {  // src_lane wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_intersect_beam(
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, const int32_t* __restrict__ order_in,
+    const uint8_t* __restrict__ prev_cls, const int32_t* __restrict__ prev_slot,
+    int32_t* __restrict__ order_out, int nq, const float4* __restrict__ susphere,
+    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
+    const float4* __restrict__ crec, const double* __restrict__ fverts,
+    const double* __restrict__ c0, int n_clusters, int n_super, double eps_int, double eps_size,
+    double eps_start, const int32_t* __restrict__ catagory, int32_t* __restrict__ rec_tri,
+    double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls, int32_t* __restrict__ hist,
+    uint8_t* __restrict__ wave_done) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.x * BLOCK + tid;
+  const int qwave = q >> 6;
+  if ((qwave << 6) >= nq) return;  // (whole wave; no block-level synchronisation in this kernel)
+  const int n = *n_ptr;
+
+  // which ray does this lane visit: the source ray order_in[q] in the first pass, afterwards the
+  // child of the ray this lane visited in the previous pass (-1: it has none)
+  int i = -1;
+  if (q < nq) {
+    const int ip = order_in[q];
+    if (prev_cls == nullptr) i = ip;
+    else if (ip >= 0 && prev_cls[ip] == (uint8_t)CLS_ACTIVE) i = prev_slot[ip];
+    if (i >= n) i = -1;
+    if (order_out != nullptr) order_out[q] = i;
+  }
+  const bool live = i >= 0;
+  if (__ballot(live) == 0ull) {  // nothing to do here (and nothing for the grouped kernel either)
+    if (lane == 0) wave_done[qwave] = 1;
+    return;
+  }
+  const int64_t ii = live ? i : 0;
+  using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
+  RT own[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) own[k] = static_cast<RT>(rays[k * stride + ii]);
+  const int skip = (live && last_tri != nullptr) ? last_tri[ii] : -1;
+
+  __shared__ uint16_t slist[WAVES][BEAM_SLIST];
+  __shared__ uint16_t clist[WAVES][BEAM_CLIST];
+  __shared__ uint32_t flist[WAVES][BEAM_FLIST];
+  __shared__ uint8_t x_slot[WAVES][128];
+  __shared__ int32_t x_face[WAVES][128];
+  __shared__ unsigned long long best_k[WAVES][64];
+  __shared__ int32_t best_i[WAVES][64];
+  best_k[wave][lane] = dkey(INFINITY);
+  best_i[wave][lane] = -1;
+
+  // ---- the bundle
+  const double cx = c0[0], cy = c0[1], cz = c0[2];
+  const float cxf = (float)cx, cyf = (float)cy, czf = (float)cz;  // exact: c0 is rounded to float32
+  auto rel = [](const RT v, const double c, const float cf) -> float {
+    if constexpr (sizeof(T) <= 4) return (float)v - cf;
+    else return (float)((double)v - c);
+  };
+  const float sx = rel(own[0], cx, cxf), sy = rel(own[1], cy, cyf), sz = rel(own[2], cz, czf);
+  const float dx = (float)(own[3] - own[0]), dy = (float)(own[4] - own[1]),
+              dz = (float)(own[5] - own[2]);
+  const float len2 = dx * dx + dy * dy + dz * dz;
+  // (a zero-length or non-finite ray can hit nothing: it takes no part and ends up dead)
+  const bool ok = live && len2 > 0.f && len2 < 3.0e38f;
+  const float inv = ok ? 1.0f / __builtin_sqrtf(len2) : 0.f;
+  const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+  const float cnt = wave_sum_f(ok ? 1.f : 0.f);
+  bool narrow = true;
+  Beam bm;
+  bm.ox = bm.oy = bm.oz = bm.wx = bm.wy = bm.wz = bm.R0 = bm.S = 0.f;
+  bm.tmin = -INFINITY;
+  if (cnt > 0.f) {
+    const float swx = wave_sum_f(ok ? ux : 0.f), swy = wave_sum_f(ok ? uy : 0.f),
+                swz = wave_sum_f(ok ? uz : 0.f);
+    const float sox = wave_sum_f(ok ? sx : 0.f), soy = wave_sum_f(ok ? sy : 0.f),
+                soz = wave_sum_f(ok ? sz : 0.f);
+    const float wl2 = swx * swx + swy * swy + swz * swz;
+    narrow = wl2 > 0.49f * cnt * cnt;  // (NaN: false)
+    const float wi = narrow ? 1.0f / __builtin_sqrtf(wl2) : 0.f;
+    bm.wx = swx * wi; bm.wy = swy * wi; bm.wz = swz * wi;
+    bm.ox = sox / cnt; bm.oy = soy / cnt; bm.oz = soz / cnt;
+    const float cosk = ux * bm.wx + uy * bm.wy + uz * bm.wz;
+    if (__any(ok && !(cosk > 0.7f))) narrow = false;
+    const float ic = 1.0f / (ok ? cosk : 1.f);
+    const float mx = (ux - cosk * bm.wx) * ic, my = (uy - cosk * bm.wy) * ic,
+                mz = (uz - cosk * bm.wz) * ic;
+    const float px = sx - bm.ox, py = sy - bm.oy, pz = sz - bm.oz;
+    const float ts = px * bm.wx + py * bm.wy + pz * bm.wz;
+    const float ax = px - ts * bm.wx - ts * mx, ay = py - ts * bm.wy - ts * my,
+                az = pz - ts * bm.wz - ts * mz;
+    const float R0 = wave_max_f(ok ? __builtin_sqrtf(ax * ax + ay * ay + az * az) : 0.f);
+    const float S = wave_max_f(ok ? __builtin_sqrtf(mx * mx + my * my + mz * mz) : 0.f);
+    const float tmin = wave_min_f(ok ? ts : INFINITY);
+    const float Lw = wave_max_f(ok ? fabsf(sx) + fabsf(sy) + fabsf(sz) : 0.f) + fabsf(bm.ox) +
+                     fabsf(bm.oy) + fabsf(bm.oz);
+    // bounds inflated far beyond their float32 rounding (offsets ~ 2^-23 Lw, slopes ~ 2^-23)
+    bm.R0 = R0 * 1.001f + 4e-6f * Lw;
+    bm.S = S * 1.001f + 2e-6f;
+    // (first pass of a trace: sources normally sit outside the scene, nothing lies behind them;
+    // and only while hits must lie ahead of the start: ray_start_epsilion >= 0)
+    if (last_tri != nullptr && eps_start >= 0.0) bm.tmin = tmin - 1e-5f * Lw - 1e-5f * fabsf(tmin);
+    if (!(bm.R0 < 3.0e38f && bm.S < 3.0e38f)) narrow = false;  // (also NaN)
+  }
+
+  // ---- levels: lane = node
+  int ns = 0, nc = 0, nf = 0;
+  if (narrow && cnt > 0.f) {
+    for (int b = 0; b < n_super; b += 64) {
+      const int node = b + lane;
+      bool hit = false;
+      if (node < n_super) hit = beam_touch(bm, susphere[node]);
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int pos = ns + rank_below(m);
+        if (pos < BEAM_SLIST) slist[wave][pos] = (uint16_t)node;
+      }
+      ns += __popcll(m);
+    }
+    narrow = ns <= BEAM_SLIST && n_super <= 65536;
+  }
+  wave_fence();
+  if (narrow && ns > 0) {
+    for (int b = 0; b < ns * SUPER; b += 64) {
+      const int k = b + lane;
+      bool hit = false;
+      int cl = 0;
+      if (k < ns * SUPER) {
+        cl = (int)slist[wave][k >> 3] * SUPER + (k & 7);
+        if (cl < n_clusters) hit = beam_touch(bm, clsphere[cl]);
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int pos = nc + rank_below(m);
+        if (pos < BEAM_CLIST) clist[wave][pos] = (uint16_t)cl;
+      }
+      nc += __popcll(m);
+    }
+    narrow = nc <= BEAM_CLIST && n_clusters <= 65536;
+  }
+  wave_fence();
+  if (narrow && nc > 0) {
+    for (int b = 0; b < nc * CLUSTER; b += 64) {
+      const int k = b + lane;
+      bool hit = false;
+      unsigned slot = 0;
+      if (k < nc * CLUSTER) {
+        slot = (unsigned)clist[wave][k >> 4] * CLUSTER + (unsigned)(k & 15);
+        hit = beam_touch(bm, csphere[slot]);
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int pos = nf + rank_below(m);
+        if (pos < BEAM_FLIST) flist[wave][pos] = slot;
+      }
+      nf += __popcll(m);
+    }
+    narrow = nf <= BEAM_FLIST;
+  }
+  wave_fence();
+  if (!narrow) {  // not a narrow bundle: the grouped kernel does this wave
+    if (lane == 0) wave_done[qwave] = 0;
+    return;
+  }
+
+  // ---- faces: lane = ray
+  const float es_f = (float)eps_size, er_f = (float)eps_start;
+  double best_d = INFINITY;  // this lane's nearest hit so far (refreshed after every decision batch)
+  int xn = 0;                // (ray, face) pairs waiting for the exact test (wave-uniform)
+
+  auto ray_of = [&](const int slot, double s[3], double e[3]) {  // (all lanes active)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s[k] = static_cast<double>(__shfl(own[k], slot, 64));
+      e[k] = static_cast<double>(__shfl(own[3 + k], slot, 64));
+    }
+  };
+  // exact float64 test, one (ray, face) per lane; nearest hit per ray by 64-bit min on an
+  // order-preserving key of ray_u, ties to the lower face index (tf.argmin's first index)
+  auto decide = [&](const int nb) {
+    bool have = false;
+    unsigned long long key = 0, old = 0;
+    int j = -1;
+    const int slot = lane < nb ? (int)x_slot[wave][lane] : 0;
+    double s[3], e[3];
+    ray_of(slot, s, e);
+    if (lane < nb) {
+      j = x_face[wave][lane];
+      old = best_k[wave][slot];
+      double P[9];
+      const double* fp = fverts + 9 * (int64_t)j;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) P[k] = fp[k];
+      const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
+      if (h.valid) {
+        have = true;
+        key = dkey(h.ray_u);
+      }
+    }
+    wave_fence();
+    if (have) atomicMin(&best_k[wave][slot], key);
+    wave_fence();
+    bool win = false;
+    if (have) {
+      const unsigned long long now = best_k[wave][slot];
+      win = key == now;
+      if (win && now < old) best_i[wave][slot] = 0x7FFFFFFF;  // a nearer hit: restart the tie-break
+    }
+    wave_fence();
+    if (win) atomicMin(&best_i[wave][slot], j);
+    wave_fence();
+  };
+
+  for (int f0 = 0; f0 < nf; f0 += 64) {
+    const int nb = min(64, nf - f0);
+    // each lane fetches one candidate's float32 record (P0 - c0 | face index, E1, E2) ...
+    float4 r0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), r1 = r0, r2 = r0;
+    if (lane < nb) {
+      const int64_t memb = (int64_t)flist[wave][f0 + lane];
+      r0 = crec[3 * memb];
+      r1 = crec[3 * memb + 1];
+      r2 = crec[3 * memb + 2];
+    }
+    // ... and hands it to the whole wave when its turn comes
+    for (int c = 0; c < nb; ++c) {
+      const float p0x = bcast_f(r0.x, c), p0y = bcast_f(r0.y, c), p0z = bcast_f(r0.z, c);
+      const int j = __builtin_amdgcn_readlane(__float_as_int(r0.w), c);
+      const float e1x = bcast_f(r1.x, c), e1y = bcast_f(r1.y, c), e1z = bcast_f(r1.z, c);
+      const float e2x = bcast_f(r2.x, c), e2y = bcast_f(r2.y, c), e2z = bcast_f(r2.z, c);
+      bool keep = false;
+      if (ok && j >= 0 && j != skip) {
+        const float tx = sx - p0x, ty = sy - p0y, tz = sz - p0z;
+        // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t scales
+        // with their magnitudes, not with |t|
+        const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(sx) + fabsf(sy) +
+                             fabsf(sz) + fabsf(p0x) + fabsf(p0y) + fabsf(p0z);
+        keep = may_hit_core(dx, dy, dz, e1x, e1y, e1z, e2x, e2y, e2z, tx, ty, tz, nt_err, es_f,
+                            er_f, best_d);
+      }
+      const unsigned long long km = __ballot(keep);
+      if (keep) {
+        const int pos = xn + rank_below(km);
+        x_slot[wave][pos] = (uint8_t)lane;
+        x_face[wave][pos] = j;
+      }
+      xn += __popcll(km);
+      if (xn >= 64) {
+        wave_fence();
+        decide(64);
+        int ts = 0, tf = 0;  // fewer than 64 remain: move them to the front
+        if (lane < xn - 64) {
+          ts = x_slot[wave][64 + lane];
+          tf = x_face[wave][64 + lane];
+        }
+        wave_fence();
+        if (lane < xn - 64) {
+          x_slot[wave][lane] = (uint8_t)ts;
+          x_face[wave][lane] = tf;
+        }
+        xn -= 64;
+        best_d = dkey_inv(best_k[wave][lane]);
+        wave_fence();
+      }
+    }
+  }
+  wave_fence();
+  if (xn > 0) decide(xn);
+
+  // ---- hit record, class and the class histogram of the ray's 256-slot block (react's scan)
+  if (live) {
+    const int bi = best_i[wave][lane];
+    const int cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
+    rec_tri[i] = bi;
+    rec_t[i] = dkey_inv(best_k[wave][lane]);
+    rec_cls[i] = (uint8_t)cls;
+    atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
+  }
+  if (lane == 0) wave_done[qwave] = 1;
 }
 
 // -------------------------------------------------------------------------- classify
@@ -1448,6 +1819,9 @@ struct SelfScan {
   int32_t* n_next = nullptr;             // ray count of the next pass
   unsigned long long* n_tests = nullptr;
   int M = 0;
+  // visiting-order traces: the class histogram of the NEXT pass (the intersect kernels add into
+  // it with atomics); every block clears its own row here, one pass ahead
+  int32_t* hist_next = nullptr;
 };
 
 template <typename T>
@@ -1480,6 +1854,7 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
     if (threadIdx.x == 0) *ss.n_next = 0;
   }
   if (base >= n) return;
+  if (ss.hist_next != nullptr && threadIdx.x < 4) ss.hist_next[blockIdx.x * 4 + threadIdx.x] = 0;
   const int i = base + threadIdx.x;
   const int cls = (i < n) ? (int)rec_cls[i] : -1;
 
@@ -2034,7 +2409,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec;
+  size_t csphere, cface, clsphere, susphere, crec, order_a, order_b, hist_a, hist_b, wave_done;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -2066,6 +2441,13 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.clsphere = take(ncl * sizeof(float4));
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
+  // visiting-order traces (tfrt_scene3d.ray_order): the order of two consecutive passes, two
+  // class histograms (one being read, one being built), one flag per wavefront
+  L.order_a = take(n * sizeof(int32_t));
+  L.order_b = take(n * sizeof(int32_t));
+  L.hist_a = take((size_t)pl.nblk * 4 * sizeof(int32_t));
+  L.hist_b = take((size_t)pl.nblk * 4 * sizeof(int32_t));
+  L.wave_done = take((n + 63) / 64);
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -2102,6 +2484,18 @@ struct Classify3 {
   int32_t* blockcnt = nullptr;
 };
 
+// Visiting-order trace (tfrt_scene3d.ray_order): what the two intersect kernels of a pass need.
+struct Ordered3 {
+  const int32_t* order_in = nullptr;   // pass 0: the caller's ray order; later: previous pass's
+  const uint8_t* prev_cls = nullptr;   // previous pass's class / child slot records (pass > 0)
+  const int32_t* prev_slot = nullptr;
+  int32_t* order_cur = nullptr;        // this pass's order (written by k_intersect_beam)
+  int nq = 0;                          // slots of the order (= source rays)
+  int32_t* hist = nullptr;             // class histogram of this pass (atomics)
+  uint8_t* wave_done = nullptr;
+  int n_super = 0;
+};
+
 template <typename T>
 static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int64_t stride,
                             const int32_t* n_ptr, const int32_t* last_tri, const float4* sphere,
@@ -2109,7 +2503,7 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                             int M, double ei, double es, double er, double* part_t,
                             int32_t* part_i, int64_t part_stride, const Accel3* ac,
                             bool prep_ready = false, const Classify3* classify = nullptr,
-                            bool* classified = nullptr) {
+                            bool* classified = nullptr, const Ordered3* od = nullptr) {
   const bool grouped = ac != nullptr && ac->order != nullptr;
   Classify3 fz;
   if (grouped && pl.g_chunks == 1 && classify != nullptr && classify->rec_cls != nullptr)
@@ -2130,6 +2524,19 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     rec.n_faces = M;
     (void)hipEventRecord(rec.a, st);
   }
+  if (grouped && od != nullptr) {
+    // coherent wavefronts first; the grouped kernel then does the wavefronts that were not
+    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, BLOCK)), dim3(BLOCK), 0, st, rays,
+                       stride, n_ptr, last_tri, od->order_in, od->prev_cls, od->prev_slot,
+                       od->order_cur, od->nq, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
+                       fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
+                       fz.rec_tri, fz.rec_t, fz.rec_cls, od->hist, od->wave_done);
+    grid = dim3(cdiv(od->nq, BLOCK), 1);
+  }
+  const int32_t* g_order = od != nullptr ? od->order_cur : nullptr;
+  const int g_nq = od != nullptr ? od->nq : 0;
+  const uint8_t* g_done = od != nullptr ? od->wave_done : nullptr;
+  int32_t* g_hist = od != nullptr ? od->hist : nullptr;
 #define TFRT_LAUNCH_R(RR)                                                                      \
   if (grouped)                                                                                 \
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
@@ -2137,7 +2544,8 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        ac->cface, fverts, c0, prep_inline ? nullptr : prep, pstride,           \
                        ac->n_clusters,                                                         \
                        pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride,           \
-                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt);            \
+                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt, g_order,    \
+                       g_nq, g_done, g_hist);                                                  \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
@@ -2171,7 +2579,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                              int32_t* unfinished_id, int32_t* counts, void* workspace,
                              size_t workspace_bytes, hipStream_t st) {
   const int M = (int)sc->n_faces;
-  const Plan3 pl = make_plan(N, M);
+  Plan3 pl = make_plan(N, M);
   const Layout3 lay = make_layout(N, M, P, dtype, pl);
   if (workspace_bytes < lay.total) return TFRT_E_WORKSPACE;
   char* ws = static_cast<char*>(workspace);
@@ -2206,6 +2614,19 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   ac.clsphere = reinterpret_cast<float4*>(ws + lay.clsphere);
   ac.susphere = reinterpret_cast<float4*>(ws + lay.susphere);
   ac.crec = reinterpret_cast<float4*>(ws + lay.crec);
+  // Visiting order: rays are visited in the caller's coherent order (coherent wavefronts take
+  // k_intersect_beam's shared walk); one cluster chunk, classification in the kernels' epilogues
+  const bool visiting = sc->ray_order != nullptr && ac.order != nullptr && N >= 64;
+  int32_t* order_ab[2] = {reinterpret_cast<int32_t*>(ws + lay.order_a),
+                          reinterpret_cast<int32_t*>(ws + lay.order_b)};
+  int32_t* hist_ab[2] = {reinterpret_cast<int32_t*>(ws + lay.hist_a),
+                         reinterpret_cast<int32_t*>(ws + lay.hist_b)};
+  if (visiting) {
+    pl.gR = 1;
+    pl.g_blocks = cdiv(N, (int64_t)BLOCK);
+    pl.g_chunks = 1;
+    pl.g_chunk_clusters = (ac.n_clusters + 7) / 8 * 8;
+  }
   if (M > 0) {
     if (ac.order != nullptr) {  // (the hierarchy kernel also does k_center's work)
       const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
@@ -2213,7 +2634,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
-                         (int)N, tail, ticket);
+                         (int)N, tail, ticket, hist_ab[0], visiting ? pl.nblk * 4 : 0);
     } else {
       hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
                          (int)N, tail, ticket);
@@ -2236,19 +2657,34 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     fz.rec_cls = rec_cls + (size_t)p * n;
     fz.blockcnt = blockcnt;
     bool classified = false;
+    Ordered3 od;
+    if (visiting) {
+      od.order_in = p == 0 ? sc->ray_order : order_ab[(p - 1) & 1];
+      od.prev_cls = p == 0 ? nullptr : rec_cls + (size_t)(p - 1) * n;
+      od.prev_slot = p == 0 ? nullptr : rec_slot + (size_t)(p - 1) * n;
+      od.order_cur = order_ab[p & 1];
+      od.nq = (int)N;
+      od.hist = hist_ab[p & 1];
+      od.wave_done = reinterpret_cast<uint8_t*>(ws + lay.wave_done);
+      od.n_super = cdiv(ac.n_clusters, SUPER);
+      fz.blockcnt = od.hist;
+    }
     if (launch_intersect<T>(pl, st, rin, sin, nrays + p, ltin, sphere, sc->face_verts, c0, prep,
                             (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion,
                             sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac,
-                            /*prep_ready=*/p > 0, &fz, &classified) != 0)
+                            /*prep_ready=*/p > 0, &fz, &classified,
+                            visiting ? &od : nullptr) != 0)
       return TFRT_E_LAUNCH;
+    int32_t* blockcnt_p = visiting ? od.hist : blockcnt;
     if (!classified)
       hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, chunks_used,
                          part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
-                         rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt);
+                         rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt_p);
     const bool grid_scan = pl.nblk >= SCAN_GRID_MIN_ROWS;
     SelfScan ss;
+    if (visiting) ss.hist_next = hist_ab[(p + 1) & 1];
     if (pl.nblk <= SELF_SCAN_MAX_BLOCKS) {
-      ss.blockcnt = blockcnt;
+      ss.blockcnt = blockcnt_p;
       ss.prev_counts = p > 0 ? counts + (size_t)(p - 1) * TFRT_COUNTS_PER_PASS : nullptr;
       ss.counts_row = counts + (size_t)p * TFRT_COUNTS_PER_PASS;
       ss.totals = tail;
@@ -2257,11 +2693,11 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       ss.M = M;
     } else if (grid_scan)
       hipLaunchKernelGGL(k_scan3d, dim3(cdiv(pl.nblk, 1024)), dim3(1024), 0, st, nrays + p,
-                         blockcnt, blockoff, rowtot, rowbase, ticket,
+                         blockcnt_p, blockoff, rowtot, rowbase, ticket,
                          counts + (size_t)p * TFRT_COUNTS_PER_PASS, tail, nrays + p + 1,
                          reinterpret_cast<unsigned long long*>(tail + 4), M);
     else
-      hipLaunchKernelGGL(k_scan3d_one, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt, blockoff,
+      hipLaunchKernelGGL(k_scan3d_one, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt_p, blockoff,
                          counts + (size_t)p * TFRT_COUNTS_PER_PASS, tail, nrays + p + 1,
                          reinterpret_cast<unsigned long long*>(tail + 4), M);
     hipLaunchKernelGGL((k_react3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,

@@ -563,7 +563,7 @@ class OpticalEngine:
                  dead_ray_length=None, compile_geometry_specific_result=False,
                  new_ray_length=1.0, simple_ray_inheritance={"wavelength"}, ray_dtype=None,
                  ray_shard="auto", accelerate="auto", deterministic=False,
-                 finite_tir_gradient=False):
+                 finite_tir_gradient=False, coherent="auto"):
         if dimension not in (2, 3):
             raise ValueError(f"RayEngine: dimension must be 2 or 3, but was given {dimension}.")
         self._dimension = dimension
@@ -597,6 +597,15 @@ class OpticalEngine:
         # integers): gradients are bit-identical from run to run (tfrt_scene3d.deterministic);
         # default False: float64 atomics, whose last bits depend on the arrival order.
         self.deterministic = bool(deterministic)
+        # 3-D hierarchy mode: visit the rays in a coherent order (ops.ray_order: a Hilbert-curve order
+        # of their lines, computed once per source on the device) so that wavefronts of 64
+        # neighbouring rays share one walk of the face hierarchy.  Only the visiting order changes:
+        # every output keeps the reference's order.  "auto" (default): from the second trace of
+        # the same source rays on (a static source in an optimisation loop pays the sort once; a
+        # source that changes every step never does); True: always; False: never.
+        if coherent not in ("auto", True, False):
+            raise ValueError(f"OpticalEngine: coherent must be 'auto', True or False, got {coherent!r}")
+        self.coherent = coherent
         # 2-D only.  False (default, the reference): a totally reflected ray has a NaN gradient
         # (tf.asin in the unselected tf.where branch, geometry.py:640-646) which poisons every
         # boundary entry it touched; SGD_Optimizer zeroes those (optimizer.py:226-229).  True:
@@ -826,9 +835,11 @@ class OpticalEngine:
         # while the caller hands in the very same tensors (static sources between steps)
         key = tuple((id(rays[f]), rays[f]._version) for f in geo) + (dt,)
         cache = getattr(self, "_input_cache", None)
+        repeated = False
         if (cache is not None and cache[0] == key
                 and not any(rays[f].requires_grad for f in geo)):
             block = cache[1]
+            repeated = True
         else:
             block = torch.stack([rays[f] for f in geo]).to(dt)
             self._input_cache = (key, block, [rays[f] for f in geo])
@@ -850,6 +861,7 @@ class OpticalEngine:
         if self.dimension == 3:
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       deterministic=self.deterministic)
+            scene.ray_order = self._ray_order(block, key, repeated, mode, system)
         else:
             scene = system.scene_args(n_table, index_mode, ghost,
                                       finite_tir_gradient=self.finite_tir_gradient)
@@ -859,6 +871,22 @@ class OpticalEngine:
             if fv is None:
                 fv = torch.zeros((0, 9), dtype=torch.float64, device=block.device)
         return block, scene, fv
+
+    def _ray_order(self, block, key, repeated, mode, system):
+        """The coherent visiting order of the source block (see ``coherent``), cached with it."""
+        if (mode == "all-pairs" or self.coherent is False or block.shape[1] < 4096
+                or not block.is_cuda):
+            return None
+        cached = getattr(self, "_order_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if self.coherent == "auto" and not repeated:
+            return None
+        fv = system._merged_face_verts
+        centre = fv.detach().reshape(-1, 3).mean(dim=0) if fv is not None and fv.shape[0] else None
+        order = ops.ray_order(block, centre)
+        self._order_cache = (key, order)
+        return order
 
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""

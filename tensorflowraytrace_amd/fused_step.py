@@ -394,7 +394,8 @@ class FusedStep:
                 tuple(id(src[f]) for f in _GEO3) if src else (), int(opt.trace_depth),
                 eng._flags(), eng.new_ray_length, eng.dead_ray_length, eng._trace_mode(),
                 id(opt.error_function), id(opt.error_function.goal), opt.error_function.fields,
-                tdist.world_size(), eng.optical_system.scene_signature(), bool(eng.deterministic))
+                tdist.world_size(), eng.optical_system.scene_signature(), bool(eng.deterministic),
+                id((getattr(eng, "_order_cache", None) or (None, None))[1]))
 
     def step(self, accumulators, lr_scale):
         """One optimiser step.  Returns the error tensor {sum, n_terms, mean} (device)."""

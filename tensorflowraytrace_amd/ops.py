@@ -318,7 +318,7 @@ class Scene3DArgs:
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
                  ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None,
-                 deterministic=False):
+                 deterministic=False, ray_order=None):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -329,6 +329,9 @@ class Scene3DArgs:
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
         self.deterministic = bool(deterministic)               # ordered reverse-sweep sums
+        # (N) int32 or None: a coherent visiting order of the SOURCE rays (see ray_order());
+        # may be reassigned between traces (it belongs to the source, not to the boundaries)
+        self.ray_order = ray_order
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -338,6 +341,7 @@ class Scene3DArgs:
             # every other field points at tensors this object owns: only the face pointer moves
             sc = cached[1]
             sc.face_verts = face_verts.data_ptr() if M else None
+            sc.ray_order = self._ray_order_ptr()
             return sc
         sc = Scene3D()
         sc.face_verts = face_verts.data_ptr() if M else None
@@ -361,8 +365,17 @@ class Scene3DArgs:
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
         sc.reserved0 = 0
         sc.deterministic = 1 if self.deterministic else 0
+        sc.ray_order = self._ray_order_ptr()
         self._struct_cache = (M, sc)
         return sc
+
+    def _ray_order_ptr(self):
+        ro = self.ray_order
+        if ro is None:
+            return None
+        if ro.dtype != torch.int32 or not ro.is_contiguous() or not ro.is_cuda:
+            raise TfrtError("ray_order must be a contiguous int32 tensor on the GPU")
+        return ro.data_ptr()
 
 
 class TraceTape:
@@ -496,6 +509,8 @@ class _Trace3D(torch.autograd.Function):
         dead = alloc(_lib.COMPILE_DEAD, capN)
         unf = torch.empty((6, capN), dtype=src.dtype, device=dev)
         unf_id = ints.take(capN)
+        if scene.ray_order is not None and scene.ray_order.numel() != N:
+            raise TfrtError(f"ray_order has {scene.ray_order.numel()} entries for {N} rays")
         sc = scene.struct(face_verts)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace3d_forward(
@@ -671,6 +686,80 @@ def intersect3d(rays, face_verts, intersect_epsilion=1e-10, size_epsilion=1e-10,
         _p(x), _p(y), _p(z), _p(valid), _p(ray_u), _p(trig_u), _p(trig_v), _p(gather),
         _p(ws), wsb, _stream(rays)), "tfrt_intersect3d")
     return x, y, z, valid.bool(), ray_u, trig_u, trig_v, gather
+
+
+def hilbert_key(x, y, bits=16):
+    """Index along the Hilbert curve of the integer grid points (x, y), 0 <= x, y < 2**bits
+    (int64 tensors).  Unlike a Morton code the curve has no jumps: points with neighbouring
+    indices are neighbouring cells."""
+    x, y = x.clone(), y.clone()
+    d = torch.zeros_like(x)
+    n = 1 << bits
+    s = n >> 1
+    while s > 0:
+        rx = ((x & s) > 0).to(torch.int64)
+        ry = ((y & s) > 0).to(torch.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        swap = ry == 0
+        flip = swap & (rx == 1)
+        x = torch.where(flip, n - 1 - x, x)
+        y = torch.where(flip, n - 1 - y, y)
+        x, y = torch.where(swap, y, x), torch.where(swap, x, y)
+        s >>= 1
+    return d
+
+
+def ray_order(rays, centre=None):
+    """A coherent visiting order of the rays of a (6, N) block: int32 permutation in which rays
+    whose lines run close together are neighbours, so that 64 consecutive entries form a narrow
+    bundle.  Pass it as ``Scene3DArgs.ray_order`` / ``tfrt_scene3d.ray_order``: the trace visits
+    rays in this order and coherent wavefronts share one walk of the face hierarchy
+    (k_intersect_beam); results do not depend on it.
+
+    Rays that mostly share a direction are ordered along a Hilbert curve through the points where
+    their lines pass ``centre`` (default: the mean of their end points), in the plane perpendicular
+    to the mean direction; a bundle without a common direction (an isotropic point source) along a
+    Hilbert curve over the octahedral map of the directions.  Device-side torch ops, O(N log N)
+    once per source."""
+    r = rays.detach().to(torch.float64)
+    s, e = r[:3], r[3:]
+    d = e - s
+    length = torch.linalg.norm(d, dim=0)
+    good = torch.isfinite(length) & (length > 0)
+    u = torch.where(good, d / torch.clamp(length, min=1e-300), torch.zeros_like(d))
+    n_good = torch.clamp(good.sum(), min=1)
+    w = u.sum(dim=1)
+    wl = torch.linalg.norm(w)
+    if centre is None:
+        centre = torch.where(good, e, torch.zeros_like(e)).sum(dim=1) / n_good
+    centre = torch.as_tensor(centre, dtype=torch.float64, device=r.device).reshape(3, 1)
+    if float(wl) > 0.5 * float(n_good):
+        w = (w / wl).reshape(3, 1)
+        # foot of the perpendicular from the centre to every line, in a basis (a, b) _|_ w
+        p = s + ((centre - s) * u).sum(dim=0, keepdim=True) * u - centre
+        k = int(torch.argmin(w.abs().reshape(-1)))
+        ek = torch.zeros(3, 1, dtype=torch.float64, device=r.device)
+        ek[k] = 1.0
+        a = torch.linalg.cross(w, ek, dim=0)
+        a = a / torch.linalg.norm(a)
+        b = torch.linalg.cross(w, a, dim=0)
+        x, y = (p * a).sum(dim=0), (p * b).sum(dim=0)
+    else:
+        # octahedral map of the unit directions onto [-1, 1]^2
+        l1 = torch.clamp(u.abs().sum(dim=0), min=1e-300)
+        ox, oy, oz = u[0] / l1, u[1] / l1, u[2] / l1
+        fx = torch.where(oz < 0, (1 - oy.abs()) * torch.sign(ox + 1e-300), ox)
+        fy = torch.where(oz < 0, (1 - ox.abs()) * torch.sign(oy + 1e-300), oy)
+        x, y = fx, fy
+
+    def grid(v):
+        v = torch.where(good & torch.isfinite(v), v, torch.zeros_like(v))
+        lo, hi = v.min(), v.max()
+        return ((v - lo) / torch.clamp(hi - lo, min=1e-300) * 65535.0).clamp(0, 65535).to(torch.int64)
+
+    key = hilbert_key(grid(x), grid(y))
+    key = torch.where(good, key, torch.full_like(key, 1 << 40))     # rays that can hit nothing: last
+    return torch.argsort(key, stable=True).to(torch.int32).contiguous()
 
 
 def morton_order(face_verts):

@@ -515,3 +515,92 @@ def test_ordered_reverse_sweep_is_bit_reproducible_and_agrees_with_the_atomic_on
     for a, b in zip(runs[0], ref):
         assert float((a - b).abs().max()) <= 1e-10 * float(b.abs().max())
         assert float(b.abs().max()) > 0
+
+
+# --------------------------------------------------------------------------------------------
+# Visiting order (tfrt_scene3d.ray_order): coherent wavefronts share one walk of the hierarchy
+# (k_intersect_beam), the others take the per-ray walk (k_intersect_group) -- only the order in
+# which rays are VISITED changes, never an output.
+
+def _orders(src):
+    from tensorflowraytrace_amd import ops
+    n = src.shape[1]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    return {
+        "hilbert": ops.ray_order(src),                                   # coherent: the beam kernel
+        "random": torch.randperm(n, generator=g).int().to(src.device),   # incoherent: every wave falls back
+        "identity": torch.arange(n, dtype=torch.int32, device=src.device),
+    }
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n_rays,k_front", [(20000, 12), (70000, 20)])
+def test_visiting_order_changes_no_output(dtype, n_rays, k_front):
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(n_rays, k_front=k_front, k_back=6)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster="group")
+    assert sc.ray_order is None
+    ref = ops.trace3d(src, fv, sc, max_passes=4, flags=flags)
+
+    def loss(o):
+        fin = o["finished"]
+        goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fin.device)[o["finished_id"].long()]
+        return ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
+    g_ref = torch.autograd.grad(loss(ref), [p_f, p_b])
+    for name, order in _orders(src).items():
+        sc.ray_order = order
+        out = ops.trace3d(src, fv, sc, max_passes=4, flags=flags)
+        assert np.array_equal(out["counts"], ref["counts"]), name
+        assert out["n_tests"] == ref["n_tests"], name
+        for cls in ("finished", "active", "dead", "stopped", "unfinished"):
+            assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), (name, cls)
+            if cls != "unfinished":
+                assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), (name, cls)
+            assert torch.equal(out[cls], ref[cls]), (name, cls)          # every bit
+        g = torch.autograd.grad(loss(out), [p_f, p_b])
+        for a, b in zip(g, g_ref):                                       # (same tape; sums reordered)
+            assert float((a - b).abs().max() / b.abs().max()) < 1e-11, name
+    sc.ray_order = None
+
+
+def test_visiting_order_on_adversarial_soups():
+    """Random triangle soups, random rays (no coherence at all, grazing rays, ties, stops): any
+    visiting order gives the all-pairs result bit for bit, holes (rays without children) included."""
+    from tensorflowraytrace_amd import ops, _lib
+    import test_gpu_stress as st
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    for seed in (35, 2, 16, 25, 7):
+        sc0 = st._soup(seed)
+        fv = sc0["P"].to(DEV)
+        rays = sc0["rays"].to(DEV)
+        if rays.shape[1] < 64:
+            continue
+        base = dict(n_in=sc0["n_in"].to(DEV), n_out=sc0["n_out"].to(DEV))
+        plain = ops.Scene3DArgs(fv, sc0["cat"].int().to(DEV), **base)
+        ref = ops.trace3d(rays, fv, plain, max_passes=4, flags=flags, new_ray_length=sc0["L"])
+        for name, order in _orders(rays).items():
+            args = ops.Scene3DArgs(fv, sc0["cat"].int().to(DEV), cluster_order=ops.cluster_order(fv),
+                                   ray_order=order, **base)
+            out = ops.trace3d(rays, fv, args, max_passes=4, flags=flags, new_ray_length=sc0["L"])
+            for cls in ("finished", "active", "dead", "stopped", "unfinished"):
+                assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), (seed, name, cls)
+                assert torch.equal(out[cls], ref[cls]), (seed, name, cls)
+
+
+def test_engine_coherent_order_is_invisible():
+    """OpticalEngine(coherent=True / 'auto' / False): same ray sets through the public API; 'auto'
+    starts using the order at the second trace of the same source rays."""
+    import bench
+    outs = {}
+    for mode in (False, True, "auto"):
+        eng, system, params = bench.build_scene(60_000, 20, 6, torch.float32)
+        eng.coherent = mode
+        eng.ray_trace(3)
+        used = [getattr(eng, "_order_cache", None) is not None]
+        eng.ray_trace(3)
+        used.append(getattr(eng, "_order_cache", None) is not None)
+        assert used == {False: [False, False], True: [True, True], "auto": [False, True]}[mode]
+        fin = eng.finished_rays
+        outs[mode] = torch.stack([fin[f] for f in ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")])
+    assert torch.equal(outs[True], outs[False]) and torch.equal(outs["auto"], outs[False])
