@@ -182,13 +182,18 @@ typedef struct tfrt_scene3d {
    * hence order-independent), then converted back: bit-identical results on every run, at a
    * resolution of 2^-40 of the pass's largest term. */
   int32_t deterministic;
-  /* (n_rays) i32, optional, with cluster_order: a permutation of the source rays in which rays
-   * whose lines run close together are neighbours (e.g. a Hilbert-curve order of their aperture
-   * points).  The trace then visits rays in this order -- later passes visit the children of a
-   * wavefront's rays -- and a wavefront whose 64 rays form a narrow bundle walks the hierarchy
-   * ONCE for all of them (k_intersect_beam); other wavefronts take the per-ray walk.  Only the
-   * visiting order changes: every output (sets, order, hit faces, coordinates) is identical. */
-  const int32_t* ray_order;
+  /* Optional, with cluster_order: the source rays once more, as n_rays RECORDS in a coherent
+   * visiting order -- rays whose lines run close together are neighbours (e.g. a Hilbert-curve
+   * order of their aperture points):
+   *     float32 / float16 ray state:  { float  start[3], end[3]; int32 index; int32 -1; }    32 B
+   *     float64 ray state:            { double start[3], end[3]; int32 index; int32 -1; int32 0, 0; } 64 B
+   * record q holds source ray `index` (the values of src_rays[.., index], exactly) and the
+   * indices are a permutation of 0..n_rays-1.  The trace then visits rays in this order -- later
+   * passes visit the children of a wavefront's rays -- and a wavefront whose 64 rays form a
+   * narrow bundle walks the face hierarchy ONCE for all of them (k_intersect_beam); other
+   * wavefronts take the per-ray walk.  Only the visiting order changes: every output (sets,
+   * their order, hit faces, coordinates) is identical with and without it. */
+  const void* visit_records;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in

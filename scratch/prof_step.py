@@ -6,6 +6,7 @@ import bench
 import tfrt.optimizer as optimizer
 N = int(sys.argv[1]); mode = sys.argv[2]; K = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 eng, system, params = bench.build_scene(N, 41, 9, torch.float32)
+if os.environ.get("TFRT_COHERENT"): eng.coherent = {"0": False, "1": True}.get(os.environ["TFRT_COHERENT"], "auto")
 opt = optimizer.SGD_Optimizer(eng, params, bench.make_error_function(), trace_depth=3, learning_rate=1e-6,
                               grad_clip=1e-3, fused=False if mode == "generic" else "auto",
                               graph="auto" if mode == "graph" else False)

@@ -686,6 +686,47 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
   }
 }
 
+// ------------------------------------------------------------------- visiting order
+//
+// A trace with a visiting order (tfrt_scene3d.visit_records) keeps, next to the ray blocks, the
+// rays of the current pass as RECORDS in the order in which the intersect kernels visit them:
+// slot q = {start, end, index of the ray in this pass's ray block (-1: none), face it starts on}.
+// A wavefront reads its 64 records with coalesced loads; k_react3d pushes every child ray to the
+// slot its parent was visited at (the parent's slot comes back through rec_q), so a wavefront keeps
+// visiting the descendants of the same 64 source rays -- neighbours stay neighbours.
+template <typename RT>
+struct VisitRec;
+template <>
+struct __attribute__((aligned(16))) VisitRec<float> {   // 32 B (float32 and float16 ray state)
+  float r[6];
+  int32_t idx, last_tri;
+};
+template <>
+struct __attribute__((aligned(16))) VisitRec<double> {  // 64 B
+  double r[6];
+  int32_t idx, last_tri, pad0, pad1;
+};
+template <typename T>
+using VisitRecOf = VisitRec<std::conditional_t<sizeof(T) <= 4, float, double>>;
+
+template <typename RT>
+__device__ __forceinline__ VisitRec<RT> load_visit(const VisitRec<RT>* __restrict__ v, int64_t q) {
+  VisitRec<RT> out;
+  const float4* src = reinterpret_cast<const float4*>(v + q);
+  float4* dst = reinterpret_cast<float4*>(&out);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(VisitRec<RT>) / 16); ++k) dst[k] = src[k];
+  return out;
+}
+template <typename RT>
+__device__ __forceinline__ void store_visit(VisitRec<RT>* __restrict__ v, int64_t q,
+                                            const VisitRec<RT>& rec) {
+  float4* dst = reinterpret_cast<float4*>(v + q);
+  const float4* src = reinterpret_cast<const float4*>(&rec);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(VisitRec<RT>) / 16); ++k) dst[k] = src[k];
+}
+
 // ---------------------------------------------------------------- grouped intersect
 //
 // Two-level filter in the rays' natural order (no sort).
@@ -757,8 +798,9 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ blockcnt, const int32_t* __restrict__ order, int nq,
-    const uint8_t* __restrict__ wave_done, int32_t* __restrict__ hist) {
+    int32_t* __restrict__ blockcnt, const VisitRecOf<T>* __restrict__ visit, int nq,
+    const uint8_t* __restrict__ wave_done, int32_t* __restrict__ hist,
+    int32_t* __restrict__ rec_q) {
   constexpr int RW = 64 * R;      // rays per wave
 #ifndef TFRT_GROUP_TILE
 #define TFRT_GROUP_TILE 256
@@ -768,10 +810,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   const int base = blockIdx.x * (BLOCK * R);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  // Visiting order (R == 1 only): slot q of the launch visits ray order[q] (-1: none), and only
-  // the wavefronts k_intersect_beam has left (wave_done == 0) are done here.  A wave with nothing
-  // to do still walks the tiles with its block (the staging barriers), without any tests.
-  const bool ordered = order != nullptr;
+  // Visiting order (R == 1 only): slot q of the launch visits the ray of record visit[q], and
+  // only the wavefronts k_intersect_beam has left (wave_done == 0) are done here.  A wave with
+  // nothing to do still walks the tiles with its block (the staging barriers), without any tests.
+  const bool ordered = visit != nullptr;
   bool idle_wave = false;
   if (ordered) {
     if (base >= nq) return;  // block-uniform
@@ -784,12 +826,14 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     return;  // block-uniform
   }
   // ray visited by slot r * 64 + lane of this wave (-1: none)
+  VisitRecOf<T> vrec;
+  vrec.idx = -1;
+  vrec.last_tri = -1;
+  if (ordered && !idle_wave && base + tid < nq) vrec = load_visit(visit, base + tid);
   auto ray_index = [&](const int r) -> int {
     const int qq = base + r * BLOCK + tid;
     if (!ordered) return qq < n ? qq : -1;
-    if (idle_wave || qq >= nq) return -1;
-    const int v = order[qq];
-    return v < n ? v : -1;
+    return vrec.idx < n ? vrec.idx : -1;
   };
   const int c_lo = blockIdx.y * chunk_clusters;
   const int c_hi = min(n_clusters, c_lo + chunk_clusters);
@@ -851,8 +895,13 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
   if constexpr (RAY_SHUFFLE) {
     const int i0 = ray_index(0);
     const int64_t ii = i0 >= 0 ? i0 : 0;
+    if (ordered) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<RT>(rays[q * stride + ii]);
+      for (int q = 0; q < 6; ++q) own_ray[q] = i0 >= 0 ? vrec.r[q] : RT(0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<RT>(rays[q * stride + ii]);
+    }
   }
   // (all lanes active: a lane that is masked off would hand out zeros)
   auto ray_of = [&](const int slot, double s[3], double e[3]) {
@@ -885,9 +934,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
 #pragma unroll
       for (int q = 0; q < 6; ++q) ray_l[wave][q][slot] = rays[q * stride + ii];
 #endif
-      skip_l[wave][slot] = (last_tri != nullptr && i >= 0) ? last_tri[ii] : -1;
+      skip_l[wave][slot] = ordered ? (i >= 0 ? vrec.last_tri : -1)
+                                   : ((last_tri != nullptr && i >= 0) ? last_tri[ii] : -1);
     }
-    if (i >= 0 && prep != nullptr) {
+    if (i >= 0 && prep != nullptr && !ordered) {
       ax[r] = prep[i];
       ay[r] = prep[pstride + i];
       az[r] = prep[2 * pstride + i];
@@ -900,8 +950,20 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       // first pass of a trace: nobody has written the filter state of these rays yet.  Forming
       // it here (k_rayprep's arithmetic, ~60 float64 instructions) saves that kernel's launch,
       // its 32 B per ray written and the same 32 B read back
+      // (visiting order: always -- the ray is in the lane's record, its filter state would be
+      // eight scattered reads)
       double s[3], e[3], u[3], scv[3];
-      load_ray3(rays, stride, i, s, e);
+      if (ordered) {
+        if constexpr (R == 1) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            s[k] = static_cast<double>(vrec.r[k]);
+            e[k] = static_cast<double>(vrec.r[3 + k]);
+          }
+        }
+      } else {
+        load_ray3(rays, stride, i, s, e);
+      }
       float o[8];
       ray_filter_state(s, e, c0, o, u, scv);
       ax[r] = o[0];
@@ -1281,7 +1343,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       rec_t[i] = dkey_inv(best_k[wave][slot]);
       rec_cls[i] = (uint8_t)cls;
       // visiting order: the rays of a wave belong to many 256-slot blocks of the ray block
-      if (ordered) atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
+      if (ordered) {
+        atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
+        rec_q[i] = base + tid;
+      }
     }
     if (ordered) break;                // (R == 1; block-uniform)
     if (base + r * BLOCK >= n) break;  // block-uniform: no rays in this 256-ray slice
@@ -1303,10 +1368,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
 // ------------------------------------------------------------- coherent-wave intersect
 //
 // k_intersect_beam: the same decisions as k_intersect_group for wavefronts whose 64 rays form a
-// narrow bundle.  Rays are visited in a caller-supplied order (tfrt_scene3d.ray_order: a
-// permutation of the source rays that puts rays with neighbouring lines next to each other, e.g.
-// a Hilbert-curve order of their aperture points; later passes visit the children of a wave's
-// rays, wherever the stable compaction put them).  Then a wave shares ONE walk of the hierarchy:
+// narrow bundle.  Rays are visited in a caller-supplied order (tfrt_scene3d.visit_records: the
+// source rays as records in an order that puts rays with neighbouring lines next to each other,
+// e.g. a Hilbert-curve order of their aperture points; later passes visit the children of a
+// wave's rays, see VisitRec).  Then a wave shares ONE walk of the hierarchy:
 //
 //   bundle     axis (o, w) = mean start / mean direction of the wave's rays; every point of every
 //              ray's line at axial coordinate t lies within R0 + S |t| of the axis (R0, S: wave
@@ -1346,70 +1411,89 @@ __device__ __forceinline__ bool beam_touch(const Beam& b, const float4 sp) {
   return (v2 - t * t <= B * B + 2e-6f * v2) && !(t + r < b.tmin);
 }
 
+// Wave-wide reductions with DPP (data-parallel primitives: the operand of a VALU instruction
+// comes from another lane of the row / a neighbouring row): six vector instructions, no trip
+// through the LDS crossbar (ds_bpermute costs an LDS round trip per step).  Every lane must hold
+// a value (the caller substitutes the neutral element).  The result is wave-uniform.
+template <typename Op>
+__device__ __forceinline__ float wave_reduce_f(float v, Op op) {
+  auto dpp = [](float x, auto ctrl, auto row_mask) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x),
+                                                      decltype(ctrl)::value,
+                                                      decltype(row_mask)::value, 0xF, false));
+  };
+  using std::integral_constant;
+  v = op(v, dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{}));   // quad_perm [1,0,3,2]
+  v = op(v, dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{}));   // quad_perm [2,3,0,1]
+  v = op(v, dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{}));  // row_half_mirror
+  v = op(v, dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{}));  // row_mirror
+  // now every lane holds its row's result; fold the four rows into lane 63
+  v = op(v, dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{}));  // row_bcast:15 -> rows 1, 3
+  v = op(v, dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{}));  // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  return wave_reduce_f(v, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
-  return v;
+  return wave_reduce_f(v, [](float a, float b) { return fmaxf(a, b); });
 }
 __device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
-  return v;
+  return wave_reduce_f(v, [](float a, float b) { return fminf(a, b); });
 }
 __device__ __forceinline__ float bcast_f(float v, int src_lane) {  // src_lane wave-uniform
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
+#ifndef TFRT_BEAM_WAVES
+#define TFRT_BEAM_WAVES 0
+#endif
+#if TFRT_BEAM_WAVES > 0
+#define TFRT_BEAM_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_BEAM_WAVES, TFRT_BEAM_WAVES)))
+#else
+#define TFRT_BEAM_ATTR
+#endif
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_intersect_beam(
-    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
-    const int32_t* __restrict__ last_tri, const int32_t* __restrict__ order_in,
-    const uint8_t* __restrict__ prev_cls, const int32_t* __restrict__ prev_slot,
-    int32_t* __restrict__ order_out, int nq, const float4* __restrict__ susphere,
-    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
-    const float4* __restrict__ crec, const double* __restrict__ fverts,
-    const double* __restrict__ c0, int n_clusters, int n_super, double eps_int, double eps_size,
-    double eps_start, const int32_t* __restrict__ catagory, int32_t* __restrict__ rec_tri,
-    double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls, int32_t* __restrict__ hist,
-    uint8_t* __restrict__ wave_done) {
+__global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
+    const int32_t* __restrict__ n_ptr, const VisitRecOf<T>* __restrict__ visit,
+    VisitRecOf<T>* __restrict__ visit_next, int first_pass, int nq,
+    const float4* __restrict__ susphere, const float4* __restrict__ clsphere,
+    const float4* __restrict__ csphere, const float4* __restrict__ crec,
+    const double* __restrict__ fverts, const double* __restrict__ c0, int n_clusters, int n_super,
+    double eps_int, double eps_size, double eps_start, const int32_t* __restrict__ catagory,
+    int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
+    int32_t* __restrict__ rec_q, int32_t* __restrict__ hist, uint8_t* __restrict__ wave_done) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x * BLOCK + tid;
   const int qwave = q >> 6;
   if ((qwave << 6) >= nq) return;  // (whole wave; no block-level synchronisation in this kernel)
   const int n = *n_ptr;
 
-  // which ray does this lane visit: the source ray order_in[q] in the first pass, afterwards the
-  // child of the ray this lane visited in the previous pass (-1: it has none)
-  int i = -1;
+  // this lane's record: one coalesced 32 / 64-byte read
+  using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
+  VisitRec<RT> vrec;
+  vrec.idx = -1;
+  vrec.last_tri = -1;
   if (q < nq) {
-    const int ip = order_in[q];
-    if (prev_cls == nullptr) i = ip;
-    else if (ip >= 0 && prev_cls[ip] == (uint8_t)CLS_ACTIVE) i = prev_slot[ip];
-    if (i >= n) i = -1;
-    if (order_out != nullptr) order_out[q] = i;
+    vrec = load_visit(visit, q);
+    // the slot is empty in the next pass unless k_react3d pushes a child into it
+    if (visit_next != nullptr) visit_next[q].idx = -1;
   }
+  const int i = vrec.idx < n ? vrec.idx : -1;
   const bool live = i >= 0;
   if (__ballot(live) == 0ull) {  // nothing to do here (and nothing for the grouped kernel either)
     if (lane == 0) wave_done[qwave] = 1;
     return;
   }
-  const int64_t ii = live ? i : 0;
-  using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
   RT own[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) own[k] = static_cast<RT>(rays[k * stride + ii]);
-  const int skip = (live && last_tri != nullptr) ? last_tri[ii] : -1;
+  for (int k = 0; k < 6; ++k) own[k] = live ? vrec.r[k] : RT(0);
+  const int skip = live ? vrec.last_tri : -1;
 
   __shared__ uint16_t slist[WAVES][BEAM_SLIST];
   __shared__ uint16_t clist[WAVES][BEAM_CLIST];
   __shared__ uint32_t flist[WAVES][BEAM_FLIST];
-  __shared__ uint8_t x_slot[WAVES][128];
-  __shared__ int32_t x_face[WAVES][128];
+  __shared__ uint32_t x_pair[WAVES][128];  // face << 6 | lane of the ray (faces < 2^24)
   __shared__ unsigned long long best_k[WAVES][64];
   __shared__ int32_t best_i[WAVES][64];
   best_k[wave][lane] = dkey(INFINITY);
@@ -1464,17 +1548,20 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     bm.S = S * 1.001f + 2e-6f;
     // (first pass of a trace: sources normally sit outside the scene, nothing lies behind them;
     // and only while hits must lie ahead of the start: ray_start_epsilion >= 0)
-    if (last_tri != nullptr && eps_start >= 0.0) bm.tmin = tmin - 1e-5f * Lw - 1e-5f * fabsf(tmin);
+    if (!first_pass && eps_start >= 0.0) bm.tmin = tmin - 1e-5f * Lw - 1e-5f * fabsf(tmin);
     if (!(bm.R0 < 3.0e38f && bm.S < 3.0e38f)) narrow = false;  // (also NaN)
   }
 
   // ---- levels: lane = node
   int ns = 0, nc = 0, nf = 0;
   if (narrow && cnt > 0.f) {
+    const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
+    float4 nxt = lane < n_super ? susphere[lane] : never;
     for (int b = 0; b < n_super; b += 64) {
       const int node = b + lane;
-      bool hit = false;
-      if (node < n_super) hit = beam_touch(bm, susphere[node]);
+      const float4 cur = nxt;  // (the next 64 spheres are on their way while these are tested)
+      nxt = node + 64 < n_super ? susphere[node + 64] : never;
+      const bool hit = beam_touch(bm, cur);
       const unsigned long long m = __ballot(hit);
       if (hit) {
         const int pos = ns + rank_below(m);
@@ -1546,11 +1633,12 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     bool have = false;
     unsigned long long key = 0, old = 0;
     int j = -1;
-    const int slot = lane < nb ? (int)x_slot[wave][lane] : 0;
+    const uint32_t xp = lane < nb ? x_pair[wave][lane] : 0u;
+    const int slot = (int)(xp & 63u);
     double s[3], e[3];
     ray_of(slot, s, e);
     if (lane < nb) {
-      j = x_face[wave][lane];
+      j = (int)(xp >> 6);
       old = best_k[wave][slot];
       double P[9];
       const double* fp = fverts + 9 * (int64_t)j;
@@ -1603,25 +1691,15 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
                             er_f, best_d);
       }
       const unsigned long long km = __ballot(keep);
-      if (keep) {
-        const int pos = xn + rank_below(km);
-        x_slot[wave][pos] = (uint8_t)lane;
-        x_face[wave][pos] = j;
-      }
+      if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lane;
       xn += __popcll(km);
       if (xn >= 64) {
         wave_fence();
         decide(64);
-        int ts = 0, tf = 0;  // fewer than 64 remain: move them to the front
-        if (lane < xn - 64) {
-          ts = x_slot[wave][64 + lane];
-          tf = x_face[wave][64 + lane];
-        }
+        uint32_t tp = 0u;  // fewer than 64 remain: move them to the front
+        if (lane < xn - 64) tp = x_pair[wave][64 + lane];
         wave_fence();
-        if (lane < xn - 64) {
-          x_slot[wave][lane] = (uint8_t)ts;
-          x_face[wave][lane] = tf;
-        }
+        if (lane < xn - 64) x_pair[wave][lane] = tp;
         xn -= 64;
         best_d = dkey_inv(best_k[wave][lane]);
         wave_fence();
@@ -1638,6 +1716,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     rec_tri[i] = bi;
     rec_t[i] = dkey_inv(best_k[wave][lane]);
     rec_cls[i] = (uint8_t)cls;
+    rec_q[i] = q;
     atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
   }
   if (lane == 0) wave_done[qwave] = 1;
@@ -1835,7 +1914,8 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
     int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_tri_out,
     int32_t* __restrict__ rec_slot, tfrt_ray_out fin, tfrt_ray_out act, tfrt_ray_out stp,
     tfrt_ray_out dead, int32_t* __restrict__ err, float* __restrict__ prep_next, int64_t pstride,
-    const double* __restrict__ c0, SelfScan ss) {
+    const double* __restrict__ c0, SelfScan ss, VisitRecOf<T>* __restrict__ visit_next,
+    const int32_t* __restrict__ rec_q) {
   const int n = *n_ptr;
   const int base = blockIdx.x * BLOCK;
   // Self-scan mode (few ray blocks): no scan launch ran.  Every block sums the class histograms
@@ -1951,6 +2031,19 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
       ray_id_out[slot] = rid;
       last_tri_out[slot] = tri;
       rec_slot[i] = slot;
+      if (visit_next != nullptr) {
+        // visiting order: the child (AS STORED) goes to the slot its parent was visited at
+        VisitRecOf<T> rec;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          rec.r[k] = static_cast<decltype(rec.r[0] + 0)>(static_cast<T>(h[k]));
+          rec.r[3 + k] = static_cast<decltype(rec.r[0] + 0)>(static_cast<T>(e2[k]));
+        }
+        rec.idx = slot;
+        rec.last_tri = tri;
+        if constexpr (sizeof(rec) == 64) rec.pad0 = rec.pad1 = 0;
+        store_visit(visit_next, (int64_t)rec_q[i], rec);
+      }
       if (prep_next != nullptr) {
         // the child's filter state for the next pass (saves a k_rayprep launch and a re-read of
         // the ray block), from the child AS STORED: the exact tests see the rounded state
@@ -2409,7 +2502,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec, order_a, order_b, hist_a, hist_b, wave_done;
+  size_t csphere, cface, clsphere, susphere, crec, visit_a, visit_b, rec_q, hist_a, hist_b, wave_done;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -2441,10 +2534,12 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.clsphere = take(ncl * sizeof(float4));
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
-  // visiting-order traces (tfrt_scene3d.ray_order): the order of two consecutive passes, two
-  // class histograms (one being read, one being built), one flag per wavefront
-  L.order_a = take(n * sizeof(int32_t));
-  L.order_b = take(n * sizeof(int32_t));
+  // visiting-order traces (tfrt_scene3d.visit_records): the records of two consecutive passes,
+  // each ray's slot in the visiting order, two class histograms (one being read, one being
+  // built), one flag per wavefront
+  L.visit_a = take(n * (dtype == TFRT_F64 ? 64 : 32));
+  L.visit_b = take(n * (dtype == TFRT_F64 ? 64 : 32));
+  L.rec_q = take(n * sizeof(int32_t));
   L.hist_a = take((size_t)pl.nblk * 4 * sizeof(int32_t));
   L.hist_b = take((size_t)pl.nblk * 4 * sizeof(int32_t));
   L.wave_done = take((n + 63) / 64);
@@ -2484,14 +2579,14 @@ struct Classify3 {
   int32_t* blockcnt = nullptr;
 };
 
-// Visiting-order trace (tfrt_scene3d.ray_order): what the two intersect kernels of a pass need.
+// Visiting-order trace (tfrt_scene3d.visit_records): what the two intersect kernels of a pass need.
 struct Ordered3 {
-  const int32_t* order_in = nullptr;   // pass 0: the caller's ray order; later: previous pass's
-  const uint8_t* prev_cls = nullptr;   // previous pass's class / child slot records (pass > 0)
-  const int32_t* prev_slot = nullptr;
-  int32_t* order_cur = nullptr;        // this pass's order (written by k_intersect_beam)
-  int nq = 0;                          // slots of the order (= source rays)
-  int32_t* hist = nullptr;             // class histogram of this pass (atomics)
+  const void* visit = nullptr;       // this pass's records (pass 0: the caller's)
+  void* visit_next = nullptr;        // the next pass's (nullptr after the last pass)
+  int first_pass = 0;
+  int nq = 0;                        // slots of the visiting order (= source rays)
+  int32_t* rec_q = nullptr;          // slot each ray of this pass was visited at
+  int32_t* hist = nullptr;           // class histogram of this pass (atomics)
   uint8_t* wave_done = nullptr;
   int n_super = 0;
 };
@@ -2524,19 +2619,21 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     rec.n_faces = M;
     (void)hipEventRecord(rec.a, st);
   }
+  using VR = VisitRecOf<T>;
   if (grouped && od != nullptr) {
     // coherent wavefronts first; the grouped kernel then does the wavefronts that were not
-    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, BLOCK)), dim3(BLOCK), 0, st, rays,
-                       stride, n_ptr, last_tri, od->order_in, od->prev_cls, od->prev_slot,
-                       od->order_cur, od->nq, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
+    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, BLOCK)), dim3(BLOCK), 0, st, n_ptr,
+                       static_cast<const VR*>(od->visit), static_cast<VR*>(od->visit_next),
+                       od->first_pass, od->nq, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
                        fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
-                       fz.rec_tri, fz.rec_t, fz.rec_cls, od->hist, od->wave_done);
+                       fz.rec_tri, fz.rec_t, fz.rec_cls, od->rec_q, od->hist, od->wave_done);
     grid = dim3(cdiv(od->nq, BLOCK), 1);
   }
-  const int32_t* g_order = od != nullptr ? od->order_cur : nullptr;
+  const VR* g_visit = od != nullptr ? static_cast<const VR*>(od->visit) : nullptr;
   const int g_nq = od != nullptr ? od->nq : 0;
   const uint8_t* g_done = od != nullptr ? od->wave_done : nullptr;
   int32_t* g_hist = od != nullptr ? od->hist : nullptr;
+  int32_t* g_recq = od != nullptr ? od->rec_q : nullptr;
 #define TFRT_LAUNCH_R(RR)                                                                      \
   if (grouped)                                                                                 \
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
@@ -2544,8 +2641,8 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        ac->cface, fverts, c0, prep_inline ? nullptr : prep, pstride,           \
                        ac->n_clusters,                                                         \
                        pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride,           \
-                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt, g_order,    \
-                       g_nq, g_done, g_hist);                                                  \
+                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt, g_visit,    \
+                       g_nq, g_done, g_hist, g_recq);                                          \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
@@ -2616,9 +2713,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   ac.crec = reinterpret_cast<float4*>(ws + lay.crec);
   // Visiting order: rays are visited in the caller's coherent order (coherent wavefronts take
   // k_intersect_beam's shared walk); one cluster chunk, classification in the kernels' epilogues
-  const bool visiting = sc->ray_order != nullptr && ac.order != nullptr && N >= 64;
-  int32_t* order_ab[2] = {reinterpret_cast<int32_t*>(ws + lay.order_a),
-                          reinterpret_cast<int32_t*>(ws + lay.order_b)};
+  const bool visiting = sc->visit_records != nullptr && ac.order != nullptr && N >= 64;
+  void* visit_ab[2] = {ws + lay.visit_a, ws + lay.visit_b};
   int32_t* hist_ab[2] = {reinterpret_cast<int32_t*>(ws + lay.hist_a),
                          reinterpret_cast<int32_t*>(ws + lay.hist_b)};
   if (visiting) {
@@ -2659,10 +2755,10 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     bool classified = false;
     Ordered3 od;
     if (visiting) {
-      od.order_in = p == 0 ? sc->ray_order : order_ab[(p - 1) & 1];
-      od.prev_cls = p == 0 ? nullptr : rec_cls + (size_t)(p - 1) * n;
-      od.prev_slot = p == 0 ? nullptr : rec_slot + (size_t)(p - 1) * n;
-      od.order_cur = order_ab[p & 1];
+      od.visit = p == 0 ? sc->visit_records : visit_ab[(p - 1) & 1];
+      od.visit_next = p + 1 < P ? visit_ab[p & 1] : nullptr;
+      od.first_pass = p == 0;
+      od.rec_q = reinterpret_cast<int32_t*>(ws + lay.rec_q);
       od.nq = (int)N;
       od.hist = hist_ab[p & 1];
       od.wave_done = reinterpret_cast<uint8_t*>(ws + lay.wave_done);
@@ -2708,8 +2804,10 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                        (int64_t)n, rayid + (size_t)p * n, lasttri + (size_t)p * n,
                        rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
                        stp ? *stp : none, dead ? *dead : none, tail + 6,
-                       (p + 1 < P) ? prep : nullptr,
-                       (int64_t)n, c0, ss);
+                       (p + 1 < P && !visiting) ? prep : nullptr,
+                       (int64_t)n, c0, ss,
+                       visiting ? static_cast<VisitRecOf<T>*>(od.visit_next) : nullptr,
+                       visiting ? od.rec_q : nullptr);
   }
   if (unfinished != nullptr && P > 0) {
     hipLaunchKernelGGL((k_copy_rays<T>), dim3(pl.nblk), dim3(BLOCK), 0, st,

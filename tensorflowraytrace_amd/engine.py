@@ -597,7 +597,7 @@ class OpticalEngine:
         # integers): gradients are bit-identical from run to run (tfrt_scene3d.deterministic);
         # default False: float64 atomics, whose last bits depend on the arrival order.
         self.deterministic = bool(deterministic)
-        # 3-D hierarchy mode: visit the rays in a coherent order (ops.ray_order: a Hilbert-curve order
+        # 3-D hierarchy mode: visit the rays in a coherent order (ops.visit_records: a Hilbert-curve order
         # of their lines, computed once per source on the device) so that wavefronts of 64
         # neighbouring rays share one walk of the face hierarchy.  Only the visiting order changes:
         # every output keeps the reference's order.  "auto" (default): from the second trace of
@@ -861,7 +861,7 @@ class OpticalEngine:
         if self.dimension == 3:
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       deterministic=self.deterministic)
-            scene.ray_order = self._ray_order(block, key, repeated, mode, system)
+            scene.visit_records = self._visit_records(block, key, repeated, mode, system)
         else:
             scene = system.scene_args(n_table, index_mode, ghost,
                                       finite_tir_gradient=self.finite_tir_gradient)
@@ -872,8 +872,9 @@ class OpticalEngine:
                 fv = torch.zeros((0, 9), dtype=torch.float64, device=block.device)
         return block, scene, fv
 
-    def _ray_order(self, block, key, repeated, mode, system):
-        """The coherent visiting order of the source block (see ``coherent``), cached with it."""
+    def _visit_records(self, block, key, repeated, mode, system):
+        """The source block as records in a coherent visiting order (see ``coherent``), cached
+        with it."""
         if (mode == "all-pairs" or self.coherent is False or block.shape[1] < 4096
                 or not block.is_cuda):
             return None
@@ -884,9 +885,9 @@ class OpticalEngine:
             return None
         fv = system._merged_face_verts
         centre = fv.detach().reshape(-1, 3).mean(dim=0) if fv is not None and fv.shape[0] else None
-        order = ops.ray_order(block, centre)
-        self._order_cache = (key, order)
-        return order
+        records = ops.visit_records(block, centre=centre)
+        self._order_cache = (key, records)
+        return records
 
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""

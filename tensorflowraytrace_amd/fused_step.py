@@ -268,7 +268,8 @@ class FusedStep:
                 taps = tap_log.get(id(p), [])
                 if not taps:
                     self.untapped = True
-                if capturing and taps:
+                checked = self._tap_checks >= self.graph_warmup and not self.untapped
+                if (capturing or checked) and taps:
                     inputs.extend(taps)
                     owner.extend([i] * len(taps))
                 else:

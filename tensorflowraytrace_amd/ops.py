@@ -318,7 +318,7 @@ class Scene3DArgs:
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
                  ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None,
-                 deterministic=False, ray_order=None):
+                 deterministic=False, visit_records=None):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -329,9 +329,9 @@ class Scene3DArgs:
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
         self.deterministic = bool(deterministic)               # ordered reverse-sweep sums
-        # (N) int32 or None: a coherent visiting order of the SOURCE rays (see ray_order());
+        # None, or the SOURCE rays as records in a coherent visiting order (see visit_records());
         # may be reassigned between traces (it belongs to the source, not to the boundaries)
-        self.ray_order = ray_order
+        self.visit_records = visit_records
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -341,7 +341,7 @@ class Scene3DArgs:
             # every other field points at tensors this object owns: only the face pointer moves
             sc = cached[1]
             sc.face_verts = face_verts.data_ptr() if M else None
-            sc.ray_order = self._ray_order_ptr()
+            sc.visit_records = self._visit_ptr()
             return sc
         sc = Scene3D()
         sc.face_verts = face_verts.data_ptr() if M else None
@@ -365,17 +365,19 @@ class Scene3DArgs:
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
         sc.reserved0 = 0
         sc.deterministic = 1 if self.deterministic else 0
-        sc.ray_order = self._ray_order_ptr()
+        sc.visit_records = self._visit_ptr()
         self._struct_cache = (M, sc)
         return sc
 
-    def _ray_order_ptr(self):
-        ro = self.ray_order
-        if ro is None:
+    def _visit_ptr(self):
+        vr = self.visit_records
+        if vr is None:
             return None
-        if ro.dtype != torch.int32 or not ro.is_contiguous() or not ro.is_cuda:
-            raise TfrtError("ray_order must be a contiguous int32 tensor on the GPU")
-        return ro.data_ptr()
+        if vr.dim() != 2 or vr.shape[1] != 8 or not vr.is_contiguous() or not vr.is_cuda \
+                or vr.dtype not in (torch.float32, torch.float64):
+            raise TfrtError("visit_records must come from ops.visit_records(): (N, 8) float32 / "
+                            "float64, contiguous, on the GPU")
+        return vr.data_ptr()
 
 
 class TraceTape:
@@ -509,8 +511,11 @@ class _Trace3D(torch.autograd.Function):
         dead = alloc(_lib.COMPILE_DEAD, capN)
         unf = torch.empty((6, capN), dtype=src.dtype, device=dev)
         unf_id = ints.take(capN)
-        if scene.ray_order is not None and scene.ray_order.numel() != N:
-            raise TfrtError(f"ray_order has {scene.ray_order.numel()} entries for {N} rays")
+        vr = scene.visit_records
+        if vr is not None and (vr.shape[0] != N or vr.dtype != (
+                torch.float64 if src.dtype == torch.float64 else torch.float32)):
+            raise TfrtError(f"visit_records {tuple(vr.shape)} {vr.dtype} do not belong to a "
+                            f"{src.dtype} block of {N} rays")
         sc = scene.struct(face_verts)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace3d_forward(
@@ -712,9 +717,10 @@ def hilbert_key(x, y, bits=16):
 def ray_order(rays, centre=None):
     """A coherent visiting order of the rays of a (6, N) block: int32 permutation in which rays
     whose lines run close together are neighbours, so that 64 consecutive entries form a narrow
-    bundle.  Pass it as ``Scene3DArgs.ray_order`` / ``tfrt_scene3d.ray_order``: the trace visits
-    rays in this order and coherent wavefronts share one walk of the face hierarchy
-    (k_intersect_beam); results do not depend on it.
+    bundle.  ``visit_records(rays, order)`` turns it into what ``Scene3DArgs.visit_records`` /
+    ``tfrt_scene3d.visit_records`` take: the trace then visits rays in this order and coherent
+    wavefronts share one walk of the face hierarchy (k_intersect_beam); results do not depend
+    on it.
 
     Rays that mostly share a direction are ordered along a Hilbert curve through the points where
     their lines pass ``centre`` (default: the mean of their end points), in the plane perpendicular
@@ -760,6 +766,25 @@ def ray_order(rays, centre=None):
     key = hilbert_key(grid(x), grid(y))
     key = torch.where(good, key, torch.full_like(key, 1 << 40))     # rays that can hit nothing: last
     return torch.argsort(key, stable=True).to(torch.int32).contiguous()
+
+
+def visit_records(rays, order=None, centre=None):
+    """The rays of a (6, N) block as records in the visiting order ``order`` (default:
+    ``ray_order(rays, centre)``), the form ``Scene3DArgs.visit_records`` /
+    ``tfrt_scene3d.visit_records`` takes: (N, 8) float32 (float32 / float16 ray state) or float64,
+    row q = start xyz, end xyz of ray ``order[q]``, then {index, -1} as two int32 (float32: one
+    per column; float64: both in column 6)."""
+    if order is None:
+        order = ray_order(rays, centre)
+    order = order.to(device=rays.device, dtype=torch.int64)
+    dt = torch.float64 if rays.dtype == torch.float64 else torch.float32
+    rec = torch.zeros((rays.shape[1], 8), dtype=dt, device=rays.device)
+    rec[:, :6] = rays.detach()[:, order].t().to(dt)
+    ints = rec.view(torch.int32)
+    at = 6 if dt == torch.float32 else 12
+    ints[:, at] = order.to(torch.int32)
+    ints[:, at + 1] = -1
+    return rec
 
 
 def morton_order(face_verts):

@@ -518,7 +518,7 @@ def test_ordered_reverse_sweep_is_bit_reproducible_and_agrees_with_the_atomic_on
 
 
 # --------------------------------------------------------------------------------------------
-# Visiting order (tfrt_scene3d.ray_order): coherent wavefronts share one walk of the hierarchy
+# Visiting order (tfrt_scene3d.visit_records): coherent wavefronts share one walk of the hierarchy
 # (k_intersect_beam), the others take the per-ray walk (k_intersect_group) -- only the order in
 # which rays are VISITED changes, never an output.
 
@@ -540,16 +540,16 @@ def test_visiting_order_changes_no_output(dtype, n_rays, k_front):
     scene = scene_util.lens_scene(n_rays, k_front=k_front, k_back=6)
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
     src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster="group")
-    assert sc.ray_order is None
+    assert sc.visit_records is None
     ref = ops.trace3d(src, fv, sc, max_passes=4, flags=flags)
 
     def loss(o):
         fin = o["finished"]
         goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fin.device)[o["finished_id"].long()]
         return ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
-    g_ref = torch.autograd.grad(loss(ref), [p_f, p_b])
+    g_ref = torch.autograd.grad(loss(ref), [p_f, p_b], retain_graph=True)
     for name, order in _orders(src).items():
-        sc.ray_order = order
+        sc.visit_records = ops.visit_records(src, order)
         out = ops.trace3d(src, fv, sc, max_passes=4, flags=flags)
         assert np.array_equal(out["counts"], ref["counts"]), name
         assert out["n_tests"] == ref["n_tests"], name
@@ -558,10 +558,10 @@ def test_visiting_order_changes_no_output(dtype, n_rays, k_front):
             if cls != "unfinished":
                 assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), (name, cls)
             assert torch.equal(out[cls], ref[cls]), (name, cls)          # every bit
-        g = torch.autograd.grad(loss(out), [p_f, p_b])
+        g = torch.autograd.grad(loss(out), [p_f, p_b], retain_graph=True)
         for a, b in zip(g, g_ref):                                       # (same tape; sums reordered)
             assert float((a - b).abs().max() / b.abs().max()) < 1e-11, name
-    sc.ray_order = None
+    sc.visit_records = None
 
 
 def test_visiting_order_on_adversarial_soups():
@@ -569,6 +569,7 @@ def test_visiting_order_on_adversarial_soups():
     visiting order gives the all-pairs result bit for bit, holes (rays without children) included."""
     from tensorflowraytrace_amd import ops, _lib
     import test_gpu_stress as st
+    DEV = "cuda:0"
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
     for seed in (35, 2, 16, 25, 7):
         sc0 = st._soup(seed)
@@ -581,7 +582,7 @@ def test_visiting_order_on_adversarial_soups():
         ref = ops.trace3d(rays, fv, plain, max_passes=4, flags=flags, new_ray_length=sc0["L"])
         for name, order in _orders(rays).items():
             args = ops.Scene3DArgs(fv, sc0["cat"].int().to(DEV), cluster_order=ops.cluster_order(fv),
-                                   ray_order=order, **base)
+                                   visit_records=ops.visit_records(rays, order), **base)
             out = ops.trace3d(rays, fv, args, max_passes=4, flags=flags, new_ray_length=sc0["L"])
             for cls in ("finished", "active", "dead", "stopped", "unfinished"):
                 assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), (seed, name, cls)
