@@ -1,0 +1,32 @@
+"""Counters of k_intersect_beam per pass on the bench scene (needs a -DTFRT_TUNING build:
+TFRT_LIB_PATH=scratch/variants_live/lib_tune.so).  Usage: beam_stats.py [rays]"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import numpy as np, torch, bench
+from tensorflowraytrace_amd import _lib
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+eng, system, params = bench.build_scene(N, 41, 9, torch.float32)
+eng.coherent = True
+h = ctypes.CDLL(_lib.LIB_PATH)
+buf = (ctypes.c_ulonglong * 16)()
+prev = np.zeros(16)
+last = np.zeros(16)
+for P in (1, 2, 3):
+    torch.cuda.synchronize(); h.tfrt_debug_group_stats(buf)
+    eng.ray_trace(P); torch.cuda.synchronize()
+    h.tfrt_debug_group_stats(buf)
+    tot = np.array([buf[i] for i in range(16)], dtype=np.float64)
+    whole = tot                             # all P passes of this trace (reading clears the counters)
+    cur = whole - last; last = whole        # its last pass
+    w = max(cur[8], 1)
+    print(f"pass {P}: wavefronts {cur[8]:.0f}, left over {cur[9:13].sum():.0f} (spread {cur[9]:.0f}, supers {cur[10]:.0f}, "
+          f"clusters {cur[11]:.0f}, faces {cur[12]:.0f}); per beam wave: candidate faces {cur[13]/w:.1f}, "
+          f"pairs past the screen {cur[14]/w:.1f}; group kernel: queued clusters {cur[2]:.0f}", flush=True)
+    if cur[9:13].sum() == 1:
+        q0 = int(cur[15])
+        rec = eng._order_cache[1]
+        print("left-over range starts at slot", q0)
+        r = rec[q0 - 8:q0 + 16].cpu()
+        idx = r.view(torch.int32)[:, 6]
+        for k in range(r.shape[0]):
+            print(q0 - 8 + k, int(idx[k]), [round(float(v), 5) for v in r[k, :6]])

@@ -788,8 +788,8 @@ __device__ __forceinline__ void shift_in_le(unsigned& acc, const float q, const 
 #define TFRT_GROUP_ATTR
 #endif
 template <typename T, int R>
-__global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
-    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+__device__ __forceinline__ void group_walk(
+    const T* __restrict__ rays, int64_t stride, const int n,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
     const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
     const float4* __restrict__ crec, const int32_t* __restrict__ cface,
@@ -798,38 +798,29 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ blockcnt, const VisitRecOf<T>* __restrict__ visit, int nq,
-    const uint8_t* __restrict__ wave_done, int32_t* __restrict__ hist,
-    int32_t* __restrict__ rec_q) {
+    int32_t* __restrict__ blockcnt, const VisitRecOf<T>* __restrict__ visit,
+    int32_t* __restrict__ hist, int32_t* __restrict__ rec_q, const int base, const int qwave,
+    const int nq) {
   constexpr int RW = 64 * R;      // rays per wave
 #ifndef TFRT_GROUP_TILE
 #define TFRT_GROUP_TILE 256
 #endif
   constexpr int GT = TFRT_GROUP_TILE;   // cluster spheres per LDS tile
-  const int n = *n_ptr;
-  const int base = blockIdx.x * (BLOCK * R);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  // Visiting order (R == 1 only): slot q of the launch visits the ray of record visit[q], and
-  // only the wavefronts k_intersect_beam has left (wave_done == 0) are done here.  A wave with
-  // nothing to do still walks the tiles with its block (the staging barriers), without any tests.
+  // Visiting order (R == 1 only): this wave does wavefront `qwave` of the visiting order -- one
+  // that k_intersect_beam has left to this kernel -- i.e. the rays of records visit[64 qwave ..].
+  // qwave < 0: nothing; the wave still walks the tiles with its block (the staging barriers),
+  // without any tests.
   const bool ordered = visit != nullptr;
-  bool idle_wave = false;
-  if (ordered) {
-    if (base >= nq) return;  // block-uniform
-    const int w0 = base >> 6;
-    bool any_left = false;
-    for (int w = 0; w < WAVES; ++w) any_left = any_left || (((w0 + w) << 6) < nq && wave_done[w0 + w] == 0);
-    if (!any_left) return;   // block-uniform
-    idle_wave = !((((w0 + wave) << 6) < nq) && wave_done[w0 + wave] == 0);
-  } else if (base >= n) {
-    return;  // block-uniform
-  }
+  const bool idle_wave = ordered && qwave < 0;
+  if (!ordered && base >= n) return;  // block-uniform
   // ray visited by slot r * 64 + lane of this wave (-1: none)
   VisitRecOf<T> vrec;
   vrec.idx = -1;
   vrec.last_tri = -1;
-  if (ordered && !idle_wave && base + tid < nq) vrec = load_visit(visit, base + tid);
+  if (ordered && !idle_wave && qwave * 64 + lane < nq)
+    vrec = load_visit(visit, (int64_t)qwave * 64 + lane);
   auto ray_index = [&](const int r) -> int {
     const int qq = base + r * BLOCK + tid;
     if (!ordered) return qq < n ? qq : -1;
@@ -1345,7 +1336,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       // visiting order: the rays of a wave belong to many 256-slot blocks of the ray block
       if (ordered) {
         atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
-        rec_q[i] = base + tid;
+        rec_q[i] = qwave * 64 + lane;
       }
     }
     if (ordered) break;                // (R == 1; block-uniform)
@@ -1362,6 +1353,42 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
       blockcnt[(blockIdx.x * R + r) * 4 + tid] = sum;
     }
     __syncthreads();
+  }
+}
+
+template <typename T, int R>
+__global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
+    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
+    const float4* __restrict__ crec, const int32_t* __restrict__ cface,
+    const double* __restrict__ fverts, const double* __restrict__ c0,
+    const float* __restrict__ prep, int64_t pstride, int n_clusters, int chunk_clusters,
+    double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
+    int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
+    int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
+    int32_t* __restrict__ blockcnt, const VisitRecOf<T>* __restrict__ visit,
+    const int32_t* __restrict__ left_list, const int32_t* __restrict__ left_count, int nq,
+    int32_t* __restrict__ hist, int32_t* __restrict__ rec_q) {
+  const int n = *n_ptr;
+  if (visit == nullptr) {  // natural order: one workgroup per 256 R rays
+    group_walk<T, R>(rays, stride, n, last_tri, susphere, clsphere, csphere, crec, cface, fverts,
+                     c0, prep, pstride, n_clusters, chunk_clusters, eps_int, eps_size, eps_start,
+                     part_t, part_i, part_stride, catagory, rec_tri, rec_t, rec_cls, blockcnt,
+                     visit, hist, rec_q, (int)blockIdx.x * (BLOCK * R), -1, 0);
+    return;
+  }
+  // visiting order: the wavefronts k_intersect_beam has left (usually none: the workgroups read
+  // one counter and retire), four per workgroup and round
+  const int total = *left_count;
+  for (int item = blockIdx.x; item * WAVES < total; item += gridDim.x) {
+    const int k = item * WAVES + (int)(threadIdx.x >> 6);
+    const int qwave = k < total ? left_list[k] : -1;
+    group_walk<T, R>(rays, stride, n, last_tri, susphere, clsphere, csphere, crec, cface, fverts,
+                     c0, prep, pstride, n_clusters, chunk_clusters, eps_int, eps_size, eps_start,
+                     part_t, part_i, part_stride, catagory, rec_tri, rec_t, rec_cls, blockcnt,
+                     visit, hist, rec_q, 0, qwave, nq);
+    __syncthreads();  // (the next round reuses the LDS tile and lists)
   }
 }
 
@@ -1390,8 +1417,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
 // Every stage only removes pairs that cannot win (the bundle bounds are inflated well beyond
 // their float32 rounding), so results are bit-identical to k_intersect_group / k_intersect3d.
 // A wave whose rays do NOT form a narrow bundle (directions spread, or more than BEAM_CLIST
-// clusters / BEAM_FLIST faces touched) gives up early, leaves wave_done = 0, and the grouped
-// kernel -- launched behind this one over the same visiting order -- does that wave.
+// clusters / BEAM_FLIST faces touched) gives up early and puts itself on the list of wavefronts
+// that the grouped kernel -- launched behind this one -- does.
 constexpr int BEAM_SLIST = 64;    // touched superclusters a narrow bundle may have
 constexpr int BEAM_CLIST = 32;    // ... clusters
 constexpr int BEAM_FLIST = 192;   // ... candidate faces
@@ -1462,7 +1489,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     const double* __restrict__ fverts, const double* __restrict__ c0, int n_clusters, int n_super,
     double eps_int, double eps_size, double eps_start, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ rec_q, int32_t* __restrict__ hist, uint8_t* __restrict__ wave_done) {
+    int32_t* __restrict__ rec_q, int32_t* __restrict__ hist, int32_t* __restrict__ left_list,
+    int32_t* __restrict__ left_count) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x * BLOCK + tid;
   const int qwave = q >> 6;
@@ -1481,10 +1509,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   }
   const int i = vrec.idx < n ? vrec.idx : -1;
   const bool live = i >= 0;
-  if (__ballot(live) == 0ull) {  // nothing to do here (and nothing for the grouped kernel either)
-    if (lane == 0) wave_done[qwave] = 1;
-    return;
-  }
+  if (__ballot(live) == 0ull) return;  // nothing to do here (nor for the grouped kernel)
   RT own[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) own[k] = live ? vrec.r[k] : RT(0);
@@ -1499,7 +1524,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   best_k[wave][lane] = dkey(INFINITY);
   best_i[wave][lane] = -1;
 
-  // ---- the bundle
   const double cx = c0[0], cy = c0[1], cz = c0[2];
   const float cxf = (float)cx, cyf = (float)cy, czf = (float)cz;  // exact: c0 is rounded to float32
   auto rel = [](const RT v, const double c, const float cf) -> float {
@@ -1514,108 +1538,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   const bool ok = live && len2 > 0.f && len2 < 3.0e38f;
   const float inv = ok ? 1.0f / __builtin_sqrtf(len2) : 0.f;
   const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-  const float cnt = wave_sum_f(ok ? 1.f : 0.f);
-  bool narrow = true;
-  Beam bm;
-  bm.ox = bm.oy = bm.oz = bm.wx = bm.wy = bm.wz = bm.R0 = bm.S = 0.f;
-  bm.tmin = -INFINITY;
-  if (cnt > 0.f) {
-    const float swx = wave_sum_f(ok ? ux : 0.f), swy = wave_sum_f(ok ? uy : 0.f),
-                swz = wave_sum_f(ok ? uz : 0.f);
-    const float sox = wave_sum_f(ok ? sx : 0.f), soy = wave_sum_f(ok ? sy : 0.f),
-                soz = wave_sum_f(ok ? sz : 0.f);
-    const float wl2 = swx * swx + swy * swy + swz * swz;
-    narrow = wl2 > 0.49f * cnt * cnt;  // (NaN: false)
-    const float wi = narrow ? 1.0f / __builtin_sqrtf(wl2) : 0.f;
-    bm.wx = swx * wi; bm.wy = swy * wi; bm.wz = swz * wi;
-    bm.ox = sox / cnt; bm.oy = soy / cnt; bm.oz = soz / cnt;
-    const float cosk = ux * bm.wx + uy * bm.wy + uz * bm.wz;
-    if (__any(ok && !(cosk > 0.7f))) narrow = false;
-    const float ic = 1.0f / (ok ? cosk : 1.f);
-    const float mx = (ux - cosk * bm.wx) * ic, my = (uy - cosk * bm.wy) * ic,
-                mz = (uz - cosk * bm.wz) * ic;
-    const float px = sx - bm.ox, py = sy - bm.oy, pz = sz - bm.oz;
-    const float ts = px * bm.wx + py * bm.wy + pz * bm.wz;
-    const float ax = px - ts * bm.wx - ts * mx, ay = py - ts * bm.wy - ts * my,
-                az = pz - ts * bm.wz - ts * mz;
-    const float R0 = wave_max_f(ok ? __builtin_sqrtf(ax * ax + ay * ay + az * az) : 0.f);
-    const float S = wave_max_f(ok ? __builtin_sqrtf(mx * mx + my * my + mz * mz) : 0.f);
-    const float tmin = wave_min_f(ok ? ts : INFINITY);
-    const float Lw = wave_max_f(ok ? fabsf(sx) + fabsf(sy) + fabsf(sz) : 0.f) + fabsf(bm.ox) +
-                     fabsf(bm.oy) + fabsf(bm.oz);
-    // bounds inflated far beyond their float32 rounding (offsets ~ 2^-23 Lw, slopes ~ 2^-23)
-    bm.R0 = R0 * 1.001f + 4e-6f * Lw;
-    bm.S = S * 1.001f + 2e-6f;
-    // (first pass of a trace: sources normally sit outside the scene, nothing lies behind them;
-    // and only while hits must lie ahead of the start: ray_start_epsilion >= 0)
-    if (!first_pass && eps_start >= 0.0) bm.tmin = tmin - 1e-5f * Lw - 1e-5f * fabsf(tmin);
-    if (!(bm.R0 < 3.0e38f && bm.S < 3.0e38f)) narrow = false;  // (also NaN)
-  }
 
-  // ---- levels: lane = node
-  int ns = 0, nc = 0, nf = 0;
-  if (narrow && cnt > 0.f) {
-    const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-    float4 nxt = lane < n_super ? susphere[lane] : never;
-    for (int b = 0; b < n_super; b += 64) {
-      const int node = b + lane;
-      const float4 cur = nxt;  // (the next 64 spheres are on their way while these are tested)
-      nxt = node + 64 < n_super ? susphere[node + 64] : never;
-      const bool hit = beam_touch(bm, cur);
-      const unsigned long long m = __ballot(hit);
-      if (hit) {
-        const int pos = ns + rank_below(m);
-        if (pos < BEAM_SLIST) slist[wave][pos] = (uint16_t)node;
-      }
-      ns += __popcll(m);
-    }
-    narrow = ns <= BEAM_SLIST && n_super <= 65536;
-  }
-  wave_fence();
-  if (narrow && ns > 0) {
-    for (int b = 0; b < ns * SUPER; b += 64) {
-      const int k = b + lane;
-      bool hit = false;
-      int cl = 0;
-      if (k < ns * SUPER) {
-        cl = (int)slist[wave][k >> 3] * SUPER + (k & 7);
-        if (cl < n_clusters) hit = beam_touch(bm, clsphere[cl]);
-      }
-      const unsigned long long m = __ballot(hit);
-      if (hit) {
-        const int pos = nc + rank_below(m);
-        if (pos < BEAM_CLIST) clist[wave][pos] = (uint16_t)cl;
-      }
-      nc += __popcll(m);
-    }
-    narrow = nc <= BEAM_CLIST && n_clusters <= 65536;
-  }
-  wave_fence();
-  if (narrow && nc > 0) {
-    for (int b = 0; b < nc * CLUSTER; b += 64) {
-      const int k = b + lane;
-      bool hit = false;
-      unsigned slot = 0;
-      if (k < nc * CLUSTER) {
-        slot = (unsigned)clist[wave][k >> 4] * CLUSTER + (unsigned)(k & 15);
-        hit = beam_touch(bm, csphere[slot]);
-      }
-      const unsigned long long m = __ballot(hit);
-      if (hit) {
-        const int pos = nf + rank_below(m);
-        if (pos < BEAM_FLIST) flist[wave][pos] = slot;
-      }
-      nf += __popcll(m);
-    }
-    narrow = nf <= BEAM_FLIST;
-  }
-  wave_fence();
-  if (!narrow) {  // not a narrow bundle: the grouped kernel does this wave
-    if (lane == 0) wave_done[qwave] = 0;
-    return;
-  }
-
-  // ---- faces: lane = ray
   const float es_f = (float)eps_size, er_f = (float)eps_start;
   double best_d = INFINITY;  // this lane's nearest hit so far (refreshed after every decision batch)
   int xn = 0;                // (ray, face) pairs waiting for the exact test (wave-uniform)
@@ -1664,47 +1587,202 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     wave_fence();
   };
 
-  for (int f0 = 0; f0 < nf; f0 += 64) {
-    const int nb = min(64, nf - f0);
-    // each lane fetches one candidate's float32 record (P0 - c0 | face index, E1, E2) ...
-    float4 r0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), r1 = r0, r2 = r0;
-    if (lane < nb) {
-      const int64_t memb = (int64_t)flist[wave][f0 + lane];
-      r0 = crec[3 * memb];
-      r1 = crec[3 * memb + 1];
-      r2 = crec[3 * memb + 2];
-    }
-    // ... and hands it to the whole wave when its turn comes
-    for (int c = 0; c < nb; ++c) {
-      const float p0x = bcast_f(r0.x, c), p0y = bcast_f(r0.y, c), p0z = bcast_f(r0.z, c);
-      const int j = __builtin_amdgcn_readlane(__float_as_int(r0.w), c);
-      const float e1x = bcast_f(r1.x, c), e1y = bcast_f(r1.y, c), e1z = bcast_f(r1.z, c);
-      const float e2x = bcast_f(r2.x, c), e2y = bcast_f(r2.y, c), e2z = bcast_f(r2.z, c);
-      bool keep = false;
-      if (ok && j >= 0 && j != skip) {
-        const float tx = sx - p0x, ty = sy - p0y, tz = sz - p0z;
-        // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t scales
-        // with their magnitudes, not with |t|
-        const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(sx) + fabsf(sy) +
-                             fabsf(sz) + fabsf(p0x) + fabsf(p0y) + fabsf(p0z);
-        keep = may_hit_core(dx, dy, dz, e1x, e1y, e1z, e2x, e2y, e2z, tx, ty, tz, nt_err, es_f,
-                            er_f, best_d);
+  // The wavefront's lanes are taken as ONE bundle; if that bundle is not narrow (the visiting
+  // order jumps inside the wavefront: a Hilbert curve leaves and re-enters a round aperture) it is
+  // cut where neighbouring lanes -- neighbours in the visiting order -- lie farthest apart, and
+  // the parts are taken one after the other, down to single rays if need be (one ray is always a
+  // narrow bundle).  `cuts` bit k: a bundle ends before lane k.  A wavefront whose rays are
+  // simply not coherent -- directions spread, a quarter of the scene's clusters touched, or more
+  // than BEAM_ATTEMPTS bundles tried -- is left to the grouped kernel instead: sixty-four
+  // single-ray walks cost ten times its work.
+  TFRT_STAT(8, 1);
+  constexpr int BEAM_ATTEMPTS = 20;
+  // distance of this lane's line from the previous lane's, near the scene: feet of the
+  // perpendiculars from the frame origin, plus the directions' difference over that distance
+  float gap = 0.f;
+  {
+    const float su = sx * ux + sy * uy + sz * uz;
+    const float fx = sx - su * ux, fy = sy - su * uy, fz = sz - su * uz;
+    const float gx = fx - __shfl_up(fx, 1, 64), gy = fy - __shfl_up(fy, 1, 64),
+                gz = fz - __shfl_up(fz, 1, 64);
+    const float hx = ux - __shfl_up(ux, 1, 64), hy = uy - __shfl_up(uy, 1, 64),
+                hz = uz - __shfl_up(uz, 1, 64);
+    const bool prev_ok = __shfl_up(ok ? 1 : 0, 1, 64) != 0;
+    if (ok && prev_ok && lane > 0)
+      gap = gx * gx + gy * gy + gz * gz + (sx * sx + sy * sy + sz * sz) * (hx * hx + hy * hy + hz * hz);
+    if (!(gap >= 0.f)) gap = 0.f;  // (NaN)
+  }
+  unsigned long long cuts = 0ull;
+  int lo = 0, attempts = 0;
+  bool spread = false;
+  while (lo < 64) {
+    ++attempts;
+    const unsigned long long above = lo < 63 ? (cuts >> (lo + 1)) << (lo + 1) : 0ull;
+    const int hi = above != 0ull ? __ffsll((long long)above) - 1 : 64;
+    const int len = hi - lo;
+    const bool sel = ok && lane >= lo && lane < hi;
+    const float cnt = wave_sum_f(sel ? 1.f : 0.f);
+    bool narrow = true;
+    int ns = 0, nc = 0, nf = 0;
+    if (cnt > 0.f) {
+      // ---- the bundle
+      Beam bm;
+      const float swx = wave_sum_f(sel ? ux : 0.f), swy = wave_sum_f(sel ? uy : 0.f),
+                  swz = wave_sum_f(sel ? uz : 0.f);
+      const float sox = wave_sum_f(sel ? sx : 0.f), soy = wave_sum_f(sel ? sy : 0.f),
+                  soz = wave_sum_f(sel ? sz : 0.f);
+      const float wl2 = swx * swx + swy * swy + swz * swz;
+      narrow = wl2 > 0.49f * cnt * cnt;  // (NaN: false)
+      spread = !narrow;
+      const float wi = narrow ? 1.0f / __builtin_sqrtf(wl2) : 0.f;
+      bm.wx = swx * wi; bm.wy = swy * wi; bm.wz = swz * wi;
+      bm.ox = sox / cnt; bm.oy = soy / cnt; bm.oz = soz / cnt;
+      const float cosk = ux * bm.wx + uy * bm.wy + uz * bm.wz;
+      if (__any(sel && !(cosk > 0.7f))) narrow = false, spread = true;
+      const float ic = 1.0f / (sel ? cosk : 1.f);
+      const float mx = (ux - cosk * bm.wx) * ic, my = (uy - cosk * bm.wy) * ic,
+                  mz = (uz - cosk * bm.wz) * ic;
+      const float px = sx - bm.ox, py = sy - bm.oy, pz = sz - bm.oz;
+      const float ts = px * bm.wx + py * bm.wy + pz * bm.wz;
+      const float ax = px - ts * bm.wx - ts * mx, ay = py - ts * bm.wy - ts * my,
+                  az = pz - ts * bm.wz - ts * mz;
+      const float R0 = wave_max_f(sel ? __builtin_sqrtf(ax * ax + ay * ay + az * az) : 0.f);
+      const float S = wave_max_f(sel ? __builtin_sqrtf(mx * mx + my * my + mz * mz) : 0.f);
+      const float tmin = wave_min_f(sel ? ts : INFINITY);
+      const float Lw = wave_max_f(sel ? fabsf(sx) + fabsf(sy) + fabsf(sz) : 0.f) + fabsf(bm.ox) +
+                       fabsf(bm.oy) + fabsf(bm.oz);
+      // bounds inflated far beyond their float32 rounding (offsets ~ 2^-23 Lw, slopes ~ 2^-23)
+      bm.R0 = R0 * 1.001f + 4e-6f * Lw;
+      bm.S = S * 1.001f + 2e-6f;
+      // (first pass of a trace: sources normally sit outside the scene, nothing lies behind
+      // them; and only while hits must lie ahead of the start: ray_start_epsilion >= 0)
+      bm.tmin = (!first_pass && eps_start >= 0.0) ? tmin - 1e-5f * Lw - 1e-5f * fabsf(tmin)
+                                                  : -INFINITY;
+      if (!(bm.R0 < 3.0e38f && bm.S < 3.0e38f)) narrow = false;  // (also NaN)
+
+      // ---- levels: lane = node
+      if (narrow) {
+        const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
+        float4 nxt = lane < n_super ? susphere[lane] : never;
+        for (int b = 0; b < n_super; b += 64) {
+          const int node = b + lane;
+          const float4 cur = nxt;  // (the next 64 spheres are on their way while these are tested)
+          nxt = node + 64 < n_super ? susphere[node + 64] : never;
+          const bool hit = beam_touch(bm, cur);
+          const unsigned long long m = __ballot(hit);
+          if (hit) {
+            const int pos = ns + rank_below(m);
+            if (pos < BEAM_SLIST) slist[wave][pos] = (uint16_t)node;
+          }
+          ns += __popcll(m);
+        }
+        narrow = ns <= BEAM_SLIST && n_super <= 65536;
       }
-      const unsigned long long km = __ballot(keep);
-      if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lane;
-      xn += __popcll(km);
-      if (xn >= 64) {
-        wave_fence();
-        decide(64);
-        uint32_t tp = 0u;  // fewer than 64 remain: move them to the front
-        if (lane < xn - 64) tp = x_pair[wave][64 + lane];
-        wave_fence();
-        if (lane < xn - 64) x_pair[wave][lane] = tp;
-        xn -= 64;
-        best_d = dkey_inv(best_k[wave][lane]);
-        wave_fence();
+      wave_fence();
+      if (narrow && ns > 0) {
+        for (int b = 0; b < ns * SUPER; b += 64) {
+          const int k = b + lane;
+          bool hit = false;
+          int cl = 0;
+          if (k < ns * SUPER) {
+            cl = (int)slist[wave][k >> 3] * SUPER + (k & 7);
+            if (cl < n_clusters) hit = beam_touch(bm, clsphere[cl]);
+          }
+          const unsigned long long m = __ballot(hit);
+          if (hit) {
+            const int pos = nc + rank_below(m);
+            if (pos < BEAM_CLIST) clist[wave][pos] = (uint16_t)cl;
+          }
+          nc += __popcll(m);
+        }
+        narrow = nc <= BEAM_CLIST && n_clusters <= 65536;
+      }
+      wave_fence();
+      if (narrow && nc > 0) {
+        for (int b = 0; b < nc * CLUSTER; b += 64) {
+          const int k = b + lane;
+          bool hit = false;
+          unsigned slot = 0;
+          if (k < nc * CLUSTER) {
+            slot = (unsigned)clist[wave][k >> 4] * CLUSTER + (unsigned)(k & 15);
+            hit = beam_touch(bm, csphere[slot]);
+          }
+          const unsigned long long m = __ballot(hit);
+          if (hit) {
+            const int pos = nf + rank_below(m);
+            if (pos < BEAM_FLIST) flist[wave][pos] = slot;
+          }
+          nf += __popcll(m);
+        }
+        narrow = nf <= BEAM_FLIST;
+      }
+      wave_fence();
+    }
+    if (!narrow) {
+      const bool hopeless = (len == 64 && (spread || (nc > 64 && nc > n_clusters / 4))) ||
+                            attempts >= BEAM_ATTEMPTS;
+      if (len > 1 && !hopeless) {  // cut at the widest gap inside [lo, hi), try the first part
+        const bool inside = lane > lo && lane < hi;
+        const float widest = wave_max_f(inside ? gap : -1.f);
+        const unsigned long long at = __ballot(inside && gap == widest);
+        // (all gaps equal -- e.g. zero: lanes without a ray -- : halve)
+        const int g = (widest > 0.f && at != 0ull) ? __ffsll((long long)at) - 1 : lo + (len >> 1);
+        cuts |= 1ull << g;
+        continue;
+      }
+      // not a wavefront of (a few) narrow bundles: the grouped kernel does it
+      TFRT_STAT(ns > BEAM_SLIST ? 10 : (nc > BEAM_CLIST ? 11 : (nf > BEAM_FLIST ? 12 : 9)), 1);
+      TFRT_STAT(15, qwave * 64 + lo);
+      if (lane == 0) left_list[atomicAdd(left_count, 1)] = qwave;
+      return;
+    }
+
+    // ---- faces: lane = ray
+    TFRT_STAT(13, nf);
+    for (int f0 = 0; f0 < nf; f0 += 64) {
+      const int nb = min(64, nf - f0);
+      // each lane fetches one candidate's float32 record (P0 - c0 | face index, E1, E2) ...
+      float4 r0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), r1 = r0, r2 = r0;
+      if (lane < nb) {
+        const int64_t memb = (int64_t)flist[wave][f0 + lane];
+        r0 = crec[3 * memb];
+        r1 = crec[3 * memb + 1];
+        r2 = crec[3 * memb + 2];
+      }
+      // ... and hands it to the whole wave when its turn comes
+      for (int c = 0; c < nb; ++c) {
+        const float p0x = bcast_f(r0.x, c), p0y = bcast_f(r0.y, c), p0z = bcast_f(r0.z, c);
+        const int j = __builtin_amdgcn_readlane(__float_as_int(r0.w), c);
+        const float e1x = bcast_f(r1.x, c), e1y = bcast_f(r1.y, c), e1z = bcast_f(r1.z, c);
+        const float e2x = bcast_f(r2.x, c), e2y = bcast_f(r2.y, c), e2z = bcast_f(r2.z, c);
+        bool keep = false;
+        if (sel && j >= 0 && j != skip) {
+          const float tx = sx - p0x, ty = sy - p0y, tz = sz - p0z;
+          // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t
+          // scales with their magnitudes, not with |t|
+          const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(sx) + fabsf(sy) +
+                               fabsf(sz) + fabsf(p0x) + fabsf(p0y) + fabsf(p0z);
+          keep = may_hit_core(dx, dy, dz, e1x, e1y, e1z, e2x, e2y, e2z, tx, ty, tz, nt_err, es_f,
+                              er_f, best_d);
+        }
+        const unsigned long long km = __ballot(keep);
+        if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lane;
+        xn += __popcll(km);
+        TFRT_STAT(14, __popcll(km));
+        if (xn >= 64) {
+          wave_fence();
+          decide(64);
+          uint32_t tp = 0u;  // fewer than 64 remain: move them to the front
+          if (lane < xn - 64) tp = x_pair[wave][64 + lane];
+          wave_fence();
+          if (lane < xn - 64) x_pair[wave][lane] = tp;
+          xn -= 64;
+          best_d = dkey_inv(best_k[wave][lane]);
+          wave_fence();
+        }
       }
     }
+    lo = hi;  // this bundle is done: the next one starts behind it
   }
   wave_fence();
   if (xn > 0) decide(xn);
@@ -1719,7 +1797,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     rec_q[i] = q;
     atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
   }
-  if (lane == 0) wave_done[qwave] = 1;
 }
 
 // -------------------------------------------------------------------------- classify
@@ -1901,6 +1978,7 @@ struct SelfScan {
   // visiting-order traces: the class histogram of the NEXT pass (the intersect kernels add into
   // it with atomics); every block clears its own row here, one pass ahead
   int32_t* hist_next = nullptr;
+  int hist_rows = 0;
 };
 
 template <typename T>
@@ -1935,6 +2013,8 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
   }
   if (base >= n) return;
   if (ss.hist_next != nullptr && threadIdx.x < 4) ss.hist_next[blockIdx.x * 4 + threadIdx.x] = 0;
+  if (ss.hist_next != nullptr && blockIdx.x == 0 && threadIdx.x == 4)
+    ss.hist_next[ss.hist_rows * 4] = 0;  // (the count of wavefronts left to the grouped kernel)
   const int i = base + threadIdx.x;
   const int cls = (i < n) ? (int)rec_cls[i] : -1;
 
@@ -2502,7 +2582,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec, visit_a, visit_b, rec_q, hist_a, hist_b, wave_done;
+  size_t csphere, cface, clsphere, susphere, crec, visit_a, visit_b, rec_q, hist_a, hist_b, left_list;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -2540,9 +2620,9 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.visit_a = take(n * (dtype == TFRT_F64 ? 64 : 32));
   L.visit_b = take(n * (dtype == TFRT_F64 ? 64 : 32));
   L.rec_q = take(n * sizeof(int32_t));
-  L.hist_a = take((size_t)pl.nblk * 4 * sizeof(int32_t));
-  L.hist_b = take((size_t)pl.nblk * 4 * sizeof(int32_t));
-  L.wave_done = take((n + 63) / 64);
+  L.hist_a = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   // (+ the count of wavefronts
+  L.hist_b = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   //  left to the grouped kernel)
+  L.left_list = take((n + 63) / 64 * sizeof(int32_t));
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -2587,7 +2667,8 @@ struct Ordered3 {
   int nq = 0;                        // slots of the visiting order (= source rays)
   int32_t* rec_q = nullptr;          // slot each ray of this pass was visited at
   int32_t* hist = nullptr;           // class histogram of this pass (atomics)
-  uint8_t* wave_done = nullptr;
+  int32_t* left_list = nullptr;      // wavefronts k_intersect_beam leaves to the grouped kernel
+  int32_t* left_count = nullptr;
   int n_super = 0;
 };
 
@@ -2626,12 +2707,15 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        static_cast<const VR*>(od->visit), static_cast<VR*>(od->visit_next),
                        od->first_pass, od->nq, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
                        fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
-                       fz.rec_tri, fz.rec_t, fz.rec_cls, od->rec_q, od->hist, od->wave_done);
-    grid = dim3(cdiv(od->nq, BLOCK), 1);
+                       fz.rec_tri, fz.rec_t, fz.rec_cls, od->rec_q, od->hist, od->left_list,
+                       od->left_count);
+    // (enough workgroups to fill the chip when every wavefront is left over; they loop)
+    grid = dim3(min(cdiv(od->nq, BLOCK), 1280), 1);
   }
   const VR* g_visit = od != nullptr ? static_cast<const VR*>(od->visit) : nullptr;
   const int g_nq = od != nullptr ? od->nq : 0;
-  const uint8_t* g_done = od != nullptr ? od->wave_done : nullptr;
+  const int32_t* g_left = od != nullptr ? od->left_list : nullptr;
+  const int32_t* g_nleft = od != nullptr ? od->left_count : nullptr;
   int32_t* g_hist = od != nullptr ? od->hist : nullptr;
   int32_t* g_recq = od != nullptr ? od->rec_q : nullptr;
 #define TFRT_LAUNCH_R(RR)                                                                      \
@@ -2642,7 +2726,7 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        ac->n_clusters,                                                         \
                        pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride,           \
                        fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt, g_visit,    \
-                       g_nq, g_done, g_hist, g_recq);                                          \
+                       g_left, g_nleft, g_nq, g_hist, g_recq);                                 \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
@@ -2730,7 +2814,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
-                         (int)N, tail, ticket, hist_ab[0], visiting ? pl.nblk * 4 : 0);
+                         (int)N, tail, ticket, hist_ab[0], visiting ? pl.nblk * 4 + 1 : 0);
     } else {
       hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
                          (int)N, tail, ticket);
@@ -2761,7 +2845,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       od.rec_q = reinterpret_cast<int32_t*>(ws + lay.rec_q);
       od.nq = (int)N;
       od.hist = hist_ab[p & 1];
-      od.wave_done = reinterpret_cast<uint8_t*>(ws + lay.wave_done);
+      od.left_list = reinterpret_cast<int32_t*>(ws + lay.left_list);
+      od.left_count = od.hist + (size_t)pl.nblk * 4;
       od.n_super = cdiv(ac.n_clusters, SUPER);
       fz.blockcnt = od.hist;
     }
@@ -2778,7 +2863,10 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                          rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt_p);
     const bool grid_scan = pl.nblk >= SCAN_GRID_MIN_ROWS;
     SelfScan ss;
-    if (visiting) ss.hist_next = hist_ab[(p + 1) & 1];
+    if (visiting) {
+      ss.hist_next = hist_ab[(p + 1) & 1];
+      ss.hist_rows = pl.nblk;
+    }
     if (pl.nblk <= SELF_SCAN_MAX_BLOCKS) {
       ss.blockcnt = blockcnt_p;
       ss.prev_counts = p > 0 ? counts + (size_t)(p - 1) * TFRT_COUNTS_PER_PASS : nullptr;
