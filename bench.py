@@ -45,6 +45,7 @@ CYCLES_PER_WAVE_OP = 2.0   # MI355X_MICROARCH.md: v_fma_f32 (wave64) throughput,
 PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak (6290 measured copy)
 FLOPS_PER_TEST = 45        # SURVEY.md section 8d algorithmic cost model (Moeller-Trumbore)
 BYTES_PER_RAY_FWD = 64     # 32 B read + 32 B written per active ray per pass
+BYTES_PER_RAY_BWD = 116    # tape 32 + upstream 24 + downstream 24 + 9 atomics 36
 BYTES_PER_FACE = 48
 
 
@@ -300,9 +301,11 @@ def main(argv=None):
         if profile:
             import ctypes
             buf = (ctypes.c_float * 8192)()
-            nrec = lib.tfrt_profile_read(buf, 8192)
+            kernel_ms = {}
+            for kind, name in enumerate(("intersect", "react", "backward", "accumulate")):
+                nrec = lib.tfrt_profile_read_kind(kind, buf, 8192)
+                kernel_ms[name] = [buf[i] for i in range(max(nrec, 0))]
             lib.tfrt_profile_enable(0)
-            kernel_ms = [buf[i] for i in range(max(nrec, 0))]
         tests_total = float(tests_local)
         if world > 1:
             stats = torch.tensor([dt, float(tests_local)], dtype=torch.float64, device="cuda")
@@ -314,6 +317,7 @@ def main(argv=None):
         out = dict(dt=dt, steps=steps, tests=tests_total, kernel_ms=kernel_ms,
                    counts=eng.last_trace["counts"], M=int(system._merged_face_verts.shape[0]),
                    mode=eng._trace_mode(system),
+                   visiting=getattr(eng, "_order_cache", None) is not None,
                    graph_replays=fs.graph_replays if fs is not None else 0,
                    capture_error=repr(fs.capture_error) if fs is not None and fs.capture_error
                    else None)
@@ -346,11 +350,33 @@ def main(argv=None):
 
     M, mode, counts = main_leg["M"], main_leg["mode"], main_leg["counts"]
     n_active = [int(c[:4].sum()) for c in counts]          # rays entering each pass (rank 0)
-    kernel_name = {"all-pairs": "tfrt::k_intersect3d", "group": "tfrt::k_intersect_group"}[mode]
+    P = len(n_active)
+    visiting = bool(main_leg["visiting"]) and mode == "group"
+    kernel_name = ("tfrt::k_intersect_beam" if visiting else
+                   {"all-pairs": "tfrt::k_intersect3d", "group": "tfrt::k_intersect_group"}[mode])
     roofline = {"kernel": kernel_name, "bound": "valu"}
-    if prof_leg is not None and prof_leg["kernel_ms"]:
-        P = len(n_active)
-        ms = np.asarray(prof_leg["kernel_ms"], dtype=np.float64)
+    same_workload = (args.rays == 1_000_000 and world == 1 and args.k_front == 41
+                     and args.k_back == 9 and args.dtype == "f32")
+    src_hash = _source_hash()
+
+    def pmc_of(tag):
+        """Counters of one kernel from profiles/ (separate rocprofv3 --pmc runs of the same step,
+        scratch/collect_profiles.sh) -- only for the kernel sources and workload they were
+        collected on."""
+        path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % tag)
+        if not (same_workload and os.path.exists(path)):
+            return None, path
+        doc = json.load(open(path))
+        return (doc if doc.get("source_hash") == src_hash else None), path
+
+    def traffic_of(doc):
+        fetch = float(np.mean([p["FETCH_SIZE_KB"] for p in doc["passes"]])) * 1024.0
+        write = float(np.mean([p["WRITE_SIZE_KB"] for p in doc["passes"]])) * 1024.0
+        return 2.0 * fetch + write      # guide: FETCH_SIZE counts half of wide reads on gfx950
+
+    kms = prof_leg["kernel_ms"] if prof_leg is not None else {}
+    if kms.get("intersect"):
+        ms = np.asarray(kms["intersect"], dtype=np.float64)
         ms = ms[:len(ms) // P * P].reshape(-1, P)
         per_pass_ms = ms.mean(axis=0)
         avg_ms = float(ms.mean())
@@ -360,7 +386,10 @@ def main(argv=None):
             "avg_launch_ms": avg_ms, "per_pass_launch_ms": [float(x) for x in per_pass_ms],
             "launches_timed": int(ms.size),
             "timed_by": "HIP events on the launch stream (tfrt_profile_*), eager fused sequence "
-                        "run after the timed region with the same steps",
+                        "run after the timed region with the same steps"
+                        + ("; one record = the pass's k_intersect_beam launch + the "
+                           "k_intersect_group launch for left-over wavefronts (none on this "
+                           "workload: it reads one counter and retires)" if visiting else ""),
             "tests_per_launch": tests_per_launch,
             # SURVEY.md 8d cost model, kept as a separately named field: pairs DECIDED x 45 flop.
             # The kernel decides pairs through conservative sphere tests, so this is not a
@@ -373,26 +402,26 @@ def main(argv=None):
                 "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
             },
         })
-        # executed work: VALU wave-instructions per launch from separate rocprofv3 --pmc passes of
-        # the same kernel on the same workload (profiles/, scratch/collect_profiles.sh), combined
-        # with the launch time measured live above
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % mode.replace("-", "_"))
-        pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else None
-        same_workload = (args.rays == 1_000_000 and args.gpus == 1 and args.k_front == 41
-                         and args.k_back == 9 and args.dtype == "f32")
-        if pmc is not None and same_workload and pmc.get("source_hash") == _source_hash():
+        # executed work: VALU wave-instructions per launch from the PMC passes, combined with the
+        # launch time measured live above
+        tag = "beam" if visiting else mode.replace("-", "_")
+        pmc, pmc_path = pmc_of(tag)
+        if pmc is not None:
             valu = float(np.mean([p["SQ_INSTS_VALU"] for p in pmc["passes"]]))
             issue_rate = valu / (avg_ms * 1e-3)                     # wave-instructions / s
             peak = VALU_SIMDS * CLOCK_HZ / CYCLES_PER_WAVE_OP
-            fetch = float(np.mean([p["FETCH_SIZE_KB"] for p in pmc["passes"]])) * 1024.0
-            write = float(np.mean([p["WRITE_SIZE_KB"] for p in pmc["passes"]])) * 1024.0
-            traffic = 2.0 * fetch + write       # guide: FETCH_SIZE counts half of wide reads
+            traffic = traffic_of(pmc)
             roofline.update({
                 "achieved": issue_rate, "peak": peak, "unit": "VALU wave-instructions/s",
                 "frac": issue_rate / peak,
                 "peak_model": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 op "
                               "(MI355X_MICROARCH.md, v_fma_f32 row)",
                 "valu_wave_instructions_per_launch": valu,
+                "salu_per_valu": float(np.mean([p["SQ_INSTS_SALU"] / p["SQ_INSTS_VALU"]
+                                                for p in pmc["passes"]])),
+                "lds_bank_conflict_ratio": float(np.mean(
+                    [p["SQ_LDS_BANK_CONFLICT"] / max(p["SQ_LDS_IDX_ACTIVE"], 1.0)
+                     for p in pmc["passes"]])),
                 "executed_valu_lane_ops_per_test": valu * 64.0 / tests_per_launch,
                 "wait_fraction_of_wave_cycles": float(np.mean(
                     [p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"] for p in pmc["passes"]])),
@@ -409,6 +438,43 @@ def main(argv=None):
                 "pmc_note": "no PMC profile of this kernel source / workload under profiles/ "
                             "(regenerate with scratch/collect_profiles.sh); counter-derived "
                             "fields withheld"})
+        # every hot kernel of the step: live launch time, the roof that bounds it, SURVEY 8d's
+        # algorithmic bytes beside the counter traffic
+        n_fwd = float(np.mean(n_active))
+        rows = [dict(name=kernel_name, kind="intersect", launches_per_step=P, bound="valu",
+                     avg_ms=avg_ms, frac=roofline.get("frac"),
+                     algorithmic_bytes=alg_bytes, traffic=roofline.get("traffic"))]
+        for kind, kname, per_step, alg, note in (
+                ("react", "tfrt::k_react3d", P, n_fwd * BYTES_PER_RAY_FWD,
+                 "SURVEY 8d forward bytes: 64 B per ray entering the pass"),
+                ("backward", "tfrt::k_backward3d", P, n_fwd * BYTES_PER_RAY_BWD,
+                 "SURVEY 8d backward bytes: 116 B per ray of the pass (the 36 B of face-gradient "
+                 "terms leave through the stash and k_face_accumulate)"),
+                ("accumulate", "tfrt::k_face_accumulate", 1, float(sum(n_active)) * 40.0,
+                 "the stash read once: 36 B of terms + 4 B face index per ray and pass")):
+            v = np.asarray(kms.get(kind) or [], dtype=np.float64)
+            if not v.size:
+                continue
+            k_ms = float(v.mean())
+            doc, path = pmc_of(kind)
+            traffic = traffic_of(doc) if doc is not None else None
+            rows.append(dict(
+                name=kname, kind=kind, launches_per_step=per_step, bound="hbm", avg_ms=k_ms,
+                algorithmic_bytes=alg, algorithmic_note=note,
+                achieved_GBps=alg / (k_ms * 1e-3) / 1e9,
+                frac=alg / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                traffic=traffic,
+                traffic_frac=(traffic / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS)
+                if traffic is not None else None,
+                pmc_source=os.path.relpath(path, ROOT) if doc is not None else None))
+        roofline["kernels"] = rows
+        roofline["kernels_note"] = ("avg_ms: HIP events per launch (eager fused sequence); "
+                                    "frac: VALU issue fraction (intersect) or algorithmic bytes / "
+                                    "time / 8 TB/s (HBM-bound kernels); traffic: 2 x FETCH_SIZE + "
+                                    "WRITE_SIZE per launch from profiles/ when collected on these "
+                                    "kernel sources, else null")
+        step_ms = sum(r["avg_ms"] * r["launches_per_step"] for r in rows)
+        roofline["hot_kernels_ms_per_step"] = step_ms
     dt, tests_total = main_leg["dt"], main_leg["tests"]
     line = {
         "metric": "ray-surface intersection tests/sec (fwd+bwd)",
@@ -435,7 +501,9 @@ def main(argv=None):
             "rays_per_gpu": global_rays // world, "global_rays": global_rays, "faces": M,
             "trace_depth": 3,
             "trace_mode": {"all-pairs": "all-pairs float32 sphere filter",
-                           "group": "sphere hierarchy over k-d face clusters (default)"}[mode],
+                           "group": "sphere hierarchy over k-d face clusters (default)"}[mode]
+            + (", rays visited in a coherent (Hilbert) order: wavefronts share one walk "
+               "(k_intersect_beam)" if visiting else ""),
             "step_mode": {"graph": "fused launch sequence (GoalError), HIP-graph replay",
                           "fused": "fused launch sequence (GoalError), eager launches",
                           "generic": "error function as torch code through autograd"}[
@@ -452,6 +520,14 @@ def main(argv=None):
                       "other_legs.all_pairs is the same step with every pair executed",
         "roofline": roofline,
     }
+    # whole step against the HBM roof: SURVEY 8d bytes (64 B forward + 116 B backward per ray
+    # entering a pass, 48 B per face and pass) / ms_per_step / 8 TB/s
+    step_bytes = (sum(n_active) * (BYTES_PER_RAY_FWD + BYTES_PER_RAY_BWD) * world   # (rank 0's shard x ranks)
+                  + P * M * BYTES_PER_FACE * world)
+    line["roofline"]["hbm_frac_step"] = step_bytes / (dt / main_leg["steps"]) / 1e9 / PEAK_HBM_GBPS
+    line["roofline"]["hbm_frac_step_note"] = (
+        "SURVEY 8d algorithmic bytes of one optimiser step (%.1f MB) / ms_per_step / 8 TB/s"
+        % (step_bytes / 1e6))
     if main_leg["capture_error"]:
         line["config"]["graph_capture_error"] = main_leg["capture_error"]
     line.update(side)

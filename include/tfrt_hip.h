@@ -287,13 +287,25 @@ int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Benchmark instrumentation (the only global state in the library; not used by the product
- * path).  While enabled, every launch of the dominant kernel (k_intersect3d) made by
- * tfrt_trace3d_forward / tfrt_intersect3d is bracketed by a HIP event pair recorded on the
- * launch stream.  tfrt_profile_read synchronises those events and writes the elapsed
+ * path).  While enabled, the launches of the hot kernels made by tfrt_trace3d_forward /
+ * tfrt_trace3d_backward / tfrt_intersect3d are bracketed by HIP event pairs recorded on the
+ * launch stream, one record per pass and kind:
+ *   TFRT_PROF_INTERSECT   the pass's intersect launch(es): k_intersect_beam + k_intersect_group,
+ *                         or k_intersect_group, or k_intersect3d
+ *   TFRT_PROF_REACT       k_react3d
+ *   TFRT_PROF_BACKWARD    k_backward3d (one per pass, last pass first)
+ *   TFRT_PROF_ACCUMULATE  k_face_accumulate (one per reverse sweep)
+ * tfrt_profile_read_kind synchronises the events of one kind and writes the elapsed
  * milliseconds, in launch order, into ms[0..max_records); it returns the record count (or a
- * negative error).  tfrt_profile_enable(0|1) also clears the records. */
+ * negative error).  tfrt_profile_read = the intersect records.  tfrt_profile_enable(0|1) also
+ * clears the records. */
+#define TFRT_PROF_INTERSECT 0
+#define TFRT_PROF_REACT 1
+#define TFRT_PROF_BACKWARD 2
+#define TFRT_PROF_ACCUMULATE 3
 int tfrt_profile_enable(int enable);
 int tfrt_profile_read(float* ms, int32_t max_records);
+int tfrt_profile_read_kind(int32_t kind, float* ms, int32_t max_records);
 
 /* ------------------------------------------------------------------------------------------
  * Seam-level single kernels (same math, no pass loop).

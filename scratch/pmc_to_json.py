@@ -1,4 +1,4 @@
-"""rocprofv3 --pmc counter_collection.csv files -> profiles/r02_pmc_<mode>.json: per-pass medians
+"""rocprofv3 --pmc counter_collection.csv files -> profiles/rNN_pmc_<kernel>.json: per-pass medians
 of every collected counter for the dominant intersect kernel of the bench step.
 
 Usage: pmc_to_json.py OUT.json KERNEL_SUBSTRING PASSES DIR [DIR ...]

@@ -59,6 +59,7 @@ SIGNATURES = {
     "tfrt_strerror": (ctypes.c_char_p, [c_i32]),
     "tfrt_profile_enable": (c_i32, [c_i32]),
     "tfrt_profile_read": (c_i32, [c_vp, c_i32]),
+    "tfrt_profile_read_kind": (c_i32, [c_i32, c_vp, c_i32]),
     "tfrt_build_faces_forward": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tfrt_build_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp,
                                           c_vp, c_vp]),

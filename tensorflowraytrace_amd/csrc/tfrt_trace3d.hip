@@ -2640,14 +2640,31 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   return L;
 }
 
-// ---- optional per-launch timing of k_intersect3d (benchmark use only; see tfrt_profile_*)
+// ---- optional per-launch timing of the hot kernels (benchmark use only; see tfrt_profile_*)
 struct ProfRec {
   hipEvent_t a, b;
-  int64_t n_rays_cap;
-  int32_t n_faces;
+  int32_t kind;  // TFRT_PROF_*
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+// brackets the launches made while it is alive with an event pair on the launch stream
+struct ProfScope {
+  ProfRec rec;
+  hipStream_t st;
+  bool on;
+  ProfScope(int kind, hipStream_t stream) : st(stream), on(g_prof_on) {
+    if (!on) return;
+    rec.kind = kind;
+    (void)hipEventCreate(&rec.a);
+    (void)hipEventCreate(&rec.b);
+    (void)hipEventRecord(rec.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.b, st);
+    g_prof.push_back(rec);
+  }
+};
 
 // Where the grouped kernel leaves the classified hit records when it runs as one cluster chunk
 // (it then does k_classify3d's work in its epilogue).
@@ -2692,14 +2709,7 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        prep, pstride);
   dim3 grid(pl.ray_blocks, pl.chunks);
   if (grouped) grid = dim3(pl.g_blocks, pl.g_chunks);
-  ProfRec rec;
-  if (g_prof_on) {
-    (void)hipEventCreate(&rec.a);
-    (void)hipEventCreate(&rec.b);
-    rec.n_rays_cap = (int64_t)pl.ray_blocks * BLOCK * pl.R;
-    rec.n_faces = M;
-    (void)hipEventRecord(rec.a, st);
-  }
+  ProfScope prof(TFRT_PROF_INTERSECT, st);
   using VR = VisitRecOf<T>;
   if (grouped && od != nullptr) {
     // coherent wavefronts first; the grouped kernel then does the wavefronts that were not
@@ -2736,10 +2746,6 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
   else if (Ruse == 4) { TFRT_LAUNCH_R(4); }
   else { TFRT_LAUNCH_R(2); }
 #undef TFRT_LAUNCH_R
-  if (g_prof_on) {
-    (void)hipEventRecord(rec.b, st);
-    g_prof.push_back(rec);
-  }
   return 0;
 }
 
@@ -2884,6 +2890,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_scan3d_one, dim3(1), dim3(1024), 0, st, nrays + p, blockcnt_p, blockoff,
                          counts + (size_t)p * TFRT_COUNTS_PER_PASS, tail, nrays + p + 1,
                          reinterpret_cast<unsigned long long*>(tail + 4), M);
+    ProfScope prof_react(TFRT_PROF_REACT, st);
     hipLaunchKernelGGL((k_react3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
                        idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
                        rec_cls + (size_t)p * n, blockoff,
@@ -2962,6 +2969,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     const int64_t out_stride = p == 0 ? N : (int64_t)n;
     G* stash_g = stash_g_all + (size_t)p * 9 * n;
     int32_t* stash_face = stash_face_all + (size_t)p * n;
+    ProfScope prof_bwd(TFRT_PROF_BACKWARD, st);
     hipLaunchKernelGGL((k_backward3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
                        idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
                        rec_cls + (size_t)p * n, rec_slot + (size_t)p * n,
@@ -2981,6 +2989,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                          g_fverts);
     }
   }
+  ProfScope prof_acc(TFRT_PROF_ACCUMULATE, st);
   if (stash && !ordered && P > 0)
     hipLaunchKernelGGL((k_face_accumulate<G>), dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
                        nrays, P, (int64_t)n, stash_face_all, stash_g_all, acc_chunk, M, g_fverts);
@@ -3142,8 +3151,13 @@ int tfrt_profile_enable(int enable) {
 }
 
 int tfrt_profile_read(float* ms, int32_t max_records) {
+  return tfrt_profile_read_kind(TFRT_PROF_INTERSECT, ms, max_records);
+}
+
+int tfrt_profile_read_kind(int32_t kind, float* ms, int32_t max_records) {
   int n = 0;
   for (auto& r : g_prof) {
+    if (r.kind != kind) continue;
     if (n >= max_records) break;
     if (hipEventSynchronize(r.b) != hipSuccess) return TFRT_E_LAUNCH;
     float t = 0.f;
