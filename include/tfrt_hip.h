@@ -194,6 +194,13 @@ typedef struct tfrt_scene3d {
    * wavefronts take the per-ray walk.  Only the visiting order changes: every output (sets,
    * their order, hit faces, coordinates) is identical with and without it. */
   const void* visit_records;
+  /* With visit_records.  0: behind k_intersect_beam the grouped kernel is launched for the
+   * wavefronts that are no (few) narrow bundles; their number, summed over the passes, comes back
+   * in counts[TFRT_COUNTS_LEN - 1].  1: no such launch -- k_intersect_beam finishes every
+   * wavefront itself, cutting it down to single rays if need be: always correct, but slow for
+   * rays that are not coherent; meant for a source whose earlier traces left no wavefront over
+   * (saves one kernel launch per pass). */
+  int32_t visit_all;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in
@@ -213,7 +220,8 @@ size_t tfrt_trace3d_workspace_bytes(int64_t n_rays, int64_t n_faces, int32_t max
 
 /* Number of int32 in `counts`: per pass 8 ints {n_active,n_finished,n_stopped,n_dead,
  * base_active,base_finished,base_stopped,base_dead}, then 8 trailing ints:
- * {total_active,total_finished,total_stopped,total_dead,n_tests_lo,n_tests_hi,error,0}. */
+ * {total_active,total_finished,total_stopped,total_dead,n_tests_lo,n_tests_hi,error,
+ *  wavefronts left to the grouped kernel (visiting-order traces)}. */
 #define TFRT_COUNTS_PER_PASS 8
 #define TFRT_COUNTS_LEN(max_passes) (8 * ((max_passes) + 1))
 

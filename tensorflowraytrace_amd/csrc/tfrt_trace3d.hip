@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     double eps_int, double eps_size, double eps_start, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
     int32_t* __restrict__ rec_q, int32_t* __restrict__ hist, int32_t* __restrict__ left_list,
-    int32_t* __restrict__ left_count) {
+    int32_t* __restrict__ left_count, int32_t* __restrict__ left_total, int visit_all) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x * BLOCK + tid;
   const int qwave = q >> 6;
@@ -1719,8 +1719,11 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       wave_fence();
     }
     if (!narrow) {
-      const bool hopeless = (len == 64 && (spread || (nc > 64 && nc > n_clusters / 4))) ||
-                            attempts >= BEAM_ATTEMPTS;
+      // (visit_all: the caller launches no grouped kernel behind this one -- it has seen this
+      // source leave no wavefront over -- so every wavefront is finished here, however wide)
+      const bool hopeless = !visit_all &&
+                            ((len == 64 && (spread || (nc > 64 && nc > n_clusters / 4))) ||
+                             attempts >= BEAM_ATTEMPTS);
       if (len > 1 && !hopeless) {  // cut at the widest gap inside [lo, hi), try the first part
         const bool inside = lane > lo && lane < hi;
         const float widest = wave_max_f(inside ? gap : -1.f);
@@ -1730,10 +1733,55 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
         cuts |= 1ull << g;
         continue;
       }
+      if (len == 1 && !hopeless) {
+        // ONE ray whose line touches more nodes than the lists hold (it runs along a surface, or
+        // the scene is huge): that ray against every face's sphere, lane = face (its line within
+        // r of the centre, the bound of beam_touch for a single line); survivors go straight to
+        // the exact test.  Rare and slow (M / 64 rounds), but never wrong.
+        const float bsx = bcast_f(sx, lo), bsy = bcast_f(sy, lo), bsz = bcast_f(sz, lo);
+        const float bux = bcast_f(ux, lo), buy = bcast_f(uy, lo), buz = bcast_f(uz, lo);
+        const int bskip = __builtin_amdgcn_readlane(skip, lo);
+        const int n_slots = n_clusters * CLUSTER;
+        for (int b = 0; b < n_slots; b += 64) {
+          const int slot = b + lane;
+          bool hit = false;
+          int j = -1;
+          if (slot < n_slots) {
+            const float4 sp = csphere[slot];
+            const float vx = sp.x - bsx, vy = sp.y - bsy, vz = sp.z - bsz;
+            const float vu = vx * bux + vy * buy + vz * buz;
+            const float v2 = vx * vx + vy * vy + vz * vz;
+            hit = v2 - vu * vu <= sp.w * 1.00001f + 4e-6f * v2;   // (padding: w < 0, never)
+            if (hit) {
+              j = __float_as_int(crec[3 * (int64_t)slot].w);
+              hit = j >= 0 && j != bskip;
+            }
+          }
+          const unsigned long long km = __ballot(hit);
+          if (hit) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lo;
+          xn += __popcll(km);
+          if (xn >= 64) {
+            wave_fence();
+            decide(64);
+            uint32_t tp = 0u;
+            if (lane < xn - 64) tp = x_pair[wave][64 + lane];
+            wave_fence();
+            if (lane < xn - 64) x_pair[wave][lane] = tp;
+            xn -= 64;
+            best_d = dkey_inv(best_k[wave][lane]);
+            wave_fence();
+          }
+        }
+        lo = hi;
+        continue;
+      }
       // not a wavefront of (a few) narrow bundles: the grouped kernel does it
       TFRT_STAT(ns > BEAM_SLIST ? 10 : (nc > BEAM_CLIST ? 11 : (nf > BEAM_FLIST ? 12 : 9)), 1);
       TFRT_STAT(15, qwave * 64 + lo);
-      if (lane == 0) left_list[atomicAdd(left_count, 1)] = qwave;
+      if (lane == 0) {
+        left_list[atomicAdd(left_count, 1)] = qwave;
+        atomicAdd(left_total, 1);
+      }
       return;
     }
 
@@ -2686,6 +2734,8 @@ struct Ordered3 {
   int32_t* hist = nullptr;           // class histogram of this pass (atomics)
   int32_t* left_list = nullptr;      // wavefronts k_intersect_beam leaves to the grouped kernel
   int32_t* left_count = nullptr;
+  int32_t* left_total = nullptr;     // ... summed over the passes of the trace (counts tail [7])
+  int visit_all = 0;                 // no grouped-kernel launch: k_intersect_beam finishes all
   int n_super = 0;
 };
 
@@ -2718,7 +2768,7 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        od->first_pass, od->nq, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
                        fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
                        fz.rec_tri, fz.rec_t, fz.rec_cls, od->rec_q, od->hist, od->left_list,
-                       od->left_count);
+                       od->left_count, od->left_total, od->visit_all);
     // (enough workgroups to fill the chip when every wavefront is left over; they loop)
     grid = dim3(min(cdiv(od->nq, BLOCK), 1280), 1);
   }
@@ -2742,7 +2792,9 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
                        part_t, part_i, part_stride)
   const int Ruse = grouped ? pl.gR : pl.R;
-  if (Ruse == 1) { TFRT_LAUNCH_R(1); }
+  if (grouped && od != nullptr && od->visit_all) {
+    // (every wavefront was finished by k_intersect_beam)
+  } else if (Ruse == 1) { TFRT_LAUNCH_R(1); }
   else if (Ruse == 4) { TFRT_LAUNCH_R(4); }
   else { TFRT_LAUNCH_R(2); }
 #undef TFRT_LAUNCH_R
@@ -2853,6 +2905,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       od.hist = hist_ab[p & 1];
       od.left_list = reinterpret_cast<int32_t*>(ws + lay.left_list);
       od.left_count = od.hist + (size_t)pl.nblk * 4;
+      od.left_total = tail + 7;
+      od.visit_all = sc->visit_all != 0;
       od.n_super = cdiv(ac.n_clusters, SUPER);
       fz.blockcnt = od.hist;
     }

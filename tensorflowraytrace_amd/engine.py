@@ -862,6 +862,10 @@ class OpticalEngine:
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       deterministic=self.deterministic)
             scene.visit_records = self._visit_records(block, key, repeated, mode, system)
+            # a source that left no wavefront to the grouped kernel last time: no such launch
+            scene.visit_all = (scene.visit_records is not None
+                               and getattr(self, "_visit_all_key", None) == key)
+            self._visit_key = key if scene.visit_records is not None else None
         else:
             scene = system.scene_args(n_table, index_mode, ghost,
                                       finite_tir_gradient=self.finite_tir_gradient)
@@ -889,12 +893,20 @@ class OpticalEngine:
         self._order_cache = (key, records)
         return records
 
+    def _note_left_over(self, left_over):
+        """Visiting-order trace: remember whether the source left wavefronts to the grouped kernel
+        (then the next trace of the same source launches it again)."""
+        key = getattr(self, "_visit_key", None)
+        self._visit_all_key = key if (key is not None and int(left_over) == 0) else None
+
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
         block, scene, fv = self._trace_inputs(rays)
         if self.dimension == 3:
-            return ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
-                               self.dead_ray_length, flags, predicted_counts=predicted)
+            out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
+                              self.dead_ray_length, flags, predicted_counts=predicted)
+            self._note_left_over(out.get("left_over", 0))
+            return out
         return ops.trace2d(block, scene, max_passes, self.new_ray_length,
                            self.dead_ray_length, flags, predicted_counts=predicted)
 

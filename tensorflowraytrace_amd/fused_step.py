@@ -396,7 +396,8 @@ class FusedStep:
                 eng._flags(), eng.new_ray_length, eng.dead_ray_length, eng._trace_mode(),
                 id(opt.error_function), id(opt.error_function.goal), opt.error_function.fields,
                 tdist.world_size(), eng.optical_system.scene_signature(), bool(eng.deterministic),
-                id((getattr(eng, "_order_cache", None) or (None, None))[1]))
+                id((getattr(eng, "_order_cache", None) or (None, None))[1]),
+                getattr(eng, "_visit_all_key", None) is not None)
 
     def step(self, accumulators, lr_scale):
         """One optimiser step.  Returns the error tensor {sum, n_terms, mean} (device)."""
@@ -470,6 +471,11 @@ class FusedStep:
         # off for this optimizer and the steps go on eagerly
         try:
             torch.cuda.synchronize(dev)
+            # (the device is idle: one read tells whether the visiting-order trace of the step just
+            # run left wavefronts to the grouped kernel; if not, the captured sequence omits it)
+            if self._state is not None:
+                self.opt.engine._note_left_over(int(self._state["counts"][-1]))
+            sig = self._signature(accumulators)
             pool = torch.cuda.graph_pool_handle()
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga, pool=pool, stream=side):

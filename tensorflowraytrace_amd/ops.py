@@ -332,6 +332,9 @@ class Scene3DArgs:
         # None, or the SOURCE rays as records in a coherent visiting order (see visit_records());
         # may be reassigned between traces (it belongs to the source, not to the boundaries)
         self.visit_records = visit_records
+        # with visit_records: True = launch no grouped kernel behind k_intersect_beam (a source
+        # whose earlier traces left no wavefront over: out["left_over"] == 0)
+        self.visit_all = False
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -342,6 +345,7 @@ class Scene3DArgs:
             sc = cached[1]
             sc.face_verts = face_verts.data_ptr() if M else None
             sc.visit_records = self._visit_ptr()
+            sc.visit_all = 1 if (self.visit_all and self.visit_records is not None) else 0
             return sc
         sc = Scene3D()
         sc.face_verts = face_verts.data_ptr() if M else None
@@ -366,6 +370,7 @@ class Scene3DArgs:
         sc.reserved0 = 0
         sc.deterministic = 1 if self.deterministic else 0
         sc.visit_records = self._visit_ptr()
+        sc.visit_all = 1 if (self.visit_all and self.visit_records is not None) else 0
         self._struct_cache = (M, sc)
         return sc
 
@@ -592,6 +597,8 @@ def _slice_outputs(full, aux, counts, P, ncols_prefix=None):
     out = {
         "counts": counts[:P * 8].reshape(P, 8).copy(),
         "n_tests": int(np.uint32(tail[4])) | (int(np.uint32(tail[5])) << 32),
+        # visiting-order traces: wavefronts that were no narrow bundles (done by the grouped kernel)
+        "left_over": int(tail[7]),
     }
     totals = {"active": int(tail[0]), "finished": int(tail[1]), "stopped": int(tail[2]),
               "dead": int(tail[3])}

@@ -548,9 +548,19 @@ def test_visiting_order_changes_no_output(dtype, n_rays, k_front):
         goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fin.device)[o["finished_id"].long()]
         return ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
     g_ref = torch.autograd.grad(loss(ref), [p_f, p_b], retain_graph=True)
-    for name, order in _orders(src).items():
+    runs = [(name, order, False) for name, order in _orders(src).items()]
+    # visit_all: no grouped-kernel launch behind k_intersect_beam, which then finishes every
+    # wavefront itself -- also the incoherent ones (cut down to single rays)
+    runs += [(name + "+visit_all", order, True) for name, order in _orders(src).items()
+             if name != "identity"]
+    for name, order, visit_all in runs:
         sc.visit_records = ops.visit_records(src, order)
+        sc.visit_all = visit_all
         out = ops.trace3d(src, fv, sc, max_passes=4, flags=flags)
+        if name == "hilbert":
+            assert out["left_over"] == 0           # coherent: nothing for the grouped kernel
+        if name == "random":
+            assert out["left_over"] > 0
         assert np.array_equal(out["counts"], ref["counts"]), name
         assert out["n_tests"] == ref["n_tests"], name
         for cls in ("finished", "active", "dead", "stopped", "unfinished"):
@@ -562,6 +572,7 @@ def test_visiting_order_changes_no_output(dtype, n_rays, k_front):
         for a, b in zip(g, g_ref):                                       # (same tape; sums reordered)
             assert float((a - b).abs().max() / b.abs().max()) < 1e-11, name
     sc.visit_records = None
+    sc.visit_all = False
 
 
 def test_visiting_order_on_adversarial_soups():
