@@ -184,6 +184,10 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
 // vertex by 1/(k+1)) towards the minimal enclosing ball of the 48 vertices: ~10 % less radius,
 // ~20 % fewer rays per cluster.
 constexpr int CLUSTER = 16;
+#ifndef TFRT_BC_STEPS
+#define TFRT_BC_STEPS 6
+#endif
+constexpr int BC_STEPS = TFRT_BC_STEPS;  // Badoiu-Clarkson steps of the cluster / supercluster balls
 
 // Funnel counters of k_intersect_group: tuning builds only (-DTFRT_TUNING, csrc/tfrt_tuning.h;
 // never in the shipped library).
@@ -245,7 +249,7 @@ __device__ __forceinline__ void cluster_spheres_block(
   for (int q = 0; q < 3; ++q) mean[q] = sum16(f >= 0 ? ctr[q] : 0.0) / fmax(cnt, 1.0);
   const int lane = threadIdx.x & 63;
   double R = 0.0;
-  for (int it = 1; it <= 13; ++it) {
+  for (int it = 1; it <= BC_STEPS + 1; ++it) {
     // this lane's farthest vertex from the current centre
     double best = -1.0;
     int bv = 0;
@@ -260,7 +264,7 @@ __device__ __forceinline__ void cluster_spheres_block(
       }
     }
     const double top = max16(best);
-    if (it == 13) {  // final radius about the final centre
+    if (it == BC_STEPS + 1) {  // final radius about the final centre
       R = sqrt(fmax(top, 0.0));
       break;
     }
@@ -343,7 +347,7 @@ __device__ __forceinline__ void super_spheres_block(
   for (int q = 0; q < 3; ++q)
     mean[q] = block_sum(f >= 0 ? (V[0][q] + V[1][q] + V[2][q]) / 3.0 : 0.0) / cnt;
   double R = 0.0;
-  for (int it = 1; it <= 13; ++it) {
+  for (int it = 1; it <= BC_STEPS + 1; ++it) {
     double best = -1.0;
     int bv = 0;
     if (f >= 0) {
@@ -357,7 +361,7 @@ __device__ __forceinline__ void super_spheres_block(
       }
     }
     const double top = block_max(best);
-    if (it == 13) {
+    if (it == BC_STEPS + 1) {
       R = sqrt(fmax(top, 0.0));
       break;
     }
@@ -1507,6 +1511,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     // the slot is empty in the next pass unless k_react3d pushes a child into it
     if (visit_next != nullptr) visit_next[q].idx = -1;
   }
+  // (the first supercluster spheres travel together with the record: one round trip less in
+  // the chain record -> bundle -> level 0 -> level 1 -> level 2 -> faces)
+  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
+  const float4 su_first = lane < n_super ? susphere[lane] : never;
   const int i = vrec.idx < n ? vrec.idx : -1;
   const bool live = i >= 0;
   if (__ballot(live) == 0ull) return;  // nothing to do here (nor for the grouped kernel)
@@ -1519,6 +1527,9 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   __shared__ uint16_t clist[WAVES][BEAM_CLIST];
   __shared__ uint32_t flist[WAVES][BEAM_FLIST];
   __shared__ uint32_t x_pair[WAVES][128];  // face << 6 | lane of the ray (faces < 2^24)
+  __shared__ uint16_t plist[WAVES][128];   // candidate of the chunk << 6 | lane of the ray
+  __shared__ float4 ctab[WAVES][64][3];    // float32 face records of the chunk's candidates
+  __shared__ float4 rtab[WAVES][64][2];    // the wave's rays: s - c0, d = e - s, face they start on
   __shared__ unsigned long long best_k[WAVES][64];
   __shared__ int32_t best_i[WAVES][64];
   best_k[wave][lane] = dkey(INFINITY);
@@ -1540,8 +1551,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
 
   const float es_f = (float)eps_size, er_f = (float)eps_start;
-  double best_d = INFINITY;  // this lane's nearest hit so far (refreshed after every decision batch)
-  int xn = 0;                // (ray, face) pairs waiting for the exact test (wave-uniform)
+  int pn = 0;  // (ray, candidate) pairs waiting for the screen (wave-uniform)
+  int xn = 0;  // (ray, face) pairs waiting for the exact test (wave-uniform)
+  rtab[wave][lane][0] = make_float4(sx, sy, sz, dx);
+  rtab[wave][lane][1] = make_float4(dy, dz, __int_as_float(skip), 0.f);
 
   auto ray_of = [&](const int slot, double s[3], double e[3]) {  // (all lanes active)
 #pragma unroll
@@ -1597,21 +1610,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   // single-ray walks cost ten times its work.
   TFRT_STAT(8, 1);
   constexpr int BEAM_ATTEMPTS = 20;
-  // distance of this lane's line from the previous lane's, near the scene: feet of the
-  // perpendiculars from the frame origin, plus the directions' difference over that distance
-  float gap = 0.f;
-  {
-    const float su = sx * ux + sy * uy + sz * uz;
-    const float fx = sx - su * ux, fy = sy - su * uy, fz = sz - su * uz;
-    const float gx = fx - __shfl_up(fx, 1, 64), gy = fy - __shfl_up(fy, 1, 64),
-                gz = fz - __shfl_up(fz, 1, 64);
-    const float hx = ux - __shfl_up(ux, 1, 64), hy = uy - __shfl_up(uy, 1, 64),
-                hz = uz - __shfl_up(uz, 1, 64);
-    const bool prev_ok = __shfl_up(ok ? 1 : 0, 1, 64) != 0;
-    if (ok && prev_ok && lane > 0)
-      gap = gx * gx + gy * gy + gz * gz + (sx * sx + sy * sy + sz * sz) * (hx * hx + hy * hy + hz * hz);
-    if (!(gap >= 0.f)) gap = 0.f;  // (NaN)
-  }
+  float gap = -1.f;  // (formed when the first cut is needed)
   unsigned long long cuts = 0ull;
   int lo = 0, attempts = 0;
   bool spread = false;
@@ -1662,8 +1661,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
 
       // ---- levels: lane = node
       if (narrow) {
-        const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-        float4 nxt = lane < n_super ? susphere[lane] : never;
+        float4 nxt = su_first;
         for (int b = 0; b < n_super; b += 64) {
           const int node = b + lane;
           const float4 cur = nxt;  // (the next 64 spheres are on their way while these are tested)
@@ -1725,6 +1723,22 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
                             ((len == 64 && (spread || (nc > 64 && nc > n_clusters / 4))) ||
                              attempts >= BEAM_ATTEMPTS);
       if (len > 1 && !hopeless) {  // cut at the widest gap inside [lo, hi), try the first part
+        if (cuts == 0ull) {
+          // distance of this lane's line from the previous lane's, near the scene: feet of the
+          // perpendiculars from the frame origin, plus the directions' difference over that distance
+          const float su = sx * ux + sy * uy + sz * uz;
+          const float fx = sx - su * ux, fy = sy - su * uy, fz = sz - su * uz;
+          const float gx = fx - __shfl_up(fx, 1, 64), gy = fy - __shfl_up(fy, 1, 64),
+                      gz = fz - __shfl_up(fz, 1, 64);
+          const float hx = ux - __shfl_up(ux, 1, 64), hy = uy - __shfl_up(uy, 1, 64),
+                      hz = uz - __shfl_up(uz, 1, 64);
+          const bool prev_ok = __shfl_up(ok ? 1 : 0, 1, 64) != 0;
+          gap = 0.f;
+          if (ok && prev_ok && lane > 0)
+            gap = gx * gx + gy * gy + gz * gz +
+                  (sx * sx + sy * sy + sz * sz) * (hx * hx + hy * hy + hz * hz);
+          if (!(gap >= 0.f)) gap = 0.f;  // (NaN)
+        }
         const bool inside = lane > lo && lane < hi;
         const float widest = wave_max_f(inside ? gap : -1.f);
         const unsigned long long at = __ballot(inside && gap == widest);
@@ -1768,7 +1782,6 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
             wave_fence();
             if (lane < xn - 64) x_pair[wave][lane] = tp;
             xn -= 64;
-            best_d = dkey_inv(best_k[wave][lane]);
             wave_fence();
           }
         }
@@ -1785,47 +1798,80 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       return;
     }
 
-    // ---- faces: lane = ray
+    // ---- faces
+    // (1) lane = ray, one candidate face at a time: is the ray's line within r of the face's
+    //     sphere?  (sphere broadcast from the lane that fetched it: scalar operands, 12 vector
+    //     instructions per face) -- the (ray, face) pairs that pass queue up;
+    // (2) lane = pair: float32 screen (may_hit_core) with the face record and the ray from LDS
+    //     tables; (3) lane = pair: exact float64 decision.
     TFRT_STAT(13, nf);
     for (int f0 = 0; f0 < nf; f0 += 64) {
       const int nb = min(64, nf - f0);
-      // each lane fetches one candidate's float32 record (P0 - c0 | face index, E1, E2) ...
-      float4 r0 = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), r1 = r0, r2 = r0;
+      float4 sp = make_float4(0.f, 0.f, 0.f, -1.f);
       if (lane < nb) {
         const int64_t memb = (int64_t)flist[wave][f0 + lane];
-        r0 = crec[3 * memb];
-        r1 = crec[3 * memb + 1];
-        r2 = crec[3 * memb + 2];
+        sp = csphere[memb];
+        sp.w *= 1.00001f;
+        // the candidate's float32 record (P0 - c0 | face index, E1, E2) for the screen
+        ctab[wave][lane][0] = crec[3 * memb];
+        ctab[wave][lane][1] = crec[3 * memb + 1];
+        ctab[wave][lane][2] = crec[3 * memb + 2];
       }
-      // ... and hands it to the whole wave when its turn comes
-      for (int c = 0; c < nb; ++c) {
-        const float p0x = bcast_f(r0.x, c), p0y = bcast_f(r0.y, c), p0z = bcast_f(r0.z, c);
-        const int j = __builtin_amdgcn_readlane(__float_as_int(r0.w), c);
-        const float e1x = bcast_f(r1.x, c), e1y = bcast_f(r1.y, c), e1z = bcast_f(r1.z, c);
-        const float e2x = bcast_f(r2.x, c), e2y = bcast_f(r2.y, c), e2z = bcast_f(r2.z, c);
-        bool keep = false;
-        if (sel && j >= 0 && j != skip) {
-          const float tx = sx - p0x, ty = sy - p0y, tz = sz - p0z;
-          // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t
-          // scales with their magnitudes, not with |t|
-          const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(sx) + fabsf(sy) +
-                               fabsf(sz) + fabsf(p0x) + fabsf(p0y) + fabsf(p0z);
-          keep = may_hit_core(dx, dy, dz, e1x, e1y, e1z, e2x, e2y, e2z, tx, ty, tz, nt_err, es_f,
-                              er_f, best_d);
+      wave_fence();
+      for (int c = 0; c <= nb; ++c) {
+        if (c < nb) {
+          const float ccx = bcast_f(sp.x, c), ccy = bcast_f(sp.y, c), ccz = bcast_f(sp.z, c);
+          const float cw = bcast_f(sp.w, c);
+          const float vx = ccx - sx, vy = ccy - sy, vz = ccz - sz;
+          const float vu = vx * ux + vy * uy + vz * uz;
+          const float v2 = vx * vx + vy * vy + vz * vz;
+          // (4e-6 v2: the rounding of v2 - vu^2 and of a float32 unit direction at range |v|)
+          const bool near = sel && (v2 - vu * vu <= cw + 4e-6f * v2);
+          const unsigned long long nm = __ballot(near);
+          if (near) plist[wave][pn + rank_below(nm)] = (uint16_t)((c << 6) | lane);
+          pn += __popcll(nm);
         }
-        const unsigned long long km = __ballot(keep);
-        if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lane;
-        xn += __popcll(km);
-        TFRT_STAT(14, __popcll(km));
-        if (xn >= 64) {
+        // a full batch of pairs -- or, after the chunk's last face, what is left (the table of
+        // face records is about to be overwritten)
+        while (pn >= 64 || (c == nb && pn > 0)) {
+          const int np = min(pn, 64);
           wave_fence();
-          decide(64);
-          uint32_t tp = 0u;  // fewer than 64 remain: move them to the front
-          if (lane < xn - 64) tp = x_pair[wave][64 + lane];
+          bool keep = false;
+          int j = -1, rl = 0;
+          if (lane < np) {
+            const unsigned pr = plist[wave][lane];
+            rl = (int)(pr & 63u);
+            const float4 r0 = ctab[wave][pr >> 6][0], r1 = ctab[wave][pr >> 6][1],
+                         r2 = ctab[wave][pr >> 6][2];
+            const float4 ra = rtab[wave][rl][0], rb = rtab[wave][rl][1];  // s (c0 frame), d, skip
+            j = __float_as_int(r0.w);
+            const float tx = ra.x - r0.x, ty = ra.y - r0.y, tz = ra.z - r0.z;
+            // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t
+            // scales with their magnitudes, not with |t|
+            const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(ra.x) + fabsf(ra.y) +
+                                 fabsf(ra.z) + fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z);
+            keep = j >= 0 && j != __float_as_int(rb.z) &&
+                   may_hit_core(ra.w, rb.x, rb.y, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z, tx, ty, tz,
+                                nt_err, es_f, er_f, dkey_inv(best_k[wave][rl]));
+          }
+          const unsigned long long km = __ballot(keep);
+          if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)rl;
+          xn += __popcll(km);
+          TFRT_STAT(14, __popcll(km));
+          uint32_t tq = 0u;  // fewer than 64 pairs remain: move them to the front
+          if (lane < pn - np) tq = plist[wave][np + lane];
           wave_fence();
-          if (lane < xn - 64) x_pair[wave][lane] = tp;
-          xn -= 64;
-          best_d = dkey_inv(best_k[wave][lane]);
+          if (lane < pn - np) plist[wave][lane] = (uint16_t)tq;
+          pn -= np;
+          if (xn >= 64) {
+            wave_fence();
+            decide(64);
+            uint32_t tp = 0u;
+            if (lane < xn - 64) tp = x_pair[wave][64 + lane];
+            wave_fence();
+            if (lane < xn - 64) x_pair[wave][lane] = tp;
+            xn -= 64;
+          }
           wave_fence();
         }
       }

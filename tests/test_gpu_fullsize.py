@@ -83,6 +83,29 @@ def test_full_size_hierarchy_equals_all_pairs(full):
         assert torch.equal(out[cls], ref[cls]), cls
 
 
+def test_full_size_visiting_order_changes_nothing(full):
+    """cfg4 at full size with the coherent visiting order (tfrt_scene3d.visit_records: Hilbert
+    order of the source, k_intersect_beam): every wavefront is a narrow bundle (nothing is left to
+    the grouped kernel) and every output equals the natural-order trace bit for bit -- with and
+    without the grouped-kernel launch behind it (visit_all)."""
+    from tensorflowraytrace_amd import ops
+    sc, out = full["sc"], full["out"]
+    sc.visit_records = ops.visit_records(full["src"])
+    try:
+        for visit_all in (False, True):
+            sc.visit_all = visit_all
+            got = ops.trace3d(full["src"], full["fv"], sc, max_passes=PASSES, flags=full["flags"])
+            assert got["left_over"] == 0
+            assert np.array_equal(got["counts"], out["counts"]) and got["n_tests"] == out["n_tests"]
+            for cls in ("finished", "active", "stopped", "dead", "unfinished"):
+                assert torch.equal(got[cls + "_id"], out[cls + "_id"]), cls
+                if cls != "unfinished":
+                    assert torch.equal(got[cls + "_face"], out[cls + "_face"]), cls
+                assert torch.equal(got[cls].detach(), out[cls].detach()), cls
+    finally:
+        sc.visit_records, sc.visit_all = None, False
+
+
 def test_full_size_sample_against_the_oracle(full):
     scene, out = full["scene"], full["out"]
     rng = np.random.default_rng(17)
@@ -449,6 +472,24 @@ def test_cfg5a_hierarchy_equals_all_pairs(cfg5a):
         assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), cls
         assert torch.equal(out[cls + "_face"], ref[cls + "_face"]), cls
         assert torch.equal(out[cls].detach(), ref[cls].detach()), cls
+
+
+def test_cfg5a_visiting_order_changes_nothing(cfg5a):
+    """4M rays, 8 passes, lens + light guide: rays finish after different numbers of bounces, so
+    the visiting order grows holes, and bundles widen with every bounce off the faceted wall
+    (wavefronts are cut, some are left to the grouped kernel) -- the ray sets stay identical."""
+    eng2, _, _ = _build_5a(torch.float32)
+    eng2.coherent = True
+    eng2.ray_trace(PASSES_5A)
+    got, out = eng2.last_trace, cfg5a["out"]
+    assert getattr(eng2, "_order_cache", None) is not None
+    assert np.array_equal(got["counts"], out["counts"]) and got["n_tests"] == out["n_tests"]
+    for cls in ("finished", "active", "stopped", "dead"):
+        assert torch.equal(got[cls + "_id"], out[cls + "_id"]), cls
+        assert torch.equal(got[cls + "_face"], out[cls + "_face"]), cls
+        assert torch.equal(got[cls].detach(), out[cls].detach()), cls
+    print(f"cfg5a visiting order: {got['left_over']} wavefront-passes left to the grouped kernel "
+          f"of {PASSES_5A * N_5A // 64}")
 
 
 def _oracle_5a(parts):
