@@ -182,25 +182,24 @@ typedef struct tfrt_scene3d {
    * hence order-independent), then converted back: bit-identical results on every run, at a
    * resolution of 2^-40 of the pass's largest term. */
   int32_t deterministic;
-  /* Optional, with cluster_order: the source rays once more, as n_rays RECORDS in a coherent
-   * visiting order -- rays whose lines run close together are neighbours (e.g. a Hilbert-curve
-   * order of their aperture points):
-   *     float32 / float16 ray state:  { float  start[3], end[3]; int32 index; int32 -1; }    32 B
-   *     float64 ray state:            { double start[3], end[3]; int32 index; int32 -1; int32 0, 0; } 64 B
-   * record q holds source ray `index` (the values of src_rays[.., index], exactly) and the
-   * indices are a permutation of 0..n_rays-1.  The trace then visits rays in this order -- later
-   * passes visit the children of a wavefront's rays -- and a wavefront whose 64 rays form a
-   * narrow bundle walks the face hierarchy ONCE for all of them (k_intersect_beam); other
-   * wavefronts take the per-ray walk.  Only the visiting order changes: every output (sets,
-   * their order, hit faces, coordinates) is identical with and without it. */
-  const void* visit_records;
-  /* With visit_records.  0: behind k_intersect_beam the grouped kernel is launched for the
+  /* With cluster_order.  1: the caller hands the source rays over in a COHERENT order --
+   * neighbouring rays have neighbouring lines, e.g. sorted along a Hilbert curve through their
+   * aperture points (tensorflowraytrace_amd.ops.ray_order).  A wavefront of 64 consecutive rays is
+   * then tried as ONE narrow bundle that walks the face hierarchy once for all of them
+   * (k_intersect_beam; wavefronts that are no narrow bundles are cut, or left to the grouped
+   * per-ray walk), and the reverse sweep sums the face gradients of a wavefront's rays before
+   * touching memory.  The outputs are what they always are -- every class compacted stably in the
+   * order of the rays handed in -- so a caller that sorted its rays maps the ray ids back and
+   * restores its own order per pass (the Python engine does).  Results never depend on the flag;
+   * with rays that are not coherent it only costs time. */
+  int32_t coherent_rays;
+  /* With coherent_rays.  0: behind k_intersect_beam the grouped kernel is launched for the
    * wavefronts that are no (few) narrow bundles; their number, summed over the passes, comes back
    * in counts[TFRT_COUNTS_LEN - 1].  1: no such launch -- k_intersect_beam finishes every
    * wavefront itself, cutting it down to single rays if need be: always correct, but slow for
    * rays that are not coherent; meant for a source whose earlier traces left no wavefront over
    * (saves one kernel launch per pass). */
-  int32_t visit_all;
+  int32_t coherent_only;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in
@@ -221,7 +220,7 @@ size_t tfrt_trace3d_workspace_bytes(int64_t n_rays, int64_t n_faces, int32_t max
 /* Number of int32 in `counts`: per pass 8 ints {n_active,n_finished,n_stopped,n_dead,
  * base_active,base_finished,base_stopped,base_dead}, then 8 trailing ints:
  * {total_active,total_finished,total_stopped,total_dead,n_tests_lo,n_tests_hi,error,
- *  wavefronts left to the grouped kernel (visiting-order traces)}. */
+ *  wavefronts left to the grouped kernel (coherent-ray traces)}. */
 #define TFRT_COUNTS_PER_PASS 8
 #define TFRT_COUNTS_LEN(max_passes) (8 * ((max_passes) + 1))
 

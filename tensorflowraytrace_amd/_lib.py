@@ -29,7 +29,7 @@ class Scene3D(ctypes.Structure):
         ("n_table", c_vp), ("n_table_stride", c_i64), ("n_materials", c_i32),
         ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
         ("face_grad_mask", c_vp), ("cluster_order", c_vp), ("reserved0", c_i32),
-        ("deterministic", c_i32), ("visit_records", c_vp), ("visit_all", c_i32),
+        ("deterministic", c_i32), ("coherent_rays", c_i32), ("coherent_only", c_i32),
     ]
 
 

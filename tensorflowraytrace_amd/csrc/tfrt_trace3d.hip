@@ -396,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
     float4* __restrict__ crec, float4* __restrict__ susphere, int32_t* nrays0, int n,
     int32_t* tail8, unsigned int* scan_ticket, int32_t* __restrict__ hist0, int hist_len) {
-  // (visiting-order traces: the class histogram the first pass's intersect kernels add into)
+  // (coherent-ray traces: the class histogram the first pass's intersect kernels add into)
   for (int k = blockIdx.x * BLOCK + threadIdx.x; k < hist_len; k += gridDim.x * BLOCK) hist0[k] = 0;
   __shared__ double c0[3];
   if (threadIdx.x < 64) {
@@ -690,47 +690,6 @@ __global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
   }
 }
 
-// ------------------------------------------------------------------- visiting order
-//
-// A trace with a visiting order (tfrt_scene3d.visit_records) keeps, next to the ray blocks, the
-// rays of the current pass as RECORDS in the order in which the intersect kernels visit them:
-// slot q = {start, end, index of the ray in this pass's ray block (-1: none), face it starts on}.
-// A wavefront reads its 64 records with coalesced loads; k_react3d pushes every child ray to the
-// slot its parent was visited at (the parent's slot comes back through rec_q), so a wavefront keeps
-// visiting the descendants of the same 64 source rays -- neighbours stay neighbours.
-template <typename RT>
-struct VisitRec;
-template <>
-struct __attribute__((aligned(16))) VisitRec<float> {   // 32 B (float32 and float16 ray state)
-  float r[6];
-  int32_t idx, last_tri;
-};
-template <>
-struct __attribute__((aligned(16))) VisitRec<double> {  // 64 B
-  double r[6];
-  int32_t idx, last_tri, pad0, pad1;
-};
-template <typename T>
-using VisitRecOf = VisitRec<std::conditional_t<sizeof(T) <= 4, float, double>>;
-
-template <typename RT>
-__device__ __forceinline__ VisitRec<RT> load_visit(const VisitRec<RT>* __restrict__ v, int64_t q) {
-  VisitRec<RT> out;
-  const float4* src = reinterpret_cast<const float4*>(v + q);
-  float4* dst = reinterpret_cast<float4*>(&out);
-#pragma unroll
-  for (int k = 0; k < (int)(sizeof(VisitRec<RT>) / 16); ++k) dst[k] = src[k];
-  return out;
-}
-template <typename RT>
-__device__ __forceinline__ void store_visit(VisitRec<RT>* __restrict__ v, int64_t q,
-                                            const VisitRec<RT>& rec) {
-  float4* dst = reinterpret_cast<float4*>(v + q);
-  const float4* src = reinterpret_cast<const float4*>(&rec);
-#pragma unroll
-  for (int k = 0; k < (int)(sizeof(VisitRec<RT>) / 16); ++k) dst[k] = src[k];
-}
-
 // ---------------------------------------------------------------- grouped intersect
 //
 // Two-level filter in the rays' natural order (no sort).
@@ -802,9 +761,8 @@ __device__ __forceinline__ void group_walk(
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ blockcnt, const VisitRecOf<T>* __restrict__ visit,
-    int32_t* __restrict__ hist, int32_t* __restrict__ rec_q, const int base, const int qwave,
-    const int nq) {
+    int32_t* __restrict__ blockcnt, int32_t* __restrict__ hist, const int base,
+    const int qwave) {
   constexpr int RW = 64 * R;      // rays per wave
 #ifndef TFRT_GROUP_TILE
 #define TFRT_GROUP_TILE 256
@@ -812,23 +770,16 @@ __device__ __forceinline__ void group_walk(
   constexpr int GT = TFRT_GROUP_TILE;   // cluster spheres per LDS tile
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  // Visiting order (R == 1 only): this wave does wavefront `qwave` of the visiting order -- one
-  // that k_intersect_beam has left to this kernel -- i.e. the rays of records visit[64 qwave ..].
-  // qwave < 0: nothing; the wave still walks the tiles with its block (the staging barriers),
-  // without any tests.
-  const bool ordered = visit != nullptr;
+  // Coherent-ray traces (R == 1 only): this wave does wavefront `qwave` -- one that
+  // k_intersect_beam has left to this kernel -- i.e. rays 64 qwave ... 64 qwave + 63.  qwave < 0:
+  // nothing; the wave still walks the tiles with its block (the staging barriers), without tests.
+  const bool ordered = hist != nullptr;
   const bool idle_wave = ordered && qwave < 0;
   if (!ordered && base >= n) return;  // block-uniform
-  // ray visited by slot r * 64 + lane of this wave (-1: none)
-  VisitRecOf<T> vrec;
-  vrec.idx = -1;
-  vrec.last_tri = -1;
-  if (ordered && !idle_wave && qwave * 64 + lane < nq)
-    vrec = load_visit(visit, (int64_t)qwave * 64 + lane);
+  // ray of slot r * 64 + lane of this wave (-1: none)
   auto ray_index = [&](const int r) -> int {
-    const int qq = base + r * BLOCK + tid;
-    if (!ordered) return qq < n ? qq : -1;
-    return vrec.idx < n ? vrec.idx : -1;
+    const int qq = ordered ? qwave * 64 + lane : base + r * BLOCK + tid;
+    return (!idle_wave && qq < n) ? qq : -1;
   };
   const int c_lo = blockIdx.y * chunk_clusters;
   const int c_hi = min(n_clusters, c_lo + chunk_clusters);
@@ -890,13 +841,8 @@ __device__ __forceinline__ void group_walk(
   if constexpr (RAY_SHUFFLE) {
     const int i0 = ray_index(0);
     const int64_t ii = i0 >= 0 ? i0 : 0;
-    if (ordered) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) own_ray[q] = i0 >= 0 ? vrec.r[q] : RT(0);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<RT>(rays[q * stride + ii]);
-    }
+    for (int q = 0; q < 6; ++q) own_ray[q] = static_cast<RT>(rays[q * stride + ii]);
   }
   // (all lanes active: a lane that is masked off would hand out zeros)
   auto ray_of = [&](const int slot, double s[3], double e[3]) {
@@ -929,8 +875,7 @@ __device__ __forceinline__ void group_walk(
 #pragma unroll
       for (int q = 0; q < 6; ++q) ray_l[wave][q][slot] = rays[q * stride + ii];
 #endif
-      skip_l[wave][slot] = ordered ? (i >= 0 ? vrec.last_tri : -1)
-                                   : ((last_tri != nullptr && i >= 0) ? last_tri[ii] : -1);
+      skip_l[wave][slot] = (last_tri != nullptr && i >= 0) ? last_tri[ii] : -1;
     }
     if (i >= 0 && prep != nullptr && !ordered) {
       ax[r] = prep[i];
@@ -945,20 +890,10 @@ __device__ __forceinline__ void group_walk(
       // first pass of a trace: nobody has written the filter state of these rays yet.  Forming
       // it here (k_rayprep's arithmetic, ~60 float64 instructions) saves that kernel's launch,
       // its 32 B per ray written and the same 32 B read back
-      // (visiting order: always -- the ray is in the lane's record, its filter state would be
-      // eight scattered reads)
+      // (coherent-ray traces: always -- k_react3d does not write a filter state that hardly any
+      // wavefront would read)
       double s[3], e[3], u[3], scv[3];
-      if (ordered) {
-        if constexpr (R == 1) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            s[k] = static_cast<double>(vrec.r[k]);
-            e[k] = static_cast<double>(vrec.r[3 + k]);
-          }
-        }
-      } else {
-        load_ray3(rays, stride, i, s, e);
-      }
+      load_ray3(rays, stride, i, s, e);
       float o[8];
       ray_filter_state(s, e, c0, o, u, scv);
       ax[r] = o[0];
@@ -1337,13 +1272,15 @@ __device__ __forceinline__ void group_walk(
       rec_tri[i] = bi;
       rec_t[i] = dkey_inv(best_k[wave][slot]);
       rec_cls[i] = (uint8_t)cls;
-      // visiting order: the rays of a wave belong to many 256-slot blocks of the ray block
-      if (ordered) {
-        atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
-        rec_q[i] = qwave * 64 + lane;
-      }
     }
-    if (ordered) break;                // (R == 1; block-uniform)
+    if (ordered) {  // (R == 1) this wavefront's share of its 256-ray block's class histogram
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int cnt_c = __popcll(__ballot(cls == c));
+        if (lane == c && cnt_c > 0 && qwave >= 0) atomicAdd(&hist[(qwave >> 2) * 4 + c], cnt_c);
+      }
+      break;  // (block-uniform)
+    }
     if (base + r * BLOCK >= n) break;  // block-uniform: no rays in this 256-ray slice
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1371,19 +1308,18 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ blockcnt, const VisitRecOf<T>* __restrict__ visit,
-    const int32_t* __restrict__ left_list, const int32_t* __restrict__ left_count, int nq,
-    int32_t* __restrict__ hist, int32_t* __restrict__ rec_q) {
+    int32_t* __restrict__ blockcnt, const int32_t* __restrict__ left_list,
+    const int32_t* __restrict__ left_count, int32_t* __restrict__ hist) {
   const int n = *n_ptr;
-  if (visit == nullptr) {  // natural order: one workgroup per 256 R rays
+  if (hist == nullptr) {  // one workgroup per 256 R rays
     group_walk<T, R>(rays, stride, n, last_tri, susphere, clsphere, csphere, crec, cface, fverts,
                      c0, prep, pstride, n_clusters, chunk_clusters, eps_int, eps_size, eps_start,
                      part_t, part_i, part_stride, catagory, rec_tri, rec_t, rec_cls, blockcnt,
-                     visit, hist, rec_q, (int)blockIdx.x * (BLOCK * R), -1, 0);
+                     nullptr, (int)blockIdx.x * (BLOCK * R), -1);
     return;
   }
-  // visiting order: the wavefronts k_intersect_beam has left (usually none: the workgroups read
-  // one counter and retire), four per workgroup and round
+  // coherent-ray traces: the wavefronts k_intersect_beam has left (usually none: the workgroups
+  // read one counter and retire), four per workgroup and round
   const int total = *left_count;
   for (int item = blockIdx.x; item * WAVES < total; item += gridDim.x) {
     const int k = item * WAVES + (int)(threadIdx.x >> 6);
@@ -1391,7 +1327,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     group_walk<T, R>(rays, stride, n, last_tri, susphere, clsphere, csphere, crec, cface, fverts,
                      c0, prep, pstride, n_clusters, chunk_clusters, eps_int, eps_size, eps_start,
                      part_t, part_i, part_stride, catagory, rec_tri, rec_t, rec_cls, blockcnt,
-                     visit, hist, rec_q, 0, qwave, nq);
+                     hist, 0, qwave);
     __syncthreads();  // (the next round reuses the LDS tile and lists)
   }
 }
@@ -1399,10 +1335,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
 // ------------------------------------------------------------- coherent-wave intersect
 //
 // k_intersect_beam: the same decisions as k_intersect_group for wavefronts whose 64 rays form a
-// narrow bundle.  Rays are visited in a caller-supplied order (tfrt_scene3d.visit_records: the
-// source rays as records in an order that puts rays with neighbouring lines next to each other,
-// e.g. a Hilbert-curve order of their aperture points; later passes visit the children of a
-// wave's rays, see VisitRec).  Then a wave shares ONE walk of the hierarchy:
+// narrow bundle -- which they do when the caller hands the source rays over in a coherent order
+// (tfrt_scene3d.coherent_rays: neighbouring rays have neighbouring lines, e.g. sorted along a
+// Hilbert curve through their aperture points; the stable compaction keeps the children of
+// neighbouring rays neighbours in every later pass).  Then a wave shares ONE walk of the hierarchy:
 //
 //   bundle     axis (o, w) = mean start / mean direction of the wave's rays; every point of every
 //              ray's line at axial coordinate t lies within R0 + S |t| of the axis (R0, S: wave
@@ -1486,42 +1422,35 @@ __device__ __forceinline__ float bcast_f(float v, int src_lane) {  // src_lane w
 #endif
 template <typename T>
 __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
-    const int32_t* __restrict__ n_ptr, const VisitRecOf<T>* __restrict__ visit,
-    VisitRecOf<T>* __restrict__ visit_next, int first_pass, int nq,
-    const float4* __restrict__ susphere, const float4* __restrict__ clsphere,
-    const float4* __restrict__ csphere, const float4* __restrict__ crec,
-    const double* __restrict__ fverts, const double* __restrict__ c0, int n_clusters, int n_super,
-    double eps_int, double eps_size, double eps_start, const int32_t* __restrict__ catagory,
-    int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ rec_q, int32_t* __restrict__ hist, int32_t* __restrict__ left_list,
-    int32_t* __restrict__ left_count, int32_t* __restrict__ left_total, int visit_all) {
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
+    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
+    const float4* __restrict__ crec, const double* __restrict__ fverts,
+    const double* __restrict__ c0, int n_clusters, int n_super, double eps_int, double eps_size,
+    double eps_start, const int32_t* __restrict__ catagory, int32_t* __restrict__ rec_tri,
+    double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls, int32_t* __restrict__ hist,
+    int32_t* __restrict__ left_list, int32_t* __restrict__ left_count,
+    int32_t* __restrict__ left_total, int coherent_only) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x * BLOCK + tid;
   const int qwave = q >> 6;
-  if ((qwave << 6) >= nq) return;  // (whole wave; no block-level synchronisation in this kernel)
   const int n = *n_ptr;
+  if ((qwave << 6) >= n) return;  // (whole wave; no block-level synchronisation in this kernel)
+  const bool first_pass = last_tri == nullptr;
 
-  // this lane's record: one coalesced 32 / 64-byte read
+  // this lane's ray: coalesced reads of the ray block
   using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
-  VisitRec<RT> vrec;
-  vrec.idx = -1;
-  vrec.last_tri = -1;
-  if (q < nq) {
-    vrec = load_visit(visit, q);
-    // the slot is empty in the next pass unless k_react3d pushes a child into it
-    if (visit_next != nullptr) visit_next[q].idx = -1;
-  }
-  // (the first supercluster spheres travel together with the record: one round trip less in
-  // the chain record -> bundle -> level 0 -> level 1 -> level 2 -> faces)
-  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-  const float4 su_first = lane < n_super ? susphere[lane] : never;
-  const int i = vrec.idx < n ? vrec.idx : -1;
+  const int i = q < n ? q : -1;
   const bool live = i >= 0;
-  if (__ballot(live) == 0ull) return;  // nothing to do here (nor for the grouped kernel)
+  const int64_t ii = live ? i : 0;
   RT own[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) own[k] = live ? vrec.r[k] : RT(0);
-  const int skip = live ? vrec.last_tri : -1;
+  for (int k = 0; k < 6; ++k) own[k] = static_cast<RT>(rays[k * stride + ii]);
+  const int skip = (live && last_tri != nullptr) ? last_tri[ii] : -1;
+  // (the first supercluster spheres travel together with the ray: one round trip less in the
+  // chain ray -> bundle -> level 0 -> level 1 -> level 2 -> faces)
+  const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
+  const float4 su_first = lane < n_super ? susphere[lane] : never;
 
   __shared__ uint16_t slist[WAVES][BEAM_SLIST];
   __shared__ uint16_t clist[WAVES][BEAM_CLIST];
@@ -1600,9 +1529,9 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     wave_fence();
   };
 
-  // The wavefront's lanes are taken as ONE bundle; if that bundle is not narrow (the visiting
-  // order jumps inside the wavefront: a Hilbert curve leaves and re-enters a round aperture) it is
-  // cut where neighbouring lanes -- neighbours in the visiting order -- lie farthest apart, and
+  // The wavefront's lanes are taken as ONE bundle; if that bundle is not narrow (the ray order
+  // jumps inside the wavefront: a Hilbert curve leaves and re-enters a round aperture) it is
+  // cut where neighbouring lanes lie farthest apart, and
   // the parts are taken one after the other, down to single rays if need be (one ray is always a
   // narrow bundle).  `cuts` bit k: a bundle ends before lane k.  A wavefront whose rays are
   // simply not coherent -- directions spread, a quarter of the scene's clusters touched, or more
@@ -1717,9 +1646,9 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       wave_fence();
     }
     if (!narrow) {
-      // (visit_all: the caller launches no grouped kernel behind this one -- it has seen this
+      // (coherent_only: the caller launches no grouped kernel behind this one -- it has seen this
       // source leave no wavefront over -- so every wavefront is finished here, however wide)
-      const bool hopeless = !visit_all &&
+      const bool hopeless = !coherent_only &&
                             ((len == 64 && (spread || (nc > 64 && nc > n_clusters / 4))) ||
                              attempts >= BEAM_ATTEMPTS);
       if (len > 1 && !hopeless) {  // cut at the widest gap inside [lo, hi), try the first part
@@ -1881,15 +1810,19 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   wave_fence();
   if (xn > 0) decide(xn);
 
-  // ---- hit record, class and the class histogram of the ray's 256-slot block (react's scan)
+  // ---- hit record, class and this wavefront's share of its 256-ray block's class histogram
+  int cls = -1;
   if (live) {
     const int bi = best_i[wave][lane];
-    const int cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
+    cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
     rec_tri[i] = bi;
     rec_t[i] = dkey_inv(best_k[wave][lane]);
     rec_cls[i] = (uint8_t)cls;
-    rec_q[i] = q;
-    atomicAdd(&hist[(i >> 8) * 4 + cls], 1);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int cnt_c = __popcll(__ballot(cls == c));
+    if (lane == c && cnt_c > 0) atomicAdd(&hist[(qwave >> 2) * 4 + c], cnt_c);
   }
 }
 
@@ -2069,7 +2002,7 @@ struct SelfScan {
   int32_t* n_next = nullptr;             // ray count of the next pass
   unsigned long long* n_tests = nullptr;
   int M = 0;
-  // visiting-order traces: the class histogram of the NEXT pass (the intersect kernels add into
+  // coherent-ray traces: the class histogram of the NEXT pass (the intersect kernels add into
   // it with atomics); every block clears its own row here, one pass ahead
   int32_t* hist_next = nullptr;
   int hist_rows = 0;
@@ -2086,8 +2019,7 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
     int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_tri_out,
     int32_t* __restrict__ rec_slot, tfrt_ray_out fin, tfrt_ray_out act, tfrt_ray_out stp,
     tfrt_ray_out dead, int32_t* __restrict__ err, float* __restrict__ prep_next, int64_t pstride,
-    const double* __restrict__ c0, SelfScan ss, VisitRecOf<T>* __restrict__ visit_next,
-    const int32_t* __restrict__ rec_q) {
+    const double* __restrict__ c0, SelfScan ss) {
   const int n = *n_ptr;
   const int base = blockIdx.x * BLOCK;
   // Self-scan mode (few ray blocks): no scan launch ran.  Every block sums the class histograms
@@ -2205,19 +2137,6 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
       ray_id_out[slot] = rid;
       last_tri_out[slot] = tri;
       rec_slot[i] = slot;
-      if (visit_next != nullptr) {
-        // visiting order: the child (AS STORED) goes to the slot its parent was visited at
-        VisitRecOf<T> rec;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          rec.r[k] = static_cast<decltype(rec.r[0] + 0)>(static_cast<T>(h[k]));
-          rec.r[3 + k] = static_cast<decltype(rec.r[0] + 0)>(static_cast<T>(e2[k]));
-        }
-        rec.idx = slot;
-        rec.last_tri = tri;
-        if constexpr (sizeof(rec) == 64) rec.pad0 = rec.pad1 = 0;
-        store_visit(visit_next, (int64_t)rec_q[i], rec);
-      }
       if (prep_next != nullptr) {
         // the child's filter state for the next pass (saves a k_rayprep launch and a re-read of
         // the ray block), from the child AS STORED: the exact tests see the rounded state
@@ -2291,10 +2210,60 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     const double* __restrict__ g_dead, int64_t cap_dead,
     typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
     int64_t out_stride, double* __restrict__ g_fverts,
-    typename SweepStore<T>::type* __restrict__ stash_g, int32_t* __restrict__ stash_face) {
+    typename SweepStore<T>::type* __restrict__ stash_g, int32_t* __restrict__ stash_face,
+    int wave_sums) {
   const int n = *n_ptr;
   const int q0 = blockIdx.x * BLOCK + threadIdx.x;
   const int i = q0;
+  if (wave_sums) {
+    // Coherent rays (tfrt_scene3d.coherent_rays): the 64 rays of a wavefront hit a handful of
+    // faces.  Their terms are summed per face in LDS first (one slot per distinct face of the
+    // wavefront, LDS float64 adds), then every (face, term) sum goes to memory with ONE atomic:
+    // no per-ray stash written and read back, no accumulate launch.
+    if ((q0 & ~63) >= n) return;  // (whole wave)
+    constexpr int SLOTS = 24;
+    __shared__ double wacc[WAVES][SLOTS][9];
+    __shared__ int32_t wface[WAVES][SLOTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double gP[9];
+    int tri = -1;
+    if (i < n)
+      tri = backward_ray<T>(i, rays_in, stride_in, ray_id_in, rec_tri, rec_t, rec_cls, rec_slot,
+                            pass_counts, sc, L, dead_len, g_child, child_stride, g_fin, cap_fin,
+                            g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead, g_out, g_src_out,
+                            out_stride, gP);
+    for (int k = lane; k < SLOTS * 9; k += 64) (&wacc[wave][0][0])[k] = 0.0;
+    int slot = -1, ns = 0;
+    unsigned long long todo = __ballot(tri >= 0);
+    while (todo != 0ull && ns < SLOTS) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k = __shfl(tri, leader, 64);
+      const bool mine = tri == k;
+      if (mine) slot = ns;
+      if (lane == leader) wface[wave][ns] = k;
+      ++ns;
+      todo &= ~__ballot(mine);
+    }
+    wave_fence();
+    if (tri >= 0) {
+      if (slot >= 0) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+          if (gP[c] != 0.0) unsafeAtomicAdd(&wacc[wave][slot][c], gP[c]);
+      } else {  // (more distinct faces than slots: rays that are not coherent after all)
+        double* gp = g_fverts + 9 * (int64_t)tri;
+#pragma unroll
+        for (int c = 0; c < 9; ++c)
+          if (gP[c] != 0.0) unsafeAtomicAdd(gp + c, gP[c]);
+      }
+    }
+    wave_fence();
+    for (int k = lane; k < ns * 9; k += 64) {
+      const double v = (&wacc[wave][0][0])[k];
+      if (v != 0.0) unsafeAtomicAdd(g_fverts + 9 * (int64_t)wface[wave][k / 9] + (k % 9), v);
+    }
+    return;
+  }
   if (i >= n) return;
   double gP[9];
   const int tri = backward_ray<T>(i, rays_in, stride_in, ray_id_in, rec_tri, rec_t, rec_cls,
@@ -2676,7 +2645,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec, visit_a, visit_b, rec_q, hist_a, hist_b, left_list;
+  size_t csphere, cface, clsphere, susphere, crec, hist_a, hist_b, left_list;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -2708,12 +2677,8 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.clsphere = take(ncl * sizeof(float4));
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
-  // visiting-order traces (tfrt_scene3d.visit_records): the records of two consecutive passes,
-  // each ray's slot in the visiting order, two class histograms (one being read, one being
-  // built), one flag per wavefront
-  L.visit_a = take(n * (dtype == TFRT_F64 ? 64 : 32));
-  L.visit_b = take(n * (dtype == TFRT_F64 ? 64 : 32));
-  L.rec_q = take(n * sizeof(int32_t));
+  // coherent-ray traces (tfrt_scene3d.coherent_rays): two class histograms (one being read, one
+  // being built with atomics by both intersect kernels), the wavefronts left to the grouped kernel
   L.hist_a = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   // (+ the count of wavefronts
   L.hist_b = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   //  left to the grouped kernel)
   L.left_list = take((n + 63) / 64 * sizeof(int32_t));
@@ -2770,18 +2735,14 @@ struct Classify3 {
   int32_t* blockcnt = nullptr;
 };
 
-// Visiting-order trace (tfrt_scene3d.visit_records): what the two intersect kernels of a pass need.
+// Coherent-ray trace (tfrt_scene3d.coherent_rays): what the two intersect kernels of a pass need.
 struct Ordered3 {
-  const void* visit = nullptr;       // this pass's records (pass 0: the caller's)
-  void* visit_next = nullptr;        // the next pass's (nullptr after the last pass)
-  int first_pass = 0;
-  int nq = 0;                        // slots of the visiting order (= source rays)
-  int32_t* rec_q = nullptr;          // slot each ray of this pass was visited at
+  int nq = 0;                        // source rays
   int32_t* hist = nullptr;           // class histogram of this pass (atomics)
   int32_t* left_list = nullptr;      // wavefronts k_intersect_beam leaves to the grouped kernel
   int32_t* left_count = nullptr;
   int32_t* left_total = nullptr;     // ... summed over the passes of the trace (counts tail [7])
-  int visit_all = 0;                 // no grouped-kernel launch: k_intersect_beam finishes all
+  int coherent_only = 0;             // no grouped-kernel launch: k_intersect_beam finishes all
   int n_super = 0;
 };
 
@@ -2806,24 +2767,19 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
   dim3 grid(pl.ray_blocks, pl.chunks);
   if (grouped) grid = dim3(pl.g_blocks, pl.g_chunks);
   ProfScope prof(TFRT_PROF_INTERSECT, st);
-  using VR = VisitRecOf<T>;
   if (grouped && od != nullptr) {
     // coherent wavefronts first; the grouped kernel then does the wavefronts that were not
-    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, BLOCK)), dim3(BLOCK), 0, st, n_ptr,
-                       static_cast<const VR*>(od->visit), static_cast<VR*>(od->visit_next),
-                       od->first_pass, od->nq, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
+    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, BLOCK)), dim3(BLOCK), 0, st, rays,
+                       stride, n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
                        fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
-                       fz.rec_tri, fz.rec_t, fz.rec_cls, od->rec_q, od->hist, od->left_list,
-                       od->left_count, od->left_total, od->visit_all);
+                       fz.rec_tri, fz.rec_t, fz.rec_cls, od->hist, od->left_list,
+                       od->left_count, od->left_total, od->coherent_only);
     // (enough workgroups to fill the chip when every wavefront is left over; they loop)
     grid = dim3(min(cdiv(od->nq, BLOCK), 1280), 1);
   }
-  const VR* g_visit = od != nullptr ? static_cast<const VR*>(od->visit) : nullptr;
-  const int g_nq = od != nullptr ? od->nq : 0;
   const int32_t* g_left = od != nullptr ? od->left_list : nullptr;
   const int32_t* g_nleft = od != nullptr ? od->left_count : nullptr;
   int32_t* g_hist = od != nullptr ? od->hist : nullptr;
-  int32_t* g_recq = od != nullptr ? od->rec_q : nullptr;
 #define TFRT_LAUNCH_R(RR)                                                                      \
   if (grouped)                                                                                 \
     hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
@@ -2831,14 +2787,14 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
                        ac->cface, fverts, c0, prep_inline ? nullptr : prep, pstride,           \
                        ac->n_clusters,                                                         \
                        pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride,           \
-                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt, g_visit,    \
-                       g_left, g_nleft, g_nq, g_hist, g_recq);                                 \
+                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt, g_left,     \
+                       g_nleft, g_hist);                                                       \
   else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
                        part_t, part_i, part_stride)
   const int Ruse = grouped ? pl.gR : pl.R;
-  if (grouped && od != nullptr && od->visit_all) {
+  if (grouped && od != nullptr && od->coherent_only) {
     // (every wavefront was finished by k_intersect_beam)
   } else if (Ruse == 1) { TFRT_LAUNCH_R(1); }
   else if (Ruse == 4) { TFRT_LAUNCH_R(4); }
@@ -2899,13 +2855,12 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   ac.clsphere = reinterpret_cast<float4*>(ws + lay.clsphere);
   ac.susphere = reinterpret_cast<float4*>(ws + lay.susphere);
   ac.crec = reinterpret_cast<float4*>(ws + lay.crec);
-  // Visiting order: rays are visited in the caller's coherent order (coherent wavefronts take
-  // k_intersect_beam's shared walk); one cluster chunk, classification in the kernels' epilogues
-  const bool visiting = sc->visit_records != nullptr && ac.order != nullptr && N >= 64;
-  void* visit_ab[2] = {ws + lay.visit_a, ws + lay.visit_b};
+  // Coherent rays: wavefronts take k_intersect_beam's shared walk first; one cluster chunk,
+  // classification in the kernels' epilogues
+  const bool coherent = sc->coherent_rays != 0 && ac.order != nullptr && N >= 64;
   int32_t* hist_ab[2] = {reinterpret_cast<int32_t*>(ws + lay.hist_a),
                          reinterpret_cast<int32_t*>(ws + lay.hist_b)};
-  if (visiting) {
+  if (coherent) {
     pl.gR = 1;
     pl.g_blocks = cdiv(N, (int64_t)BLOCK);
     pl.g_chunks = 1;
@@ -2918,7 +2873,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
-                         (int)N, tail, ticket, hist_ab[0], visiting ? pl.nblk * 4 + 1 : 0);
+                         (int)N, tail, ticket, hist_ab[0], coherent ? pl.nblk * 4 + 1 : 0);
     } else {
       hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
                          (int)N, tail, ticket);
@@ -2942,17 +2897,13 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     fz.blockcnt = blockcnt;
     bool classified = false;
     Ordered3 od;
-    if (visiting) {
-      od.visit = p == 0 ? sc->visit_records : visit_ab[(p - 1) & 1];
-      od.visit_next = p + 1 < P ? visit_ab[p & 1] : nullptr;
-      od.first_pass = p == 0;
-      od.rec_q = reinterpret_cast<int32_t*>(ws + lay.rec_q);
+    if (coherent) {
       od.nq = (int)N;
       od.hist = hist_ab[p & 1];
       od.left_list = reinterpret_cast<int32_t*>(ws + lay.left_list);
       od.left_count = od.hist + (size_t)pl.nblk * 4;
       od.left_total = tail + 7;
-      od.visit_all = sc->visit_all != 0;
+      od.coherent_only = sc->coherent_only != 0;
       od.n_super = cdiv(ac.n_clusters, SUPER);
       fz.blockcnt = od.hist;
     }
@@ -2960,16 +2911,16 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                             (int64_t)n, M, sc->intersect_epsilion, sc->size_epsilion,
                             sc->ray_start_epsilion, part_t, part_i, (int64_t)n, &ac,
                             /*prep_ready=*/p > 0, &fz, &classified,
-                            visiting ? &od : nullptr) != 0)
+                            coherent ? &od : nullptr) != 0)
       return TFRT_E_LAUNCH;
-    int32_t* blockcnt_p = visiting ? od.hist : blockcnt;
+    int32_t* blockcnt_p = coherent ? od.hist : blockcnt;
     if (!classified)
       hipLaunchKernelGGL(k_classify3d, dim3(pl.nblk), dim3(BLOCK), 0, st, nrays + p, chunks_used,
                          part_t, part_i, (int64_t)n, sc->catagory, rec_tri + (size_t)p * n,
                          rec_t + (size_t)p * n, rec_cls + (size_t)p * n, blockcnt_p);
     const bool grid_scan = pl.nblk >= SCAN_GRID_MIN_ROWS;
     SelfScan ss;
-    if (visiting) {
+    if (coherent) {
       ss.hist_next = hist_ab[(p + 1) & 1];
       ss.hist_rows = pl.nblk;
     }
@@ -2999,10 +2950,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                        (int64_t)n, rayid + (size_t)p * n, lasttri + (size_t)p * n,
                        rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
                        stp ? *stp : none, dead ? *dead : none, tail + 6,
-                       (p + 1 < P && !visiting) ? prep : nullptr,
-                       (int64_t)n, c0, ss,
-                       visiting ? static_cast<VisitRecOf<T>*>(od.visit_next) : nullptr,
-                       visiting ? od.rec_q : nullptr);
+                       (p + 1 < P && !coherent) ? prep : nullptr,
+                       (int64_t)n, c0, ss);
   }
   if (unfinished != nullptr && P > 0) {
     hipLaunchKernelGGL((k_copy_rays<T>), dim3(pl.nblk), dim3(BLOCK), 0, st,
@@ -3041,7 +2990,9 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // then so many that they see little contention.
   const int windows = cdiv(M > 0 ? M : 1, FACE_WINDOW);
   const bool ordered = sc->deterministic != 0 && M > 0 && g_fverts != nullptr;
-  const bool stash = ordered || (M > 0 && N >= 16384 && windows <= 32);
+  // (coherent rays: the wavefront's rays hit few faces; k_backward3d sums them itself)
+  const bool wave_sums = !ordered && sc->coherent_rays != 0 && M > 0 && g_fverts != nullptr;
+  const bool stash = ordered || (!wave_sums && M > 0 && N >= 16384 && windows <= 32);
   unsigned long long* fix_acc = reinterpret_cast<unsigned long long*>(ws + lay.fix_acc);
   uint8_t* fix_flag = reinterpret_cast<uint8_t*>(ws + lay.fix_flag);
   unsigned long long* fix_max = reinterpret_cast<unsigned long long*>(ws + lay.fix_max);
@@ -3076,7 +3027,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
                        (int64_t)n, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
                        cap_dead, g_out, g_src_out, out_stride, g_fverts,
-                       stash ? stash_g : nullptr, stash ? stash_face : nullptr);
+                       stash ? stash_g : nullptr, stash ? stash_face : nullptr, wave_sums ? 1 : 0);
     if (ordered) {
       // two-entry scale buffer, alternating per pass (each pass's conversion clears the other)
       unsigned long long* mx = fix_max + ((P - 1 - p) & 1);

@@ -597,12 +597,16 @@ class OpticalEngine:
         # integers): gradients are bit-identical from run to run (tfrt_scene3d.deterministic);
         # default False: float64 atomics, whose last bits depend on the arrival order.
         self.deterministic = bool(deterministic)
-        # 3-D hierarchy mode: visit the rays in a coherent order (ops.visit_records: a Hilbert-curve order
-        # of their lines, computed once per source on the device) so that wavefronts of 64
-        # neighbouring rays share one walk of the face hierarchy.  Only the visiting order changes:
-        # every output keeps the reference's order.  "auto" (default): from the second trace of
-        # the same source rays on (a static source in an optimisation loop pays the sort once; a
-        # source that changes every step never does); True: always; False: never.
+        # 3-D hierarchy mode: trace the rays in a coherent order (ops.ray_order: a Hilbert-curve
+        # order of their lines, computed once per source on the device) so that wavefronts of 64
+        # neighbouring rays share one walk of the face hierarchy, and bring every ray set back to
+        # the reference's order afterwards (ops.restore_order) -- invisible to the caller.  "auto"
+        # (default): in the fused optimiser step (fused_step.FusedStep, which needs no ray set in
+        # the reference's order to form error and gradient), from the second step with the same
+        # source rays on (a static source pays the sort once; a source that changes every step
+        # never does); plain ray_trace() stays in natural order, because restoring a million rows
+        # costs about what the coherent kernels save.  True: always, ray_trace() included; False:
+        # never.
         if coherent not in ("auto", True, False):
             raise ValueError(f"OpticalEngine: coherent must be 'auto', True or False, got {coherent!r}")
         self.coherent = coherent
@@ -824,9 +828,12 @@ class OpticalEngine:
             f |= _lib.COMPILE_DEAD
         return f
 
-    def _trace_inputs(self, rays):
+    def _trace_inputs(self, rays, coherent_ok=True):
         """(ray block, scene arguments, merged face tensor) of a trace over the ray set ``rays``;
-        ray block, n(lambda) table and scene arguments are cached per input tensor identity."""
+        ray block, n(lambda) table and scene arguments are cached per input tensor identity.
+        With a coherent order (``coherent``, ``self._trace_perm`` is then the permutation) the
+        block and the per-ray n(lambda) table come back PERMUTED: ray j is ``rays[perm[j]]``."""
+        self._trace_perm = None
         system = self.optical_system
         geo = _GEO3 if self.dimension == 3 else _GEO2
         dt = self.ray_dtype or config.get_ray_dtype()
@@ -859,13 +866,19 @@ class OpticalEngine:
                 self._table_cache = (wkey, n_table, wl)
         mode = self._trace_mode(system)
         if self.dimension == 3:
+            perm = None
+            if coherent_ok and not any(rays[f].requires_grad for f in geo):
+                perm = self._coherent_order(block, n_table, key, repeated, mode, system)
+            if perm is not None:
+                _, perm, block, n_table = self._order_cache[:4]
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       deterministic=self.deterministic)
-            scene.visit_records = self._visit_records(block, key, repeated, mode, system)
+            scene.coherent_rays = perm is not None
             # a source that left no wavefront to the grouped kernel last time: no such launch
-            scene.visit_all = (scene.visit_records is not None
-                               and getattr(self, "_visit_all_key", None) == key)
-            self._visit_key = key if scene.visit_records is not None else None
+            scene.coherent_only = (perm is not None
+                                   and getattr(self, "_visit_all_key", None) == key)
+            self._visit_key = key if perm is not None else None
+            self._trace_perm = perm
         else:
             scene = system.scene_args(n_table, index_mode, ghost,
                                       finite_tir_gradient=self.finite_tir_gradient)
@@ -876,22 +889,30 @@ class OpticalEngine:
                 fv = torch.zeros((0, 9), dtype=torch.float64, device=block.device)
         return block, scene, fv
 
-    def _visit_records(self, block, key, repeated, mode, system):
-        """The source block as records in a coherent visiting order (see ``coherent``), cached
-        with it."""
+    def _coherent_order(self, block, n_table, key, repeated, mode, system):
+        """The coherent order of the source block (see ``coherent``), cached with the permuted
+        block and n(lambda) table: ``self._order_cache = (key, perm, block_p, n_table_p, ...)``."""
         if (mode == "all-pairs" or self.coherent is False or block.shape[1] < 4096
                 or not block.is_cuda):
             return None
         cached = getattr(self, "_order_cache", None)
         if cached is not None and cached[0] == key:
+            if cached[4] != id(n_table):     # (other materials / wavelengths: same order)
+                cached = cached[:3] + (
+                    None if n_table is None else n_table[:, cached[1].long()].contiguous(),
+                    id(n_table), n_table)
+                self._order_cache = cached
             return cached[1]
         if self.coherent == "auto" and not repeated:
             return None
         fv = system._merged_face_verts
         centre = fv.detach().reshape(-1, 3).mean(dim=0) if fv is not None and fv.shape[0] else None
-        records = ops.visit_records(block, centre=centre)
-        self._order_cache = (key, records)
-        return records
+        perm = ops.ray_order(block, centre)
+        p64 = perm.long()
+        self._order_cache = (key, perm, block[:, p64].contiguous(),
+                             None if n_table is None else n_table[:, p64].contiguous(),
+                             id(n_table), n_table)      # (the table is held: its id stays its own)
+        return perm
 
     def _note_left_over(self, left_over):
         """Visiting-order trace: remember whether the source left wavefronts to the grouped kernel
@@ -901,11 +922,15 @@ class OpticalEngine:
 
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
-        block, scene, fv = self._trace_inputs(rays)
+        # (a speculative trace cuts its outputs before the counts are known: natural order only)
+        block, scene, fv = self._trace_inputs(
+            rays, coherent_ok=predicted is None and self.coherent is True)
         if self.dimension == 3:
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
                               self.dead_ray_length, flags, predicted_counts=predicted)
             self._note_left_over(out.get("left_over", 0))
+            if self._trace_perm is not None:
+                out = ops.restore_order(out, self._trace_perm)
             return out
         return ops.trace2d(block, scene, max_passes, self.new_ray_length,
                            self.dead_ray_length, flags, predicted_counts=predicted)

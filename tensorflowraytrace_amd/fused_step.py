@@ -223,6 +223,15 @@ class FusedStep:
         erf = opt.error_function
         goal = erf.table(src)
         block, scene, fv = eng._trace_inputs(src)
+        perm = eng._trace_perm
+        if perm is not None:
+            # coherent order: the trace runs over src[perm] (its ray ids are positions in that
+            # order), so the goal rows go along; the ray sets are restored when somebody asks
+            gkey = (id(goal), id(perm))
+            cached = getattr(self, "_goal_perm", None)
+            if cached is None or cached[0] != gkey:
+                cached = self._goal_perm = (gkey, goal[:, perm.long()].contiguous(), goal, perm)
+            goal = cached[1]
         P, flags = int(opt.trace_depth), eng._flags() | _lib.COMPILE_FINISHED
         dt = ops._DT[block.dtype]
         fvc = fv.detach()
@@ -294,15 +303,20 @@ class FusedStep:
                 grads[i] = g
             if not capturing:
                 self._tap_checks += 1
-        self._publish_lazily(st, src, P, flags)
+        self._publish_lazily(st, src, P, flags, perm)
         return grads, st["err"]
 
-    def _publish_lazily(self, st, src, P, flags):
+    def _publish_lazily(self, st, src, P, flags, perm=None):
         eng = self.opt.engine
         eng._trace_src = src
         eng._trace_sig = (src["x_start"].shape[0], P, flags)
         full, aux = st["full"], st["aux"]
-        eng._pending_trace = lambda: ops._finish_trace(dict(full), dict(aux), P, None)
+        self._last_perm = perm
+
+        def publish():
+            out = ops._finish_trace(dict(full), dict(aux), P, None)
+            return out if perm is None else ops.restore_order(out, perm)
+        eng._pending_trace = publish
 
     def _enqueue_apply(self, grads, accumulators):
         """non-finite -> 0, scale, clip, accumulate, SGD apply (optimizer.py:223-257, 316) with
@@ -447,7 +461,8 @@ class FusedStep:
         st = self._state
         eng = self.opt.engine
         eng.clear_ray_history()
-        self._publish_lazily(st, eng._trace_src, st["P"], st["flags"])
+        self._publish_lazily(st, eng._trace_src, st["P"], st["flags"],
+                             getattr(self, "_last_perm", None))
 
     def _capture(self, sig, accumulators, world):
         """Run THIS step eagerly on the capture stream, then capture the sequence there (capturing

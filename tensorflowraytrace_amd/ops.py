@@ -318,7 +318,7 @@ class Scene3DArgs:
     def __init__(self, face_verts, catagory, mat_in=None, mat_out=None, n_in=None, n_out=None,
                  n_table=None, intersect_epsilion=1e-10, size_epsilion=1e-10,
                  ray_start_epsilion=1e-10, face_grad_mask=None, cluster_order=None,
-                 deterministic=False, visit_records=None):
+                 deterministic=False, coherent_rays=False):
         self.face_verts = face_verts  # (M,9) f64, may require grad
         self.catagory = _c(catagory, torch.int32)
         self.mat_in = _c(mat_in, torch.int32)
@@ -329,12 +329,13 @@ class Scene3DArgs:
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
         self.deterministic = bool(deterministic)               # ordered reverse-sweep sums
-        # None, or the SOURCE rays as records in a coherent visiting order (see visit_records());
-        # may be reassigned between traces (it belongs to the source, not to the boundaries)
-        self.visit_records = visit_records
-        # with visit_records: True = launch no grouped kernel behind k_intersect_beam (a source
+        # True: the rays handed to the trace are in a coherent order (see ray_order()): wavefronts
+        # share one walk of the hierarchy (k_intersect_beam), the reverse sweep sums per wavefront.
+        # May be reassigned between traces (it belongs to the source, not to the boundaries).
+        self.coherent_rays = bool(coherent_rays)
+        # with coherent_rays: True = launch no grouped kernel behind k_intersect_beam (a source
         # whose earlier traces left no wavefront over: out["left_over"] == 0)
-        self.visit_all = False
+        self.coherent_only = False
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -344,8 +345,8 @@ class Scene3DArgs:
             # every other field points at tensors this object owns: only the face pointer moves
             sc = cached[1]
             sc.face_verts = face_verts.data_ptr() if M else None
-            sc.visit_records = self._visit_ptr()
-            sc.visit_all = 1 if (self.visit_all and self.visit_records is not None) else 0
+            sc.coherent_rays = 1 if self.coherent_rays else 0
+            sc.coherent_only = 1 if (self.coherent_only and self.coherent_rays) else 0
             return sc
         sc = Scene3D()
         sc.face_verts = face_verts.data_ptr() if M else None
@@ -369,20 +370,10 @@ class Scene3DArgs:
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
         sc.reserved0 = 0
         sc.deterministic = 1 if self.deterministic else 0
-        sc.visit_records = self._visit_ptr()
-        sc.visit_all = 1 if (self.visit_all and self.visit_records is not None) else 0
+        sc.coherent_rays = 1 if self.coherent_rays else 0
+        sc.coherent_only = 1 if (self.coherent_only and self.coherent_rays) else 0
         self._struct_cache = (M, sc)
         return sc
-
-    def _visit_ptr(self):
-        vr = self.visit_records
-        if vr is None:
-            return None
-        if vr.dim() != 2 or vr.shape[1] != 8 or not vr.is_contiguous() or not vr.is_cuda \
-                or vr.dtype not in (torch.float32, torch.float64):
-            raise TfrtError("visit_records must come from ops.visit_records(): (N, 8) float32 / "
-                            "float64, contiguous, on the GPU")
-        return vr.data_ptr()
 
 
 class TraceTape:
@@ -516,11 +507,6 @@ class _Trace3D(torch.autograd.Function):
         dead = alloc(_lib.COMPILE_DEAD, capN)
         unf = torch.empty((6, capN), dtype=src.dtype, device=dev)
         unf_id = ints.take(capN)
-        vr = scene.visit_records
-        if vr is not None and (vr.shape[0] != N or vr.dtype != (
-                torch.float64 if src.dtype == torch.float64 else torch.float32)):
-            raise TfrtError(f"visit_records {tuple(vr.shape)} {vr.dtype} do not belong to a "
-                            f"{src.dtype} block of {N} rays")
         sc = scene.struct(face_verts)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
         check(L.tfrt_trace3d_forward(
@@ -571,6 +557,7 @@ class _Trace3D(torch.autograd.Function):
 
 
 _CLASS_NAMES = ("finished", "active", "stopped", "dead")
+_CLASS_NAMES_BY_COUNT_COLUMN = ("active", "finished", "stopped", "dead")   # counts[:, CLS_*]
 
 
 class _LazyRows:
@@ -724,10 +711,10 @@ def hilbert_key(x, y, bits=16):
 def ray_order(rays, centre=None):
     """A coherent visiting order of the rays of a (6, N) block: int32 permutation in which rays
     whose lines run close together are neighbours, so that 64 consecutive entries form a narrow
-    bundle.  ``visit_records(rays, order)`` turns it into what ``Scene3DArgs.visit_records`` /
-    ``tfrt_scene3d.visit_records`` take: the trace then visits rays in this order and coherent
-    wavefronts share one walk of the face hierarchy (k_intersect_beam); results do not depend
-    on it.
+    bundle.  Trace ``rays[:, order]`` (and per-ray tables in the same order) with
+    ``Scene3DArgs.coherent_rays`` / ``tfrt_scene3d.coherent_rays`` set: coherent wavefronts share one
+    walk of the face hierarchy (k_intersect_beam); ``restore_order(out, order)`` gives the ray sets
+    of ``rays`` itself.
 
     Rays that mostly share a direction are ordered along a Hilbert curve through the points where
     their lines pass ``centre`` (default: the mean of their end points), in the plane perpendicular
@@ -775,23 +762,67 @@ def ray_order(rays, centre=None):
     return torch.argsort(key, stable=True).to(torch.int32).contiguous()
 
 
-def visit_records(rays, order=None, centre=None):
-    """The rays of a (6, N) block as records in the visiting order ``order`` (default:
-    ``ray_order(rays, centre)``), the form ``Scene3DArgs.visit_records`` /
-    ``tfrt_scene3d.visit_records`` takes: (N, 8) float32 (float32 / float16 ray state) or float64,
-    row q = start xyz, end xyz of ray ``order[q]``, then {index, -1} as two int32 (float32: one
-    per column; float64: both in column 6)."""
-    if order is None:
-        order = ray_order(rays, centre)
-    order = order.to(device=rays.device, dtype=torch.int64)
-    dt = torch.float64 if rays.dtype == torch.float64 else torch.float32
-    rec = torch.zeros((rays.shape[1], 8), dtype=dt, device=rays.device)
-    rec[:, :6] = rays.detach()[:, order].t().to(dt)
-    ints = rec.view(torch.int32)
-    at = 6 if dt == torch.float32 else 12
-    ints[:, at] = order.to(torch.int32)
-    ints[:, at + 1] = -1
-    return rec
+def restore_order(out, perm):
+    """Outputs of a trace over PERMUTED rays (``src[:, perm]``, e.g. ``perm = ray_order(src)``, the
+    form tfrt_scene3d.coherent_rays wants) brought back to what the trace of ``src`` itself gives:
+    ray ids mapped through ``perm``, and inside every class the rays of one pass sorted by ray id
+    again (the reference's per-pass boolean_mask order, engine.py:2069-2111).  ``out``: the dict of
+    trace3d(); returns a new dict.  O(N) per class and pass (a rank by prefix sum, no sort)."""
+    perm = perm.to(torch.int64)
+    n_src = perm.numel()
+    dev = perm.device
+    counts = out["counts"]
+    new = dict(out)
+
+    def reorder(ids_p, segments):
+        """inv such that rows[inv] is in reference order; ids in original numbering.  The key
+        (pass, original id) of a row is unique: rows are scattered into a table indexed by the key
+        and read back in key order (a counting sort: no comparison sort, no host sync)."""
+        ids_o = perm[ids_p.long()]
+        n = ids_o.numel()
+        live = [k for k, c in enumerate(segments) if c > 0]
+        row = torch.arange(1, n + 1, dtype=torch.int32, device=dev)
+        if len(live) * n_src <= (1 << 26):
+            if len(live) == 1:
+                key = ids_o
+            else:
+                slot = {k: j for j, k in enumerate(live)}
+                seg_of = torch.repeat_interleave(
+                    torch.tensor([slot[k] for k in live], dtype=torch.int64, device=dev),
+                    torch.tensor([segments[k] for k in live], dtype=torch.int64, device=dev),
+                    output_size=n)
+                key = seg_of * n_src + ids_o
+            table = torch.zeros(len(live) * n_src, dtype=torch.int32, device=dev)
+            table[key] = row
+            at = torch.nonzero_static(table, size=n).reshape(-1)      # ascending keys
+            return table[at].long() - 1, ids_o
+        inv = torch.empty(n, dtype=torch.int64, device=dev)         # (huge P x N: pass by pass)
+        base = 0
+        for n_seg in segments:
+            if n_seg == 0:
+                continue
+            table = torch.zeros(n_src, dtype=torch.int32, device=dev)
+            table[ids_o[base:base + n_seg]] = row[base:base + n_seg]
+            at = torch.nonzero_static(table, size=n_seg).reshape(-1)
+            inv[base:base + n_seg] = table[at].long() - 1
+            base += n_seg
+        return inv, ids_o
+
+    for col, cls in enumerate(_CLASS_NAMES_BY_COUNT_COLUMN):
+        if cls not in out or out[cls].shape[1] == 0 or out.get(cls + "_id") is None:
+            continue
+        inv, ids_o = reorder(out[cls + "_id"], [int(c) for c in counts[:, col]])
+        new[cls] = out[cls].index_select(1, inv)
+        new[cls + "_id"] = ids_o[inv].to(out[cls + "_id"].dtype)
+        if out.get(cls + "_face") is not None:
+            new[cls + "_face"] = out[cls + "_face"][inv]
+        new.pop(cls + "_rows", None)
+    if "unfinished" in out and out["unfinished"].shape[1]:
+        n_u = out["unfinished"].shape[1]
+        inv, ids_o = reorder(out["unfinished_id"], [n_u])
+        new["unfinished"] = out["unfinished"].index_select(1, inv)
+        new["unfinished_id"] = ids_o[inv].to(out["unfinished_id"].dtype)
+    return new
 
 
 def morton_order(face_verts):

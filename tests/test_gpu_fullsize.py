@@ -83,27 +83,30 @@ def test_full_size_hierarchy_equals_all_pairs(full):
         assert torch.equal(out[cls], ref[cls]), cls
 
 
-def test_full_size_visiting_order_changes_nothing(full):
-    """cfg4 at full size with the coherent visiting order (tfrt_scene3d.visit_records: Hilbert
-    order of the source, k_intersect_beam): every wavefront is a narrow bundle (nothing is left to
-    the grouped kernel) and every output equals the natural-order trace bit for bit -- with and
-    without the grouped-kernel launch behind it (visit_all)."""
+def test_full_size_coherent_order_changes_nothing(full):
+    """cfg4 at full size traced in the coherent order (tfrt_scene3d.coherent_rays: the source
+    sorted along a Hilbert curve, k_intersect_beam): every wavefront is a narrow bundle (nothing is
+    left to the grouped kernel) and ops.restore_order gives the natural-order trace back bit for
+    bit -- with and without the grouped-kernel launch behind the beam kernel (coherent_only)."""
     from tensorflowraytrace_amd import ops
-    sc, out = full["sc"], full["out"]
-    sc.visit_records = ops.visit_records(full["src"])
-    try:
-        for visit_all in (False, True):
-            sc.visit_all = visit_all
-            got = ops.trace3d(full["src"], full["fv"], sc, max_passes=PASSES, flags=full["flags"])
-            assert got["left_over"] == 0
-            assert np.array_equal(got["counts"], out["counts"]) and got["n_tests"] == out["n_tests"]
-            for cls in ("finished", "active", "stopped", "dead", "unfinished"):
-                assert torch.equal(got[cls + "_id"], out[cls + "_id"]), cls
-                if cls != "unfinished":
-                    assert torch.equal(got[cls + "_face"], out[cls + "_face"]), cls
-                assert torch.equal(got[cls].detach(), out[cls].detach()), cls
-    finally:
-        sc.visit_records, sc.visit_all = None, False
+    sc, out, src = full["sc"], full["out"], full["src"]
+    order = ops.ray_order(src)
+    p64 = order.long()
+    sc2 = ops.Scene3DArgs(full["fv"], sc.catagory, mat_in=sc.mat_in, mat_out=sc.mat_out,
+                          n_table=sc.n_table[:, p64].contiguous(), face_grad_mask=sc.face_grad_mask,
+                          cluster_order=sc.cluster_order, coherent_rays=True)
+    src_p = src[:, p64].contiguous()
+    for only in (False, True):
+        sc2.coherent_only = only
+        raw = ops.trace3d(src_p, full["fv"], sc2, max_passes=PASSES, flags=full["flags"])
+        assert raw["left_over"] == 0
+        got = ops.restore_order(raw, order)
+        assert np.array_equal(got["counts"], out["counts"]) and got["n_tests"] == out["n_tests"]
+        for cls in ("finished", "active", "stopped", "dead", "unfinished"):
+            assert torch.equal(got[cls + "_id"], out[cls + "_id"]), cls
+            if cls != "unfinished":
+                assert torch.equal(got[cls + "_face"], out[cls + "_face"]), cls
+            assert torch.equal(got[cls].detach(), out[cls].detach()), cls
 
 
 def test_full_size_sample_against_the_oracle(full):
@@ -474,10 +477,10 @@ def test_cfg5a_hierarchy_equals_all_pairs(cfg5a):
         assert torch.equal(out[cls].detach(), ref[cls].detach()), cls
 
 
-def test_cfg5a_visiting_order_changes_nothing(cfg5a):
-    """4M rays, 8 passes, lens + light guide: rays finish after different numbers of bounces, so
-    the visiting order grows holes, and bundles widen with every bounce off the faceted wall
-    (wavefronts are cut, some are left to the grouped kernel) -- the ray sets stay identical."""
+def test_cfg5a_coherent_order_changes_nothing(cfg5a):
+    """4M rays, 8 passes, lens + light guide through the public API with coherent=True: bundles
+    widen with every bounce off the faceted wall (wavefronts are cut, some are left to the grouped
+    kernel) -- the ray sets stay identical."""
     eng2, _, _ = _build_5a(torch.float32)
     eng2.coherent = True
     eng2.ray_trace(PASSES_5A)
@@ -488,7 +491,7 @@ def test_cfg5a_visiting_order_changes_nothing(cfg5a):
         assert torch.equal(got[cls + "_id"], out[cls + "_id"]), cls
         assert torch.equal(got[cls + "_face"], out[cls + "_face"]), cls
         assert torch.equal(got[cls].detach(), out[cls].detach()), cls
-    print(f"cfg5a visiting order: {got['left_over']} wavefront-passes left to the grouped kernel "
+    print(f"cfg5a coherent order: {got['left_over']} wavefront-passes left to the grouped kernel "
           f"of {PASSES_5A * N_5A // 64}")
 
 

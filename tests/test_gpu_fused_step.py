@@ -172,3 +172,40 @@ def test_goal_error_kernel_sum_is_reproducible_and_matches_torch():
     assert float(err[1]) == 2 * n and abs(float(err[2]) - float(want) / (2 * n)) <= 1e-15
     assert torch.equal(g_fin[4:6, :n], 2.0 * r)
     assert not bool(g_fin[:4].any()) and not bool(g_fin[4:6, n:].any())
+
+
+def test_fused_step_in_coherent_order_equals_the_generic_path():
+    """From 4096 rays on the fused step sorts a static source along a Hilbert curve (engine
+    ``coherent='auto'``: k_intersect_beam, per-wavefront face sums) from its second step on.  The
+    sorted trace must be invisible: same errors and parameters as the generic natural-order path,
+    and the lazily cut ray sets come back in the reference's order."""
+    steps = 8
+    runs = {}
+    for mode in ("generic", "graph"):
+        opt, eng, system, lens, *_rest, acc = _make(20000, mode, k=6, ray_dtype=torch.float64)
+        errs = _run(opt, None, steps)
+        runs[mode] = (errs, _params(lens), opt, eng)
+    g = runs["graph"][2]._fused_step
+    assert g.capture_error is None and g.graph_replays >= 2
+    assert getattr(runs["graph"][3], "_order_cache", None) is not None      # the sorted source
+    assert getattr(runs["generic"][3], "_order_cache", None) is None
+    np.testing.assert_allclose(runs["graph"][0], runs["generic"][0], rtol=1e-10, atol=0)
+    for a, b in zip(runs["graph"][1], runs["generic"][1]):
+        assert float((a - b).abs().max()) <= 1e-11
+    # ray sets of the last step: fused + sorted (restored lazily) against a natural-order trace of
+    # the same parameters
+    eng = runs["graph"][3]
+    fin = {f: eng.finished_rays[f].detach().clone() for f in ("x_start", "y_end", "z_end", "wavelength",
+                                                              "object_coords")}
+    ids = eng.last_trace["finished_id"].clone()
+    opt2, eng2, system2, lens2, *_ = _make(20000, "generic", k=6, ray_dtype=torch.float64)
+    for _ in range(steps - 1):
+        opt2.single_step(None)
+    system2.update()
+    eng2.ray_trace(3)
+    assert torch.equal(ids, eng2.last_trace["finished_id"])
+    # (the two runs' parameters differ by ~1e-11 after seven steps; a ray's end point on the target
+    # ten units away moves by a few hundred times that)
+    for f, v in fin.items():
+        np.testing.assert_allclose(v.cpu().numpy(), eng2.finished_rays[f].detach().cpu().numpy(),
+                                   rtol=0, atol=1e-8, err_msg=f)
