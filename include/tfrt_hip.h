@@ -200,6 +200,11 @@ typedef struct tfrt_scene3d {
    * rays that are not coherent; meant for a source whose earlier traces left no wavefront over
    * (saves one kernel launch per pass). */
   int32_t coherent_only;
+  /* Reverse sweep only, "value" mode (n_in / n_out given): (M) f64 each, ACCUMULATED into, or
+   * NULL -- d error / d n_in[face], d error / d n_out[face] (tfrt/operation.py:268-272 reads the
+   * two fields as ordinary tensors, which a tape can differentiate).  Both or neither. */
+  double* grad_n_in;
+  double* grad_n_out;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in

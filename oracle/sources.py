@@ -2,10 +2,19 @@
 numpy restatement of the ray-set assembly of tfrt/sources.py (TEST INFRASTRUCTURE -- see
 oracle/__init__.py): the dense / undense domain logic of ``SourceBase._resize`` / ``make_vars`` /
 ``publish_extra_fields`` (sources.py:170-315) and the ``_internal_update`` of ``PointSource``
-(:590-635, 2-D and 3-D without rotation), ``AngularSource`` (:820-866) and ``AperatureSource``
-(:1045-1064).  3-D rotations are left out: the reference takes them from ``tfquaternion``,
-which is not available here (parity unpinned for them); the configurations
-of BASELINE.json use identity / translation-only placement.
+(:590-635), ``AngularSource`` (:820-866) and ``AperatureSource`` (:1045-1064), and the static
+point generators of tfrt/distributions.py (``StaticUniformSquare`` :1361-1372, ``StaticUniformSphere``
+:1726-1747, ``StaticLambertianSphere`` :1778-1810).
+
+3-D rotations (sources.py:428-458): the reference takes ``rotate_vector_by_quaternion`` and
+``get_rotation_quaternion_from_u_to_v`` from the third-party package ``tfquaternion`` (unpinned:
+not listed in the reference's requirements, absent from /root/reference and from this image).
+They are restated here from their published definition -- Hamilton convention, q = (w, x, y, z),
+v' = q (0, v) q*, and the shortest-arc quaternion normalise(|u||v| + u.v, u x v) -- and anchored on
+what the reference's own call sites need of them: the quaternion of angle_type "vector" turns the
+x axis into the central vector (sources.py:428-433), lengths and mutual angles of the rotated
+directions and base points are kept, a "quaternion" source rotates by exactly the given
+quaternion.  No reference test or fixture pins them: parity unpinned for 3-D source rotation.
 
 Dense sources combine every domain with every other: ``tf.meshgrid(*ranges)`` with the default
 'xy' indexing, flattened -- so with domains [d0, d1, d2, ...] in insertion order the FIRST TWO
@@ -144,3 +153,125 @@ def angular_source_2d(center, central_angle, angles, base_points, wavelengths, d
     if wavelengths is not None:
         out["wavelength"] = v["wavelengths"]
     return out
+
+
+# ---------------------------------------------------------------------------- quaternions
+
+def quat_mul(a, b):
+    """Hamilton product of quaternions (w, x, y, z); broadcasts over leading axes."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    aw, ax, ay, az = np.moveaxis(a, -1, 0)
+    bw, bx, by, bz = np.moveaxis(b, -1, 0)
+    return np.stack([aw * bw - ax * bx - ay * by - az * bz,
+                     aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw], axis=-1)
+
+
+def rotate_vector_by_quaternion(q, v):
+    """tfq.rotate_vector_by_quaternion (sources.py:443, 458): v' = q (0, v) q* for the unit
+    quaternion q / |q|; v (..., 3)."""
+    q = np.asarray(q, dtype=np.float64)
+    q = q / np.sqrt((q * q).sum())
+    v = np.asarray(v, dtype=np.float64)
+    qv = np.concatenate([np.zeros(v.shape[:-1] + (1,)), v], axis=-1)
+    conj = q * np.array([1.0, -1.0, -1.0, -1.0])
+    return quat_mul(quat_mul(q, qv), conj)[..., 1:]
+
+
+def get_rotation_quaternion_from_u_to_v(u, v, eps=1e-6):
+    """tfq.get_rotation_quaternion_from_u_to_v (sources.py:428): the shortest-arc rotation that
+    turns direction u into direction v, normalise(|u||v| + u.v, u x v); for opposite directions a
+    half turn about an axis perpendicular to u."""
+    u, v = np.asarray(u, dtype=np.float64), np.asarray(v, dtype=np.float64)
+    w = np.sqrt((u * u).sum() * (v * v).sum()) + (u * v).sum()
+    if w < eps * np.sqrt((u * u).sum() * (v * v).sum()):
+        axis = np.array([-u[1], u[0], 0.0]) if abs(u[0]) > abs(u[2]) else np.array([0.0, -u[2], u[1]])
+        q = np.concatenate([[0.0], axis])
+    else:
+        q = np.concatenate([[w], np.cross(u, v)])
+    return q / np.sqrt((q * q).sum())
+
+
+def _central_quaternion(central_angle, angle_type):
+    """RotationBase.central_angle setter, 3-D (sources.py:414-438)."""
+    if angle_type == "vector":
+        return get_rotation_quaternion_from_u_to_v(np.array([1.0, 0.0, 0.0]), central_angle)
+    return np.asarray(central_angle, dtype=np.float64)
+
+
+def point_source_3d(center, central_angle, angles, wavelengths, dense, start_on_center=True,
+                    ray_length=1.0, angle_type="vector"):
+    """PointSource._internal_update, 3-D (sources.py:590-635): the direction vectors of the angular
+    distribution rotated by the central quaternion, rays from the centre."""
+    iv = {"angles": ("angle", angles)}
+    if wavelengths is not None:
+        iv["wavelengths"] = ("wavelength", wavelengths)
+    v, _, _ = make_vars(iv, dense)
+    d = rotate_vector_by_quaternion(_central_quaternion(central_angle, angle_type), v["angles"])
+    start = np.broadcast_to(np.asarray(center, dtype=np.float64), d.shape)
+    end = start + ray_length * d
+    if not start_on_center:
+        start, end = end, start
+    out = {a + "_start": start[:, k] for k, a in enumerate("xyz")}
+    out.update({a + "_end": end[:, k] for k, a in enumerate("xyz")})
+    if wavelengths is not None:
+        out["wavelength"] = v["wavelengths"]
+    return out
+
+
+def angular_source_3d(center, central_angle, angles, base_points, wavelengths, dense,
+                      start_on_base=True, ray_length=1.0, angle_type="vector"):
+    """AngularSource._internal_update, 3-D (sources.py:820-866): base points (2-D ones lie in the
+    y-z plane, sources.py:450-456) and directions rotated by the central quaternion, base points
+    then shifted to the centre."""
+    iv = {"angles": ("angle", angles), "base_points": ("base_point", base_points)}
+    if wavelengths is not None:
+        iv["wavelengths"] = ("wavelength", wavelengths)
+    v, _, _ = make_vars(iv, dense)
+    q = _central_quaternion(central_angle, angle_type)
+    bp = v["base_points"]
+    if bp.shape[1] == 2:
+        bp = np.concatenate([np.zeros((bp.shape[0], 1)), bp], axis=1)
+    start = np.asarray(center, dtype=np.float64) + rotate_vector_by_quaternion(q, bp)
+    end = start + ray_length * rotate_vector_by_quaternion(q, v["angles"])
+    if not start_on_base:
+        start, end = end, start
+    out = {a + "_start": start[:, k] for k, a in enumerate("xyz")}
+    out.update({a + "_end": end[:, k] for k, a in enumerate("xyz")})
+    if wavelengths is not None:
+        out["wavelength"] = v["wavelengths"]
+    return out
+
+
+# ----------------------------------------------------------------------- point generators
+
+def static_uniform_square(x_size, x_res, y_size=None, y_res=None):
+    """StaticUniformSquare._make_points (distributions.py:1361-1372): meshgrid ('xy') of two
+    linspaces, flattened row by row."""
+    y_size = x_size if y_size is None else y_size
+    y_res = x_res if y_res is None else y_res
+    x, y = np.meshgrid(np.linspace(-x_size, x_size, x_res), np.linspace(-y_size, y_size, y_res))
+    return np.stack([x.reshape(-1), y.reshape(-1)], axis=1)
+
+
+def _sphere_points(cos_phi, count, radius, theta_start, theta_end):
+    theta = np.pi * (1 + 5 ** 0.5) * (np.arange(count, dtype=np.float64) + 0.5)
+    if not (theta_start == 0 and theta_end == 2 * np.pi):         # ThetaMod, distributions.py:1431-1447
+        theta = np.mod(theta, theta_end - theta_start) + theta_start
+    phi = np.arccos(cos_phi)
+    return radius * np.stack([np.cos(phi), np.sin(phi) * np.cos(theta), np.sin(phi) * np.sin(theta)],
+                             axis=1)
+
+
+def static_uniform_sphere(count, angular_size, radius=1.0, theta_start=0.0, theta_end=2 * np.pi):
+    """StaticUniformSphere._update (distributions.py:1726-1747): cos(phi) uniform in
+    [cos(angular_size), 1], golden-angle azimuths."""
+    return _sphere_points(np.linspace(1.0, np.cos(angular_size), count), count, radius,
+                          theta_start, theta_end)
+
+
+def static_lambertian_sphere(count, angular_size, radius=1.0, theta_start=0.0, theta_end=2 * np.pi):
+    """StaticLambertianSphere._update (distributions.py:1794-1810): cos^2(phi) uniform."""
+    return _sphere_points(np.sqrt(np.linspace(1.0, np.cos(angular_size) ** 2, count)), count,
+                          radius, theta_start, theta_end)

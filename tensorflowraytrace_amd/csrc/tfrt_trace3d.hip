@@ -2501,7 +2501,14 @@ __device__ __forceinline__ int backward_ray(
 #pragma unroll
       for (int q = 0; q < 9; ++q) P[q] = fp[q];
       if (has_child) face_indices(sc, tri, rid, &n_in, &n_out);
-      adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP);
+      double gn[2];
+      const bool want_n = has_child && sc.grad_n_in != nullptr && sc.n_table == nullptr;
+      adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP,
+                want_n ? gn : nullptr);
+      if (want_n) {  // "value" mode: d error / d (per-face refractive indices)
+        if (gn[0] != 0.0) unsafeAtomicAdd(sc.grad_n_in + tri, gn[0]);
+        if (gn[1] != 0.0) unsafeAtomicAdd(sc.grad_n_out + tri, gn[1]);
+      }
       if (sc.face_grad_mask == nullptr || sc.face_grad_mask[tri] != 0) face_out = tri;
     }
   }

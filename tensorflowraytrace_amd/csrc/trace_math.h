@@ -204,11 +204,15 @@ TFRT_HD double snell2d_angle(double xs, double ys, double xe, double ye, double 
 // Inputs:  g_s   upstream gradient on s used as an output start (history/finished/stopped)
 //          g_h   upstream gradient on h from outputs whose *end* is h, plus the child's start
 //          g_ce  upstream gradient on the child's end (h + L w); ignored unless has_child
-// Outputs: gs, ge (gradient wrt this pass's input ray), gP[9] (wrt P0,P1,P2 of the hit face).
+// Outputs: gs, ge (gradient wrt this pass's input ray), gP[9] (wrt P0,P1,P2 of the hit face),
+//          gn[2] (optional: wrt n_in, n_out of the reaction -- "value" mode reads them as ordinary
+//          tensors, operation.py:268-272; zero for a mirror / total internal reflection, whose
+//          direction does not depend on the ratio, geometry.py:735-747).
 TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], double ray_u,
                        bool has_child, double n_in, double n_out, double L,
                        const double g_s[3], const double g_h[3], const double g_ce[3],
-                       double gs[3], double ge[3], double gP[9]) {
+                       double gs[3], double ge[3], double gP[9], double* gn = nullptr) {
+  if (gn != nullptr) gn[0] = gn[1] = 0.0;
   const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
   const double E1[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]};
   const double E2[3] = {P[6] - P[0], P[7] - P[1], P[8] - P[2]};
@@ -261,6 +265,19 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
       const double alpha = sg * rk - nu_eta;
       const double ab = dot3(wb, n);
       nub = ab * (sg * eta * nu_eta / rk - eta);
+      if (gn != nullptr) {
+        // w = alpha n + eta u, alpha = sg sqrt(1 - eta^2 + eta^2 nu^2) - eta nu
+        const double etab = dot3(wb, u) + ab * (sg * eta * (nu * nu - 1.0) / rk - nu);
+        if (internal) {            // eta = n_in / n_out
+          if (out_safe) {
+            gn[0] = in_safe ? etab / nos : 0.0;
+            gn[1] = -etab * eta / nos;
+          }
+        } else if (in_safe) {      // eta = n_out / n_in
+          gn[1] = out_safe ? etab / nis : 0.0;
+          gn[0] = -etab * eta / nis;
+        }
+      }
       for (int i = 0; i < 3; ++i) {
         nb[i] = alpha * wb[i];
         ub[i] = eta * wb[i];

@@ -80,20 +80,24 @@ def rotate_vector_by_quaternion(q, v):
     return v + w * t + torch.linalg.cross(u, t, dim=-1)
 
 
-def get_rotation_quaternion_from_u_to_v(u, v):
-    """Shortest-arc quaternion rotating direction u onto direction v."""
+def get_rotation_quaternion_from_u_to_v(u, v, eps=1e-6):
+    """Shortest-arc quaternion rotating direction u onto direction v: normalise(|u||v| + u.v,
+    u x v) -- tfquaternion's definition, as far as it is published (the package is not available
+    here; oracle/sources.py states the same).  Opposite directions: a half turn about
+    (-u_y, u_x, 0), or (0, -u_z, u_y) when |u_x| <= |u_z|."""
     u = _f64(u)
     v = _f64(v)
-    u = u / torch.linalg.norm(u)
-    v = v / torch.linalg.norm(v)
-    d = torch.dot(u, v)
-    if float(d) < -1.0 + 1e-12:  # opposite: rotate pi about any axis orthogonal to u
-        axis = torch.linalg.cross(u, _f64([1.0, 0.0, 0.0]))
-        if float(torch.linalg.norm(axis)) < 1e-6:
-            axis = torch.linalg.cross(u, _f64([0.0, 1.0, 0.0]))
-        axis = axis / torch.linalg.norm(axis)
-        return torch.cat([_f64([0.0]), axis])
-    q = torch.cat([(1.0 + d).reshape(1), torch.linalg.cross(u, v)])
+    scale = torch.sqrt(torch.dot(u, u) * torch.dot(v, v))
+    w = scale + torch.dot(u, v)
+    if float(w) < eps * float(scale):
+        zero = torch.zeros((), dtype=u.dtype, device=u.device)
+        if abs(float(u[0])) > abs(float(u[2])):
+            axis = torch.stack([-u[1], u[0], zero])
+        else:
+            axis = torch.stack([zero, -u[2], u[1]])
+        q = torch.cat([zero.reshape(1), axis])
+    else:
+        q = torch.cat([w.reshape(1), torch.linalg.cross(u, v)])
     return q / torch.linalg.norm(q)
 
 
@@ -347,20 +351,24 @@ class SquareBase(BasePointDistributionBase):
 
 
 class StaticUniformSquare(SquareBase):
+    """x_size / y_size are centre-to-edge distances; the ranks are the points divided by the longer
+    of the two (distributions.py:1352-1372)."""
+
     def _update(self):
         dev = config.get_device()
-        x = torch.linspace(-1.0, 1.0, self.x_res, dtype=torch.float64, device=dev)
-        y = torch.linspace(-1.0, 1.0, self.y_res, dtype=torch.float64, device=dev)
+        x = torch.linspace(-self.x_size, self.x_size, self.x_res, dtype=torch.float64, device=dev)
+        y = torch.linspace(-self.y_size, self.y_size, self.y_res, dtype=torch.float64, device=dev)
         gx, gy = torch.meshgrid(x, y, indexing="xy")
-        self._ranks = torch.stack([gx.reshape(-1), gy.reshape(-1)], dim=1)
-        self._points = self._ranks * _f64([self.x_size / 2, self.y_size / 2])
+        self._points = torch.stack([gx.reshape(-1), gy.reshape(-1)], dim=1)
+        self._ranks = self._points / max(self.x_size, self.y_size)
 
 
 class RandomUniformSquare(SquareBase):
     def _update(self):
         n = self.x_res * self.y_res
-        self._ranks = torch.stack([_uniform(n, -1, 1), _uniform(n, -1, 1)], dim=1)
-        self._points = self._ranks * _f64([self.x_size / 2, self.y_size / 2])
+        self._points = torch.stack([_uniform(n, -self.x_size, self.x_size),
+                                    _uniform(n, -self.y_size, self.y_size)], dim=1)
+        self._ranks = self._points / max(self.x_size, self.y_size)
 
 
 class ThetaMod:

@@ -325,6 +325,9 @@ class Scene3DArgs:
         self.mat_out = _c(mat_out, torch.int32)
         self.n_in = _c(n_in, torch.float64)
         self.n_out = _c(n_out, torch.float64)
+        # "value" mode: the tensors as handed in (they may require grad: d error / d index)
+        self.n_in_arg = n_in if isinstance(n_in, torch.Tensor) else None
+        self.n_out_arg = n_out if isinstance(n_out, torch.Tensor) else None
         self.n_table = _c(n_table, torch.float64)  # (n_materials, N)
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
@@ -473,7 +476,9 @@ def _class_grads(ctx_present, caps, n_rows, dev, grads):
 
 class _Trace3D(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, face_verts, scene, opts):
+    def forward(ctx, src, face_verts, n_in, n_out, scene, opts):
+        # (n_in / n_out: the per-face indices of "value" mode when they require grad -- the values
+        # are read through `scene`; listing them here gives their gradients a place to go)
         _need_gpu(src, face_verts)
         dev = src.device
         if src.dtype not in _DT:
@@ -544,16 +549,25 @@ class _Trace3D(torch.autograd.Function):
         g_src = torch.zeros((6, t.src.shape[1]), dtype=torch.float64, device=dev) if need_src else None
         gs = _class_grads(ctx.present, t.caps, 6, dev, grads)
         sc = t.scene.struct(t.face_verts)
-        check(_lib.lib().tfrt_trace3d_backward(
-            _p(t.src), t.src.shape[1], t.src.shape[1], ctypes.byref(sc),
-            float(t.opts["new_ray_length"]), float(t.opts["dead_ray_length"] or 0.0),
-            int(t.opts["max_passes"]), t.dt,
-            _p(gs[0]), t.caps[0], _p(gs[1]), t.caps[1], _p(gs[2]), t.caps[2], _p(gs[3]), t.caps[3],
-            _p(g_fv), _p(g_src), _p(t.counts), _p(t.ws), t.wsb, _stream(t.src)),
-            "tfrt_trace3d_backward")
+        want_n = (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and M > 0
+        g_n = torch.zeros((2, M), dtype=torch.float64, device=dev) if want_n else None
+        if want_n:
+            sc.grad_n_in, sc.grad_n_out = g_n[0].data_ptr(), g_n[1].data_ptr()
+        try:
+            check(_lib.lib().tfrt_trace3d_backward(
+                _p(t.src), t.src.shape[1], t.src.shape[1], ctypes.byref(sc),
+                float(t.opts["new_ray_length"]), float(t.opts["dead_ray_length"] or 0.0),
+                int(t.opts["max_passes"]), t.dt,
+                _p(gs[0]), t.caps[0], _p(gs[1]), t.caps[1], _p(gs[2]), t.caps[2], _p(gs[3]),
+                t.caps[3], _p(g_fv), _p(g_src), _p(t.counts), _p(t.ws), t.wsb, _stream(t.src)),
+                "tfrt_trace3d_backward")
+        finally:
+            sc.grad_n_in = sc.grad_n_out = None       # (the struct is cached on the scene)
         if g_src is not None:
             g_src = g_src.to(t.src.dtype)
-        return g_src, g_fv, None, None
+        g_in = g_n[0] if (want_n and ctx.needs_input_grad[2]) else None
+        g_out = g_n[1] if (want_n and ctx.needs_input_grad[3]) else None
+        return g_src, g_fv, g_in, g_out, None, None
 
 
 _CLASS_NAMES = ("finished", "active", "stopped", "dead")
@@ -653,7 +667,9 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
                 dead_ray_length=dead_ray_length, flags=flags,
                 zero_init=predicted_counts is not None)
-    outs = _Trace3D.apply(src, face_verts, scene, opts)
+    grad_n = lambda t: t if (isinstance(t, torch.Tensor) and t.requires_grad) else None
+    outs = _Trace3D.apply(src, face_verts, grad_n(scene.n_in_arg), grad_n(scene.n_out_arg),
+                          scene, opts)
     aux = opts.pop("_aux")
     blocks, rows = _split_rows(outs, [aux[name + "_id"] is not None for name in _CLASS_NAMES], 6)
     full = dict(zip(_CLASS_NAMES, blocks))

@@ -68,6 +68,18 @@ void hm_adjoint3d(int64_t n, const double* s, const double* e, const double* P,
   }
 }
 
+// ... with the gradient w.r.t. the two refractive indices ("value" mode, operation.py:268-272)
+void hm_adjoint3d_n(int64_t n, const double* s, const double* e, const double* P,
+                    const double* ray_u, const uint8_t* has_child, const double* n_in,
+                    const double* n_out, double L, const double* g_s, const double* g_h,
+                    const double* g_ce, double* gs, double* ge, double* gP, double* gn) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::adjoint3d(s + 3 * i, e + 3 * i, P + 9 * i, ray_u[i], has_child[i] != 0, n_in[i], n_out[i], L,
+                    g_s + 3 * i, g_h + 3 * i, g_ce + 3 * i, gs + 3 * i, ge + 3 * i, gP + 9 * i,
+                    gn + 2 * i);
+  }
+}
+
 void hm_exact_segment(int64_t n, const double* s, const double* e, const double* seg,
                       double eps_int, double eps_size, double eps_start, double* ray_u,
                       double* seg_u, double* xy, uint8_t* valid) {

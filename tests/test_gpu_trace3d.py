@@ -182,6 +182,50 @@ def test_value_mode_matches_index_mode():
     np.testing.assert_allclose(a["finished"].detach().cpu().numpy(), b["finished"].detach().cpu().numpy(), atol=1e-12)
 
 
+@pytest.mark.parametrize("coherent", [False, True])
+def test_value_mode_gradient_with_respect_to_the_refractive_indices(coherent):
+    """StandardReaction('value') reads n_in / n_out as ordinary tensors (operation.py:268-272), so
+    a tape can differentiate an error w.r.t. them: the reverse sweep accumulates d error /
+    d n_in[face], d n_out[face] (tfrt_scene3d.grad_n_in / grad_n_out) -- against torch.autograd
+    through the oracle, per-face indices drawn at random around the acrylic value."""
+    from tensorflowraytrace_amd import ops
+    scene = scene_util.lens_scene(6000, k_front=4, k_back=3)
+    src, fv, sc, _ = _gpu_scene(scene, torch.float64, cluster="group")
+    M = fv.shape[0]
+    rng = np.random.default_rng(9)
+    optical = (sc.catagory == 0).cpu().numpy()
+    n_in_np = np.where(optical, 1.49 + 0.05 * rng.standard_normal(M), 1.0)
+    n_out_np = np.where(optical, 1.0 + 0.02 * rng.random(M), 1.0)
+    n_in = torch.tensor(n_in_np, device=fv.device, requires_grad=True)
+    n_out = torch.tensor(n_out_np, device=fv.device, requires_grad=True)
+    sv = ops.Scene3DArgs(fv.detach(), sc.catagory, n_in=n_in, n_out=n_out,
+                         cluster_order=sc.cluster_order, coherent_rays=coherent)
+    out = ops.trace3d(src, fv.detach(), sv, max_passes=4)
+    goal = torch.tensor(scene["goal"], dtype=torch.float64, device=fv.device)[out["finished_id"].long()]
+    fin = out["finished"]
+    loss = ((fin[4] - goal[:, 0]) ** 2 + (fin[5] - goal[:, 1]) ** 2).sum()
+    g_in, g_out = torch.autograd.grad(loss, [n_in, n_out])
+
+    system, _, fields = oracle_util.lens_oracle(scene)
+    nf = fields["front"]["xp"].shape[0] + fields["back"]["xp"].shape[0]
+    o_in = torch.tensor(n_in_np[:nf], requires_grad=True)
+    o_out = torch.tensor(n_out_np[:nf], requires_grad=True)
+    system.optical["n_in"], system.optical["n_out"] = o_in, o_out
+    ref = tracer.ray_trace(system, oracle_util.source_dict(scene["rays"], scene["wavelength"]),
+                           max_iterations=4, inherit=("wavelength", "ray_id"), index_type="value")
+    rf = ref["finished"]
+    assert np.array_equal(out["finished_id"].cpu().numpy(), rf["ray_id"].numpy().astype(np.int32))
+    rgoal = torch.tensor(scene["goal"], dtype=torch.float64)[rf["ray_id"].long()]
+    rloss = ((rf["y_end"] - rgoal[:, 0]) ** 2 + (rf["z_end"] - rgoal[:, 1]) ** 2).sum()
+    r_in, r_out = torch.autograd.grad(rloss, [o_in, o_out])
+    assert abs(loss.item() - rloss.item()) <= 1e-9 * rloss.item()
+    for got, want in ((g_in, r_in), (g_out, r_out)):
+        assert float(want.abs().max()) > 0
+        rel = float((got.cpu()[:nf] - want).abs().max() / want.abs().max())
+        assert rel < 1e-8, rel
+        assert float(got[nf:].abs().max()) == 0.0          # the target plane refracts nothing
+
+
 def test_empty_and_degenerate_inputs():
     from tensorflowraytrace_amd import ops, _lib
     scene = scene_util.lens_scene(64, k_front=2, k_back=2)

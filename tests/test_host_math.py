@@ -83,6 +83,17 @@ def test_snell3d_and_adjoint3d(host_math):
     assert _rel(gs, gs_r.numpy()) < 1e-10
     assert _rel(ge, ge_r.numpy()) < 1e-10
     assert _rel(gP, gP_r.numpy()) < 1e-10
+    # d / d (n_in, n_out): "value" mode reads the indices as tensors (operation.py:268-272).  Only
+    # rays with a child see them; mirrors (n_in = 0) and totally reflected rays give exactly zero
+    ni, no = torch.tensor(n_in, requires_grad=True), torch.tensor(n_out, requires_grad=True)
+    o = geom.snells_law_3D(st[:, 0], st[:, 1], st[:, 2], x, y, z, norm, ni, no, L)
+    ce = torch.stack(o[3:], 1)
+    gni, gno = torch.autograd.grad((cm * ce * torch.tensor(g[3])).sum(), [ni, no])
+    gn = np.zeros((n, 2))
+    host_math.hm_adjoint3d_n(I(n), P(s), P(e), P(P9), P(ruu), P(child), P(n_in), P(n_out), D(L),
+                             P(g[0]), P(gh), P(g[3]), P(gs), P(ge), P(gP), P(gn))
+    assert _rel(gn[:, 0], gni.numpy()) < 1e-10 and _rel(gn[:, 1], gno.numpy()) < 1e-10
+    assert np.abs(gni.numpy()).max() > 0 and (gn[n_in == 0.0] == 0).all()
 
 
 def test_segment_exact_and_adjoint2d(host_math):

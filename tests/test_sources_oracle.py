@@ -91,3 +91,107 @@ def test_sources_equal_the_reference_restatement_on_the_device():
     import tensorflowraytrace_amd as tfa
     tfa.set_device("cuda:0")
     _cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# 3-D source rotations (sources.py:428-458) and the static point generators
+# (distributions.py:1361-1372, 1726-1810) against the numpy restatement
+
+def test_quaternion_restatement_meets_what_the_reference_call_sites_need():
+    """get_rotation_quaternion_from_u_to_v(x axis, v) turns the x axis into v / |v| (angle_type
+    'vector', sources.py:428-433); rotations keep lengths and mutual angles; a half turn for
+    opposite directions; composition = Hamilton product."""
+    rng = np.random.default_rng(3)
+    x = np.array([1.0, 0.0, 0.0])
+    for _ in range(50):
+        v = rng.normal(size=3) * 10 ** rng.uniform(-2, 2)
+        q = osrc.get_rotation_quaternion_from_u_to_v(x, v)
+        np.testing.assert_allclose(np.linalg.norm(q), 1.0, atol=1e-15)
+        np.testing.assert_allclose(osrc.rotate_vector_by_quaternion(q, x), v / np.linalg.norm(v), atol=1e-14)
+        pts = rng.normal(size=(20, 3))
+        rot = osrc.rotate_vector_by_quaternion(q, pts)
+        np.testing.assert_allclose(rot @ rot.T, pts @ pts.T, atol=1e-13)       # Gram matrix kept
+        np.testing.assert_allclose(np.linalg.det(np.stack([osrc.rotate_vector_by_quaternion(q, e)
+                                                           for e in np.eye(3)])), 1.0, atol=1e-13)
+        q2 = rng.normal(size=4)
+        q2 /= np.linalg.norm(q2)
+        np.testing.assert_allclose(
+            osrc.rotate_vector_by_quaternion(q2, osrc.rotate_vector_by_quaternion(q, pts)),
+            osrc.rotate_vector_by_quaternion(osrc.quat_mul(q2, q), pts), atol=1e-13)
+    q = osrc.get_rotation_quaternion_from_u_to_v(x, -x)                         # half turn
+    np.testing.assert_allclose(osrc.rotate_vector_by_quaternion(q, x), -x, atol=1e-15)
+    # a quarter turn about z in the Hamilton convention turns x into +y
+    qz = np.array([np.cos(np.pi / 4), 0.0, 0.0, np.sin(np.pi / 4)])
+    np.testing.assert_allclose(osrc.rotate_vector_by_quaternion(qz, x), [0.0, 1.0, 0.0], atol=1e-15)
+
+
+def _cases_3d():
+    import tensorflowraytrace_amd.distributions as distributions
+    import tensorflowraytrace_amd.sources as sources
+
+    rng = np.random.default_rng(4)
+    # the product's quaternion helpers against the restatement
+    for _ in range(20):
+        u, v, pts = rng.normal(size=3), rng.normal(size=3), rng.normal(size=(7, 3))
+        q = distributions.get_rotation_quaternion_from_u_to_v(u, v)
+        np.testing.assert_allclose(_np(q), osrc.get_rotation_quaternion_from_u_to_v(u, v), atol=1e-14)
+        np.testing.assert_allclose(_np(distributions.rotate_vector_by_quaternion(q, pts)),
+                                   osrc.rotate_vector_by_quaternion(_np(q), pts), atol=1e-14)
+
+    sphere = distributions.StaticUniformSphere(0.4, 9)
+    want_pts = osrc.static_uniform_sphere(9, 0.4)
+    np.testing.assert_allclose(_np(sphere.points), want_pts, atol=1e-14)
+    lamb = distributions.StaticLambertianSphere(0.7, 11, radius=2.0, theta_start=0.3, theta_end=2.0)
+    np.testing.assert_allclose(_np(lamb.points), osrc.static_lambertian_sphere(11, 0.7, 2.0, 0.3, 2.0),
+                               atol=1e-14)
+    square = distributions.StaticUniformSquare(0.5, 4, y_size=0.2, y_res=3)
+    want_sq = osrc.static_uniform_square(0.5, 4, 0.2, 3)
+    np.testing.assert_allclose(_np(square.points), want_sq, atol=1e-15)
+    np.testing.assert_allclose(_np(square.ranks), want_sq / 0.5, atol=1e-15)   # distributions.py:1354
+
+    # 1. 3-D dense PointSource, angle_type "vector", a non-trivial central vector, converging
+    wl = [450.0, 600.0]
+    src = sources.PointSource(3, (0.5, -1.0, 2.0), (0.3, -0.8, 0.5), sphere, wl, start_on_center=False,
+                              ray_length=1.5)
+    want = osrc.point_source_3d((0.5, -1.0, 2.0), (0.3, -0.8, 0.5), want_pts, wl, True,
+                                start_on_center=False, ray_length=1.5)
+    assert src["x_start"].shape[0] == 18
+    _check(src, want, GEO3 + ("wavelength",))
+
+    # 2. 3-D dense AngularSource, angle_type "quaternion" (not normalised), 2-D base points (they
+    #    lie in the y-z plane), 9 directions x 12 base points x 1 wavelength
+    q = (0.8, 0.1, -0.5, 0.3)
+    src = sources.AngularSource(3, (-2.0, 0.25, 1.0), q, sphere, square, [575.0], angle_type="quaternion",
+                                ray_length=0.7)
+    want = osrc.angular_source_3d((-2.0, 0.25, 1.0), q, want_pts, want_sq, [575.0], True,
+                                  ray_length=0.7, angle_type="quaternion")
+    assert src["x_start"].shape[0] == 108
+    _check(src, want, GEO3 + ("wavelength",))
+
+    # 3. undense AngularSource, angle_type "vector" opposite to the x axis (the half-turn branch),
+    #    3-D base points, rays that END on the base points
+    base3 = distributions.StaticUniformSphere(0.9, 9, radius=0.3)
+    src = sources.AngularSource(3, (0.0, 0.0, 0.0), (-2.0, 0.0, 0.0), sphere, base3, [500.0], dense=False,
+                                start_on_base=False)
+    want = osrc.angular_source_3d((0.0, 0.0, 0.0), (-2.0, 0.0, 0.0), want_pts,
+                                  osrc.static_uniform_sphere(9, 0.9, 0.3), [500.0], False,
+                                  start_on_base=False)
+    _check(src, want, GEO3 + ("wavelength",))
+
+
+def test_3d_sources_with_rotations_equal_the_restatement_on_the_host():
+    import tensorflowraytrace_amd as tfa
+    import tensorflowraytrace_amd.config as config
+    old = config._device
+    tfa.set_device("cpu")
+    try:
+        _cases_3d()
+    finally:
+        config._device = old
+
+
+@pytest.mark.gpu
+def test_3d_sources_with_rotations_equal_the_restatement_on_the_device():
+    import tensorflowraytrace_amd as tfa
+    tfa.set_device("cuda:0")
+    _cases_3d()
