@@ -87,7 +87,8 @@ __global__ __launch_bounds__(BLOCK) void k_goal_finish(const double* __restrict_
     const double terms = (double)(*n_ptr) * (double)n_fields;
     err_out[0] = tot;
     err_out[1] = terms;
-    err_out[2] = tot / (terms > 1.0 ? terms : 1.0);  // reduce_mean of optimizer.py:257
+    // reduce_mean of optimizer.py:257 (no finished ray: the mean of nothing is NaN there too)
+    err_out[2] = terms > 0.0 ? tot / terms : __builtin_nan("");
     if (tests_total != nullptr && tests_lo_hi != nullptr)
       *tests_total += (long long)((unsigned long long)(uint32_t)tests_lo_hi[0] |
                                   ((unsigned long long)(uint32_t)tests_lo_hi[1] << 32));

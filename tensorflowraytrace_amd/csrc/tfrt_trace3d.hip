@@ -722,6 +722,9 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// class byte of the tape: bits 0-1 the ray class, bits 2-3 the branches of the forward reaction
+constexpr int TAPE_INTERNAL = 4, TAPE_REFLECT = 8;
+
 __device__ __forceinline__ int cat_to_cls(int cat) {
   return cat == CAT_OPTICAL ? CLS_ACTIVE : (cat == CAT_TARGET ? CLS_FINISHED : CLS_STOPPED);
 }
@@ -2012,7 +2015,7 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_react3d(
     const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
-    const double* __restrict__ rec_t, const uint8_t* __restrict__ rec_cls,
+    const double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
     const int32_t* __restrict__ blockoff, const int32_t* __restrict__ rowbase,
     const int32_t* __restrict__ pass_counts,
     tfrt_scene3d sc, double L, double dead_len, uint32_t flags, T* __restrict__ rays_out,
@@ -2131,6 +2134,10 @@ __global__ __launch_bounds__(BLOCK) void k_react3d(
       face_normal(P, N, C, &clen);
       face_indices(sc, tri, rid, &n_in, &n_out);
       const Snell3 f = snell3d(s, h, N, n_in, n_out);
+      // the branches this reaction took go on the tape (bits 2, 3 of the class byte): the reverse
+      // sweep re-derives everything else, but with other roundings (reciprocals instead of
+      // quotients), and at grazing incidence or at the critical angle must not take another side
+      rec_cls[i] = (uint8_t)(cls | (f.nu > 0.0 ? TAPE_INTERNAL : 0) | (f.reflect ? TAPE_REFLECT : 0));
       double e2[3];
       for (int k = 0; k < 3; ++k) e2[k] = advance(h[k], L, f.w[k]);
       store_ray3(rays_out, stride_out, slot, h, e2);
@@ -2396,7 +2403,12 @@ __device__ __forceinline__ double fixed_scale(unsigned long long maxbits) {
   if (maxbits == 0ull) return 0.0;
   int e;
   (void)frexp(__longlong_as_double((long long)maxbits), &e);  // max = f * 2^e, f in [0.5, 1)
-  return ldexp(1.0, FIXED_BITS - e);                            // |term| * scale < 2^40
+  // |term| * scale < 2^40.  (A pass whose largest term lies below 2^-980 would need a scale
+  // beyond the float64 range: the exponent is clamped, such terms round to zero -- they are
+  // ~1e-295 of anything that matters.)
+  int shift = FIXED_BITS - e;
+  if (shift > 1000) shift = 1000;
+  return ldexp(1.0, shift);
 }
 
 template <typename S>
@@ -2461,7 +2473,8 @@ __device__ __forceinline__ int backward_ray(
     typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
     int64_t out_stride, double gP[9]) {
   int face_out = -1;
-  const int cls = rec_cls[i];
+  const int tape = rec_cls[i];
+  const int cls = tape & 3;
   const int slot = rec_slot[i];
   double s[3], e[3];
   load_ray3(rays_in, stride_in, i, s, e);
@@ -2504,7 +2517,8 @@ __device__ __forceinline__ int backward_ray(
       double gn[2];
       const bool want_n = has_child && sc.grad_n_in != nullptr && sc.n_table == nullptr;
       adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP,
-                want_n ? gn : nullptr);
+                want_n ? gn : nullptr,
+                ((tape & TAPE_INTERNAL) ? 1 : 0) | ((tape & TAPE_REFLECT) ? 2 : 0));
       if (want_n) {  // "value" mode: d error / d (per-face refractive indices)
         if (gn[0] != 0.0) unsafeAtomicAdd(sc.grad_n_in + tri, gn[0]);
         if (gn[1] != 0.0) unsafeAtomicAdd(sc.grad_n_out + tri, gn[1]);

@@ -211,7 +211,11 @@ TFRT_HD double snell2d_angle(double xs, double ys, double xe, double ye, double 
 TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], double ray_u,
                        bool has_child, double n_in, double n_out, double L,
                        const double g_s[3], const double g_h[3], const double g_ce[3],
-                       double gs[3], double ge[3], double gP[9], double* gn = nullptr) {
+                       double gs[3], double ge[3], double gP[9], double* gn = nullptr,
+                       int branch = -1) {
+  // branch: -1 = re-derive the forward's branches here; else bit 0 = the ray met the face from
+  // the inside (n.u > 0), bit 1 = it was reflected (mirror or total internal reflection), as the
+  // forward pass decided them
   if (gn != nullptr) gn[0] = gn[1] = 0.0;
   const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
   const double E1[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]};
@@ -242,11 +246,14 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
     const double nu = dot3(n, u);
     const bool in_safe = n_in != 0.0, out_safe = n_out != 0.0;
     const double nis = in_safe ? n_in : 1.0, nos = out_safe ? n_out : 1.0;
-    const bool internal = nu > 0.0;
+    const bool internal = branch >= 0 ? (branch & 1) != 0 : nu > 0.0;
     const double eta = internal ? (out_safe ? nis / nos : 0.0) : (in_safe ? nos / nis : 0.0);
     const double nu_eta = eta * nu;
-    const double k = 1.0 - eta * eta + nu_eta * nu_eta;
-    const bool reflect = (k < 0.0) || (n_in == 0.0);
+    double k = 1.0 - eta * eta + nu_eta * nu_eta;
+    const bool reflect = branch >= 0 ? (branch & 2) != 0 : ((k < 0.0) || (n_in == 0.0));
+    // (the forward refracted, so ITS radicand was >= 0; the one re-derived here may come out a few
+    // ulp below zero at the critical angle)
+    if (!reflect && k < 0.0) k = 0.0;
     double wb[3], ub[3], nb[3];
     for (int i = 0; i < 3; ++i) {
       hb[i] += g_ce[i];
@@ -260,7 +267,8 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
         nb[i] = -2.0 * nu * wb[i];
       }
     } else {
-      const double sg = (nu > 0.0) ? 1.0 : ((nu < 0.0) ? -1.0 : 0.0);
+      const double sg = branch >= 0 ? (internal ? 1.0 : (nu < 0.0 ? -1.0 : 0.0))
+                                    : ((nu > 0.0) ? 1.0 : ((nu < 0.0) ? -1.0 : 0.0));
       const double rk = sqrt(k);
       const double alpha = sg * rk - nu_eta;
       const double ab = dot3(wb, n);

@@ -386,7 +386,8 @@ class FusedStep:
             red.append(flat[o:o + g.numel()].reshape(g.shape))
             o += g.numel()
         self._enqueue_apply(red, accumulators)
-        mean = flat[o] / torch.clamp(flat[o + 1], min=1.0)
+        mean = torch.where(flat[o + 1] > 0, flat[o] / torch.clamp(flat[o + 1], min=1.0),
+                           torch.full_like(flat[o], float("nan")))
         self._err_view = torch.stack([flat[o], flat[o + 1], mean])
 
     # ------------------------------------------------------------------------------ step

@@ -299,10 +299,12 @@ class SGD_Optimizer:
             if accumulators[i] is not None:
                 grad = self._matrix_product(self._acc_cache, i, accumulators[i], grad)
             processed.append(grad)
+        # (tf.reduce_mean, optimizer.py:257: the mean of no error terms is NaN)
         if isinstance(n_terms, torch.Tensor):
-            mean = error_sum / torch.clamp(n_terms, min=1.0)
+            mean = torch.where(n_terms > 0, error_sum / torch.clamp(n_terms, min=1.0),
+                               torch.full_like(error_sum, float("nan")))
         else:
-            mean = error_sum / max(n_terms, 1)
+            mean = error_sum / n_terms if n_terms > 0 else error_sum * float("nan")
         return processed, mean, applied
 
     _smoother_cache = {}

@@ -226,6 +226,67 @@ def test_value_mode_gradient_with_respect_to_the_refractive_indices(coherent):
         assert float(got[nf:].abs().max()) == 0.0          # the target plane refracts nothing
 
 
+def test_gradients_at_the_critical_angle_and_float32_against_float64_state():
+    """(i) Rays inside acrylic meeting a flat face within 1e-9 rad of the critical angle, on both
+    sides: the reverse sweep takes the branch the forward pass took (recorded on the tape: two bits
+    of the class byte), so the parameter gradient is finite and refracting / reflecting rays get
+    the gradient of their own branch (oracle autograd).  (ii) The float32-state sweep (ray
+    gradients between passes stored in float32) stays within 5e-6 of the float64-state one."""
+    from tensorflowraytrace_amd import ops, _lib
+    dev = "cuda:0"
+    n_glass = 1.5
+    crit = np.arcsin(1.0 / n_glass)
+    # one big face in the plane x = 0 (norm +x: n_in = glass on the -x side), a target far away
+    P = torch.tensor([[0.0, -50.0, -50.0, 0.0, 50.0, -50.0, 0.0, 0.0, 80.0],
+                      [40.0, -500.0, -500.0, 40.0, 500.0, -500.0, 40.0, 0.0, 800.0],
+                      [-40.0, -500.0, -500.0, -40.0, 0.0, 800.0, -40.0, 500.0, -500.0],
+                      # (a wall across the surface: rays refracted to grazing exit end here)
+                      [-100.0, 30.0, -300.0, 100.0, 30.0, -300.0, 0.0, 30.0, 600.0]],
+                     dtype=torch.float64, device=dev, requires_grad=True)
+    cat = torch.tensor([0, 2, 2, 2], dtype=torch.int32, device=dev)
+    off = np.array([-1e-9, -1e-12, 1e-12, 1e-9, -0.2, 0.1])     # around the critical angle
+    ang = crit + off
+    s = np.stack([-np.cos(ang), -np.sin(ang), np.zeros_like(ang)])      # from inside the glass
+    e = np.zeros_like(s)
+    e[2] = 0.01
+    rays = torch.tensor(np.concatenate([s, e + 0.0 * s]), dtype=torch.float64, device=dev)
+    rays[3:] = rays[:3] * 0.5                                            # ends half-way to the face
+    args = ops.Scene3DArgs(P.detach(), cat, n_in=torch.tensor([n_glass, 1.0, 1.0, 1.0], device=dev),
+                           n_out=torch.ones(4, dtype=torch.float64, device=dev))
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD
+    out = ops.trace3d(rays, P, args, max_passes=2, flags=flags)
+    assert out["finished"].shape[1] == 6                                 # refracted out or reflected back
+    loss = (out["finished"][4] ** 2).sum() + out["finished"][5].sum()
+    (g,) = torch.autograd.grad(loss, [P])
+    assert bool(torch.isfinite(g).all())
+    from oracle import tracer as otr
+    Pc = P.detach().cpu().clone().requires_grad_(True)
+    faces = otr.faces_from_vertices(Pc.reshape(-1, 3), torch.arange(12).reshape(4, 3))
+    sub = lambda m: {k: v[m] for k, v in faces.items()}
+    opt_f = sub(torch.tensor([True, False, False, False]))
+    opt_f["n_in"], opt_f["n_out"] = torch.tensor([n_glass]), torch.tensor([1.0])
+    system = otr.System(3, optical=opt_f, target=sub(torch.tensor([False, True, True, True])))
+    src = {k: rays[i].cpu() for i, k in enumerate(("x_start", "y_start", "z_start", "x_end", "y_end", "z_end"))}
+    src["ray_id"] = torch.arange(6, dtype=torch.float64)
+    ref = otr.ray_trace(system, src, max_iterations=2, inherit=("ray_id",), index_type="value")
+    assert np.array_equal(out["finished_id"].cpu().numpy(), ref["finished"]["ray_id"].numpy().astype(np.int32))
+    rloss = (ref["finished"]["y_end"] ** 2).sum() + ref["finished"]["z_end"].sum()
+    (rg,) = torch.autograd.grad(rloss, [Pc])
+    assert float((g.cpu() - rg).abs().max() / rg.abs().max()) < 1e-7
+
+    # (ii) float32 against float64 ray state, lens scene, three passes
+    scene = scene_util.lens_scene(20000, k_front=8, k_back=6)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        src_b, fv, sc, (p_f, p_b) = _gpu_scene(scene, dt, cluster="group")
+        o = ops.trace3d(src_b, fv, sc, max_passes=4)
+        goal = torch.tensor(scene["goal"], dtype=torch.float64, device=dev)[o["finished_id"].long()]
+        err = ((o["finished"][4].double() - goal[:, 0]) ** 2 + (o["finished"][5].double() - goal[:, 1]) ** 2).sum()
+        grads[dt] = torch.autograd.grad(err, [p_f, p_b])
+    for a, b in zip(grads[torch.float32], grads[torch.float64]):
+        assert float((a - b).abs().max() / b.abs().max()) < 5e-6
+
+
 def test_empty_and_degenerate_inputs():
     from tensorflowraytrace_amd import ops, _lib
     scene = scene_util.lens_scene(64, k_front=2, k_back=2)
