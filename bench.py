@@ -448,12 +448,12 @@ def main(argv=None):
                 ("react", "tfrt::k_react3d", P, n_fwd * BYTES_PER_RAY_FWD,
                  "SURVEY 8d forward bytes: 64 B per ray entering the pass"),
                 ("backward", "tfrt::k_backward3d", P, n_fwd * BYTES_PER_RAY_BWD,
-                 "SURVEY 8d backward bytes: 116 B per ray of the pass (the 36 B of face-gradient "
-                 "terms leave through the stash and k_face_accumulate)"),
+                 "SURVEY 8d backward bytes: 116 B per ray of the pass (coherent rays: the face-gradient "
+                 "terms are summed per wavefront in LDS and leave as one atomic per face and term)"),
                 ("accumulate", "tfrt::k_face_accumulate", 1, float(sum(n_active)) * 40.0,
                  "the stash read once: 36 B of terms + 4 B face index per ray and pass")):
             v = np.asarray(kms.get(kind) or [], dtype=np.float64)
-            if not v.size:
+            if not v.size:      # (coherent rays: no stash, no accumulate launch)
                 continue
             k_ms = float(v.mean())
             doc, path = pmc_of(kind)

@@ -1460,8 +1460,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   __shared__ uint32_t flist[WAVES][BEAM_FLIST];
   __shared__ uint32_t x_pair[WAVES][128];  // face << 6 | lane of the ray (faces < 2^24)
   __shared__ uint16_t plist[WAVES][128];   // candidate of the chunk << 6 | lane of the ray
-  __shared__ float4 ctab[WAVES][64][3];    // float32 face records of the chunk's candidates
-  __shared__ float4 rtab[WAVES][64][2];    // the wave's rays: s - c0, d = e - s, face they start on
+  // (tables laid out [part][lane]: a lane's float4 lies next to its neighbour's -- the fills are
+  // free of bank conflicts; the screen's reads go to random entries either way)
+  __shared__ float4 ctab[WAVES][3][64];    // float32 face records of the chunk's candidates
+  __shared__ float4 rtab[WAVES][2][64];    // the wave's rays: s - c0, d = e - s, face they start on
   __shared__ unsigned long long best_k[WAVES][64];
   __shared__ int32_t best_i[WAVES][64];
   best_k[wave][lane] = dkey(INFINITY);
@@ -1485,8 +1487,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   const float es_f = (float)eps_size, er_f = (float)eps_start;
   int pn = 0;  // (ray, candidate) pairs waiting for the screen (wave-uniform)
   int xn = 0;  // (ray, face) pairs waiting for the exact test (wave-uniform)
-  rtab[wave][lane][0] = make_float4(sx, sy, sz, dx);
-  rtab[wave][lane][1] = make_float4(dy, dz, __int_as_float(skip), 0.f);
+  rtab[wave][0][lane] = make_float4(sx, sy, sz, dx);
+  rtab[wave][1][lane] = make_float4(dy, dz, __int_as_float(skip), 0.f);
 
   auto ray_of = [&](const int slot, double s[3], double e[3]) {  // (all lanes active)
 #pragma unroll
@@ -1745,9 +1747,9 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
         sp = csphere[memb];
         sp.w *= 1.00001f;
         // the candidate's float32 record (P0 - c0 | face index, E1, E2) for the screen
-        ctab[wave][lane][0] = crec[3 * memb];
-        ctab[wave][lane][1] = crec[3 * memb + 1];
-        ctab[wave][lane][2] = crec[3 * memb + 2];
+        ctab[wave][0][lane] = crec[3 * memb];
+        ctab[wave][1][lane] = crec[3 * memb + 1];
+        ctab[wave][2][lane] = crec[3 * memb + 2];
       }
       wave_fence();
       for (int c = 0; c <= nb; ++c) {
@@ -1773,9 +1775,9 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
           if (lane < np) {
             const unsigned pr = plist[wave][lane];
             rl = (int)(pr & 63u);
-            const float4 r0 = ctab[wave][pr >> 6][0], r1 = ctab[wave][pr >> 6][1],
-                         r2 = ctab[wave][pr >> 6][2];
-            const float4 ra = rtab[wave][rl][0], rb = rtab[wave][rl][1];  // s (c0 frame), d, skip
+            const float4 r0 = ctab[wave][0][pr >> 6], r1 = ctab[wave][1][pr >> 6],
+                         r2 = ctab[wave][2][pr >> 6];
+            const float4 ra = rtab[wave][0][rl], rb = rtab[wave][1][rl];  // s (c0 frame), d, skip
             j = __float_as_int(r0.w);
             const float tx = ra.x - r0.x, ty = ra.y - r0.y, tz = ra.z - r0.z;
             // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t
@@ -3061,10 +3063,11 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                          g_fverts);
     }
   }
-  ProfScope prof_acc(TFRT_PROF_ACCUMULATE, st);
-  if (stash && !ordered && P > 0)
+  if (stash && !ordered && P > 0) {
+    ProfScope prof_acc(TFRT_PROF_ACCUMULATE, st);
     hipLaunchKernelGGL((k_face_accumulate<G>), dim3(cdiv(N, acc_chunk), windows), dim3(1024), 0, st,
                        nrays, P, (int64_t)n, stash_face_all, stash_g_all, acc_chunk, M, g_fverts);
+  }
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 
