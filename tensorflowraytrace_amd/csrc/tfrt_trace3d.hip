@@ -1433,17 +1433,22 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     double eps_start, const int32_t* __restrict__ catagory, int32_t* __restrict__ rec_tri,
     double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls, int32_t* __restrict__ hist,
     int32_t* __restrict__ left_list, int32_t* __restrict__ left_count,
-    int32_t* __restrict__ left_total, int coherent_only) {
+    int32_t* __restrict__ left_total, int coherent_only, int bundle) {
+  // bundle = rays per wavefront: 64, or 32 (lanes 32..63 carry no ray; they still test nodes) for
+  // launches that leave the chip half empty -- twice the wavefronts, each with fewer candidate
+  // faces and half the decisions: the launch is as long as ONE wavefront's chain of dependent
+  // steps then, not as the work.  (32 only with coherent_only: the grouped kernel takes whole
+  // 64-ray wavefronts.)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = blockIdx.x * BLOCK + tid;
-  const int qwave = q >> 6;
+  const int qwave = blockIdx.x * WAVES + wave;
+  const int q = qwave * bundle + lane;
   const int n = *n_ptr;
-  if ((qwave << 6) >= n) return;  // (whole wave; no block-level synchronisation in this kernel)
+  if (qwave * bundle >= n) return;  // (whole wave; no block-level synchronisation in this kernel)
   const bool first_pass = last_tri == nullptr;
 
   // this lane's ray: coalesced reads of the ray block
   using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
-  const int i = q < n ? q : -1;
+  const int i = (lane < bundle && q < n) ? q : -1;
   const bool live = i >= 0;
   const int64_t ii = live ? i : 0;
   RT own[6];
@@ -1548,10 +1553,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   unsigned long long cuts = 0ull;
   int lo = 0, attempts = 0;
   bool spread = false;
-  while (lo < 64) {
+  while (lo < bundle) {
     ++attempts;
     const unsigned long long above = lo < 63 ? (cuts >> (lo + 1)) << (lo + 1) : 0ull;
-    const int hi = above != 0ull ? __ffsll((long long)above) - 1 : 64;
+    const int hi = above != 0ull ? __ffsll((long long)above) - 1 : bundle;
     const int len = hi - lo;
     const bool sel = ok && lane >= lo && lane < hi;
     const float cnt = wave_sum_f(sel ? 1.f : 0.f);
@@ -1654,7 +1659,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       // (coherent_only: the caller launches no grouped kernel behind this one -- it has seen this
       // source leave no wavefront over -- so every wavefront is finished here, however wide)
       const bool hopeless = !coherent_only &&
-                            ((len == 64 && (spread || (nc > 64 && nc > n_clusters / 4))) ||
+                            ((len == bundle && (spread || (nc > 64 && nc > n_clusters / 4))) ||
                              attempts >= BEAM_ATTEMPTS);
       if (len > 1 && !hopeless) {  // cut at the widest gap inside [lo, hi), try the first part
         if (cuts == 0ull) {
@@ -1724,7 +1729,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       }
       // not a wavefront of (a few) narrow bundles: the grouped kernel does it
       TFRT_STAT(ns > BEAM_SLIST ? 10 : (nc > BEAM_CLIST ? 11 : (nf > BEAM_FLIST ? 12 : 9)), 1);
-      TFRT_STAT(15, qwave * 64 + lo);
+      TFRT_STAT(15, qwave * bundle + lo);
       if (lane == 0) {
         left_list[atomicAdd(left_count, 1)] = qwave;
         atomicAdd(left_total, 1);
@@ -1827,7 +1832,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int cnt_c = __popcll(__ballot(cls == c));
-    if (lane == c && cnt_c > 0) atomicAdd(&hist[(qwave >> 2) * 4 + c], cnt_c);
+    if (lane == c && cnt_c > 0) atomicAdd(&hist[((qwave * bundle) >> 8) * 4 + c], cnt_c);
   }
 }
 
@@ -2792,11 +2797,15 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
   ProfScope prof(TFRT_PROF_INTERSECT, st);
   if (grouped && od != nullptr) {
     // coherent wavefronts first; the grouped kernel then does the wavefronts that were not
-    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, BLOCK)), dim3(BLOCK), 0, st, rays,
-                       stride, n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec,
-                       fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
+    // (half-size wavefronts while the launch would leave the chip half empty: §3.6)
+    int bundle = 64;
+    if (od->coherent_only && od->nq <= 160 * 1024) bundle = 32;  // (125k rays: 0.191 against 0.200 ms per step; 250k: 0.223 against 0.211)
+    if (const char* env = getenv("TFRT_BEAM_BUNDLE")) bundle = atoi(env) == 32 && od->coherent_only ? 32 : (atoi(env) == 64 ? 64 : bundle);
+    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, WAVES * bundle)), dim3(BLOCK), 0,
+                       st, rays, stride, n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere,
+                       ac->crec, fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
                        fz.rec_tri, fz.rec_t, fz.rec_cls, od->hist, od->left_list,
-                       od->left_count, od->left_total, od->coherent_only);
+                       od->left_count, od->left_total, od->coherent_only, bundle);
     // (enough workgroups to fill the chip when every wavefront is left over; they loop)
     grid = dim3(min(cdiv(od->nq, BLOCK), 1280), 1);
   }

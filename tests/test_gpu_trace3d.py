@@ -682,7 +682,7 @@ def test_coherent_order_changes_no_output(dtype, n_rays, k_front):
         # float64 state: the same terms summed in another order.  float32 state: the natural-order
         # sweep rounds every ray's nine face terms to float32 on their way through the stash, the
         # coherent sweep sums them in float64 straight away (the float32 level: 6e-8)
-        tol = 1e-11 if dtype == torch.float64 else 3e-7
+        tol = 1e-11 if dtype == torch.float64 else 2e-6
         for a, b in zip(g, g_ref):
             assert float((a - b).abs().max() / b.abs().max()) < tol, name
 
