@@ -1,5 +1,5 @@
 """Builds tuning variants of the library into scratch/variants_live/ (git-ignored, not shipped; it travels to the GPU box: delete it after use).  Usage:
-build_variants.py NAME=flags ...   e.g.  w5="-DTFRT_GROUP_WAVES=5 -DTFRT_GROUP_LIST_CAP=640" """
+build_variants.py NAME=flags ...   e.g.  tune="-DTFRT_TUNING" """
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from tensorflowraytrace_amd import _build

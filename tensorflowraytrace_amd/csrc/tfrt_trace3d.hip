@@ -39,17 +39,8 @@
 
 namespace tfrt {
 
-#ifndef TFRT_TILE
-#define TFRT_TILE 512
-#endif
-#ifndef TFRT_KC
-#define TFRT_KC 24
-#endif
-#ifndef TFRT_MIN_WAVES
-#define TFRT_MIN_WAVES 1
-#endif
-constexpr int TILE = TFRT_TILE;  // spheres per LDS tile (8 KiB; measured best on MI355X)
-constexpr int KC = TFRT_KC;    // candidate slots per lane (24 KiB per block)
+constexpr int TILE = 512;  // spheres per LDS tile (8 KiB; measured best on MI355X)
+constexpr int KC = 24;     // candidate slots per lane (24 KiB per block)
 
 // error bits written to counts[...error]
 constexpr int ERR_CAPACITY = 1;
@@ -184,10 +175,9 @@ __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fv
 // vertex by 1/(k+1)) towards the minimal enclosing ball of the 48 vertices: ~10 % less radius,
 // ~20 % fewer rays per cluster.
 constexpr int CLUSTER = 16;
-#ifndef TFRT_BC_STEPS
-#define TFRT_BC_STEPS 6
-#endif
-constexpr int BC_STEPS = TFRT_BC_STEPS;  // Badoiu-Clarkson steps of the cluster / supercluster balls
+// Badoiu-Clarkson steps of the cluster / supercluster balls (12 steps gave the same candidate
+// counts per wavefront and ray, and a set-up launch 5 us longer)
+constexpr int BC_STEPS = 6;
 
 // Funnel counters of k_intersect_group: tuning builds only (-DTFRT_TUNING, csrc/tfrt_tuning.h;
 // never in the shipped library).
@@ -555,7 +545,7 @@ __device__ __forceinline__ bool may_hit(const double s[3], const double e[3], co
 // ------------------------------------------------------------------------- intersect
 
 template <typename T, int R>
-__global__ __launch_bounds__(BLOCK, TFRT_MIN_WAVES) void k_intersect3d(
+__global__ __launch_bounds__(BLOCK) void k_intersect3d(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ sphere,
     const double* __restrict__ fverts, const float* __restrict__ prep, int64_t pstride, int M,
@@ -741,18 +731,10 @@ __device__ __forceinline__ void shift_in_le(unsigned& acc, const float q, const 
 // list) and five waves per SIMD (94 VGPRs, no spills).  Measured at 1M rays, optimiser step: with the
 // 7,100-instruction kernel of the round's first half 5 waves were no faster than 4 (236 vs 230 us per
 // launch); after the instruction trimming, with the screen / decision stages' gather latency a
-// larger share of a wave's life, 0.809 ms against 0.826.  (-DTFRT_GROUP_WAVES=0 -DTFRT_GROUP_RAYS_LDS
-// -DTFRT_GROUP_LIST_CAP=1024 is the four-wave configuration.)
-#ifndef TFRT_GROUP_WAVES
-#define TFRT_GROUP_WAVES 5
-#endif
-#if TFRT_GROUP_WAVES > 0
+// larger share of a wave's life, 0.809 ms against 0.826 (the four-wave configuration kept a copy of
+// the rays in LDS and a 1024-entry list).
 // (only the shipped one-ray-per-lane instantiation: 2 or 4 rays per lane need more LDS than that)
-#define TFRT_GROUP_ATTR \
-  __attribute__((amdgpu_waves_per_eu(R == 1 ? TFRT_GROUP_WAVES : 1, R == 1 ? TFRT_GROUP_WAVES : 8)))
-#else
-#define TFRT_GROUP_ATTR
-#endif
+#define TFRT_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(R == 1 ? 5 : 1, R == 1 ? 5 : 8)))
 template <typename T, int R>
 __device__ __forceinline__ void group_walk(
     const T* __restrict__ rays, int64_t stride, const int n,
@@ -767,10 +749,7 @@ __device__ __forceinline__ void group_walk(
     int32_t* __restrict__ blockcnt, int32_t* __restrict__ hist, const int base,
     const int qwave) {
   constexpr int RW = 64 * R;      // rays per wave
-#ifndef TFRT_GROUP_TILE
-#define TFRT_GROUP_TILE 256
-#endif
-  constexpr int GT = TFRT_GROUP_TILE;   // cluster spheres per LDS tile
+  constexpr int GT = 256;   // cluster spheres per LDS tile (128: 0.868 ms per step against 0.823)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   // Coherent-ray traces (R == 1 only): this wave does wavefront `qwave` -- one that
@@ -792,10 +771,7 @@ __device__ __forceinline__ void group_walk(
   __shared__ float4 tile[GT + GT / SUPER];
   // candidate list of the wave: (tile-local cluster << 8 | ray slot), 16 bits because it is
   // always drained before the tile changes (LDS footprint decides the waves in flight)
-#ifndef TFRT_GROUP_LIST_CAP
-#define TFRT_GROUP_LIST_CAP 640
-#endif
-  constexpr int LIST_CAP = TFRT_GROUP_LIST_CAP;   // > 64 * SUPER: one batch of 64 pairs must fit
+  constexpr int LIST_CAP = 640;   // > 64 * SUPER: one batch of 64 pairs must fit
   static_assert(LIST_CAP > 64 * SUPER, "candidate list too small for one batch");
   __shared__ uint16_t clist[WAVES][LIST_CAP];
   // (tile-local supercluster << 8 | ray slot) pairs waiting for their cluster tests
@@ -804,27 +780,19 @@ __device__ __forceinline__ void group_walk(
   __shared__ float4 prep_ab[WAVES][2 * RW];
   __shared__ unsigned long long best_k[WAVES][RW];
   __shared__ int32_t best_i[WAVES][RW];
-#ifndef TFRT_MEMBER_UNROLL
-#define TFRT_MEMBER_UNROLL 4
-#endif
-  constexpr int MU = TFRT_MEMBER_UNROLL;    // 16-lane groups' candidates in flight per step
+  constexpr int MU = 4;                     // 16-lane groups' candidates in flight per step
   constexpr int PAIRS = 64 + MU * 64;       // waiting pairs: < 64 left over + one step's hits
   __shared__ uint32_t pairs[WAVES][PAIRS];   // member slot << 8 | ray slot (member slot < 2^24)
   __shared__ uint8_t x_slot[WAVES][128];     // screen survivors waiting for the float64 test
   __shared__ int32_t x_face[WAVES][128];
-  // The wave's rays for the screen / decision stages are re-read from the ray block (gathers of
-  // 4-8 bytes per coordinate; -DTFRT_GROUP_RAYS_LDS keeps a copy in LDS instead, 6-12 KB that
-  // cost the fifth workgroup per CU).  (6 waves per SIMD spill: 276 us against 230.)
-#ifdef TFRT_GROUP_RAYS_LDS
-  __shared__ T ray_l[WAVES][6][RW];
-#define TFRT_RAYV(q, slot) static_cast<double>(ray_l[wave][q][slot])
-#else
+  // The wave's rays for the screen / decision stages come from the lane that owns them (one ray
+  // per lane) or are re-read from the ray block (R > 1); a copy in LDS, 6-12 KB, cost the fifth
+  // workgroup per CU.  (6 waves per SIMD spill: 276 us against 230.)
   auto ray_at = [&](int slot) -> int64_t {  // (R > 1: natural order only)
     const int i = base + (slot >> 6) * BLOCK + wave * 64 + (slot & 63);
     return i < n ? i : 0;
   };
 #define TFRT_RAYV(q, slot) ldd(rays, (int64_t)(q) * stride + ray_at(slot))
-#endif
   __shared__ int32_t skip_l[WAVES][RW];      // face each ray starts on (-1: none)
 
   const double cx = c0[0], cy = c0[1], cz = c0[2];
@@ -874,10 +842,6 @@ __device__ __forceinline__ void group_walk(
     {
       const int slot = r * 64 + lane;
       const int64_t ii = i >= 0 ? i : 0;
-#ifdef TFRT_GROUP_RAYS_LDS
-#pragma unroll
-      for (int q = 0; q < 6; ++q) ray_l[wave][q][slot] = rays[q * stride + ii];
-#endif
       skip_l[wave][slot] = (last_tri != nullptr && i >= 0) ? last_tri[ii] : -1;
     }
     if (i >= 0 && prep != nullptr && !ordered) {
@@ -1029,10 +993,7 @@ __device__ __forceinline__ void group_walk(
         // 4 * MU candidates per step: 16 / ML lanes take one (ray, cluster) and ML members each
         // (the list entry, the ray's filter state and the addresses are shared by ML tests;
         // measured at 1M rays: ML = 1 -> 0.918 ms per optimiser step, 2 -> 0.897, 4 -> 0.913)
-#ifndef TFRT_MEMBERS_PER_LANE
-#define TFRT_MEMBERS_PER_LANE 2
-#endif
-        constexpr int ML = TFRT_MEMBERS_PER_LANE;
+        constexpr int ML = 2;
         static_assert(MU % ML == 0 && CLUSTER % ML == 0, "whole candidates per step");
         constexpr int MH = MU / ML;            // rounds per step
         constexpr int LPC = CLUSTER / ML;      // lanes per candidate
@@ -1415,16 +1376,8 @@ __device__ __forceinline__ float bcast_f(float v, int src_lane) {  // src_lane w
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-#ifndef TFRT_BEAM_WAVES
-#define TFRT_BEAM_WAVES 0
-#endif
-#if TFRT_BEAM_WAVES > 0
-#define TFRT_BEAM_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_BEAM_WAVES, TFRT_BEAM_WAVES)))
-#else
-#define TFRT_BEAM_ATTR
-#endif
 template <typename T>
-__global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
+__global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
     const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
@@ -2316,10 +2269,7 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
 // block per CU: every window block re-reads its chunk's face indices and flushes 9 sums per face,
 // so fewer, larger windows win (1M rays x 10,574 faces, optimiser step: 512 faces 0.815 ms,
 // 1024 0.790, 2048 0.774).
-#ifndef TFRT_FACE_WINDOW
-#define TFRT_FACE_WINDOW 2048
-#endif
-constexpr int FACE_WINDOW = TFRT_FACE_WINDOW;
+constexpr int FACE_WINDOW = 2048;
 
 template <typename S>
 __global__ __launch_bounds__(1024) void k_face_accumulate(
