@@ -46,6 +46,8 @@ def build(ray_dtype):
     eng = engine.OpticalEngine(3, [operation.StandardReaction()], ray_dtype=ray_dtype,
                                simple_ray_inheritance={"wavelength"})
     eng.optical_system = system
+    if os.environ.get("TFRT_COHERENT"):
+        eng.coherent = {"0": False, "1": True}.get(os.environ["TFRT_COHERENT"], "auto")
     return eng, system
 
 ref = None
@@ -60,7 +62,8 @@ for dt in (torch.float64, torch.float32, torch.float16):
     n_fin = fin["x_end"].shape[0]
     ids = eng.last_trace["finished_id"].long()
     xy = torch.stack([fin["x_end"], fin["y_end"]]).double()
-    line = f"{str(dt)[6:]:8s} N={N} M={M} passes={PASSES}: {ms:7.2f} ms/trace, {eng.last_trace['n_tests']/ms*1e3:.3e} tests/s, finished {n_fin}"
+    line = (f"{str(dt)[6:]:8s} N={N} M={M} passes={PASSES} coherent={eng.coherent}: {ms:7.2f} ms/trace, "
+            f"{eng.last_trace['n_tests']/ms*1e3:.3e} tests/s, finished {n_fin}, left over {eng.last_trace.get('left_over')}")
     if ref is None:
         ref = (ids, xy)
     else:

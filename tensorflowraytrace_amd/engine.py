@@ -895,6 +895,8 @@ class OpticalEngine:
         if (mode == "all-pairs" or self.coherent is False or block.shape[1] < 4096
                 or not block.is_cuda):
             return None
+        if self.coherent == "auto" and getattr(self, "_incoherent_key", None) == key:
+            return None                      # (tried: this source's wavefronts are no bundles)
         cached = getattr(self, "_order_cache", None)
         if cached is not None and cached[0] == key:
             if cached[4] != id(n_table):     # (other materials / wavelengths: same order)
@@ -914,11 +916,19 @@ class OpticalEngine:
                              id(n_table), n_table)      # (the table is held: its id stays its own)
         return perm
 
-    def _note_left_over(self, left_over):
-        """Visiting-order trace: remember whether the source left wavefronts to the grouped kernel
-        (then the next trace of the same source launches it again)."""
+    def _note_left_over(self, left_over, passes=1):
+        """Coherent-ray trace: remember whether the source left wavefronts to the grouped kernel
+        (then the next trace of the same source launches it again) -- and, with coherent="auto",
+        give the sorted trace up for this source when more than 5 % of its wavefront-passes were
+        no narrow bundles (a light guide after a few bounces off its faceted wall: the cuts and the
+        fallback then cost more than the shared walks save)."""
         key = getattr(self, "_visit_key", None)
         self._visit_all_key = key if (key is not None and int(left_over) == 0) else None
+        if key is not None and self.coherent == "auto":
+            n = getattr(self, "_order_cache", (None, None, None))[2]
+            waves = max(1, (n.shape[1] // 64 if n is not None else 1) * max(int(passes), 1))
+            if int(left_over) > 0.05 * waves:
+                self._incoherent_key = key
 
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
@@ -928,7 +938,7 @@ class OpticalEngine:
         if self.dimension == 3:
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
                               self.dead_ray_length, flags, predicted_counts=predicted)
-            self._note_left_over(out.get("left_over", 0))
+            self._note_left_over(out.get("left_over", 0), max_passes)
             if self._trace_perm is not None:
                 out = ops.restore_order(out, self._trace_perm)
             return out

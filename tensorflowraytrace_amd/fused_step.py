@@ -437,6 +437,11 @@ class FusedStep:
         self._eager(accumulators, world)
         self._eager_steps += 1
         self._last_sig = sig
+        if (self._eager_steps == 3 and self._state is not None
+                and getattr(opt.engine, "_trace_perm", None) is not None):
+            # (ONE host read, early on: did the sorted source leave wavefronts to the grouped
+            # kernel?  Many: coherent="auto" goes back to natural order for this source)
+            opt.engine._note_left_over(int(self._state["counts"][-1]), self._state["P"])
         return self._err_view
 
     def _eager(self, accumulators, world):
@@ -490,7 +495,7 @@ class FusedStep:
             # (the device is idle: one read tells whether the visiting-order trace of the step just
             # run left wavefronts to the grouped kernel; if not, the captured sequence omits it)
             if self._state is not None:
-                self.opt.engine._note_left_over(int(self._state["counts"][-1]))
+                self.opt.engine._note_left_over(int(self._state["counts"][-1]), self._state["P"])
             sig = self._signature(accumulators)
             pool = torch.cuda.graph_pool_handle()
             ga = torch.cuda.CUDAGraph()
