@@ -185,6 +185,11 @@ constexpr int BC_STEPS = 6;
 #include "tfrt_tuning.h"
 #else
 #define TFRT_STAT(k, v) do { } while (0)
+#define TFRT_TICK_INIT do { } while (0)
+#define TFRT_TICK(k) do { } while (0)
+#define TFRT_WAVE_BEGIN do { } while (0)
+#define TFRT_WAVE_END(qw) do { } while (0)
+#define TFRT_WAVE_NOTE(k, v) do { } while (0)
 #endif
 
 __device__ __forceinline__ void cluster_spheres_block(
@@ -493,10 +498,12 @@ __global__ __launch_bounds__(BLOCK) void k_rayprep(const T* __restrict__ rays, i
 // d = ray end - start, (ux,uy,uz) = P1 - P0, (vx,vy,vz) = P2 - P0, t = start - P0, all float32;
 // nt_err = 1-norm bounding the absolute error of t in units of 2^-24 (|t| itself when t is the
 // rounding of an exact difference; larger when its operands were already rounded).
-__device__ __forceinline__ bool may_hit_core(float dx, float dy, float dz, float ux, float uy,
-                                             float uz, float vx, float vy, float vz, float tx,
-                                             float ty, float tz, float nt_err, float es, float er,
-                                             double best) {
+// (nd, n1, n2: 1-norms of d, e1, e2 -- callers that test one face against many rays, or one ray
+// against many faces, form them once)
+__device__ __forceinline__ bool may_hit_norms(float dx, float dy, float dz, float ux, float uy,
+                                              float uz, float vx, float vy, float vz, float tx,
+                                              float ty, float tz, float nt_err, float nd, float n1,
+                                              float n2, float es, float er, double best) {
   // p = d x e2, q = t x e1
   const float px = dy * vz - dz * vy, py = dz * vx - dx * vz, pz = dx * vy - dy * vx;
   const float qx = ty * uz - tz * uy, qy = tz * ux - tx * uz, qz = tx * uy - ty * ux;
@@ -504,9 +511,6 @@ __device__ __forceinline__ bool may_hit_core(float dx, float dy, float dz, float
   const float bu = tx * px + ty * py + tz * pz;   // trig_u * det
   const float bv = dx * qx + dy * qy + dz * qz;   // trig_v * det
   const float bw = vx * qx + vy * qy + vz * qz;   // ray_u  * det
-  const float nd = fabsf(dx) + fabsf(dy) + fabsf(dz);
-  const float n1 = fabsf(ux) + fabsf(uy) + fabsf(uz);
-  const float n2 = fabsf(vx) + fabsf(vy) + fabsf(vz);
   const float nt = nt_err;
   const float k = 32.0f * 5.9604644775390625e-08f;
   const float e_det = k * nd * n1 * n2, e_u = k * nt * nd * n2, e_v = k * nd * nt * n1;
@@ -531,6 +535,15 @@ __device__ __forceinline__ bool may_hit_core(float dx, float dy, float dz, float
     if (sw - e_w > fmaxf(bf * lo, bf * hi) + 1e-30f) return false;
   }
   return true;
+}
+
+__device__ __forceinline__ bool may_hit_core(float dx, float dy, float dz, float ux, float uy,
+                                             float uz, float vx, float vy, float vz, float tx,
+                                             float ty, float tz, float nt_err, float es, float er,
+                                             double best) {
+  return may_hit_norms(dx, dy, dz, ux, uy, uz, vx, vy, vz, tx, ty, tz, nt_err,
+                       fabsf(dx) + fabsf(dy) + fabsf(dz), fabsf(ux) + fabsf(uy) + fabsf(uz),
+                       fabsf(vx) + fabsf(vy) + fabsf(vz), es, er, best);
 }
 
 __device__ __forceinline__ bool may_hit(const double s[3], const double e[3], const double P[9],
@@ -1326,9 +1339,11 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
 constexpr int BEAM_SLIST = 64;    // touched superclusters a narrow bundle may have
 constexpr int BEAM_CLIST = 32;    // ... clusters
 constexpr int BEAM_FLIST = 192;   // ... candidate faces
+constexpr int BEAM_WIDE = 48;     // candidate faces beyond which a bundle of more than 8 rays is cut
 
 struct Beam {  // wave-uniform
-  float ox, oy, oz, wx, wy, wz, R0, S, tmin;
+  float ox, oy, oz, wx, wy, wz, R0, S, tmin;      // axis, bounds (see k_intersect_beam)
+  float e1x, e1y, e1z, e2x, e2y, e2z;             // image plane (see face_frame)
 };
 
 __device__ __forceinline__ bool beam_touch(const Beam& b, const float4 sp) {
@@ -1340,6 +1355,69 @@ __device__ __forceinline__ bool beam_touch(const Beam& b, const float4 sp) {
   const float B = r + b.R0 + b.S * (fabsf(t) + r);
   // (2e-6 v2: ten times the rounding error of v2 - t^2 and of a not exactly unit w)
   return (v2 - t * t <= B * B + 2e-6f * v2) && !(t + r < b.tmin);
+}
+
+// The faces themselves against the bundle and its rays, seen ALONG THE AXIS: points are mapped
+// to (x . e1, x . e2) with e1, e2 (about) orthonormal and perpendicular to w -- a linear map, so
+// a hit X of a ray on a face lies in the face's image, and on the ray's image
+//     p(t) = A + M t,   t = (X - o) . w,   M = (d . e1, d . e2) / (d . w),   A = p(start) - M t_start
+// (exact identities for ANY e1, e2, w).  A valid hit lies within `slack` of the triangle (trig_u,
+// trig_v >= -eps_size, trig_u + trig_v <= 1 + eps_size put X = P0 + u E1 + v E2 at most
+// 5 eps_size max(|E1|, |E2|) outside it), so t_X lies in the face's axial range [tlo, thi]
+// (corner values widened by the slack) and p(t_X) within |M| (thi - tlo) / 2 of p(tc), tc the
+// middle of the range.  With n_k, c_k the outward unit normals and offsets of the image
+// triangle's edges (n_k . p + c_k = signed distance outside edge k):
+//   LANE = FACE  face_frame(): the bundle can touch the face only if the axis' image (the origin)
+//                is within rho = R0 + S max|t| of every edge's inner half-plane, c_k <= rho, and
+//                the face does not lie behind every start;  it writes the face's record
+//                (n_k, c_k, tlo, thi, tc, h, slack, face index) for
+//   LANE = RAY   on_face(): n_k . p(tc) + c_k <= |M| h + slack for the three edges.
+// Both are necessary conditions of a valid hit with every bound inflated far beyond its float32
+// rounding (NaN: true); a triangle seen (almost) edge-on has no reliable orientation and passes
+// every ray.  r0 = (P0 - c0 | face index), r1 = E1, r2 = E2: the float32 face record.
+__device__ __forceinline__ bool face_frame(const Beam& b, const float4 r0, const float4 r1,
+                                           const float4 r2, const float es, float4 rec[4]) {
+  const float n1 = fabsf(r1.x) + fabsf(r1.y) + fabsf(r1.z);
+  const float n2 = fabsf(r2.x) + fabsf(r2.y) + fabsf(r2.z);
+  const float scale = fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z) + fabsf(b.ox) + fabsf(b.oy) +
+                      fabsf(b.oz) + n1 + n2;
+  const float slack = 5.05f * es * (n1 + n2) + 8e-6f * scale;
+  const float ax = r0.x - b.ox, ay = r0.y - b.oy, az = r0.z - b.oz;
+  const float t0 = ax * b.wx + ay * b.wy + az * b.wz;
+  const float t1 = t0 + (r1.x * b.wx + r1.y * b.wy + r1.z * b.wz);
+  const float t2 = t0 + (r2.x * b.wx + r2.y * b.wy + r2.z * b.wz);
+  const float tlo = fminf(t0, fminf(t1, t2)) - slack, thi = fmaxf(t0, fmaxf(t1, t2)) + slack;
+  // images of the corners: q0, q0 + g1, q0 + g2
+  const float q0x = ax * b.e1x + ay * b.e1y + az * b.e1z, q0y = ax * b.e2x + ay * b.e2y + az * b.e2z;
+  const float g1x = r1.x * b.e1x + r1.y * b.e1y + r1.z * b.e1z,
+              g1y = r1.x * b.e2x + r1.y * b.e2y + r1.z * b.e2z;
+  const float g2x = r2.x * b.e1x + r2.y * b.e1y + r2.z * b.e1z,
+              g2y = r2.x * b.e2x + r2.y * b.e2y + r2.z * b.e2z;
+  const float area = g1x * g2y - g1y * g2x;
+  const float l1 = g1x * g1x + g1y * g1y, l2 = g2x * g2x + g2y * g2y;
+  const bool flat = !(area * area > 1e-8f * l1 * l2);  // (edge-on, degenerate or NaN)
+  const float sg = area > 0.f ? 1.f : -1.f;
+  auto edge = [&](float px, float py, float dx, float dy, float* nx, float* ny, float* c) {
+    const float k = sg * __builtin_amdgcn_rsqf(dx * dx + dy * dy);
+    *nx = dy * k;
+    *ny = -dx * k;
+    *c = -(*nx * px + *ny * py);
+  };
+  float nx0, ny0, c0, nx1, ny1, c1, nx2, ny2, c2;
+  edge(q0x, q0y, g1x, g1y, &nx0, &ny0, &c0);
+  edge(q0x + g1x, q0y + g1y, g2x - g1x, g2y - g1y, &nx1, &ny1, &c1);
+  edge(q0x + g2x, q0y + g2y, -g2x, -g2y, &nx2, &ny2, &c2);
+  if (flat) {
+    nx0 = ny0 = nx1 = ny1 = nx2 = ny2 = 0.f;
+    c0 = c1 = c2 = -INFINITY;
+  }
+  const float slack2 = 1.5f * slack;  // (in the image: |e1|, |e2| = 1 to rounding, two components)
+  rec[0] = make_float4(nx0, ny0, c0, tlo);
+  rec[1] = make_float4(nx1, ny1, c1, thi);
+  rec[2] = make_float4(nx2, ny2, c2, 0.5f * (tlo + thi));
+  rec[3] = make_float4(0.5001f * (thi - tlo), slack2, r0.w, 0.f);
+  const float rho = (b.R0 + b.S * fmaxf(fabsf(tlo), fabsf(thi)) + slack2) * 1.0001f;
+  return !(c0 > rho) && !(c1 > rho) && !(c2 > rho) && !(thi < b.tmin);
 }
 
 // Wave-wide reductions with DPP (data-parallel primitives: the operand of a VALU instruction
@@ -1372,12 +1450,72 @@ __device__ __forceinline__ float wave_max_f(float v) {
 __device__ __forceinline__ float wave_min_f(float v) {
   return wave_reduce_f(v, [](float a, float b) { return fminf(a, b); });
 }
+__device__ __forceinline__ float uniform_f(float v) {  // v wave-uniform: into a scalar register
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
 __device__ __forceinline__ float bcast_f(float v, int src_lane) {  // src_lane wave-uniform
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
+// The exact float64 test of k_intersect_beam, one (ray, face) pair per lane; nearest hit per ray
+// by 64-bit min on an order-preserving key of ray_u, ties to the lower face index (tf.argmin's
+// first index).  x_pair[k] = face << 6 | ray slot, rt[6][64] = the wavefront's rays as stored.
+// (A function of its own, not inlined: the four places that call it share one copy, and its
+// registers -- nine float64 vertices, the six-term sums -- are not added to the caller's.)
+template <typename U>
+using LdsPtr = __attribute__((address_space(3))) U*;
+
+template <typename RT>
+__device__ __forceinline__ void beam_decide(const int nb, const int lane, LdsPtr<const uint32_t> x_pair,
+                                         LdsPtr<const RT> rt, LdsPtr<unsigned long long> best_k,
+                                         LdsPtr<int32_t> best_i, const double* __restrict__ fverts,
+                                         const double eps_int, const double eps_size,
+                                         const double eps_start) {
+  bool have = false;
+  unsigned long long key = 0, old = 0;
+  int j = -1;
+  const uint32_t xp = lane < nb ? x_pair[lane] : 0u;
+  const int slot = (int)(xp & 63u);
+  if (lane < nb) {
+    double s[3], e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      s[k] = static_cast<double>(rt[k * 64 + slot]);
+      e[k] = static_cast<double>(rt[(3 + k) * 64 + slot]);
+    }
+    j = (int)(xp >> 6);
+    old = best_k[slot];
+    double P[9];
+    const double* fp = fverts + 9 * (int64_t)j;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) P[k] = fp[k];
+    const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
+    if (h.valid) {
+      have = true;
+      key = dkey(h.ray_u);
+    }
+  }
+  wave_fence();
+  if (have) atomicMin((unsigned long long*)&best_k[slot], key);
+  wave_fence();
+  bool win = false;
+  if (have) {
+    const unsigned long long now = best_k[slot];
+    win = key == now;
+    if (win && now < old) best_i[slot] = 0x7FFFFFFF;  // a nearer hit: restart the tie-break
+  }
+  wave_fence();
+  if (win) atomicMin((int32_t*)&best_i[slot], j);
+  wave_fence();
+}
+
+#ifdef TFRT_BEAM_WAVES
+#define TFRT_BEAM_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_BEAM_WAVES, TFRT_BEAM_WAVES)))
+#else
+#define TFRT_BEAM_ATTR
+#endif
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_intersect_beam(
+__global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
     const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
@@ -1397,6 +1535,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
   const int q = qwave * bundle + lane;
   const int n = *n_ptr;
   if (qwave * bundle >= n) return;  // (whole wave; no block-level synchronisation in this kernel)
+  TFRT_TICK_INIT;
+  TFRT_WAVE_BEGIN;
   const bool first_pass = last_tri == nullptr;
 
   // this lane's ray: coalesced reads of the ray block
@@ -1404,26 +1544,23 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
   const int i = (lane < bundle && q < n) ? q : -1;
   const bool live = i >= 0;
   const int64_t ii = live ? i : 0;
-  RT own[6];
+  RT own0[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) own[k] = static_cast<RT>(rays[k * stride + ii]);
+  for (int k = 0; k < 6; ++k) own0[k] = static_cast<RT>(rays[k * stride + ii]);
   const int skip = (live && last_tri != nullptr) ? last_tri[ii] : -1;
-  // (the first supercluster spheres travel together with the ray: one round trip less in the
-  // chain ray -> bundle -> level 0 -> level 1 -> level 2 -> faces)
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-  const float4 su_first = lane < n_super ? susphere[lane] : never;
 
   __shared__ uint16_t slist[WAVES][BEAM_SLIST];
   __shared__ uint16_t clist[WAVES][BEAM_CLIST];
   __shared__ uint32_t flist[WAVES][BEAM_FLIST];
   __shared__ uint32_t x_pair[WAVES][128];  // face << 6 | lane of the ray (faces < 2^24)
-  __shared__ uint16_t plist[WAVES][128];   // candidate of the chunk << 6 | lane of the ray
-  // (tables laid out [part][lane]: a lane's float4 lies next to its neighbour's -- the fills are
-  // free of bank conflicts; the screen's reads go to random entries either way)
-  __shared__ float4 ctab[WAVES][3][64];    // float32 face records of the chunk's candidates
-  __shared__ float4 rtab[WAVES][2][64];    // the wave's rays: s - c0, d = e - s, face they start on
+  // records of a chunk's faces, nearest first (face_frame)
+  __shared__ float4 ftab[WAVES][64][4];
+  __shared__ RT rtab[WAVES][6][64];  // the wave's rays as stored (the exact test reads them by slot)
   __shared__ unsigned long long best_k[WAVES][64];
   __shared__ int32_t best_i[WAVES][64];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) rtab[wave][k][lane] = own0[k];
   best_k[wave][lane] = dkey(INFINITY);
   best_i[wave][lane] = -1;
 
@@ -1433,63 +1570,17 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     if constexpr (sizeof(T) <= 4) return (float)v - cf;
     else return (float)((double)v - c);
   };
-  const float sx = rel(own[0], cx, cxf), sy = rel(own[1], cy, cyf), sz = rel(own[2], cz, czf);
-  const float dx = (float)(own[3] - own[0]), dy = (float)(own[4] - own[1]),
-              dz = (float)(own[5] - own[2]);
-  const float len2 = dx * dx + dy * dy + dz * dz;
-  // (a zero-length or non-finite ray can hit nothing: it takes no part and ends up dead)
-  const bool ok = live && len2 > 0.f && len2 < 3.0e38f;
-  const float inv = ok ? 1.0f / __builtin_sqrtf(len2) : 0.f;
-  const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-
-  const float es_f = (float)eps_size, er_f = (float)eps_start;
-  int pn = 0;  // (ray, candidate) pairs waiting for the screen (wave-uniform)
+  const float es_f = (float)eps_size;
   int xn = 0;  // (ray, face) pairs waiting for the exact test (wave-uniform)
-  rtab[wave][0][lane] = make_float4(sx, sy, sz, dx);
-  rtab[wave][1][lane] = make_float4(dy, dz, __int_as_float(skip), 0.f);
 
-  auto ray_of = [&](const int slot, double s[3], double e[3]) {  // (all lanes active)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      s[k] = static_cast<double>(__shfl(own[k], slot, 64));
-      e[k] = static_cast<double>(__shfl(own[3 + k], slot, 64));
-    }
-  };
-  // exact float64 test, one (ray, face) per lane; nearest hit per ray by 64-bit min on an
-  // order-preserving key of ray_u, ties to the lower face index (tf.argmin's first index)
+  // exact float64 test, one (ray, face) per lane (beam_decide)
   auto decide = [&](const int nb) {
-    bool have = false;
-    unsigned long long key = 0, old = 0;
-    int j = -1;
-    const uint32_t xp = lane < nb ? x_pair[wave][lane] : 0u;
-    const int slot = (int)(xp & 63u);
-    double s[3], e[3];
-    ray_of(slot, s, e);
-    if (lane < nb) {
-      j = (int)(xp >> 6);
-      old = best_k[wave][slot];
-      double P[9];
-      const double* fp = fverts + 9 * (int64_t)j;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) P[k] = fp[k];
-      const TriHit h = exact_triangle(s, e, P, eps_int, eps_size, eps_start);
-      if (h.valid) {
-        have = true;
-        key = dkey(h.ray_u);
-      }
-    }
+    TFRT_STAT(28, 1);
+    TFRT_WAVE_NOTE(1, 1);
     wave_fence();
-    if (have) atomicMin(&best_k[wave][slot], key);
-    wave_fence();
-    bool win = false;
-    if (have) {
-      const unsigned long long now = best_k[wave][slot];
-      win = key == now;
-      if (win && now < old) best_i[wave][slot] = 0x7FFFFFFF;  // a nearer hit: restart the tie-break
-    }
-    wave_fence();
-    if (win) atomicMin(&best_i[wave][slot], j);
-    wave_fence();
+    beam_decide<RT>(nb, lane, (LdsPtr<const uint32_t>)&x_pair[wave][0],
+                    (LdsPtr<const RT>)&rtab[wave][0][0], (LdsPtr<unsigned long long>)&best_k[wave][0],
+                    (LdsPtr<int32_t>)&best_i[wave][0], fverts, eps_int, eps_size, eps_start);
   };
 
   // The wavefront's lanes are taken as ONE bundle; if that bundle is not narrow (the ray order
@@ -1502,22 +1593,45 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
   // single-ray walks cost ten times its work.
   TFRT_STAT(8, 1);
   constexpr int BEAM_ATTEMPTS = 20;
+  TFRT_TICK(0);
   float gap = -1.f;  // (formed when the first cut is needed)
   unsigned long long cuts = 0ull;
   int lo = 0, attempts = 0;
   bool spread = false;
   while (lo < bundle) {
     ++attempts;
+    TFRT_STAT(30, 1);
+    TFRT_WAVE_NOTE(0, 1);
     const unsigned long long above = lo < 63 ? (cuts >> (lo + 1)) << (lo + 1) : 0ull;
     const int hi = above != 0ull ? __ffsll((long long)above) - 1 : bundle;
     const int len = hi - lo;
+    // this lane's ray in float32, relative to c0 (formed anew for every bundle, from the LDS copy:
+    // nothing of it has to stay in registers while the faces are walked)
+    wave_fence();
+    RT own[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) own[k] = rtab[wave][k][lane];
+    const float sx = rel(own[0], cx, cxf), sy = rel(own[1], cy, cyf), sz = rel(own[2], cz, czf);
+    const float dx = (float)(own[3] - own[0]), dy = (float)(own[4] - own[1]),
+                dz = (float)(own[5] - own[2]);
+    const float len2 = dx * dx + dy * dy + dz * dz;
+    // (a zero-length or non-finite ray can hit nothing: it takes no part and ends up dead)
+    const bool ok = live && len2 > 0.f && len2 < 3.0e38f;
+    const float inv = ok ? 1.0f / __builtin_sqrtf(len2) : 0.f;
+    const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+    const float rabs = fabsf(sx) + fabsf(sy) + fabsf(sz);
     const bool sel = ok && lane >= lo && lane < hi;
+    // (the first supercluster spheres are fetched while the bundle is formed: one round trip
+    // less in the chain ray -> bundle -> level 0 -> level 1 -> level 2 -> faces)
+    const float4 su_first = lane < n_super ? susphere[lane] : never;
     const float cnt = wave_sum_f(sel ? 1.f : 0.f);
     bool narrow = true;
     int ns = 0, nc = 0, nf = 0;
+    Beam bm;
+    float ray_t = 0.f, ray_dt = 0.f, ray_terr = 0.f;  // this lane's ray along the axis: start, d . w
+    float Ax = 0.f, Ay = 0.f, Mx = 0.f, My = 0.f, Mlen = 0.f, Perr = 0.f, Pm = 0.f;  // ... its image
     if (cnt > 0.f) {
       // ---- the bundle
-      Beam bm;
       const float swx = wave_sum_f(sel ? ux : 0.f), swy = wave_sum_f(sel ? uy : 0.f),
                   swz = wave_sum_f(sel ? uz : 0.f);
       const float sox = wave_sum_f(sel ? sx : 0.f), soy = wave_sum_f(sel ? sy : 0.f),
@@ -1535,6 +1649,36 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
                   mz = (uz - cosk * bm.wz) * ic;
       const float px = sx - bm.ox, py = sy - bm.oy, pz = sz - bm.oz;
       const float ts = px * bm.wx + py * bm.wy + pz * bm.wz;
+      ray_t = ts;
+      ray_dt = dx * bm.wx + dy * bm.wy + dz * bm.wz;
+      ray_terr = 1e-5f * (rabs + fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz));
+      // the image plane: e1 = normalize(w x axis least aligned with w), e2 = w x e1
+      {
+        const float f0 = fabsf(bm.wx), f1 = fabsf(bm.wy), f2 = fabsf(bm.wz);
+        const bool k0 = f0 <= f1 && f0 <= f2, k1 = !k0 && f1 <= f2;
+        const float kx = k0 ? 1.f : 0.f, ky = k1 ? 1.f : 0.f, kz = (!k0 && !k1) ? 1.f : 0.f;
+        const float cxx = bm.wy * kz - bm.wz * ky, cyy = bm.wz * kx - bm.wx * kz,
+                    czz = bm.wx * ky - bm.wy * kx;
+        const float il = __builtin_amdgcn_rsqf(cxx * cxx + cyy * cyy + czz * czz);
+        bm.e1x = cxx * il; bm.e1y = cyy * il; bm.e1z = czz * il;
+        bm.e2x = bm.wy * bm.e1z - bm.wz * bm.e1y;
+        bm.e2y = bm.wz * bm.e1x - bm.wx * bm.e1z;
+        bm.e2z = bm.wx * bm.e1y - bm.wy * bm.e1x;
+      }
+      // this ray's image p(t) = A + M t
+      {
+        const float idt = 1.0f / (sel ? ray_dt : 1.f);
+        Mx = (dx * bm.e1x + dy * bm.e1y + dz * bm.e1z) * idt;
+        My = (dx * bm.e2x + dy * bm.e2y + dz * bm.e2z) * idt;
+        const float p1 = px * bm.e1x + py * bm.e1y + pz * bm.e1z,
+                    p2 = px * bm.e2x + py * bm.e2y + pz * bm.e2z;
+        Ax = p1 - ts * Mx;
+        Ay = p2 - ts * My;
+        Mlen = __builtin_sqrtf(Mx * Mx + My * My) * 1.0001f;
+        Pm = 2e-5f * (fabsf(Mx) + fabsf(My));
+        Perr = 2e-5f * (fabsf(p1) + fabsf(p2) + fabsf(ts) * (fabsf(Mx) + fabsf(My)) + rabs +
+                        fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz));
+      }
       const float ax = px - ts * bm.wx - ts * mx, ay = py - ts * bm.wy - ts * my,
                   az = pz - ts * bm.wz - ts * mz;
       const float R0 = wave_max_f(sel ? __builtin_sqrtf(ax * ax + ay * ay + az * az) : 0.f);
@@ -1550,6 +1694,13 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
       bm.tmin = (!first_pass && eps_start >= 0.0) ? tmin - 1e-5f * Lw - 1e-5f * fabsf(tmin)
                                                   : -INFINITY;
       if (!(bm.R0 < 3.0e38f && bm.S < 3.0e38f)) narrow = false;  // (also NaN)
+      // (wave-uniform, but computed by vector instructions: into scalar registers)
+      bm.ox = uniform_f(bm.ox); bm.oy = uniform_f(bm.oy); bm.oz = uniform_f(bm.oz);
+      bm.wx = uniform_f(bm.wx); bm.wy = uniform_f(bm.wy); bm.wz = uniform_f(bm.wz);
+      bm.R0 = uniform_f(bm.R0); bm.S = uniform_f(bm.S); bm.tmin = uniform_f(bm.tmin);
+      bm.e1x = uniform_f(bm.e1x); bm.e1y = uniform_f(bm.e1y); bm.e1z = uniform_f(bm.e1z);
+      bm.e2x = uniform_f(bm.e2x); bm.e2y = uniform_f(bm.e2y); bm.e2z = uniform_f(bm.e2z);
+      TFRT_TICK(1);
 
       // ---- levels: lane = node
       if (narrow) {
@@ -1569,6 +1720,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
         narrow = ns <= BEAM_SLIST && n_super <= 65536;
       }
       wave_fence();
+      TFRT_TICK(2);
       if (narrow && ns > 0) {
         for (int b = 0; b < ns * SUPER; b += 64) {
           const int k = b + lane;
@@ -1588,6 +1740,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
         narrow = nc <= BEAM_CLIST && n_clusters <= 65536;
       }
       wave_fence();
+      TFRT_TICK(3);
       if (narrow && nc > 0) {
         for (int b = 0; b < nc * CLUSTER; b += 64) {
           const int k = b + lane;
@@ -1604,11 +1757,15 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
           }
           nf += __popcll(m);
         }
-        narrow = nf <= BEAM_FLIST;
+        // (a bundle that touches several times the faces a coherent one does -- the ray order
+        // jumps inside it -- is cheaper as two: every ray is tested against every face left)
+        narrow = nf <= BEAM_FLIST && !(nf > BEAM_WIDE && len > 8 && attempts <= 6);
       }
       wave_fence();
+      TFRT_TICK(4);
     }
     if (!narrow) {
+      TFRT_TICK(10);
       // (coherent_only: the caller launches no grouped kernel behind this one -- it has seen this
       // source leave no wavefront over -- so every wavefront is finished here, however wide)
       const bool hopeless = !coherent_only &&
@@ -1690,88 +1847,118 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
       return;
     }
 
-    // ---- faces
-    // (1) lane = ray, one candidate face at a time: is the ray's line within r of the face's
-    //     sphere?  (sphere broadcast from the lane that fetched it: scalar operands, 12 vector
-    //     instructions per face) -- the (ray, face) pairs that pass queue up;
-    // (2) lane = pair: float32 screen (may_hit_core) with the face record and the ray from LDS
-    //     tables; (3) lane = pair: exact float64 decision.
+    // ---- faces (see face_frame)
+    // (1) LANE = FACE: the triangle itself against the bundle -- a bounding sphere has 2.4 times
+    //     the area of its face -- and the records of the faces left, nearest (along the axis)
+    //     first, into the LDS;
+    // (2) LANE = RAY, one face at a time: is the ray's image within the face's?  (a dozen
+    //     instructions on a record every lane reads from the same LDS address) -- the (ray, face)
+    //     pairs that pass queue up for
+    // (3) LANE = PAIR: the exact float64 decision.
+    // The walk ends as soon as every ray has a hit nearer than the nearest point of every face
+    // left (a lens: the second surface and the target are never tested in the first pass).
     TFRT_STAT(13, nf);
+    TFRT_WAVE_NOTE(3, nf);
+    TFRT_TICK(5);
+    // upper bound of the axial coordinate of this ray's nearest hit so far (inf: none)
+    auto reach_now = [&]() {
+      const double best = dkey_inv(best_k[wave][lane]);
+      const float bu = nextafterf((float)best, INFINITY) * ray_dt;  // (d . w > 0: cos > 0.7)
+      return ray_t + bu + 1e-5f * fabsf(bu) + ray_terr;
+    };
+    float myreach = reach_now();
+    bool queued = false;  // a pair of this ray waits for its decision
     for (int f0 = 0; f0 < nf; f0 += 64) {
       const int nb = min(64, nf - f0);
-      float4 sp = make_float4(0.f, 0.f, 0.f, -1.f);
+      float4 rec[4];
+      bool touch = false;
+      float tnear = INFINITY;
       if (lane < nb) {
         const int64_t memb = (int64_t)flist[wave][f0 + lane];
-        sp = csphere[memb];
-        sp.w *= 1.00001f;
-        // the candidate's float32 record (P0 - c0 | face index, E1, E2) for the screen
-        ctab[wave][0][lane] = crec[3 * memb];
-        ctab[wave][1][lane] = crec[3 * memb + 1];
-        ctab[wave][2][lane] = crec[3 * memb + 2];
+        const float4 r0 = crec[3 * memb], r1 = crec[3 * memb + 1], r2 = crec[3 * memb + 2];
+        touch = face_frame(bm, r0, r1, r2, es_f, rec) && __float_as_int(r0.w) >= 0;
+        tnear = rec[0].w;
+        if (tnear != tnear) tnear = -INFINITY;  // (NaN: never skipped)
+        rec[0].w = tnear;
+      }
+      // nearest first: a face's place = the number of faces that begin nearer (ties: lower lane)
+      const unsigned long long tm = __ballot(touch);
+      const int nt = __popcll(tm);
+      int place = 0;
+      for (unsigned long long rest = tm; rest != 0ull; rest &= rest - 1ull) {
+        const int o = __ffsll((long long)rest) - 1;
+        const float to = bcast_f(tnear, o);
+        place += (to < tnear || (to == tnear && o < lane)) ? 1 : 0;
+      }
+      wave_fence();  // (the previous chunk's records have been read)
+      if (touch) {
+        ftab[wave][place][0] = rec[0];
+        ftab[wave][place][1] = rec[1];
+        ftab[wave][place][2] = rec[2];
+        ftab[wave][place][3] = rec[3];
       }
       wave_fence();
-      for (int c = 0; c <= nb; ++c) {
-        if (c < nb) {
-          const float ccx = bcast_f(sp.x, c), ccy = bcast_f(sp.y, c), ccz = bcast_f(sp.z, c);
-          const float cw = bcast_f(sp.w, c);
-          const float vx = ccx - sx, vy = ccy - sy, vz = ccz - sz;
-          const float vu = vx * ux + vy * uy + vz * uz;
-          const float v2 = vx * vx + vy * vy + vz * vz;
-          // (4e-6 v2: the rounding of v2 - vu^2 and of a float32 unit direction at range |v|)
-          const bool near = sel && (v2 - vu * vu <= cw + 4e-6f * v2);
-          const unsigned long long nm = __ballot(near);
-          if (near) plist[wave][pn + rank_below(nm)] = (uint16_t)((c << 6) | lane);
-          pn += __popcll(nm);
+      TFRT_STAT(27, nt);
+      TFRT_TICK(6);
+      float span = -INFINITY;  // farthest axial coordinate of the faces taken so far
+      for (int c = 0; c < nt; ++c) {
+        // (one address for all lanes: the LDS broadcasts it)
+        const float4 q0 = ftab[wave][c][0], q1 = ftab[wave][c][1], q2 = ftab[wave][c][2],
+                     q3 = ftab[wave][c][3];
+        const float tn = q0.w;
+        // a gap in depth, and every ray has a hit or a candidate: decide what is queued -- the
+        // walk may end here
+        if (xn > 0 && tn > span &&
+            __ballot(sel && !(queued || myreach < INFINITY)) == 0ull) {
+          wave_fence();
+          decide(xn);
+          xn = 0;
+          queued = false;
+          myreach = reach_now();
+          TFRT_TICK(8);
         }
-        // a full batch of pairs -- or, after the chunk's last face, what is left (the table of
-        // face records is about to be overwritten)
-        while (pn >= 64 || (c == nb && pn > 0)) {
-          const int np = min(pn, 64);
+        if (__ballot(sel && !(myreach < tn)) == 0ull) break;  // all the faces left lie farther
+        TFRT_STAT(29, 1);
+        TFRT_WAVE_NOTE(2, 1);
+        span = fmaxf(span, q1.w);
+        const int j = __float_as_int(q3.z);
+        const float tc = q2.w;
+        const float ix = Ax + Mx * tc, iy = Ay + My * tc;
+        const float room = Mlen * q3.x + q3.y + Perr + Pm * fabsf(tc);
+        // (valid hits lie ahead of the start -- where bm.tmin says so --, and nearer than the
+        // ray's nearest hit so far)
+        const bool keep = sel && j != skip && !(myreach < tn) &&
+                          !(bm.tmin > -INFINITY && q1.w < ray_t - ray_terr) &&
+                          !(q0.x * ix + q0.y * iy + q0.z > room) &&
+                          !(q1.x * ix + q1.y * iy + q1.z > room) &&
+                          !(q2.x * ix + q2.y * iy + q2.z > room);
+        const unsigned long long km = __ballot(keep);
+        if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lane;
+        queued = queued || keep;
+        xn += __popcll(km);
+        TFRT_STAT(14, __popcll(km));
+        TFRT_TICK(7);
+        if (xn >= 64) {
           wave_fence();
-          bool keep = false;
-          int j = -1, rl = 0;
-          if (lane < np) {
-            const unsigned pr = plist[wave][lane];
-            rl = (int)(pr & 63u);
-            const float4 r0 = ctab[wave][0][pr >> 6], r1 = ctab[wave][1][pr >> 6],
-                         r2 = ctab[wave][2][pr >> 6];
-            const float4 ra = rtab[wave][0][rl], rb = rtab[wave][1][rl];  // s (c0 frame), d, skip
-            j = __float_as_int(r0.w);
-            const float tx = ra.x - r0.x, ty = ra.y - r0.y, tz = ra.z - r0.z;
-            // t = (s - c0) - (P0 - c0): both operands are float32 roundings, so the error of t
-            // scales with their magnitudes, not with |t|
-            const float nt_err = fabsf(tx) + fabsf(ty) + fabsf(tz) + fabsf(ra.x) + fabsf(ra.y) +
-                                 fabsf(ra.z) + fabsf(r0.x) + fabsf(r0.y) + fabsf(r0.z);
-            keep = j >= 0 && j != __float_as_int(rb.z) &&
-                   may_hit_core(ra.w, rb.x, rb.y, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z, tx, ty, tz,
-                                nt_err, es_f, er_f, dkey_inv(best_k[wave][rl]));
-          }
-          const unsigned long long km = __ballot(keep);
-          if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)rl;
-          xn += __popcll(km);
-          TFRT_STAT(14, __popcll(km));
-          uint32_t tq = 0u;  // fewer than 64 pairs remain: move them to the front
-          if (lane < pn - np) tq = plist[wave][np + lane];
+          decide(64);
+          uint32_t tp = 0u;
+          if (lane < xn - 64) tp = x_pair[wave][64 + lane];
           wave_fence();
-          if (lane < pn - np) plist[wave][lane] = (uint16_t)tq;
-          pn -= np;
-          if (xn >= 64) {
-            wave_fence();
-            decide(64);
-            uint32_t tp = 0u;
-            if (lane < xn - 64) tp = x_pair[wave][64 + lane];
-            wave_fence();
-            if (lane < xn - 64) x_pair[wave][lane] = tp;
-            xn -= 64;
-          }
+          if (lane < xn - 64) x_pair[wave][lane] = tp;
+          xn -= 64;
           wave_fence();
+          // (rays with a pair among those moved stay "queued")
+          myreach = reach_now();
+          TFRT_TICK(8);
         }
       }
     }
     lo = hi;  // this bundle is done: the next one starts behind it
   }
   wave_fence();
+  TFRT_TICK(6);
   if (xn > 0) decide(xn);
+  TFRT_TICK(8);
 
   // ---- hit record, class and this wavefront's share of its 256-ray block's class histogram
   int cls = -1;
@@ -1787,6 +1974,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     const int cnt_c = __popcll(__ballot(cls == c));
     if (lane == c && cnt_c > 0) atomicAdd(&hist[((qwave * bundle) >> 8) * 4 + c], cnt_c);
   }
+  TFRT_TICK(9);
+  TFRT_WAVE_END(qwave);
 }
 
 // -------------------------------------------------------------------------- classify

@@ -442,6 +442,7 @@ class FusedStep:
             # (ONE host read, early on: did the sorted source leave wavefronts to the grouped
             # kernel?  Many: coherent="auto" goes back to natural order for this source)
             opt.engine._note_left_over(int(self._state["counts"][-1]), self._state["P"])
+            self._last_sig = self._signature(accumulators)   # (what the note changes is no instability)
         return self._err_view
 
     def _eager(self, accumulators, world):
