@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   __shared__ uint16_t slist[WAVES][BEAM_SLIST];
   __shared__ uint16_t clist[WAVES][BEAM_CLIST];
   __shared__ uint32_t flist[WAVES][BEAM_FLIST];
-  __shared__ uint32_t x_pair[WAVES][128];  // face << 6 | lane of the ray (faces < 2^24)
+  __shared__ uint32_t x_pair[WAVES][192];  // face << 6 | lane of the ray (faces < 2^24)
   // records of a chunk's faces, nearest first (face_frame)
   __shared__ float4 ftab[WAVES][64][4];
   __shared__ RT rtab[WAVES][6][64];  // the wave's rays as stored (the exact test reads them by slot)
@@ -1565,7 +1565,8 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
   best_i[wave][lane] = -1;
 
   const double cx = c0[0], cy = c0[1], cz = c0[2];
-  const float cxf = (float)cx, cyf = (float)cy, czf = (float)cz;  // exact: c0 is rounded to float32
+  // (exact: c0 is rounded to float32)
+  const float cxf = uniform_f((float)cx), cyf = uniform_f((float)cy), czf = uniform_f((float)cz);
   auto rel = [](const RT v, const double c, const float cf) -> float {
     if constexpr (sizeof(T) <= 4) return (float)v - cf;
     else return (float)((double)v - c);
@@ -1624,10 +1625,10 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     // (the first supercluster spheres are fetched while the bundle is formed: one round trip
     // less in the chain ray -> bundle -> level 0 -> level 1 -> level 2 -> faces)
     const float4 su_first = lane < n_super ? susphere[lane] : never;
-    const float cnt = wave_sum_f(sel ? 1.f : 0.f);
-    bool narrow = true;
+    const float cnt = (float)__popcll(__ballot(sel));
+    bool narrow = true, brute = false;
     int ns = 0, nc = 0, nf = 0;
-    Beam bm;
+    Beam bm = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, -INFINITY, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
     float ray_t = 0.f, ray_dt = 0.f, ray_terr = 0.f;  // this lane's ray along the axis: start, d . w
     float Ax = 0.f, Ay = 0.f, Mx = 0.f, My = 0.f, Mlen = 0.f, Perr = 0.f, Pm = 0.f;  // ... its image
     if (cnt > 0.f) {
@@ -1798,53 +1799,20 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       }
       if (len == 1 && !hopeless) {
         // ONE ray whose line touches more nodes than the lists hold (it runs along a surface, or
-        // the scene is huge): that ray against every face's sphere, lane = face (its line within
-        // r of the centre, the bound of beam_touch for a single line); survivors go straight to
-        // the exact test.  Rare and slow (M / 64 rounds), but never wrong.
-        const float bsx = bcast_f(sx, lo), bsy = bcast_f(sy, lo), bsz = bcast_f(sz, lo);
-        const float bux = bcast_f(ux, lo), buy = bcast_f(uy, lo), buz = bcast_f(uz, lo);
-        const int bskip = __builtin_amdgcn_readlane(skip, lo);
-        const int n_slots = n_clusters * CLUSTER;
-        for (int b = 0; b < n_slots; b += 64) {
-          const int slot = b + lane;
-          bool hit = false;
-          int j = -1;
-          if (slot < n_slots) {
-            const float4 sp = csphere[slot];
-            const float vx = sp.x - bsx, vy = sp.y - bsy, vz = sp.z - bsz;
-            const float vu = vx * bux + vy * buy + vz * buz;
-            const float v2 = vx * vx + vy * vy + vz * vz;
-            hit = v2 - vu * vu <= sp.w * 1.00001f + 4e-6f * v2;   // (padding: w < 0, never)
-            if (hit) {
-              j = __float_as_int(crec[3 * (int64_t)slot].w);
-              hit = j >= 0 && j != bskip;
-            }
-          }
-          const unsigned long long km = __ballot(hit);
-          if (hit) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lo;
-          xn += __popcll(km);
-          if (xn >= 64) {
-            wave_fence();
-            decide(64);
-            uint32_t tp = 0u;
-            if (lane < xn - 64) tp = x_pair[wave][64 + lane];
-            wave_fence();
-            if (lane < xn - 64) x_pair[wave][lane] = tp;
-            xn -= 64;
-            wave_fence();
-          }
+        // the scene is huge): that ray against EVERY face, sixty-four member slots at a time
+        // through the same stage as the lists' faces (its bundle is the ray itself: face_frame
+        // tests the triangles against its line).  Rare and slow (M / 64 rounds), but never wrong.
+        brute = true;
+      } else {
+        // not a wavefront of (a few) narrow bundles: the grouped kernel does it
+        TFRT_STAT(ns > BEAM_SLIST ? 10 : (nc > BEAM_CLIST ? 11 : (nf > BEAM_FLIST ? 12 : 9)), 1);
+        TFRT_STAT(15, qwave * bundle + lo);
+        if (lane == 0) {
+          left_list[atomicAdd(left_count, 1)] = qwave;
+          atomicAdd(left_total, 1);
         }
-        lo = hi;
-        continue;
+        return;
       }
-      // not a wavefront of (a few) narrow bundles: the grouped kernel does it
-      TFRT_STAT(ns > BEAM_SLIST ? 10 : (nc > BEAM_CLIST ? 11 : (nf > BEAM_FLIST ? 12 : 9)), 1);
-      TFRT_STAT(15, qwave * bundle + lo);
-      if (lane == 0) {
-        left_list[atomicAdd(left_count, 1)] = qwave;
-        atomicAdd(left_total, 1);
-      }
-      return;
     }
 
     // ---- faces (see face_frame)
@@ -1868,19 +1836,27 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     };
     float myreach = reach_now();
     bool queued = false;  // a pair of this ray waits for its decision
-    for (int f0 = 0; f0 < nf; f0 += 64) {
-      const int nb = min(64, nf - f0);
-      float4 rec[4];
+    // Chunks of up to 64 candidate faces: the entries of flist -- or, for a single ray whose lists
+    // overflowed, every member slot of the scene.  The LAST chunk of the wavefront's last bundle
+    // also decides what is still queued (one place for all decisions: the float64 test's
+    // registers are not multiplied by the number of places that run it).
+    const int n_cand = brute ? n_clusters * CLUSTER : nf;
+    int f0 = 0;
+    do {
+      const int nb = min(64, n_cand - f0);
+      float4 rec[4] = {never, never, never, never};  // (set: nothing is carried around the loop)
       bool touch = false;
       float tnear = INFINITY;
       if (lane < nb) {
-        const int64_t memb = (int64_t)flist[wave][f0 + lane];
+        const int64_t memb = brute ? (int64_t)(f0 + lane) : (int64_t)flist[wave][f0 + lane];
         const float4 r0 = crec[3 * memb], r1 = crec[3 * memb + 1], r2 = crec[3 * memb + 2];
         touch = face_frame(bm, r0, r1, r2, es_f, rec) && __float_as_int(r0.w) >= 0;
         tnear = rec[0].w;
         if (tnear != tnear) tnear = -INFINITY;  // (NaN: never skipped)
         rec[0].w = tnear;
       }
+      f0 += 64;
+      const bool closing = f0 >= n_cand && hi == bundle;  // nothing comes after this chunk
       // nearest first: a face's place = the number of faces that begin nearer (ties: lower lane)
       const unsigned long long tm = __ballot(touch);
       const int nt = __popcll(tm);
@@ -1901,64 +1877,79 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       TFRT_STAT(27, nt);
       TFRT_TICK(6);
       float span = -INFINITY;  // farthest axial coordinate of the faces taken so far
-      for (int c = 0; c < nt; ++c) {
-        // (one address for all lanes: the LDS broadcasts it)
-        const float4 q0 = ftab[wave][c][0], q1 = ftab[wave][c][1], q2 = ftab[wave][c][2],
-                     q3 = ftab[wave][c][3];
-        const float tn = q0.w;
-        // a gap in depth, and every ray has a hit or a candidate: decide what is queued -- the
-        // walk may end here
-        if (xn > 0 && tn > span &&
-            __ballot(sel && !(queued || myreach < INFINITY)) == 0ull) {
-          wave_fence();
-          decide(xn);
-          xn = 0;
-          queued = false;
-          myreach = reach_now();
-          TFRT_TICK(8);
-        }
-        if (__ballot(sel && !(myreach < tn)) == 0ull) break;  // all the faces left lie farther
-        TFRT_STAT(29, 1);
-        TFRT_WAVE_NOTE(2, 1);
-        span = fmaxf(span, q1.w);
-        const int j = __float_as_int(q3.z);
-        const float tc = q2.w;
+      // one face of the record table against this lane's ray: the record's sixteen words have been
+      // read by sixteen lanes (from lane `b` on) and are handed round with v_readlane -- scalar
+      // operands; sixty-four lanes reading ONE LDS address would be served one after the other
+      auto on_face = [&](const float word, const int b, int* j, float* thi) {
+        const float tn = bcast_f(word, b + 3), tc = bcast_f(word, b + 11);
+        *thi = bcast_f(word, b + 7);
+        *j = __float_as_int(bcast_f(word, b + 14));
         const float ix = Ax + Mx * tc, iy = Ay + My * tc;
-        const float room = Mlen * q3.x + q3.y + Perr + Pm * fabsf(tc);
+        const float room = Mlen * bcast_f(word, b + 12) + bcast_f(word, b + 13) + Perr + Pm * fabsf(tc);
         // (valid hits lie ahead of the start -- where bm.tmin says so --, and nearer than the
         // ray's nearest hit so far)
-        const bool keep = sel && j != skip && !(myreach < tn) &&
-                          !(bm.tmin > -INFINITY && q1.w < ray_t - ray_terr) &&
-                          !(q0.x * ix + q0.y * iy + q0.z > room) &&
-                          !(q1.x * ix + q1.y * iy + q1.z > room) &&
-                          !(q2.x * ix + q2.y * iy + q2.z > room);
-        const unsigned long long km = __ballot(keep);
-        if (keep) x_pair[wave][xn + rank_below(km)] = ((uint32_t)j << 6) | (uint32_t)lane;
-        queued = queued || keep;
-        xn += __popcll(km);
-        TFRT_STAT(14, __popcll(km));
-        TFRT_TICK(7);
-        if (xn >= 64) {
+        return sel && *j != skip && !(myreach < tn) &&
+               !(bm.tmin > -INFINITY && *thi < ray_t - ray_terr) &&
+               !(bcast_f(word, b) * ix + bcast_f(word, b + 1) * iy + bcast_f(word, b + 2) > room) &&
+               !(bcast_f(word, b + 4) * ix + bcast_f(word, b + 5) * iy + bcast_f(word, b + 6) > room) &&
+               !(bcast_f(word, b + 8) * ix + bcast_f(word, b + 9) * iy + bcast_f(word, b + 10) > room);
+      };
+      // two faces per round (the rounds' scalar bookkeeping and branches cost as much as a face)
+      for (int c = 0;; c += 2) {
+        const bool end = c >= nt;  // (behind the chunk's last face: only decisions, if any)
+        const bool two = c + 1 < nt;
+        const float word =
+            reinterpret_cast<const float*>(&ftab[wave][end ? 0 : c][0])[lane & (two ? 31 : 15)];
+        const float tn = end ? INFINITY : bcast_f(word, 3);
+        // decide what is queued: full batches; or at a gap in depth when every ray has a hit or
+        // a candidate (the walk may end here); or at the very end
+        const bool flush =
+            end ? closing
+                : (tn > span && __ballot(sel && !(queued || myreach < INFINITY)) == 0ull);
+        while (xn >= 64 || (flush && xn > 0)) {
+          const int nd = min(xn, 64);
           wave_fence();
-          decide(64);
-          uint32_t tp = 0u;
-          if (lane < xn - 64) tp = x_pair[wave][64 + lane];
+          decide(nd);
+          // (what is left, fewer than 128 pairs, moves to the front)
+          uint32_t tp = 0u, tq = 0u;
+          if (lane < xn - nd) tp = x_pair[wave][nd + lane];
+          if (lane + 64 < xn - nd) tq = x_pair[wave][nd + 64 + lane];
           wave_fence();
-          if (lane < xn - 64) x_pair[wave][lane] = tp;
-          xn -= 64;
+          if (lane < xn - nd) x_pair[wave][lane] = tp;
+          if (lane + 64 < xn - nd) x_pair[wave][64 + lane] = tq;
+          xn -= nd;
           wave_fence();
           // (rays with a pair among those moved stay "queued")
+          if (xn == 0) queued = false;
           myreach = reach_now();
           TFRT_TICK(8);
         }
+        if (end) break;
+        if (__ballot(sel && !(myreach < tn)) == 0ull) {  // all the faces left lie farther
+          c = nt - 2;  // (the next round is the closing one)
+          continue;
+        }
+        TFRT_STAT(29, two ? 2 : 1);
+        TFRT_WAVE_NOTE(2, two ? 2 : 1);
+        int ja, jb = -1;
+        float thia, thib = -INFINITY;
+        const bool keepa = on_face(word, 0, &ja, &thia);
+        bool keepb = false;
+        if (two) keepb = on_face(word, 16, &jb, &thib);
+        span = fmaxf(span, fmaxf(thia, thib));
+        const unsigned long long kma = __ballot(keepa), kmb = __ballot(keepb);
+        const int na = __popcll(kma);
+        if (keepa) x_pair[wave][xn + rank_below(kma)] = ((uint32_t)ja << 6) | (uint32_t)lane;
+        if (keepb) x_pair[wave][xn + na + rank_below(kmb)] = ((uint32_t)jb << 6) | (uint32_t)lane;
+        queued = queued || keepa || keepb;
+        xn += na + __popcll(kmb);
+        TFRT_STAT(14, na + __popcll(kmb));
+        TFRT_TICK(7);
       }
-    }
+    } while (f0 < n_cand);
     lo = hi;  // this bundle is done: the next one starts behind it
   }
   wave_fence();
-  TFRT_TICK(6);
-  if (xn > 0) decide(xn);
-  TFRT_TICK(8);
 
   // ---- hit record, class and this wavefront's share of its 256-ray block's class histogram
   int cls = -1;
