@@ -2344,6 +2344,15 @@ __device__ __forceinline__ int backward_ray(
 // (106 VGPRs = 4 waves per SIMD; the kernel is bound by float64 VALU issue -- ~2,000 executed
 // instructions per ray, 28 of them divisions -- and forcing 5 or 6 waves with
 // amdgpu_waves_per_eu spills: 55/66 us for the lens passes became 62/74 and 89/103)
+// a float64 from another lane of the row (DPP control word CTRL), both halves
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(const double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_backward3d(
     const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
@@ -2368,8 +2377,12 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     // wavefront, LDS float64 adds), then every (face, term) sum goes to memory with ONE atomic:
     // no per-ray stash written and read back, no accumulate launch.
     if ((q0 & ~63) >= n) return;  // (whole wave)
-    constexpr int SLOTS = 24;
-    __shared__ double wacc[WAVES][SLOTS][9];
+    // (several copies of every sum, taken by the lane's low bits: lanes that add to ONE LDS address
+    // are served one after the other -- with a single copy a third of this kernel's time -- and
+    // neighbouring lanes are the ones that share a face.  Eight copies for up to 8 faces, four for
+    // up to 16, two for up to 32: sparse rays share a face with few lanes anyway)
+    constexpr int SLOTS = 32, CELLS = 576;
+    __shared__ double wacc[WAVES][CELLS];  // [slot][term][copy]
     __shared__ int32_t wface[WAVES][SLOTS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double gP[9];
@@ -2379,24 +2392,27 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
                             pass_counts, sc, L, dead_len, g_child, child_stride, g_fin, cap_fin,
                             g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead, g_out, g_src_out,
                             out_stride, gP);
-    for (int k = lane; k < SLOTS * 9; k += 64) (&wacc[wave][0][0])[k] = 0.0;
     int slot = -1, ns = 0;
     unsigned long long todo = __ballot(tri >= 0);
     while (todo != 0ull && ns < SLOTS) {
       const int leader = __ffsll((long long)todo) - 1;
-      const int k = __shfl(tri, leader, 64);
+      const int k = __builtin_amdgcn_readlane(tri, leader);
       const bool mine = tri == k;
       if (mine) slot = ns;
       if (lane == leader) wface[wave][ns] = k;
       ++ns;
       todo &= ~__ballot(mine);
     }
+    const int copies = ns <= 8 ? 8 : (ns <= 16 ? 4 : 2);
+    const int cells = ns * 9 * copies;
+    for (int k = lane; k < cells; k += 64) wacc[wave][k] = 0.0;
     wave_fence();
     if (tri >= 0) {
       if (slot >= 0) {
+        double* w = &wacc[wave][slot * 9 * copies + (lane & (copies - 1))];
 #pragma unroll
         for (int c = 0; c < 9; ++c)
-          if (gP[c] != 0.0) unsafeAtomicAdd(&wacc[wave][slot][c], gP[c]);
+          if (gP[c] != 0.0) unsafeAtomicAdd(w + c * copies, gP[c]);
       } else {  // (more distinct faces than slots: rays that are not coherent after all)
         double* gp = g_fverts + 9 * (int64_t)tri;
 #pragma unroll
@@ -2405,9 +2421,18 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
       }
     }
     wave_fence();
-    for (int k = lane; k < ns * 9; k += 64) {
-      const double v = (&wacc[wave][0][0])[k];
-      if (v != 0.0) unsafeAtomicAdd(g_fverts + 9 * (int64_t)wface[wave][k / 9] + (k % 9), v);
+    // the copies of a sum lie in neighbouring lanes now: folded with DPP, then ONE atomic per
+    // (face, term) of the wavefront goes to memory
+    for (int k0 = 0; k0 < cells; k0 += 64) {
+      const int k = k0 + lane;
+      double v = k < cells ? wacc[wave][k] : 0.0;
+      v += dpp_f64<0xB1>(v);                    // quad_perm [1,0,3,2]
+      if (copies >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+      if (copies >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the eight
+      if ((lane & (copies - 1)) == 0 && k < cells && v != 0.0) {
+        const int term = k / copies;
+        unsafeAtomicAdd(g_fverts + 9 * (int64_t)wface[wave][term / 9] + (term % 9), v);
+      }
     }
     return;
   }
