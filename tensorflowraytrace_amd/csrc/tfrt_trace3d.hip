@@ -1348,7 +1348,9 @@ struct Beam {  // wave-uniform
 
 __device__ __forceinline__ bool beam_touch(const Beam& b, const float4 sp) {
   // radius from the stored (inflated) r^2, rounded up; padding entries have w < 0: NaN, never true
-  const float r = __builtin_sqrtf(sp.w) * 1.000001f;
+  // (v_sqrt_f32 / v_rcp_f32 / v_rsq_f32 as they are, 1 ulp: every bound of this kernel is inflated
+  // far beyond that, and the IEEE forms cost ten instructions each)
+  const float r = __builtin_amdgcn_sqrtf(sp.w) * 1.000002f;
   const float vx = sp.x - b.ox, vy = sp.y - b.oy, vz = sp.z - b.oz;
   const float t = vx * b.wx + vy * b.wy + vz * b.wz;
   const float v2 = vx * vx + vy * vy + vz * vz;
@@ -1450,6 +1452,41 @@ __device__ __forceinline__ float wave_max_f(float v) {
 __device__ __forceinline__ float wave_min_f(float v) {
   return wave_reduce_f(v, [](float a, float b) { return fminf(a, b); });
 }
+// Several wave-wide reductions at once: one DPP instruction per value and step (the operand comes
+// from another lane, the operation is part of the same instruction), the values taken in turn so
+// that no instruction reads a register written by the one before it (a DPP read needs two idle
+// slots after the write -- inside inline assembly nobody else keeps count of them).  Results are
+// valid in lane 63; rows a step does not address keep their value.
+#define TFRT_DPP_STEP4(OPA, OPB, OPC, OPD, CTRL)      \
+  OPA " %0, %0, %0 " CTRL "\n\t" OPB " %1, %1, %1 " CTRL "\n\t" \
+  OPC " %2, %2, %2 " CTRL "\n\t" OPD " %3, %3, %3 " CTRL "\n\t"
+#define TFRT_DPP_ALL4(OPA, OPB, OPC, OPD)                                        \
+  "s_nop 1\n\t"                                                                  \
+  TFRT_DPP_STEP4(OPA, OPB, OPC, OPD, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") \
+  TFRT_DPP_STEP4(OPA, OPB, OPC, OPD, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") \
+  TFRT_DPP_STEP4(OPA, OPB, OPC, OPD, "row_half_mirror row_mask:0xf bank_mask:0xf")     \
+  TFRT_DPP_STEP4(OPA, OPB, OPC, OPD, "row_mirror row_mask:0xf bank_mask:0xf")          \
+  TFRT_DPP_STEP4(OPA, OPB, OPC, OPD, "row_bcast:15 row_mask:0xa bank_mask:0xf")        \
+  TFRT_DPP_STEP4(OPA, OPB, OPC, OPD, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+// four sums
+__device__ __forceinline__ void wave_sum4(float& a, float& b, float& c, float& d) {
+  __asm__ volatile(TFRT_DPP_ALL4("v_add_f32_dpp", "v_add_f32_dpp", "v_add_f32_dpp", "v_add_f32_dpp")
+                   : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+  d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+}
+// three maxima and a minimum
+__device__ __forceinline__ void wave_max3_min(float& a, float& b, float& c, float& d) {
+  __asm__ volatile(TFRT_DPP_ALL4("v_max_f32_dpp", "v_max_f32_dpp", "v_max_f32_dpp", "v_min_f32_dpp")
+                   : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 63));
+  d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+}
+
 __device__ __forceinline__ float uniform_f(float v) {  // v wave-uniform: into a scalar register
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
@@ -1618,7 +1655,7 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     const float len2 = dx * dx + dy * dy + dz * dz;
     // (a zero-length or non-finite ray can hit nothing: it takes no part and ends up dead)
     const bool ok = live && len2 > 0.f && len2 < 3.0e38f;
-    const float inv = ok ? 1.0f / __builtin_sqrtf(len2) : 0.f;
+    const float inv = ok ? __builtin_amdgcn_rsqf(len2) : 0.f;
     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
     const float rabs = fabsf(sx) + fabsf(sy) + fabsf(sz);
     const bool sel = ok && lane >= lo && lane < hi;
@@ -1633,21 +1670,20 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
     float Ax = 0.f, Ay = 0.f, Mx = 0.f, My = 0.f, Mlen = 0.f, Perr = 0.f, Pm = 0.f;  // ... its image
     if (cnt > 0.f) {
       // ---- the bundle
-      const float swx = wave_sum_f(sel ? ux : 0.f), swy = wave_sum_f(sel ? uy : 0.f),
-                  swz = wave_sum_f(sel ? uz : 0.f);
-      const float sox = wave_sum_f(sel ? sx : 0.f), soy = wave_sum_f(sel ? sy : 0.f),
-                  soz = wave_sum_f(sel ? sz : 0.f);
+      float swx = sel ? ux : 0.f, swy = sel ? uy : 0.f, swz = sel ? uz : 0.f;
+      float sox = sel ? sx : 0.f, soy = sel ? sy : 0.f, soz = sel ? sz : 0.f;
+      float pad0 = 0.f, pad1 = 0.f;
+      wave_sum4(swx, swy, swz, sox);
+      wave_sum4(soy, soz, pad0, pad1);
       const float wl2 = swx * swx + swy * swy + swz * swz;
       narrow = wl2 > 0.49f * cnt * cnt;  // (NaN: false)
       spread = !narrow;
-      const float wi = narrow ? 1.0f / __builtin_sqrtf(wl2) : 0.f;
+      const float wi = narrow ? __builtin_amdgcn_rsqf(wl2) : 0.f;
       bm.wx = swx * wi; bm.wy = swy * wi; bm.wz = swz * wi;
-      bm.ox = sox / cnt; bm.oy = soy / cnt; bm.oz = soz / cnt;
+      const float icnt = __builtin_amdgcn_rcpf(cnt);
+      bm.ox = sox * icnt; bm.oy = soy * icnt; bm.oz = soz * icnt;
       const float cosk = ux * bm.wx + uy * bm.wy + uz * bm.wz;
       if (__any(sel && !(cosk > 0.7f))) narrow = false, spread = true;
-      const float ic = 1.0f / (sel ? cosk : 1.f);
-      const float mx = (ux - cosk * bm.wx) * ic, my = (uy - cosk * bm.wy) * ic,
-                  mz = (uz - cosk * bm.wz) * ic;
       const float px = sx - bm.ox, py = sy - bm.oy, pz = sz - bm.oz;
       const float ts = px * bm.wx + py * bm.wy + pz * bm.wz;
       ray_t = ts;
@@ -1668,25 +1704,24 @@ __global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
       }
       // this ray's image p(t) = A + M t
       {
-        const float idt = 1.0f / (sel ? ray_dt : 1.f);
+        const float idt = __builtin_amdgcn_rcpf(sel ? ray_dt : 1.f);
         Mx = (dx * bm.e1x + dy * bm.e1y + dz * bm.e1z) * idt;
         My = (dx * bm.e2x + dy * bm.e2y + dz * bm.e2z) * idt;
         const float p1 = px * bm.e1x + py * bm.e1y + pz * bm.e1z,
                     p2 = px * bm.e2x + py * bm.e2y + pz * bm.e2z;
         Ax = p1 - ts * Mx;
         Ay = p2 - ts * My;
-        Mlen = __builtin_sqrtf(Mx * Mx + My * My) * 1.0001f;
+        Mlen = __builtin_amdgcn_sqrtf(Mx * Mx + My * My) * 1.0001f;
         Pm = 2e-5f * (fabsf(Mx) + fabsf(My));
         Perr = 2e-5f * (fabsf(p1) + fabsf(p2) + fabsf(ts) * (fabsf(Mx) + fabsf(My)) + rabs +
                         fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz));
       }
-      const float ax = px - ts * bm.wx - ts * mx, ay = py - ts * bm.wy - ts * my,
-                  az = pz - ts * bm.wz - ts * mz;
-      const float R0 = wave_max_f(sel ? __builtin_sqrtf(ax * ax + ay * ay + az * az) : 0.f);
-      const float S = wave_max_f(sel ? __builtin_sqrtf(mx * mx + my * my + mz * mz) : 0.f);
-      const float tmin = wave_min_f(sel ? ts : INFINITY);
-      const float Lw = wave_max_f(sel ? fabsf(sx) + fabsf(sy) + fabsf(sz) : 0.f) + fabsf(bm.ox) +
-                       fabsf(bm.oy) + fabsf(bm.oz);
+      // (offset and slope of the ray's line from the axis are those of its image: e1, e2, w are
+      // orthonormal to rounding, which the inflation below covers many times over)
+      float R0 = sel ? __builtin_amdgcn_sqrtf(Ax * Ax + Ay * Ay) : 0.f, S = sel ? Mlen : 0.f;
+      float Lw = sel ? rabs : 0.f, tmin = sel ? ts : INFINITY;
+      wave_max3_min(R0, S, Lw, tmin);
+      Lw += fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz);
       // bounds inflated far beyond their float32 rounding (offsets ~ 2^-23 Lw, slopes ~ 2^-23)
       bm.R0 = R0 * 1.001f + 4e-6f * Lw;
       bm.S = S * 1.001f + 2e-6f;
