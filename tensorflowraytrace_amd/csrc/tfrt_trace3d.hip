@@ -1546,13 +1546,8 @@ __device__ __forceinline__ void beam_decide(const int nb, const int lane, LdsPtr
   wave_fence();
 }
 
-#ifdef TFRT_BEAM_WAVES
-#define TFRT_BEAM_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_BEAM_WAVES, TFRT_BEAM_WAVES)))
-#else
-#define TFRT_BEAM_ATTR
-#endif
 template <typename T>
-__global__ __launch_bounds__(BLOCK) TFRT_BEAM_ATTR void k_intersect_beam(
+__global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
     const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
