@@ -1877,7 +1877,18 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
       float4 rec[4] = {never, never, never, never};  // (set: nothing is carried around the loop)
       bool touch = false;
       float tnear = INFINITY;
-      if (lane < nb) {
+      bool cand = lane < nb;
+      if (brute && cand) {
+        // (every slot of the scene: first the ray's line -- the axis of its bundle -- against the
+        // slot's sphere, or this would be two hundred instructions per 64 slots)
+        const float4 sp = csphere[f0 + lane];
+        const float vx = sp.x - bm.ox, vy = sp.y - bm.oy, vz = sp.z - bm.oz;
+        const float vu = vx * bm.wx + vy * bm.wy + vz * bm.wz;
+        const float v2 = vx * vx + vy * vy + vz * vz;
+        const float rr = __builtin_amdgcn_sqrtf(sp.w) * 1.000002f + bm.R0 + bm.S * fabsf(vu);
+        cand = v2 - vu * vu <= rr * rr + 4e-6f * v2;  // (padding: w < 0, NaN, never)
+      }
+      if (cand) {
         const int64_t memb = brute ? (int64_t)(f0 + lane) : (int64_t)flist[wave][f0 + lane];
         const float4 r0 = crec[3 * memb], r1 = crec[3 * memb + 1], r2 = crec[3 * memb + 2];
         touch = face_frame(bm, r0, r1, r2, es_f, rec) && __float_as_int(r0.w) >= 0;
