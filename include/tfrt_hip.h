@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFRT_VERSION 101 /* 0.1.0 */
+#define TFRT_VERSION 102 /* 0.1.0 */
 
 #define TFRT_F32 0
 #define TFRT_F64 1
@@ -107,6 +107,40 @@ int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_
                               const uint8_t* update_mask, const double* vectors, int64_t n_faces,
                               int64_t n_vertices, const int32_t* corner_start,
                               const int32_t* corner_list, double* grad_parameters, void* stream);
+
+/* The same for several surfaces of one optical system with ONE launch each way -- all the
+ * parametric boundaries of OpticalSystem3D.update (engine.py:971-1018 merges their fields with
+ * tf.concat afterwards): every surface writes its rows of the system's merged (M, 9) block
+ * directly, and a surface with `copy_from` (a fixed boundary: target, stop) has its rows copied
+ * into its place, so the merged block needs no concatenation.  At most TFRT_MAX_SURFACES
+ * descriptors (a host array; they travel by value in the kernel arguments).  The reverse is the
+ * gather form of tfrt_param_faces_backward per surface (corner lists required). */
+#define TFRT_MAX_SURFACES 8
+typedef struct tfrt_face_surface {
+  const double* zero_points;   /* (V,3)  unused with copy_from */
+  const double* vectors;       /* (V,3) */
+  const double* parameters;    /* (V,) */
+  const int32_t* faces;        /* (F,3) vertex indices */
+  int64_t n_vertices, n_faces;
+  double* face_verts;          /* (F,9) out: this surface's rows of the merged block */
+  double* norm;                /* (F,3) out, or NULL */
+  const double* copy_from;     /* (F,9) fixed faces to copy instead, or NULL */
+} tfrt_face_surface;
+typedef struct tfrt_face_surface_grad {
+  const double* grad_face_verts;  /* (F,9) or NULL */
+  const double* grad_norm;        /* (F,3) or NULL */
+  const double* face_verts;       /* (F,9) forward result (needed with grad_norm) */
+  const uint8_t* update_mask;     /* (F,3) or NULL */
+  const double* vectors;          /* (V,3) */
+  const int32_t* corner_start;    /* (V+1) */
+  const int32_t* corner_list;     /* face * 3 + corner, grouped by vertex */
+  int64_t n_vertices;
+  double* grad_parameters;        /* (V,) out (overwritten) */
+} tfrt_face_surface_grad;
+int tfrt_param_faces_forward_multi(const tfrt_face_surface* surfaces, int32_t n_surfaces,
+                                   void* stream);
+int tfrt_param_faces_backward_multi(const tfrt_face_surface_grad* surfaces, int32_t n_surfaces,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser step, parameter side (SGD_Optimizer.process_gradient / single_step,

@@ -47,6 +47,27 @@ class Scene2D(ctypes.Structure):
     ]
 
 
+MAX_SURFACES = 8   # TFRT_MAX_SURFACES
+
+
+class FaceSurface(ctypes.Structure):
+    """tfrt_face_surface (include/tfrt_hip.h)."""
+    _fields_ = [("zero_points", ctypes.c_void_p), ("vectors", ctypes.c_void_p),
+                ("parameters", ctypes.c_void_p), ("faces", ctypes.c_void_p),
+                ("n_vertices", ctypes.c_int64), ("n_faces", ctypes.c_int64),
+                ("face_verts", ctypes.c_void_p), ("norm", ctypes.c_void_p),
+                ("copy_from", ctypes.c_void_p)]
+
+
+class FaceSurfaceGrad(ctypes.Structure):
+    """tfrt_face_surface_grad (include/tfrt_hip.h)."""
+    _fields_ = [("grad_face_verts", ctypes.c_void_p), ("grad_norm", ctypes.c_void_p),
+                ("face_verts", ctypes.c_void_p), ("update_mask", ctypes.c_void_p),
+                ("vectors", ctypes.c_void_p), ("corner_start", ctypes.c_void_p),
+                ("corner_list", ctypes.c_void_p), ("n_vertices", ctypes.c_int64),
+                ("grad_parameters", ctypes.c_void_p)]
+
+
 class RayOut(ctypes.Structure):
     """struct tfrt_ray_out"""
     _fields_ = [("rays", c_vp), ("ray_id", c_vp), ("face", c_vp), ("capacity", c_i64)]
@@ -67,6 +88,8 @@ SIGNATURES = {
     "tfrt_param_faces_forward": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     "tfrt_param_faces_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp,
                                           c_vp, c_vp, c_vp]),
+    "tfrt_param_faces_forward_multi": (c_i32, [c_vp, c_i32, c_vp]),
+    "tfrt_param_faces_backward_multi": (c_i32, [c_vp, c_i32, c_vp]),
     "tfrt_line_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_f64,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_line_triangle_intersect": (c_i32, [c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,

@@ -560,6 +560,34 @@ class TriangleBoundaryBase(BoundaryBase):
     def dimension(self):
         return 3
 
+    # ``_face_verts`` / ``_norm``: the (F,9) / (F,3) tensors the kernels wrote.  A parametric
+    # surface may have handed its update to the optical system's batch (ops.ParamFacesBatch: one
+    # launch for all boundaries); whoever asks for the faces before the system has run it makes
+    # it run what it has collected.
+    def _faces_now(self):
+        batch = self.__dict__.get("_faces_pending")
+        if batch is not None:
+            batch.flush()
+            self.__dict__["_faces_pending"] = None
+
+    @property
+    def _face_verts(self):
+        self._faces_now()
+        return self.__dict__.get("_face_verts_value")
+
+    @_face_verts.setter
+    def _face_verts(self, value):
+        self.__dict__["_face_verts_value"] = value
+
+    @property
+    def _norm(self):
+        self._faces_now()
+        return self.__dict__.get("_norm_value")
+
+    @_norm.setter
+    def _norm(self, value):
+        self.__dict__["_norm_value"] = value
+
     # ---- dict protocol: geometry fields are column views of the (F,9) tensor
     def keys(self):
         ks = set(self._fields.keys())
@@ -742,8 +770,15 @@ class ParametricTriangleBoundary(TriangleBoundaryBase):
         # parameters' gradient accumulator of whatever stream built it -- alive indefinitely)
         self.__dict__["_vertices_value"] = None
         faces, mask = self._device_face_tables(self._zero_points.device)
-        self._face_verts, self._norm = ops.param_faces(
-            tap(self.parameters), self._zero_points, self._vectors, faces, mask)
+        batch = ops.current_faces_batch()
+        if batch is not None:
+            # (the optical system is updating: it runs the face updates of all its boundaries
+            # in one launch when its handles are through)
+            batch.add(self, tap(self.parameters), self._zero_points, self._vectors, faces, mask)
+        else:
+            self.__dict__["_faces_pending"] = None
+            self._face_verts, self._norm = ops.param_faces(
+                tap(self.parameters), self._zero_points, self._vectors, faces, mask)
         for k in list(_TRI_COLS) + ["norm"]:
             self._fields.pop(k, None)
         if self.auto_update_mesh:

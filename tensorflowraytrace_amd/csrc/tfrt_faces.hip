@@ -225,6 +225,81 @@ __global__ __launch_bounds__(BLOCK) void k_param_faces_bwd_gather(
   if (v < V && sub == 0) g_params[v] = acc;
 }
 
+// Several surfaces of one optical system in ONE launch each way (a system's update is a chain
+// of launches of a few thousand faces each: a dependent launch costs ~4.5 us whatever it does).
+// The descriptors travel by value in the kernel arguments; workgroups are dealt to the surfaces
+// in order (first_block).  A surface with `copy_from` is a fixed one: its rows are copied into
+// its place of the merged (M, 9) block, so the system's faces need no concatenation either.
+struct FaceSurfaces {
+  int32_t count;
+  int32_t first_block[TFRT_MAX_SURFACES + 1];
+  tfrt_face_surface s[TFRT_MAX_SURFACES];
+};
+struct FaceSurfaceGrads {
+  int32_t count;
+  int32_t first_block[TFRT_MAX_SURFACES + 1];
+  tfrt_face_surface_grad s[TFRT_MAX_SURFACES];
+};
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(BLOCK) void k_param_faces_multi(FaceSurfaces b) {
+  int k = 0;
+  while (k + 1 < b.count && (int)blockIdx.x >= b.first_block[k + 1]) ++k;  // block-uniform
+  const tfrt_face_surface& u = b.s[k];
+  const int64_t f = (int64_t)((int)blockIdx.x - b.first_block[k]) * BLOCK + threadIdx.x;
+  if (f >= u.n_faces) return;
+  if (u.copy_from != nullptr) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) u.face_verts[9 * f + q] = u.copy_from[9 * f + q];
+    return;
+  }
+  // (the same arithmetic as k_param_faces: product and sum stay separate roundings)
+  double P[9];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int64_t v = u.faces[3 * f + c];
+    if (v < 0 || v >= u.n_vertices) v = 0;  // host validates; keep the access in range regardless
+    const double p = u.parameters[v];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const double step = p * u.vectors[3 * v + q];
+      P[3 * c + q] = u.zero_points[3 * v + q] + step;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) u.face_verts[9 * f + q] = P[q];
+  if (u.norm != nullptr) {
+    double N[3], C[3], clen;
+    face_normal(P, N, C, &clen);
+    u.norm[3 * f] = N[0];
+    u.norm[3 * f + 1] = N[1];
+    u.norm[3 * f + 2] = N[2];
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_param_faces_bwd_gather_multi(FaceSurfaceGrads b) {
+  int k = 0;
+  while (k + 1 < b.count && (int)blockIdx.x >= b.first_block[k + 1]) ++k;  // block-uniform
+  const tfrt_face_surface_grad& u = b.s[k];
+  const int64_t t = (int64_t)((int)blockIdx.x - b.first_block[k]) * BLOCK + threadIdx.x;
+  const int64_t v = t / GATHER_LANES;
+  const int sub = (int)(t % GATHER_LANES);
+  double acc = 0.0;
+  if (v < u.n_vertices) {
+    for (int q = u.corner_start[v] + sub; q < u.corner_start[v + 1]; q += GATHER_LANES) {
+      const int fc = u.corner_list[q], f = fc / 3, c = fc - 3 * f;
+      if (u.update_mask != nullptr && u.update_mask[fc] == 0) continue;
+      double g[9];
+      face_grad(u.grad_face_verts, u.grad_norm, u.face_verts, f, g);
+      acc += g[3 * c] * u.vectors[3 * v] + g[3 * c + 1] * u.vectors[3 * v + 1] +
+             g[3 * c + 2] * u.vectors[3 * v + 2];
+    }
+  }
+#pragma unroll
+  for (int d = GATHER_LANES / 2; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (v < u.n_vertices && sub == 0) u.grad_parameters[v] = acc;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_snell3d(int64_t n, const double* xs, const double* ys,
                                                    const double* zs, const double* xe,
                                                    const double* ye, const double* ze,
@@ -360,6 +435,66 @@ int tfrt_param_faces_backward(const double* grad_face_verts, const double* grad_
   hipLaunchKernelGGL(k_param_faces_bwd, dim3(cdiv(n_faces, BLOCK)), dim3(BLOCK), 0,
                      static_cast<hipStream_t>(stream), grad_face_verts, grad_norm, face_verts,
                      faces, update_mask, vectors, n_faces, n_vertices, grad_parameters);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_param_faces_forward_multi(const tfrt_face_surface* surfaces, int32_t n_surfaces,
+                                   void* stream) {
+  if (n_surfaces < 0 || n_surfaces > TFRT_MAX_SURFACES || (n_surfaces > 0 && !surfaces))
+    return TFRT_E_BADARG;
+  FaceSurfaces b;
+  int blocks = 0;
+  for (int k = 0; k < TFRT_MAX_SURFACES; ++k) {
+    b.first_block[k] = blocks;
+    if (k >= n_surfaces) {
+      b.s[k] = tfrt_face_surface{};
+      continue;
+    }
+    const tfrt_face_surface& u = surfaces[k];
+    if (u.n_faces < 0 || u.n_vertices < 0) return TFRT_E_BADARG;
+    if (u.n_faces > 0) {
+      if (!u.face_verts) return TFRT_E_BADARG;
+      if (!u.copy_from &&
+          (!u.zero_points || !u.vectors || !u.parameters || !u.faces || u.n_vertices == 0))
+        return TFRT_E_BADARG;
+    }
+    b.s[k] = u;
+    blocks += cdiv(u.n_faces, BLOCK);
+  }
+  b.first_block[TFRT_MAX_SURFACES] = blocks;
+  b.count = n_surfaces;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(k_param_faces_multi, dim3(blocks), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), b);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_param_faces_backward_multi(const tfrt_face_surface_grad* surfaces, int32_t n_surfaces,
+                                    void* stream) {
+  if (n_surfaces < 0 || n_surfaces > TFRT_MAX_SURFACES || (n_surfaces > 0 && !surfaces))
+    return TFRT_E_BADARG;
+  FaceSurfaceGrads b;
+  int blocks = 0;
+  for (int k = 0; k < TFRT_MAX_SURFACES; ++k) {
+    b.first_block[k] = blocks;
+    if (k >= n_surfaces) {
+      b.s[k] = tfrt_face_surface_grad{};
+      continue;
+    }
+    const tfrt_face_surface_grad& u = surfaces[k];
+    if (u.n_vertices < 0) return TFRT_E_BADARG;
+    if (u.n_vertices > 0 &&
+        (!u.vectors || !u.grad_parameters || !u.corner_start || !u.corner_list ||
+         (!u.grad_face_verts && !u.grad_norm) || (u.grad_norm && !u.face_verts)))
+      return TFRT_E_BADARG;
+    b.s[k] = u;
+    blocks += cdiv(u.n_vertices * GATHER_LANES, BLOCK);
+  }
+  b.first_block[TFRT_MAX_SURFACES] = blocks;
+  b.count = n_surfaces;
+  if (blocks == 0) return 0;
+  hipLaunchKernelGGL(k_param_faces_bwd_gather_multi, dim3(blocks), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), b);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 

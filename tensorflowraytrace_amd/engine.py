@@ -305,11 +305,36 @@ class OpticalSystem3D(OpticalSystemBase):
     def dimension(self):
         return 3
 
+    def update(self):
+        """update.py:52-64, with one difference in HOW: the parametric boundaries hand their
+        face updates to a batch while the handles run, and the merge below runs them -- and the
+        copy of the fixed boundaries into the merged block -- as ONE launch (a system's update is
+        a chain of small dependent launches; each costs ~4.5 us whatever it does)."""
+        if self.frozen:
+            return
+        batch = ops.ParamFacesBatch()
+        with batch:
+            if self.recursively_update and bool(self.update_handles):
+                for handle in self.update_handles:
+                    handle()
+        self.__dict__["_faces_batch"] = batch
+        try:
+            self._update()
+        finally:
+            self.__dict__["_faces_batch"] = None
+            batch.flush()     # (nothing merged: e.g. no boundary sets yet)
+        for handle in self.post_update_handles:
+            handle()
+
     def _merge_boundaries(self):
         """Label and merge optical, stop, target (engine.py:971-1018).  The merged geometry
         is one (M,9) float64 tensor; catagory / material columns are cached int32."""
         sets = [(getattr(self, "_" + n), c) for n, c in
                 (("optical", OPTICAL), ("stop", STOP), ("target", TARGET))]
+        batch = self.__dict__.get("_faces_batch")
+        if batch is not None and batch.requests:
+            pending = lambda b: getattr(b, "__dict__", {}).get("_faces_pending") is batch
+            batch.flush([b for lst, _ in sets for b in lst if pending(b) or bool(b)])
         parts, cats, grads = [], [], []
         for lst, cat in sets:
             for b in lst:
@@ -326,7 +351,12 @@ class OpticalSystem3D(OpticalSystemBase):
             self._merged = {}
             self._merged_face_verts = None
             return
-        self._merged_face_verts = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        block = batch.merged if batch is not None else None
+        if (block is not None and len(block[1]) == len(cats)
+                and all(rb is b and r1 - r0 == n for (rb, r0, r1), (_, n, b) in zip(block[1], cats))):
+            self._merged_face_verts = block[0]   # (every boundary's rows are already in place)
+        else:
+            self._merged_face_verts = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
         self._merged = _MergedTriangles(self)
         key = tuple((c, n, id(b)) + tuple(
             (id(b[f]), b[f]._version) for f in ("mat_in", "mat_out", "n_in", "n_out") if f in b)

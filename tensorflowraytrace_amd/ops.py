@@ -173,6 +173,174 @@ def param_faces(parameters, zero_points, vectors, faces, update_mask=None):
     return _ParamFaces.apply(parameters, zero_points, vectors, faces, update_mask)
 
 
+class _ParamFacesMulti(torch.autograd.Function):
+    """Several parametric surfaces (and the fixed boundaries between them) -> ONE merged
+    face_verts block (M,9) and one norm block (sum of the parametric F,3), one launch each way
+    (tfrt_param_faces_*_multi).  ``spec``: list of entries in the order of the merged block,
+    ("param", zero_points, vectors, faces, update_mask) taking the next tensor of ``parameters``,
+    or ("copy", face_verts (F,9) detached)."""
+
+    @staticmethod
+    def forward(ctx, spec, *parameters):
+        dev = parameters[0].device if parameters else spec[0][1].device
+        rows = [e[3].shape[0] if e[0] == "param" else e[1].shape[0] for e in spec]
+        M = int(sum(rows))
+        n_norm = int(sum(r for e, r in zip(spec, rows) if e[0] == "param"))
+        fv = torch.empty((M, 9), dtype=torch.float64, device=dev)
+        norm = torch.empty((n_norm, 3), dtype=torch.float64, device=dev)
+        descs, keep, pars = [], [], []
+        at = na = k = 0
+        for e, F in zip(spec, rows):
+            d = _lib.FaceSurface()
+            d.n_faces = F
+            d.face_verts = fv.data_ptr() + at * 72
+            if e[0] == "param":
+                _, zero, vectors, faces, mask = e
+                par = _c(parameters[k], torch.float64).reshape(-1)
+                k += 1
+                V = zero.shape[0]
+                if par.shape[0] != V or vectors.shape != zero.shape:
+                    raise TfrtError("param_faces: parameters (V,), zero_points (V,3) and vectors "
+                                    "(V,3) must describe the same vertices")
+                d.zero_points, d.vectors, d.parameters = _p(zero), _p(vectors), _p(par)
+                d.faces, d.n_vertices = _p(faces), V
+                d.norm = norm.data_ptr() + na * 24
+                pars.append((at, na, F, V, faces, mask, vectors, par.shape))
+                keep.append(par)
+                na += F
+            else:
+                d.copy_from = _p(e[1])
+            descs.append(d)
+            at += F
+        stream = _stream(fv)
+        for i in range(0, len(descs), _lib.MAX_SURFACES):
+            chunk = descs[i:i + _lib.MAX_SURFACES]
+            arr = (_lib.FaceSurface * len(chunk))(*chunk)
+            check(_lib.lib().tfrt_param_faces_forward_multi(arr, len(chunk), stream),
+                  "tfrt_param_faces_forward_multi")
+        ctx.pars = pars
+        ctx.corners = [vertex_corners(f, V) if F > 0 else None for (_, _, F, V, f, _, _, _) in pars]
+        ctx.save_for_backward(fv)
+        ctx.set_materialize_grads(False)
+        return fv, norm
+
+    @staticmethod
+    def backward(ctx, g_fv, g_norm):
+        (fv,) = ctx.saved_tensors
+        g_fv = _c(g_fv, torch.float64)
+        g_norm = _c(g_norm, torch.float64)
+        out, descs = [], []
+        for (at, na, F, V, faces, mask, vectors, shape), corners in zip(ctx.pars, ctx.corners):
+            if (g_fv is None and g_norm is None) or F == 0:
+                out.append(torch.zeros(shape, dtype=torch.float64, device=fv.device))
+                continue
+            gp = torch.empty(shape, dtype=torch.float64, device=fv.device)
+            d = _lib.FaceSurfaceGrad()
+            d.grad_face_verts = g_fv.data_ptr() + at * 72 if g_fv is not None else None
+            d.grad_norm = g_norm.data_ptr() + na * 24 if g_norm is not None else None
+            d.face_verts = fv.data_ptr() + at * 72
+            d.update_mask, d.vectors = _p(mask), _p(vectors)
+            d.corner_start, d.corner_list = _p(corners[0]), _p(corners[1])
+            d.n_vertices, d.grad_parameters = V, _p(gp)
+            descs.append(d)
+            out.append(gp)
+        stream = _stream(fv)
+        for i in range(0, len(descs), _lib.MAX_SURFACES):
+            chunk = descs[i:i + _lib.MAX_SURFACES]
+            arr = (_lib.FaceSurfaceGrad * len(chunk))(*chunk)
+            check(_lib.lib().tfrt_param_faces_backward_multi(arr, len(chunk), stream),
+                  "tfrt_param_faces_backward_multi")
+        return (None, *out)
+
+
+_faces_batch = None   # the batch parametric boundaries hand their update to (see ParamFacesBatch)
+
+
+def current_faces_batch():
+    return _faces_batch
+
+
+class ParamFacesBatch:
+    """The face updates of one optical system's update(), collected and run as one launch.
+
+    ``with batch:`` -- inside, ParametricTriangleBoundary._update registers its parameters here
+    (``add``) instead of launching; ``flush(order)`` runs everything in ONE launch and hands every
+    boundary its rows of the merged block as ``_face_verts`` / ``_norm``.  ``order``: the
+    boundaries of the system in the order of its merged face block; boundaries without a request
+    whose faces are fixed (no gradient) are copied into place, so the block IS the system's merged
+    face tensor (``merged``) and nothing is concatenated afterwards.  A boundary that is asked
+    for its faces before that flushes what has been collected so far."""
+
+    def __init__(self):
+        self.requests = []      # (boundary, parameters (tap), zero_points, vectors, faces, mask)
+        self.merged = None      # (face block, [(boundary, first row, end row)]) after a full flush
+        self._outer = None
+
+    def __enter__(self):
+        global _faces_batch
+        self._outer, _faces_batch = _faces_batch, self
+        return self
+
+    def __exit__(self, *exc):
+        global _faces_batch
+        _faces_batch = self._outer
+        return False
+
+    def add(self, boundary, parameters, zero_points, vectors, faces, mask):
+        faces = _c(faces, torch.int32)
+        zero_points = _c(zero_points.detach(), torch.float64)
+        vectors = _c(vectors.detach(), torch.float64)
+        if mask is not None:
+            mask = _c(mask, torch.uint8)
+        _need_gpu(parameters, zero_points, vectors, faces, mask)
+        self.requests.append((boundary, parameters, zero_points, vectors, faces, mask))
+        boundary.__dict__["_faces_pending"] = self
+
+    def flush(self, order=None):
+        if not self.requests:
+            return
+        reqs, self.requests = self.requests, []
+        by_boundary = {id(r[0]): r for r in reqs}
+        layout = None
+        if order is not None:
+            layout = []
+            for b in order:
+                r = by_boundary.get(id(b))
+                if r is not None:
+                    layout.append(("param", r))
+                    continue
+                fv = b.__dict__.get("_face_verts_value")
+                if (fv is None or fv.requires_grad or not fv.is_cuda or fv.dtype != torch.float64
+                        or not fv.is_contiguous() or fv.dim() != 2 or fv.shape[1] != 9):
+                    layout = None   # (something the block cannot hold: faces only, then cat)
+                    break
+                layout.append(("copy", b, fv))
+            if layout is not None and sum(1 for e in layout if e[0] == "param") != len(reqs):
+                layout = None
+        if layout is None:
+            layout = [("param", r) for r in reqs]
+        spec = [("param", e[1][2], e[1][3], e[1][4], e[1][5]) if e[0] == "param"
+                else ("copy", e[2]) for e in layout]
+        pars = [e[1][1] for e in layout if e[0] == "param"]
+        fv, norm = _ParamFacesMulti.apply(spec, *pars)
+        at = na = 0
+        rows = []
+        for e in layout:
+            if e[0] == "param":
+                b, F = e[1][0], e[1][4].shape[0]
+                b.__dict__["_faces_pending"] = None
+                b._face_verts = fv[at:at + F]
+                b._norm = norm[na:na + F]
+                rows.append((b, at, at + F))
+                na += F
+            else:
+                F = e[2].shape[0]
+                rows.append((e[1], at, at + F))
+            at += F
+        if order is not None and len(layout) == len(order):
+            self.merged = (fv, rows)
+
+
 # ------------------------------------------------------------------- pairwise geometry
 
 def _ptr_array(tensors):

@@ -231,3 +231,67 @@ def test_parametric_boundary_uses_the_fused_update_and_serves_vertices_on_demand
     assert float((g - g2).abs().max()) < 1e-13
     surf.update_mesh_from_vertices()
     np.testing.assert_array_equal(surf.mesh.points, want.detach().cpu().numpy())
+
+
+def test_param_faces_of_several_surfaces_in_one_launch_equal_the_single_launches():
+    """ops.ParamFacesBatch / tfrt_param_faces_*_multi: two parametric surfaces and a fixed one
+    between them -> one merged block; rows, normals and parameter gradients (through the block,
+    through a boundary's own rows and through the normals) equal those of tfrt_param_faces_*."""
+    from tensorflowraytrace_amd import ops
+
+    class Holder:      # stands for a boundary: the batch writes _face_verts / _norm into it
+        pass
+
+    za, va, fa, pa0 = _param_surface(7, True, 3)
+    zb, vb, fb, pb0 = _param_surface(12, False, 4)
+    mask_b = (torch.rand(fb.shape[0], 3, generator=torch.Generator().manual_seed(2)) < 0.7).to(torch.uint8).cuda()
+    fixed = Holder()
+    fixed._face_verts = torch.randn(5, 9, dtype=torch.float64, generator=torch.Generator().manual_seed(1)).cuda()
+    fixed.__dict__["_face_verts_value"] = fixed._face_verts
+    pa, pb = pa0.clone().requires_grad_(True), pb0.clone().requires_grad_(True)
+    a, b = Holder(), Holder()
+    batch = ops.ParamFacesBatch()
+    batch.add(a, pa, za, va, fa, None)
+    batch.add(b, pb, zb, vb, fb, mask_b)
+    batch.flush([a, fixed, b])
+    block, rows = batch.merged
+    Fa, Fb = fa.shape[0], fb.shape[0]
+    assert [(r0, r1) for _, r0, r1 in rows] == [(0, Fa), (Fa, Fa + 5), (Fa + 5, Fa + 5 + Fb)]
+    qa, qb = pa0.clone().requires_grad_(True), pb0.clone().requires_grad_(True)
+    fva, na = ops.param_faces(qa, za, va, fa, None)
+    fvb, nb = ops.param_faces(qb, zb, vb, fb, mask_b)
+    assert torch.equal(block, torch.cat([fva, fixed._face_verts, fvb]))
+    assert torch.equal(a._face_verts, fva) and torch.equal(b._face_verts, fvb)
+    assert torch.equal(a._norm, na) and torch.equal(b._norm, nb)
+    gen = torch.Generator().manual_seed(9)
+    w = torch.randn(block.shape, generator=gen, dtype=torch.float64).cuda()
+    wn = torch.randn(Fb, 3, generator=gen, dtype=torch.float64).cuda()
+    loss1 = (block * w).sum() + (b._norm * wn).sum() + (a._face_verts ** 2).sum()
+    loss2 = ((fva * w[:Fa]).sum() + (fvb * w[Fa + 5:]).sum() + (nb * wn).sum() + (fva ** 2).sum())
+    g1 = torch.autograd.grad(loss1, [pa, pb])
+    g2 = torch.autograd.grad(loss2, [qa, qb])
+    for x, y in zip(g1, g2):
+        assert float((x - y).abs().max()) <= 1e-13 * max(float(y.abs().max()), 1.0)
+
+
+def test_optical_system_update_runs_the_face_updates_as_one_launch_and_needs_no_concatenation():
+    """OpticalSystem3D.update(): both lens surfaces hand their update to the batch, the target's
+    faces are copied into place, and the merged face tensor IS that block; boundaries keep their
+    own rows; the same scene updated boundary by boundary (no batch) gives the same faces."""
+    import bench
+    eng, system, params = bench.build_scene(4096, 9, 5, torch.float64)
+    system.update()
+    merged = system._merged_face_verts
+    parts = [b.face_verts for lst in (system._optical, system._stop, system._target) for b in lst if bool(b)]
+    assert torch.equal(merged, torch.cat(parts))
+    lens = [b for b in system._optical if hasattr(b, "parameters")]
+    assert len(lens) == 2
+    for b in lens:   # rows of the block, not copies
+        assert b.face_verts.untyped_storage().data_ptr() == merged.untyped_storage().data_ptr()
+    # boundary by boundary
+    for b in lens:
+        b.update()
+    for b, rows in zip(lens, (parts[0], parts[1])):
+        assert torch.equal(b.face_verts, rows)
+    g = torch.autograd.grad((merged ** 2).sum(), params, allow_unused=True)
+    assert all(x is not None and bool(torch.isfinite(x).all()) and float(x.abs().max()) > 0 for x in g)
