@@ -168,9 +168,28 @@ int tfrt_sgd_process_dev(const void* grad, void* processed, void* param, int64_t
  * optimizer.py:223-247, 316): host arrays of n_tensors device pointers (`processed` / `param`
  * and their entries may be NULL as above) and element counts; `hyper` holds {scale, clip,
  * sgd_learning_rate} per tensor, 3 * n_tensors float64 on the device. */
+/* The second stage of tfrt_goal_error3d's error sum, left to the caller
+ * (tfrt_goal_error3d_deferred): a dependent launch costs ~4.5 us whatever it does, and nothing on
+ * the device waits for the sum. */
+typedef struct tfrt_goal_pending {
+  const double* partial;       /* per-workgroup partial sums (in the goal workspace) */
+  int32_t n_partial;
+  const int32_t* n_finished;   /* device count of finished rays */
+  int32_t n_fields;
+  double* error_out;           /* {sum, n_terms, mean} */
+  const int32_t* tests_lo_hi;  /* the trace's test count (two int32) or NULL */
+  int64_t* tests_total;        /* running total it is added to, or NULL */
+} tfrt_goal_pending;
+
 int tfrt_sgd_process_multi(int32_t n_tensors, const void* const* grad, void* const* processed,
                            void* const* param, const int64_t* n, const double* hyper,
                            void* stream);
+
+/* ... and finishes a pending error sum in one more workgroup of the same launch. */
+int tfrt_sgd_process_multi_finish(int32_t n_tensors, const void* const* grad,
+                                  void* const* processed, void* const* param, const int64_t* n,
+                                  const double* hyper, const tfrt_goal_pending* pending,
+                                  void* stream);
 
 /* y = A x, A in CSR form (int64 indices, f64 values): the accumulator (optimizer.py:250-255)
  * and smoother (optimizer.py:277-282) products for the sparse matrices the mesh tools
@@ -331,6 +350,18 @@ int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t
                       int64_t goal_stride, double* grad_finished, double* error_out,
                       double* zero_buffer, int64_t zero_count, int64_t* tests_total,
                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same without the second stage of the sum: `pending` (host struct) is filled in and whoever
+ * runs next finishes it -- tfrt_sgd_process_multi_finish in a spare workgroup of the parameter
+ * update's launch, or tfrt_goal_finish (the launch tfrt_goal_error3d would have made). */
+int tfrt_goal_error3d_deferred(const void* finished_rays, int64_t capacity,
+                               const int32_t* finished_id, int32_t state_dtype,
+                               const int32_t* counts, int32_t max_passes, const int32_t* fields,
+                               int32_t n_fields, const double* goal, int64_t goal_stride,
+                               double* grad_finished, double* error_out, double* zero_buffer,
+                               int64_t zero_count, int64_t* tests_total, void* workspace,
+                               size_t workspace_bytes, tfrt_goal_pending* pending, void* stream);
+int tfrt_goal_finish(const tfrt_goal_pending* pending, void* stream);
 
 /* Benchmark instrumentation (the only global state in the library; not used by the product
  * path).  While enabled, the launches of the hot kernels made by tfrt_trace3d_forward /

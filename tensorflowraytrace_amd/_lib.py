@@ -68,6 +68,14 @@ class FaceSurfaceGrad(ctypes.Structure):
                 ("grad_parameters", ctypes.c_void_p)]
 
 
+class GoalPending(ctypes.Structure):
+    """tfrt_goal_pending (include/tfrt_hip.h)."""
+    _fields_ = [("partial", ctypes.c_void_p), ("n_partial", ctypes.c_int32),
+                ("n_finished", ctypes.c_void_p), ("n_fields", ctypes.c_int32),
+                ("error_out", ctypes.c_void_p), ("tests_lo_hi", ctypes.c_void_p),
+                ("tests_total", ctypes.c_void_p)]
+
+
 class RayOut(ctypes.Structure):
     """struct tfrt_ray_out"""
     _fields_ = [("rays", c_vp), ("ray_id", c_vp), ("face", c_vp), ("capacity", c_i64)]
@@ -99,6 +107,7 @@ SIGNATURES = {
     "tfrt_sgd_process": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_f64, c_f64, c_f64, c_vp]),
     "tfrt_sgd_process_dev": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "tfrt_sgd_process_multi": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "tfrt_sgd_process_multi_finish": (c_i32, [c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "tfrt_csr_matvec": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "tfrt_trace3d_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32, c_i32]),
     "tfrt_trace3d_forward": (c_i32, [
@@ -110,6 +119,9 @@ SIGNATURES = {
     "tfrt_goal_error3d_workspace_bytes": (c_sz, [c_i64]),
     "tfrt_goal_error3d": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64,
                                   c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_goal_error3d_deferred": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64,
+                                  c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp, c_vp]),
+    "tfrt_goal_finish": (c_i32, [c_vp, c_vp]),
     "tfrt_intersect3d_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "tfrt_intersect3d": (c_i32, [
         c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,

@@ -1,0 +1,34 @@
+// Second stage of the built-in error sum (tfrt_goal_error3d): the per-workgroup partial sums in a
+// fixed order, by ONE workgroup of BLOCK threads.  Shared by k_goal_finish (tfrt_error.hip) and
+// k_sgd_process_multi (tfrt_update.hip), which can do it in a spare workgroup of its own launch
+// (tfrt_goal_error3d_deferred / tfrt_sgd_process_multi_finish: one dependent launch less per
+// optimiser step).
+#pragma once
+#include "tfrt_common.h"
+
+namespace tfrt {
+
+__device__ __forceinline__ void goal_finish_block(const tfrt_goal_pending& g) {
+#pragma clang fp contract(off)
+  __shared__ double wsum[WAVES];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < g.n_partial; b += BLOCK) s += g.partial[b];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+  if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int w = 0; w < WAVES; ++w) tot += wsum[w];
+    const double terms = (double)(*g.n_finished) * (double)g.n_fields;
+    g.error_out[0] = tot;
+    g.error_out[1] = terms;
+    // reduce_mean of optimizer.py:257 (no finished ray: the mean of nothing is NaN there too)
+    g.error_out[2] = terms > 0.0 ? tot / terms : __builtin_nan("");
+    if (g.tests_total != nullptr && g.tests_lo_hi != nullptr)
+      *g.tests_total += (long long)((unsigned long long)(uint32_t)g.tests_lo_hi[0] |
+                                    ((unsigned long long)(uint32_t)g.tests_lo_hi[1] << 32));
+  }
+}
+
+}  // namespace tfrt

@@ -20,6 +20,7 @@
 // two runs give bit-identical errors.  HBM-bound: 4-8 B x n_fields read + 8 B x
 // n_fields written per finished ray.
 #include "tfrt_common.h"
+#include "goal_finish.h"
 
 namespace tfrt {
 
@@ -67,32 +68,8 @@ __global__ __launch_bounds__(BLOCK) void k_goal_error(
 // "the workgroup that finishes last": that needs a device-scope release fence per workgroup, and
 // with per-XCD L2s every such fence writes the XCD's dirty lines (the seed rows just stored) back
 // -- 117 us at 1M rays against ~10 us for the two launches.
-__global__ __launch_bounds__(BLOCK) void k_goal_finish(const double* __restrict__ partial,
-                                                       int n_partial,
-                                                       const int32_t* __restrict__ n_ptr,
-                                                       int n_fields, double* __restrict__ err_out,
-                                                       const int32_t* __restrict__ tests_lo_hi,
-                                                       long long* __restrict__ tests_total) {
-#pragma clang fp contract(off)
-  __shared__ double wsum[WAVES];
-  double s = 0.0;
-  for (int b = threadIdx.x; b < n_partial; b += BLOCK) s += partial[b];
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
-  if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int w = 0; w < WAVES; ++w) tot += wsum[w];
-    const double terms = (double)(*n_ptr) * (double)n_fields;
-    err_out[0] = tot;
-    err_out[1] = terms;
-    // reduce_mean of optimizer.py:257 (no finished ray: the mean of nothing is NaN there too)
-    err_out[2] = terms > 0.0 ? tot / terms : __builtin_nan("");
-    if (tests_total != nullptr && tests_lo_hi != nullptr)
-      *tests_total += (long long)((unsigned long long)(uint32_t)tests_lo_hi[0] |
-                                  ((unsigned long long)(uint32_t)tests_lo_hi[1] << 32));
-  }
+__global__ __launch_bounds__(BLOCK) void k_goal_finish(tfrt_goal_pending g) {
+  goal_finish_block(g);
 }
 
 }  // namespace tfrt
@@ -106,12 +83,13 @@ size_t tfrt_goal_error3d_workspace_bytes(int64_t capacity) {
   return align_up((size_t)cdiv(capacity > 0 ? capacity : 1, BLOCK) * sizeof(double));
 }
 
-int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
-                      int32_t state_dtype, const int32_t* counts, int32_t max_passes,
-                      const int32_t* fields, int32_t n_fields, const double* goal,
-                      int64_t goal_stride, double* grad_finished, double* error_out,
-                      double* zero_buffer, int64_t zero_count, int64_t* tests_total,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+static int goal_error_launch(const void* finished_rays, int64_t capacity,
+                             const int32_t* finished_id, int32_t state_dtype,
+                             const int32_t* counts, int32_t max_passes, const int32_t* fields,
+                             int32_t n_fields, const double* goal, int64_t goal_stride,
+                             double* grad_finished, double* error_out, double* zero_buffer,
+                             int64_t zero_count, int64_t* tests_total, void* workspace,
+                             size_t workspace_bytes, tfrt_goal_pending* pending, void* stream) {
   if (capacity < 0 || n_fields < 1 || n_fields > 6 || !fields || !counts || max_passes < 0 ||
       !error_out || !workspace || workspace_bytes < tfrt_goal_error3d_workspace_bytes(capacity) ||
       zero_count < 0 || (zero_count > 0 && !zero_buffer))
@@ -144,8 +122,54 @@ int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t
     return TFRT_E_BADARG;
   }
 #undef TFRT_GOAL
-  hipLaunchKernelGGL(k_goal_finish, dim3(1), dim3(BLOCK), 0, st, partial, nblk, n_finished,
-                     n_fields, error_out, tail + 4, reinterpret_cast<long long*>(tests_total));
+  tfrt_goal_pending g;
+  g.partial = partial;
+  g.n_partial = nblk;
+  g.n_finished = n_finished;
+  g.n_fields = n_fields;
+  g.error_out = error_out;
+  g.tests_lo_hi = tail + 4;
+  g.tests_total = tests_total;
+  if (pending != nullptr) {
+    *pending = g;  // (the caller has the sum finished: tfrt_sgd_process_multi_finish / tfrt_goal_finish)
+  } else {
+    hipLaunchKernelGGL(k_goal_finish, dim3(1), dim3(BLOCK), 0, st, g);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
+                      int32_t state_dtype, const int32_t* counts, int32_t max_passes,
+                      const int32_t* fields, int32_t n_fields, const double* goal,
+                      int64_t goal_stride, double* grad_finished, double* error_out,
+                      double* zero_buffer, int64_t zero_count, int64_t* tests_total,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  return goal_error_launch(finished_rays, capacity, finished_id, state_dtype, counts, max_passes,
+                           fields, n_fields, goal, goal_stride, grad_finished, error_out,
+                           zero_buffer, zero_count, tests_total, workspace, workspace_bytes,
+                           nullptr, stream);
+}
+
+int tfrt_goal_error3d_deferred(const void* finished_rays, int64_t capacity,
+                               const int32_t* finished_id, int32_t state_dtype,
+                               const int32_t* counts, int32_t max_passes, const int32_t* fields,
+                               int32_t n_fields, const double* goal, int64_t goal_stride,
+                               double* grad_finished, double* error_out, double* zero_buffer,
+                               int64_t zero_count, int64_t* tests_total, void* workspace,
+                               size_t workspace_bytes, tfrt_goal_pending* pending, void* stream) {
+  if (!pending) return TFRT_E_BADARG;
+  return goal_error_launch(finished_rays, capacity, finished_id, state_dtype, counts, max_passes,
+                           fields, n_fields, goal, goal_stride, grad_finished, error_out,
+                           zero_buffer, zero_count, tests_total, workspace, workspace_bytes,
+                           pending, stream);
+}
+
+int tfrt_goal_finish(const tfrt_goal_pending* pending, void* stream) {
+  if (!pending || !pending->partial || !pending->n_finished || !pending->error_out ||
+      pending->n_partial < 0)
+    return TFRT_E_BADARG;
+  hipLaunchKernelGGL(k_goal_finish, dim3(1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),
+                     *pending);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 

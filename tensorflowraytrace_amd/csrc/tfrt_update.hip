@@ -11,6 +11,7 @@
 // All of it is HBM/latency bound (tens of KB per launch); one thread per element / one wave per
 // row, coalesced loads, nothing else to tune.
 #include "tfrt_common.h"
+#include "goal_finish.h"
 
 namespace tfrt {
 
@@ -52,7 +53,13 @@ struct SgdBatch {
 };
 
 __global__ __launch_bounds__(BLOCK) void k_sgd_process_multi(SgdBatch b,
-                                                             const double* __restrict__ hyper) {
+                                                             const double* __restrict__ hyper,
+                                                             tfrt_goal_pending goal) {
+  // (one workgroup more than the tensors need, when the step's error sum is still to be finished)
+  if ((int)blockIdx.x == b.first_block[SGD_BATCH]) {
+    goal_finish_block(goal);
+    return;
+  }
   int k = 0;
   while (k + 1 < b.count && (int)blockIdx.x >= b.first_block[k + 1]) ++k;  // block-uniform
   const int64_t i = (int64_t)((int)blockIdx.x - b.first_block[k]) * BLOCK + threadIdx.x;
@@ -121,10 +128,13 @@ int tfrt_sgd_process_dev(const void* grad, void* processed, void* param, int64_t
   return sgd_process_launch(grad, processed, param, n, dtype, 0.0, 0.0, 0.0, hyper, stream);
 }
 
-int tfrt_sgd_process_multi(int32_t n_tensors, const void* const* grad, void* const* processed,
-                           void* const* param, const int64_t* n, const double* hyper,
-                           void* stream) {
+static int sgd_multi_launch(int32_t n_tensors, const void* const* grad, void* const* processed,
+                            void* const* param, const int64_t* n, const double* hyper,
+                            const tfrt_goal_pending* pending, void* stream) {
   if (n_tensors < 0 || n_tensors > SGD_BATCH || (n_tensors > 0 && (!grad || !n || !hyper)))
+    return TFRT_E_BADARG;
+  if (pending != nullptr && (!pending->partial || !pending->n_finished || !pending->error_out ||
+                             pending->n_partial < 0))
     return TFRT_E_BADARG;
   SgdBatch b;
   int blocks = 0;
@@ -140,10 +150,26 @@ int tfrt_sgd_process_multi(int32_t n_tensors, const void* const* grad, void* con
   }
   b.first_block[SGD_BATCH] = blocks;
   b.count = n_tensors;
-  if (blocks == 0) return 0;
-  hipLaunchKernelGGL(k_sgd_process_multi, dim3(blocks), dim3(BLOCK), 0,
-                     static_cast<hipStream_t>(stream), b, hyper);
+  const int grid = blocks + (pending != nullptr ? 1 : 0);
+  if (grid == 0) return 0;
+  hipLaunchKernelGGL(k_sgd_process_multi, dim3(grid), dim3(BLOCK), 0,
+                     static_cast<hipStream_t>(stream), b, hyper,
+                     pending != nullptr ? *pending : tfrt_goal_pending{});
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_sgd_process_multi(int32_t n_tensors, const void* const* grad, void* const* processed,
+                           void* const* param, const int64_t* n, const double* hyper,
+                           void* stream) {
+  return sgd_multi_launch(n_tensors, grad, processed, param, n, hyper, nullptr, stream);
+}
+
+int tfrt_sgd_process_multi_finish(int32_t n_tensors, const void* const* grad,
+                                  void* const* processed, void* const* param, const int64_t* n,
+                                  const double* hyper, const tfrt_goal_pending* pending,
+                                  void* stream) {
+  if (!pending) return TFRT_E_BADARG;
+  return sgd_multi_launch(n_tensors, grad, processed, param, n, hyper, pending, stream);
 }
 
 int tfrt_csr_matvec(const int64_t* crow_indices, const int64_t* col_indices, const double* values,

@@ -252,12 +252,23 @@ class FusedStep:
         need_back = bool(fv.requires_grad and st["M"] > 0)
         # error + gradient seed; the same launch clears the face-gradient block the reverse sweep
         # accumulates into and adds the trace's test count to the running total
-        check(L.tfrt_goal_error3d(
+        # (one rank: nothing on the device waits for the error sum, so its second stage is left
+        # to the parameter update's launch -- _enqueue_apply --; with several ranks the sum goes
+        # into the collective and is finished here)
+        goal_args = (
             ops._p(fin), st["capN"], ops._p(st["aux"]["finished_id"]), dt, ops._p(st["counts"]), P,
             st["fields"], len(erf.rows), ops._p(goal), goal.shape[1], ops._p(st["g_fin"]),
             ops._p(st["err"]), ops._p(st["g_fv"]) if need_back else None,
             st["g_fv"].numel() if need_back else 0, ops._p(self.tests_total),
-            ops._p(st["goal_ws"]), st["gws"], stream), "tfrt_goal_error3d")
+            ops._p(st["goal_ws"]), st["gws"])
+        self._goal_pending = None
+        if tdist.is_distributed():
+            check(L.tfrt_goal_error3d(*goal_args, stream), "tfrt_goal_error3d")
+        else:
+            pending = _lib.GoalPending()
+            check(L.tfrt_goal_error3d_deferred(*goal_args, ctypes.byref(pending), stream),
+                  "tfrt_goal_error3d_deferred")
+            self._goal_pending = (pending, stream)
         grads = [None] * len(opt.parameters)
         if need_back:
             check(L.tfrt_trace3d_backward(
@@ -331,12 +342,25 @@ class FusedStep:
             gp = (ctypes.c_void_p * k)(*[g.data_ptr() for g in grads])
             pp = (ctypes.c_void_p * k)(*[p.data_ptr() for p in opt.parameters])
             nn = (ctypes.c_int64 * k)(*[g.numel() for g in grads])
+            pending, self._goal_pending = getattr(self, "_goal_pending", None), None
             with torch.no_grad():
-                check(L.tfrt_sgd_process_multi(k, gp, None, pp, nn,
-                                               ctypes.c_void_p(self._hyper.dev.data_ptr()),
-                                               ops._stream(opt.parameters[0])),
-                      "tfrt_sgd_process_multi")
+                if pending is not None and pending[1].value == ops._stream(opt.parameters[0]).value:
+                    check(L.tfrt_sgd_process_multi_finish(
+                        k, gp, None, pp, nn, ctypes.c_void_p(self._hyper.dev.data_ptr()),
+                        ctypes.byref(pending[0]), ops._stream(opt.parameters[0])),
+                        "tfrt_sgd_process_multi_finish")
+                else:
+                    if pending is not None:
+                        check(L.tfrt_goal_finish(ctypes.byref(pending[0]), pending[1]),
+                              "tfrt_goal_finish")
+                    check(L.tfrt_sgd_process_multi(k, gp, None, pp, nn,
+                                                   ctypes.c_void_p(self._hyper.dev.data_ptr()),
+                                                   ops._stream(opt.parameters[0])),
+                          "tfrt_sgd_process_multi")
             return
+        pending, self._goal_pending = getattr(self, "_goal_pending", None), None
+        if pending is not None:      # (other update paths: the launch tfrt_goal_error3d would have made)
+            check(L.tfrt_goal_finish(ctypes.byref(pending[0]), pending[1]), "tfrt_goal_finish")
         for i, (g, p) in enumerate(zip(grads, opt.parameters)):
             hyper = ctypes.c_void_p(self._hyper.dev.data_ptr() + 24 * i)
             stream = ops._stream(p)
