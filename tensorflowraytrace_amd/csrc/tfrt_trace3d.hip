@@ -141,7 +141,12 @@ __device__ __forceinline__ void face_sphere(const double* __restrict__ P, const 
   const double cn = sqrt(dot3(cc, cc));
   const double u32 = 5.9604644775390625e-08;  // 2^-24
   double reff = r * (1.0 + 1e-5) + 64.0 * u32 * (cn + r);
-  if (size_eps > 0.0) reff += size_eps * (sqrt(dot3(ab, ab)) + sqrt(dot3(ac, ac)));
+  // size_epsilion: trig_u, trig_v >= -eps, trig_u + trig_v <= 1 + eps is the triangle with the
+  // corners A - eps (ab + ac), B + eps (2 ab - ac), C + eps (2 ac - ab): every valid hit lies within
+  // eps max(|ab + ac|, |2 ab - ac|, |2 ac - ab|) <= 2 eps (|ab| + |ac|) of the face.  (Until
+  // round 3 the factor was 1: a hit in the far corner of that margin could be filtered out when
+  // size_epsilion was not tiny -- found by the coherent-ray kernel, whose bound was right.)
+  if (size_eps > 0.0) reff += 2.0 * size_eps * (sqrt(dot3(ab, ab)) + sqrt(dot3(ac, ac)));
   *reff_out = reff;
 }
 
@@ -277,7 +282,7 @@ __device__ __forceinline__ void cluster_spheres_block(
   const double max_edge = max16(edge);
   if (in_range && (threadIdx.x & (CLUSTER - 1)) == 0) {
     if (cnt > 0.0) {
-      if (size_eps > 0.0) R += 2.0 * size_eps * max_edge;  // as face_sphere(): size_eps (|E1| + |E2|)
+      if (size_eps > 0.0) R += 4.0 * size_eps * max_edge;  // as face_sphere(): 2 size_eps (|E1| + |E2|)
       const double cn = sqrt(dot3(mean, mean));
       R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
       clsphere[c] = pack_sphere(mean, R);
@@ -370,7 +375,7 @@ __device__ __forceinline__ void super_spheres_block(
   }
   const double max_edge = block_max(edge);
   if (t == 0) {
-    if (size_eps > 0.0) R += 2.0 * size_eps * max_edge;
+    if (size_eps > 0.0) R += 4.0 * size_eps * max_edge;
     const double cn = sqrt(dot3(mean, mean));
     R = R * (1.0 + 1e-5) + 64.0 * 5.9604644775390625e-08 * (cn + R);
     susphere[s] = pack_sphere(mean, R);

@@ -153,6 +153,41 @@ def test_soup_traces_equal_the_oracle_including_coplanar_ties(seed):
         assert torch.equal(out["dead"].cpu()[:, row], _block(ref["dead"])[:, row])
 
 
+@pytest.mark.parametrize("seed", [16, 35, 2])
+def test_soup_traces_with_a_large_size_epsilion_equal_the_oracle(seed):
+    """size_epsilion = 0.3: trig_u, trig_v >= -0.3, trig_u + trig_v <= 1.3 accepts hits up to
+    0.3 |2 E1 - E2| outside the triangle -- more than the 0.3 (|E1| + |E2|) the bounding spheres
+    were inflated by until round 3 (one ray of soup 16 lost its hit to the filter).  Every trace
+    mode against the oracle's exact all-pairs result."""
+    from tensorflowraytrace_amd import ops, _lib
+    sc = _soup(seed)
+    eps = (1e-6, 0.3, 1e-10)
+    system = _oracle_system(sc)
+    system.eps = eps
+    src = {n: sc["rays"][i] for i, n in enumerate(NAMES)}
+    src["ray_id"] = torch.arange(sc["rays"].shape[1], dtype=torch.float64)
+    ref = tracer.ray_trace(system, src, max_iterations=3, inherit=("ray_id",), index_type="value",
+                           new_ray_length=sc["L"],
+                           flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
+    fv = sc["P"].to(DEV)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    for mode in ("all-pairs", "hierarchy", "coherent"):
+        args = ops.Scene3DArgs(fv, sc["cat"].int().to(DEV), n_in=sc["n_in"].to(DEV),
+                               n_out=sc["n_out"].to(DEV),
+                               cluster_order=None if mode == "all-pairs" else ops.cluster_order(fv),
+                               coherent_rays=mode == "coherent")
+        args.eps = eps
+        out = ops.trace3d(sc["rays"].to(DEV), fv, args, max_passes=3, flags=flags,
+                          new_ray_length=sc["L"])
+        for cls in ("finished", "active", "stopped", "dead"):
+            r = ref[cls]
+            n_ref = r["x_start"].shape[0] if r else 0
+            assert out[cls].shape[1] == n_ref, (cls, mode)
+            if n_ref:
+                assert torch.equal(out[cls + "_id"].cpu().long(), r["ray_id"].long()), (cls, mode)
+                assert torch.equal(out[cls].cpu(), _block(r)), (cls, mode)
+
+
 @pytest.mark.parametrize("op,name", [(0, "div"), (1, "sqrt"), (2, "1/sqrt"), (3, "mul+add")])
 def test_device_float64_primitives_are_correctly_rounded(op, name):
     """tfrt_selftest_f64 against numpy (IEEE division / sqrt on the host), 2M random operands over

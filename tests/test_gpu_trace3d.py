@@ -714,6 +714,53 @@ def test_coherent_flag_on_adversarial_soups():
                 assert torch.equal(out[cls], ref[cls]), (seed, name, cls)
 
 
+@pytest.mark.parametrize("eps", [(1e-10, 0.05, -0.05), (1e-10, 1e-3, 1e-6), (1e-6, 0.3, 0.0),
+                                 (1e-10, 1e300, 1e-10)])
+def test_coherent_order_with_unusual_epsilons(eps):
+    """The bounds of k_intersect_beam carry size_epsilion (a valid hit may lie that far outside
+    its triangle) and drop the "behind the start" cull when ray_start_epsilion < 0: with large,
+    negative or absurd epsilons the sorted trace still returns the natural-order one bit for bit,
+    on the lens (coherent wavefronts) and on random soups (cuts, single rays, left-over)."""
+    from tensorflowraytrace_amd import ops, _lib
+    import test_gpu_stress as st
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    scene = scene_util.lens_scene(30000, k_front=12, k_back=6)
+    src, fv, sc, _ = _gpu_scene(scene, torch.float32, cluster="group")
+    sc.eps = eps
+    ref = ops.trace3d(src, fv.detach(), sc, max_passes=4, flags=flags)
+    cases = [(src, fv.detach(), sc, ref, 1.0, "lens")]
+    for seed in (35, 16):
+        sc0 = st._soup(seed)
+        fvs, rays = sc0["P"].to("cuda:0"), sc0["rays"].to("cuda:0")
+        if rays.shape[1] < 64:
+            continue
+        base = dict(n_in=sc0["n_in"].to("cuda:0"), n_out=sc0["n_out"].to("cuda:0"))
+        plain = ops.Scene3DArgs(fvs, sc0["cat"].int().to("cuda:0"), **base)
+        plain.eps = eps
+        cases.append((rays, fvs, plain, ops.trace3d(rays, fvs, plain, max_passes=4, flags=flags,
+                                                    new_ray_length=sc0["L"]), sc0["L"], f"soup{seed}"))
+    for rays, faces, args0, want, L, tag in cases:
+        for name, order in _orders(rays).items():
+            for only in (False, True):
+                p64 = order.long()
+                kw = dict(face_grad_mask=getattr(args0, "face_grad_mask", None),
+                          cluster_order=ops.cluster_order(faces), coherent_rays=True)
+                if getattr(args0, "n_table", None) is not None:
+                    args = ops.Scene3DArgs(faces, args0.catagory, mat_in=args0.mat_in, mat_out=args0.mat_out,
+                                           n_table=args0.n_table[:, p64].contiguous(), **kw)
+                else:
+                    args = ops.Scene3DArgs(faces, args0.catagory, n_in=args0.n_in_arg, n_out=args0.n_out_arg, **kw)
+                args.eps = eps
+                args.coherent_only = only
+                raw = ops.trace3d(rays[:, p64].contiguous(), faces, args, max_passes=4, flags=flags,
+                                  new_ray_length=L)
+                out = ops.restore_order(raw, order)
+                assert np.array_equal(out["counts"], want["counts"]), (tag, name, only)
+                for cls in ("finished", "active", "dead", "stopped", "unfinished"):
+                    assert torch.equal(out[cls + "_id"], want[cls + "_id"]), (tag, name, only, cls)
+                    assert torch.equal(out[cls], want[cls]), (tag, name, only, cls)
+
+
 def test_engine_coherent_order_is_invisible():
     """OpticalEngine(coherent=True): ray_trace() runs over the sorted source and hands back the
     same ray sets, inherited fields included; 'auto' keeps plain ray_trace() in natural order (the
