@@ -2724,9 +2724,8 @@ __device__ __forceinline__ int backward_ray(
       if (has_child) face_indices(sc, tri, rid, &n_in, &n_out);
       double gn[2];
       const bool want_n = has_child && sc.grad_n_in != nullptr && sc.n_table == nullptr;
-      adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP,
-                want_n ? gn : nullptr,
-                ((tape & TAPE_INTERNAL) ? 1 : 0) | ((tape & TAPE_REFLECT) ? 2 : 0));
+      adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP, gn,
+                ((tape & TAPE_INTERNAL) ? 1 : 0) | ((tape & TAPE_REFLECT) ? 2 : 0), want_n);
       if (want_n) {  // "value" mode: d error / d (per-face refractive indices)
         if (gn[0] != 0.0) unsafeAtomicAdd(sc.grad_n_in + tri, gn[0]);
         if (gn[1] != 0.0) unsafeAtomicAdd(sc.grad_n_out + tri, gn[1]);

@@ -212,10 +212,12 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
                        bool has_child, double n_in, double n_out, double L,
                        const double g_s[3], const double g_h[3], const double g_ce[3],
                        double gs[3], double ge[3], double gP[9], double* gn = nullptr,
-                       int branch = -1) {
+                       int branch = -1, bool gn_wanted = true) {
   // branch: -1 = re-derive the forward's branches here; else bit 0 = the ray met the face from
   // the inside (n.u > 0), bit 1 = it was reflected (mirror or total internal reflection), as the
   // forward pass decided them
+  // (gn_wanted: a caller that decides at run time passes its two-element array either way -- a
+  // pointer that is sometimes null keeps the array in scratch memory on the GPU)
   if (gn != nullptr) gn[0] = gn[1] = 0.0;
   const double d[3] = {e[0] - s[0], e[1] - s[1], e[2] - s[2]};
   const double E1[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]};
@@ -273,7 +275,7 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
       const double alpha = sg * rk - nu_eta;
       const double ab = dot3(wb, n);
       nub = ab * (sg * eta * nu_eta / rk - eta);
-      if (gn != nullptr) {
+      if (gn != nullptr && gn_wanted) {
         // w = alpha n + eta u, alpha = sg sqrt(1 - eta^2 + eta^2 nu^2) - eta nu
         const double etab = dot3(wb, u) + ab * (sg * eta * (nu * nu - 1.0) / rk - nu);
         if (internal) {            // eta = n_in / n_out
