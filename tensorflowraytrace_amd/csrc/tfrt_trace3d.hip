@@ -12,7 +12,12 @@
 //                  EXACTLY in float64 with the reference's own Cramer sums and epsilons
 //                  (trace_math.h exact_triangle), so hit/miss and nearest-hit decisions are the
 //                  float64 reference's decisions; the float32 stages only remove pairs that
-//                  cannot hit.  Two kernels share that scheme:
+//                  cannot hit.  Two kernels share that scheme, a third (rays handed over in a
+//                  coherent order) shares the walk of the hierarchy among a wavefront's rays:
+//        k_intersect_beam   (tfrt_scene3d.coherent_rays) one bundle per wavefront against the
+//                           sphere hierarchy with lane = node, the candidate faces as triangles
+//                           seen along the bundle's axis, exact float64 decisions; wavefronts
+//                           that are no narrow bundle are cut or left to k_intersect_group.
 //        k_intersect_group  (default, scenes of >= 64 faces) sphere hierarchy over k-d face
 //                           clusters: 8-cluster superclusters -> 16-face clusters -> faces;
 //                           lanes queue the clusters their rays touch, the wave drains the
@@ -31,7 +36,8 @@
 //
 // Backward: k_backward3d walks the tape pass by pass in reverse, recomputes the per-ray
 // forward in float64 and applies the hand-derived adjoint (trace_math.h adjoint3d); the face
-// gradients of the rays are summed in LDS face windows (k_face_accumulate).
+// gradients of the rays are summed per wavefront in LDS (coherent rays) or left in a per-ray
+// stash that k_face_accumulate sums in LDS face windows (natural order).
 #include <vector>
 
 #include <type_traits>
@@ -1330,11 +1336,14 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
 //              hits lie ahead of the starts).
 //   levels     LANE = NODE: 64 supercluster / cluster / member spheres per instruction against the
 //              bundle (no per-ray work at all), survivors compacted into the next level's list.
-//   faces      candidate faces (a dozen for a coherent wave) are taken one at a time, LANE = RAY:
-//              the face's float32 record is broadcast from the lane that fetched it (v_readlane:
-//              scalar operands, no per-pair gathers) into the float32 screen (may_hit_core);
-//              survivors queue for the exact float64 decision, one (ray, face) per lane, nearest
-//              hit per ray by 64-bit ds_min -- as in the grouped kernel.
+//   faces      LANE = FACE: the candidate faces (a dozen for a coherent wave) as TRIANGLES, seen
+//              along the axis, against the bundle (face_frame below); those left are ordered by
+//              depth and taken two at a time, LANE = RAY: the faces' records travel in scalar
+//              registers (v_readlane), a ray keeps a face if its image lies within the face's
+//              (a dozen instructions); the pairs kept queue for the exact float64 decision, one
+//              (ray, face) per lane, nearest hit per ray by 64-bit ds_min -- the same function
+//              as in the grouped kernel.  The walk ends when every ray has a decided hit nearer
+//              than every face left.
 //
 // Every stage only removes pairs that cannot win (the bundle bounds are inflated well beyond
 // their float32 rounding), so results are bit-identical to k_intersect_group / k_intersect3d.

@@ -5,7 +5,9 @@
 //   [4] pairs past the float32 screen, [5] float64 decisions that hit.
 // k_intersect_beam: [8] wavefronts, [9] left to the grouped kernel because the directions spread,
 //   [10] / [11] / [12] because more than BEAM_SLIST superclusters / BEAM_CLIST clusters /
-//   BEAM_FLIST faces were touched, [13] candidate faces, [14] pairs past the screen, [15] decisions.
+//   BEAM_FLIST faces were touched, [13] candidate faces (member spheres touched), [14] (ray, face)
+//   pairs queued for the float64 decision, [15] first ray of the last wavefront left over,
+//   [27] faces past face_frame, [28] decision batches, [29] faces walked, [30] bundles tried.
 #pragma once
 
 __device__ unsigned long long g_group_stats[32];
