@@ -18,16 +18,19 @@ for P in (1, 2, 3):
     whole = tot                             # all P passes of this trace (reading clears the counters)
     cur = whole - last; last = whole        # its last pass
     w = max(cur[8], 1)
-    print(f"pass {P}: wavefronts {cur[8]:.0f}, left over {cur[9:13].sum():.0f} (spread {cur[9]:.0f}, supers {cur[10]:.0f}, "
-          f"clusters {cur[11]:.0f}, faces {cur[12]:.0f}); per beam wave: candidate faces {cur[13]/w:.1f}, "
-          f"pairs past the screen {cur[14]/w:.1f}; group kernel: queued clusters {cur[2]:.0f}", flush=True)
-    names = ["setup", "bundle", "level0", "level1", "level2", "chunk fill", "prefilter", "screen", "decide",
-             "epilogue", "not narrow"]
+    ticks_only = cur[8] == 0     # (-DTFRT_TICKS: the counters are off)
+    if not ticks_only:
+        print(f"pass {P}: wavefronts {cur[8]:.0f}, left over {cur[9:13].sum():.0f} (spread {cur[9]:.0f}, supers {cur[10]:.0f}, "
+              f"clusters {cur[11]:.0f}, faces {cur[12]:.0f}); per wavefront: member spheres touched {cur[13]/w:.1f}, "
+              f"faces past face_frame {cur[27]/w:.1f}, faces walked {cur[29]/w:.2f}, pairs queued {cur[14]/w:.1f}, "
+              f"decision batches {cur[28]/w:.2f}, bundles tried {cur[30]/w:.2f}; group kernel: queued clusters {cur[2]:.0f}", flush=True)
+    names = ["ray load", "bundle", "level 0", "level 1", "level 2", "(before faces)", "face_frame + order",
+             "face walk", "decisions", "epilogue", "not narrow"]
     if cur[8] == 0:
         w = {1: 15625, 2: 13682, 3: 13682}[P] * (N / 1e6)   # (-DTFRT_TICKS: the counters are off)
     tk = cur[16:16 + len(names)] / w
-    print("   ticks per wavefront: " + ", ".join(f"{n} {v:.0f}" for n, v in zip(names, tk)) + f"; total {tk.sum():.0f}", flush=True)
-    print(f"   per wavefront: pairs to the screen {cur[27]/w:.1f} in {cur[29]/w:.2f} batches, decide batches {cur[28]/w:.2f}, bundles tried {cur[30]/w:.2f}", flush=True)
+    if ticks_only:
+        print(f"pass {P}: shader-clock ticks per wavefront and stage: " + ", ".join(f"{n} {v:.0f}" for n, v in zip(names, tk)) + f"; total {tk.sum():.0f}", flush=True)
     if cur[9:13].sum() == 1:
         q0 = int(cur[15])
         rec = eng._order_cache[1]
