@@ -23,7 +23,8 @@ for P in (1, 2, 3):
         print(f"pass {P}: wavefronts {cur[8]:.0f}, left over {cur[9:13].sum():.0f} (spread {cur[9]:.0f}, supers {cur[10]:.0f}, "
               f"clusters {cur[11]:.0f}, faces {cur[12]:.0f}); per wavefront: member spheres touched {cur[13]/w:.1f}, "
               f"faces past face_frame {cur[27]/w:.1f}, faces walked {cur[29]/w:.2f}, pairs queued {cur[14]/w:.1f}, "
-              f"decision batches {cur[28]/w:.2f}, bundles tried {cur[30]/w:.2f}; group kernel: queued clusters {cur[2]:.0f}", flush=True)
+              f"decision batches {cur[28]/w:.2f}, bundles tried {cur[30]/w:.2f}; group kernel: queued clusters {cur[2]:.0f}"
+              + (f"; pairs by surface: front {cur[21]/w:.1f}, back {cur[22]/w:.1f}, target {cur[23]/w:.1f}" if cur[21:24].sum() > 0 else ""), flush=True)
     names = ["ray load", "bundle", "level 0", "level 1", "level 2", "(before faces)", "face_frame + order",
              "face walk", "decisions", "epilogue", "not narrow"]
     if cur[8] == 0:
