@@ -243,9 +243,10 @@ def test_config1_single_pass_api():
                                np.sort([0.10188, 0.07819, 0.05531, 0.03297, 0.01096] * 2), atol=2e-5)
 
 
+@pytest.mark.parametrize("size_eps", [1e-10, 0.3])
 @pytest.mark.parametrize("seed,n_seg,n_arc,n_rays", [(1, 0, 300, 3000), (2, 500, 0, 3000),
                                                      (3, 257, 65, 6000), (4, 3, 2, 40000)])
-def test_bounding_circle_filter_never_loses_a_hit_on_random_soups(seed, n_seg, n_arc, n_rays):
+def test_bounding_circle_filter_never_loses_a_hit_on_random_soups(seed, n_seg, n_arc, n_rays, size_eps):
     """Random segments (all lengths) and arcs (all spans: tiny, > pi, wrapping through +-pi,
     negative radii), many of them grazed tangentially: the float32 bounding-circle filter in
     front of the exact tests must not change any hit, class or order (one pass, float64
@@ -302,10 +303,15 @@ def test_bounding_circle_filter_never_loses_a_hit_on_random_soups(seed, n_seg, n
         rays[2:, :k] = (p - 1.0 * tan).T
     wl = np.full(n_rays, 550.0)
     scene, _, _ = _gpu_scene(sets, wl)
+    # (size_epsilion = 0.3: segments accept hits up to 0.3 of their length beyond either end,
+    # engine.py:722-724 -- the bounding circles must grow with it)
+    scene.eps = (scene.eps[0], size_eps, scene.eps[2])
+    system = _oracle_system(sets)
+    system.eps = (system.eps[0], size_eps, system.eps[2])
     src = torch.tensor(rays, dtype=torch.float64, device=DEV)
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
     out = ops.trace2d(src, scene, max_passes=1, flags=flags)
-    ref = tracer.ray_trace(_oracle_system(sets), _src2(rays, wl, False), max_iterations=1,
+    ref = tracer.ray_trace(system, _src2(rays, wl, False), max_iterations=1,
                            inherit=("wavelength", "ray_id"),
                            flags=dict(compile_dead_rays=True, compile_stopped_rays=True))
     hit = 0
