@@ -1,16 +1,30 @@
-"""Register / LDS / scratch use of the kernels in a hipcc -S listing.  Usage: kres.py FILE.s [filter]"""
-import re, sys
-t = open(sys.argv[1]).read()
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
-for m in re.finditer(r'^([_A-Za-z0-9]+):\s*;\s*@\1\n', t, re.M):
-    name = m.group(1)
-    if flt not in name: continue
-    seg = t[m.end():]
-    e = seg.find('.end_amdhsa_kernel')
-    if e < 0: continue
-    k = seg[e:e + 2500]
-    def g(key):
-        r = re.search(r';\s*' + key + r':\s*(\d+)', k)
-        return r.group(1) if r else '?'
-    nins = sum(1 for l in seg[:e].split('\n') if l.startswith('\t') and not l.strip().startswith(('.', ';')))
-    print(f"{name[:70]:70s} vgpr {g('NumVgprs'):>4s} sgpr {g('NumSgprs'):>4s} scratch {g('ScratchSize'):>4s} lds {g('LDSByteSize'):>6s} occ {g('Occupancy'):>2s} instr {nins}")
+#!/usr/bin/env python3
+"""Compact per-kernel resource table of one csrc/*.hip file (hipcc -Rpass-analysis=kernel-resource-usage).
+usage: python scratch/kres.py tfrt_trace3d.hip [name-filter] [extra hipcc flags...]"""
+import os, re, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from tensorflowraytrace_amd import _build
+src = sys.argv[1]
+filt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ""
+extra = [a for a in sys.argv[2:] if a.startswith("-")]
+cmd = [_build._hipcc(), *_build.HIPCC_FLAGS, *extra, "-I", _build.INCLUDE, "-I", _build.CSRC, "-c",
+       os.path.join(_build.CSRC, src), "-o", "/tmp/kres.o", "-Rpass-analysis=kernel-resource-usage"]
+out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode()
+rows, cur = [], None
+for line in out.splitlines():
+    m = re.search(r"remark: [^:]+:\d+:\d+: +(.*?)(?: \[-Rpass)", line) or re.search(r"remark: +(.*?)(?: \[-Rpass)", line)
+    if not m:
+        if "error" in line: print(line)
+        continue
+    t = m.group(1).strip()
+    if t.startswith("Function Name:") or t.startswith("Name:"):
+        cur = {"name": t.split(":", 1)[1].strip()}; rows.append(cur)
+    elif cur is not None and ":" in t:
+        k, v = t.split(":", 1); cur[k.strip()] = v.strip()
+dem = subprocess.run(["/usr/bin/c++filt"] + [r["name"] for r in rows], stdout=subprocess.PIPE).stdout.decode().splitlines()
+print(f"{'kernel':58s} {'SGPR':>4s} {'VGPR':>4s} {'AGPR':>4s} {'vspill':>6s} {'sspill':>6s} {'scr':>4s} {'occ':>3s} {'LDS':>6s}")
+for r, d in zip(rows, dem):
+    d = re.sub(r"\(.*", "", d).replace("void tfrt::", "").replace("tfrt::", "")
+    if filt and filt not in d: continue
+    print(f"{d[:58]:58s} {r.get('TotalSGPRs','?'):>4s} {r.get('VGPRs','?'):>4s} {r.get('AGPRs','?'):>4s} {r.get('VGPR Spill', r.get('VGPRs Spill','?')):>6s} {r.get('SGPR Spill', r.get('SGPRs Spill','?')):>6s} {r.get('ScratchSize [bytes/lane]','?'):>4s} {r.get('Occupancy [waves/SIMD]','?'):>3s} {r.get('LDS Size [bytes/block]','?'):>6s}")

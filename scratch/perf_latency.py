@@ -12,4 +12,4 @@ for N in [int(a) for a in sys.argv[1:]]:
     torch.cuda.synchronize()
     buf = (ctypes.c_float * 4096)(); n = lib.tfrt_profile_read(buf, 4096); lib.tfrt_profile_enable(0)
     ms = np.array([buf[i] for i in range(n)]).reshape(-1, 3)
-    print(f"N={N:8d} env={os.environ.get('TFRT_GROUP_TARGET_BLOCKS','-'):>5s} per-pass us {np.round(np.median(ms,0)*1e3,1)}", flush=True)
+    print(f"N={N:8d} per-pass us {np.round(np.median(ms,0)*1e3,1)}", flush=True)

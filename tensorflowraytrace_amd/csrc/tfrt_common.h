@@ -49,6 +49,14 @@ __device__ __forceinline__ int rank_below(unsigned long long mask) {
                                         __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// Ordering point between LDS accesses of ONE wave that communicate across lanes.  The LDS
+// executes a wave's instructions in issue order, so no wait is needed; this only keeps the
+// compiler from moving memory accesses across it.
+__device__ __forceinline__ void wave_fence() {
+  __asm__ volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 inline int cdiv(int64_t a, int64_t b) { return static_cast<int>((a + b - 1) / b); }
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

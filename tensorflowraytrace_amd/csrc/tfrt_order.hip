@@ -1,0 +1,903 @@
+// Coherent ray order on the device, permutations of ray sets, and the way back.
+//
+// The reference's ray sets are ordered: every class lists, pass after pass, its rays in the order
+// of the source set (tfrt/engine.py:2069-2111 boolean_mask per pass, :1379-1403 the ray-set
+// properties, :2311-2330 ray_trace owns both).  The trace kernels are fastest when 64 consecutive
+// rays are neighbours in space (k_intersect_beam, tfrt_scene3d.coherent_rays).  This file is what
+// a caller needs to have both:
+//
+//   tfrt_ray_order      rays -> int32 permutation along a Hilbert curve through the points where
+//                       their lines pass the scene (k_order_xy, k_order_key, then a stable
+//                       two-pass LSD radix sort of (key, index) with digits of up to 13 bits)
+//   tfrt_permute_rays   ray block -> ray block in that order (through 8-element records, so the
+//                       random access is one read per ray instead of six)
+//   tfrt_gather_rows    any per-ray rows (n(lambda) table, goal rows, fields) through an index
+//   tfrt_restore_order  ray ids of one output class of a trace over permuted rays -> the row
+//                       permutation that puts the class back into the reference's order
+//                       (a bitmap over (pass, original id), a popcount scan, a rank per row)
+//
+// Nothing here allocates or synchronises; every launch has data-independent arguments, so the
+// calls can be captured into the graph of an optimiser step (a source re-drawn every step is
+// ordered every step).
+#include "tfrt_common.h"
+
+namespace tfrt {
+
+// ------------------------------------------------------------------------------ order keys
+
+constexpr int ORD_FACE_SAMPLES = 64;
+
+__device__ __forceinline__ unsigned enc_f(float f) {  // monotone float -> u32
+  const unsigned u = __float_as_uint(f);
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f(unsigned k) {
+  return __uint_as_float((k >> 31) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// sum of v[0..3] over the 256 threads of the block, the same on every run (a fixed tree)
+__device__ __forceinline__ void block_sum4(double v[4], double (*red)[4]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[tid][q] = v[q];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[tid][q] += red[tid + s][q];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = red[0][q];
+  __syncthreads();
+}
+
+struct OrderFrame {
+  double c[3], w[3], a[3], b[3];
+  int planar;
+};
+
+// Per ray: where its line passes the middle of the scene, as two coordinates (x, y) -- in the
+// plane perpendicular to the bundle's mean direction when the rays mostly share one, else the
+// octahedral map of its direction (an isotropic point source).  Every block derives the same
+// frame from the same samples (64 faces, 256 rays): no launch of its own, no atomics, the same
+// result on every run.  mm[0..3]: running minima of enc(x), ~enc(x), enc(y), ~enc(y).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, int64_t stride,
+                                                    int n, const double* __restrict__ fverts,
+                                                    int M, double ax0, double ax1, double ax2,
+                                                    int has_axis, float2* __restrict__ xy,
+                                                    unsigned* __restrict__ mm) {
+  __shared__ double red[BLOCK][4];
+  __shared__ OrderFrame fr;
+  __shared__ unsigned wmm[WAVES][4];
+  const int tid = threadIdx.x;
+  const int64_t is = n > 0 ? (int64_t)tid * n / BLOCK : 0;  // this thread's sample ray
+  double ss[3] = {0, 0, 0}, se[3] = {0, 0, 0};
+  if (n > 0) load_ray3(rays, stride, is, ss, se);
+  double acc[4] = {0, 0, 0, 0};
+  if (fverts != nullptr && M > 0) {
+    if (tid < ORD_FACE_SAMPLES) {
+      const double* f = fverts + 9 * ((int64_t)tid * M / ORD_FACE_SAMPLES);
+      acc[0] = (f[0] + f[3] + f[6]) / 3.0;
+      acc[1] = (f[1] + f[4] + f[7]) / 3.0;
+      acc[2] = (f[2] + f[5] + f[8]) / 3.0;
+      acc[3] = 1.0;
+      if (!(isfinite(acc[0]) && isfinite(acc[1]) && isfinite(acc[2]))) acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    }
+  } else if (n > 0 && isfinite(se[0]) && isfinite(se[1]) && isfinite(se[2])) {
+    acc[0] = se[0];
+    acc[1] = se[1];
+    acc[2] = se[2];
+    acc[3] = 1.0;
+  }
+  block_sum4(acc, red);
+  const double cn = acc[3] > 0.0 ? acc[3] : 1.0;
+  const double cx = acc[0] / cn, cy = acc[1] / cn, cz = acc[2] / cn;
+  double dir[4] = {0, 0, 0, 0};
+  if (!has_axis && n > 0) {
+    const double dx = se[0] - ss[0], dy = se[1] - ss[1], dz = se[2] - ss[2];
+    const double len = sqrt(dx * dx + dy * dy + dz * dz);
+    if (isfinite(len) && len > 0.0) {
+      dir[0] = dx / len;
+      dir[1] = dy / len;
+      dir[2] = dz / len;
+      dir[3] = 1.0;
+    }
+  }
+  block_sum4(dir, red);
+  if (tid == 0) {
+    double w[3] = {dir[0], dir[1], dir[2]};
+    double ng = dir[3] > 0.0 ? dir[3] : 1.0;
+    if (has_axis) {
+      w[0] = ax0;
+      w[1] = ax1;
+      w[2] = ax2;
+      ng = 1.0;
+    }
+    double wl = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (has_axis && wl > 0.0) ng = wl;  // (any length of a given axis counts as "one direction")
+    fr.c[0] = cx;
+    fr.c[1] = cy;
+    fr.c[2] = cz;
+    fr.planar = (wl > 0.5 * ng) ? 1 : 0;
+    if (fr.planar) {
+      w[0] /= wl;
+      w[1] /= wl;
+      w[2] /= wl;
+      int k = 0;
+      if (fabs(w[1]) < fabs(w[k])) k = 1;
+      if (fabs(w[2]) < fabs(w[k])) k = 2;
+      const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
+      double a[3] = {w[1] * e[2] - w[2] * e[1], w[2] * e[0] - w[0] * e[2], w[0] * e[1] - w[1] * e[0]};
+      const double al = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+      a[0] /= al;
+      a[1] /= al;
+      a[2] /= al;
+      fr.b[0] = w[1] * a[2] - w[2] * a[1];
+      fr.b[1] = w[2] * a[0] - w[0] * a[2];
+      fr.b[2] = w[0] * a[1] - w[1] * a[0];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        fr.w[q] = w[q];
+        fr.a[q] = a[q];
+      }
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * BLOCK + tid;
+  float x = __builtin_nanf(""), y = __builtin_nanf("");
+  if (i < n) {
+    double s[3], e[3];
+    load_ray3(rays, stride, i, s, e);
+    const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
+    const double len = sqrt(dx * dx + dy * dy + dz * dz);
+    if (isfinite(len) && len > 0.0) {
+      const double u[3] = {dx / len, dy / len, dz / len};
+      if (fr.planar) {
+        // foot of the perpendicular from the centre to the line, relative to the centre
+        const double t = (fr.c[0] - s[0]) * u[0] + (fr.c[1] - s[1]) * u[1] + (fr.c[2] - s[2]) * u[2];
+        const double p[3] = {s[0] + t * u[0] - fr.c[0], s[1] + t * u[1] - fr.c[1],
+                             s[2] + t * u[2] - fr.c[2]};
+        x = (float)(p[0] * fr.a[0] + p[1] * fr.a[1] + p[2] * fr.a[2]);
+        y = (float)(p[0] * fr.b[0] + p[1] * fr.b[1] + p[2] * fr.b[2]);
+      } else {
+        const double l1 = fabs(u[0]) + fabs(u[1]) + fabs(u[2]);
+        const double ox = u[0] / l1, oy = u[1] / l1, oz = u[2] / l1;
+        x = (float)(oz < 0.0 ? (1.0 - fabs(oy)) * (ox >= 0.0 ? 1.0 : -1.0) : ox);
+        y = (float)(oz < 0.0 ? (1.0 - fabs(ox)) * (oy >= 0.0 ? 1.0 : -1.0) : oy);
+      }
+      if (!(isfinite(x) && isfinite(y))) x = y = __builtin_nanf("");
+    }
+    xy[i] = make_float2(x, y);
+  }
+  // extents of the finite coordinates: wave minima by shuffles, then one atomic per block and value
+  const bool ok = x == x;
+  unsigned v[4] = {ok ? enc_f(x) : 0xFFFFFFFFu, ok ? ~enc_f(x) : 0xFFFFFFFFu,
+                   ok ? enc_f(y) : 0xFFFFFFFFu, ok ? ~enc_f(y) : 0xFFFFFFFFu};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v[q] = min(v[q], (unsigned)__shfl_xor((int)v[q], d, 64));
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wmm[tid >> 6][q] = v[q];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    unsigned m = wmm[0][tid];
+    for (int w = 1; w < WAVES; ++w) m = min(m, wmm[w][tid]);
+    if (m != 0xFFFFFFFFu) atomicMin(&mm[tid], m);
+  }
+}
+
+// Index of grid point (x, y), 0 <= x, y < 2^bits, along the Hilbert curve: unlike a Morton code
+// the curve has no jumps, so 64 consecutive rays cover a compact patch (a Morton order made the
+// 99th-percentile wavefront touch 136 faces instead of 18).
+__device__ __forceinline__ unsigned hilbert_index(unsigned x, unsigned y, int bits) {
+  unsigned d = 0;
+  const unsigned n1 = (1u << bits) - 1u;
+  for (unsigned s = 1u << (bits - 1); s > 0; s >>= 1) {
+    const unsigned rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+    d += s * s * ((3u * rx) ^ ry);
+    if (ry == 0u) {
+      if (rx == 1u) {
+        x = n1 - x;
+        y = n1 - y;
+      }
+      const unsigned t = x;
+      x = y;
+      y = t;
+    }
+  }
+  return d;
+}
+
+// keys + the histogram of their low digits per sort tile (tile = BLOCK * ITEMS consecutive rays)
+template <int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_order_key(const float2* __restrict__ xy, int n,
+                                                     const unsigned* __restrict__ mm, int bits,
+                                                     unsigned* __restrict__ keys,
+                                                     unsigned* __restrict__ hist, int nblk) {
+  extern __shared__ unsigned h_lds[];
+  const int tid = threadIdx.x;
+  const int bins = 1 << bits;
+  for (int d = tid; d < bins; d += BLOCK) h_lds[d] = 0u;
+  __syncthreads();
+  const float xlo = dec_f(mm[0]), xhi = dec_f(~mm[1]), ylo = dec_f(mm[2]), yhi = dec_f(~mm[3]);
+  const float g1 = (float)(bins - 1);
+  const float sx = xhi > xlo ? g1 / (xhi - xlo) : 0.f, sy = yhi > ylo ? g1 / (yhi - ylo) : 0.f;
+  const unsigned kmax = (bits >= 16) ? 0xFFFFFFFFu : ((1u << (2 * bits)) - 1u);
+  const int base = blockIdx.x * (BLOCK * ITEMS);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const int i = base + r * BLOCK + tid;
+    if (i < n) {
+      const float2 p = xy[i];
+      unsigned key = kmax;  // rays that are no line (zero length, non-finite): last
+      if (p.x == p.x) {
+        const float fx = fminf(fmaxf((p.x - xlo) * sx, 0.f), g1);
+        const float fy = fminf(fmaxf((p.y - ylo) * sy, 0.f), g1);
+        key = hilbert_index((unsigned)fx, (unsigned)fy, bits);
+      }
+      keys[i] = key;
+      atomicAdd(&h_lds[key & (unsigned)(bins - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)d * nblk + blockIdx.x] = h_lds[d];
+}
+
+// ------------------------------------------------------------------------------ radix sort
+//
+// Stable LSD radix sort of (key, value) pairs, two passes with digits of `bits` bits each
+// (bits <= 13: 8192 bins).  Per pass: tile histograms (digit-major: hist[d * nblk + tile]), an
+// exclusive scan of that array in chunks of 4096 + chunk totals, and the scatter: every tile ranks
+// its items (wave-wide match of the digit by ballots, a counter per wave and digit in LDS), sorts
+// them by digit in LDS and writes runs of equal digits to consecutive addresses.
+
+constexpr int SCAN_CHUNK = 4096;
+
+template <int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_sort_hist(const unsigned* __restrict__ keys, int n,
+                                                     int shift, int bits,
+                                                     unsigned* __restrict__ hist, int nblk) {
+  extern __shared__ unsigned h_lds[];
+  const int tid = threadIdx.x;
+  const int bins = 1 << bits;
+  for (int d = tid; d < bins; d += BLOCK) h_lds[d] = 0u;
+  __syncthreads();
+  const int base = blockIdx.x * (BLOCK * ITEMS);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const int i = base + r * BLOCK + tid;
+    if (i < n) atomicAdd(&h_lds[(keys[i] >> shift) & (unsigned)(bins - 1)], 1u);
+  }
+  __syncthreads();
+  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)d * nblk + blockIdx.x] = h_lds[d];
+}
+
+// exclusive prefix of `v` over the 256 threads of the block (wave scan + one LDS exchange);
+// returns the block total in *total
+__device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned* wsum, unsigned* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = (unsigned)__shfl_up((int)x, d, 64);
+    if (lane >= d) x += o;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) {
+    const unsigned s = wsum[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+// in place: data[i] <- sum of data[chunk start .. i), totals[chunk] <- the chunk's sum
+__global__ __launch_bounds__(BLOCK) void k_scan_chunks(unsigned* __restrict__ data, int64_t len,
+                                                       unsigned* __restrict__ totals) {
+  __shared__ unsigned wsum[WAVES];
+  constexpr int PER = SCAN_CHUNK / BLOCK;  // 16
+  const int64_t i0 = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * PER;
+  unsigned v[PER];
+  unsigned sum = 0;
+  if (i0 + PER <= len) {
+    const uint4* p = reinterpret_cast<const uint4*>(data + i0);
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) {
+      const uint4 x = p[q];
+      v[4 * q] = x.x;
+      v[4 * q + 1] = x.y;
+      v[4 * q + 2] = x.z;
+      v[4 * q + 3] = x.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) v[q] = (i0 + q < len) ? data[i0 + q] : 0u;
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const unsigned t = v[q];
+    v[q] = sum;
+    sum += t;
+  }
+  unsigned total;
+  const unsigned base = block_exclusive(sum, wsum, &total);
+  if (i0 + PER <= len) {
+    uint4* p = reinterpret_cast<uint4*>(data + i0);
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q)
+      p[q] = make_uint4(v[4 * q] + base, v[4 * q + 1] + base, v[4 * q + 2] + base, v[4 * q + 3] + base);
+  } else {
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      if (i0 + q < len) data[i0 + q] = v[q] + base;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
+// exclusive scan, in LDS, of `cnt` values loaded from `src` (every block does this for the chunk
+// totals: a few hundred values; saves a launch).  All 256 threads take part.
+__device__ __forceinline__ void lds_exclusive_from(const unsigned* __restrict__ src, int cnt,
+                                                   unsigned* dst, unsigned* wsum) {
+  const int per = (cnt + BLOCK - 1) / BLOCK;
+  const int lo = threadIdx.x * per;
+  unsigned sum = 0;
+  for (int q = 0; q < per; ++q) {
+    const int i = lo + q;
+    const unsigned t = i < cnt ? src[i] : 0u;
+    if (i < cnt) dst[i] = sum;
+    sum += t;
+  }
+  unsigned total;
+  const unsigned base = block_exclusive(sum, wsum, &total);
+  for (int q = 0; q < per; ++q) {
+    const int i = lo + q;
+    if (i < cnt) dst[i] += base;
+  }
+  __syncthreads();
+}
+
+// One pass of the sort for one tile.  FIRST: the values are the items' own indices (not read);
+// LAST: keys are not written.  Dynamic LDS: cnt u16 [WAVES][bins] | delta i32 [bins] |
+// stage_k u32 [TILE] | stage_v i32 [TILE] | cbase u32 [nchunks].
+template <int ITEMS, bool FIRST, bool LAST>
+__global__ __launch_bounds__(BLOCK) void k_sort_scatter(
+    const unsigned* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int n, int shift,
+    int bits, const unsigned* __restrict__ hist, int nblk, const unsigned* __restrict__ totals,
+    int nchunks, unsigned* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+  constexpr int TILE = BLOCK * ITEMS;
+  extern __shared__ unsigned lds[];
+  __shared__ unsigned wsum[WAVES];
+  const int bins = 1 << bits;
+  uint16_t* cnt = reinterpret_cast<uint16_t*>(lds);                    // [WAVES][bins]
+  int32_t* delta = reinterpret_cast<int32_t*>(lds + (WAVES * bins) / 2);  // [bins]
+  unsigned* stage_k = lds + (WAVES * bins) / 2 + bins;
+  int32_t* stage_v = reinterpret_cast<int32_t*>(stage_k + TILE);
+  unsigned* cbase = stage_k + 2 * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int base = blockIdx.x * TILE;
+  const int wbase = base + wave * (64 * ITEMS);
+  const unsigned dmask = (unsigned)(bins - 1);
+
+  unsigned key[ITEMS];
+  int32_t val[ITEMS];
+  unsigned dr[ITEMS];  // digit | rank << 16
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const int i = wbase + r * 64 + lane;
+    const bool ok = i < n;
+    key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
+    if constexpr (FIRST) val[r] = i;
+    else val[r] = ok ? vals_in[i] : 0;
+    // (a slot past the end ranks as the largest digit: it is also last by position, so it ends
+    // up behind every item of the tile and is simply not written)
+    dr[r] = ok ? ((key[r] >> shift) & dmask) : dmask;
+  }
+  for (int w = tid; w < (WAVES * bins) / 2; w += BLOCK) lds[w] = 0u;
+  lds_exclusive_from(totals, nchunks, cbase, wsum);  // (ends with a barrier)
+
+  // rank of every item among the items of its wave with the same digit (stable: rounds in
+  // order, lanes in order)
+  uint16_t* my = cnt + wave * bins;
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const unsigned d = dr[r];
+    unsigned long long m = ~0ull;
+    for (int b = 0; b < bits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const int below = rank_below(m);
+    const unsigned c = my[d];
+    wave_fence();
+    if (below == 0) my[d] = (uint16_t)(c + (unsigned)__popcll(m));
+    wave_fence();
+    dr[r] = d | ((c + (unsigned)below) << 16);
+  }
+  __syncthreads();
+
+  // start of every (digit, wave) run within the tile, and the digit's distance to its place in
+  // the output
+  {
+    const int per = bins >= BLOCK ? bins / BLOCK : 1;
+    const int d0 = tid * per;
+    unsigned tsum = 0;
+    if (d0 < bins) {
+      for (int q = 0; q < per; ++q) {
+        const int d = d0 + q;
+        unsigned run = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+          const unsigned c = cnt[w * bins + d];
+          cnt[w * bins + d] = (uint16_t)run;
+          run += c;
+        }
+        delta[d] = (int32_t)run;  // (the digit's count, for now)
+        tsum += run;
+      }
+    }
+    unsigned total;
+    unsigned dbase = block_exclusive(tsum, wsum, &total);
+    if (d0 < bins) {
+      for (int q = 0; q < per; ++q) {
+        const int d = d0 + q;
+        const unsigned c = (unsigned)delta[d];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) cnt[w * bins + d] = (uint16_t)(cnt[w * bins + d] + dbase);
+        const int64_t at = (int64_t)d * nblk + blockIdx.x;
+        const unsigned goff = cbase[at / SCAN_CHUNK] + hist[at];
+        delta[d] = (int32_t)goff - (int32_t)dbase;
+        dbase += c;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const unsigned d = dr[r] & 0xFFFFu;
+    const int pos = (int)cnt[wave * bins + d] + (int)(dr[r] >> 16);
+    stage_k[pos] = key[r];
+    stage_v[pos] = val[r];
+  }
+  __syncthreads();
+  const int nvalid = min(TILE, n - base);
+  for (int p = tid; p < nvalid; p += BLOCK) {
+    const unsigned k = stage_k[p];
+    const int dest = p + delta[(k >> shift) & dmask];
+    if constexpr (!LAST) keys_out[dest] = k;
+    vals_out[dest] = stage_v[p];
+  }
+}
+
+// ------------------------------------------------------------------------------ permutations
+
+template <int BYTES>
+struct Vec;
+template <>
+struct Vec<16> { using type = uint4; };
+template <>
+struct Vec<32> { struct alignas(16) type { uint4 a, b; }; };
+template <>
+struct Vec<64> { struct alignas(16) type { uint4 a, b, c, d; }; };
+
+// ray block (SoA) -> records of 8 elements (six used), one ray each
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_rays_to_records(const T* __restrict__ rays,
+                                                           int64_t stride, int n,
+                                                           T* __restrict__ rec) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  using V = typename Vec<8 * sizeof(T)>::type;
+  T e[8];
+  V v;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) e[q] = rays[q * stride + i];
+  e[6] = e[7] = T(0);
+  __builtin_memcpy(&v, e, sizeof(V));
+  reinterpret_cast<V*>(rec)[i] = v;
+}
+
+// records, through an index -> ray block: dst[:, j] = record[index[j]]
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_records_to_rays(const T* __restrict__ rec,
+                                                           const int32_t* __restrict__ index,
+                                                           int n, T* __restrict__ dst,
+                                                           int64_t dstride) {
+  const int j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  using V = typename Vec<8 * sizeof(T)>::type;
+  T e[8];
+  const V v = reinterpret_cast<const V*>(rec)[index[j]];
+  __builtin_memcpy(e, &v, sizeof(V));
+#pragma unroll
+  for (int q = 0; q < 6; ++q) dst[q * dstride + j] = e[q];
+}
+
+// dst[k][j] = src[k][index[j]], k < rows (elements of E bytes)
+template <typename E>
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(const E* __restrict__ src, int64_t sstride,
+                                                       int rows, const int32_t* __restrict__ index,
+                                                       int64_t n, E* __restrict__ dst,
+                                                       int64_t dstride) {
+  const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const int64_t i = index[j];
+  for (int k = 0; k < rows; ++k) dst[k * dstride + j] = src[k * sstride + i];
+}
+
+// ------------------------------------------------------------------------------ the way back
+//
+// One output class of a trace over permuted rays lists, pass after pass, the rays of that pass in
+// the PERMUTED order; the reference lists them by original index.  Rows carry unique keys
+// (pass, original id): set the key's bit in a bitmap, scan the words' popcounts, and a row's place
+// is the number of bits before its own -- a counting sort, three small launches.
+
+struct Segments {  // the passes' rows of one class: n_seg segments [base, base + n)
+  const int32_t* n;
+  const int32_t* base;
+  int32_t stride, n_seg;
+  const int32_t* total;  // rows of the class (device), or NULL: `rows`
+  int32_t rows;
+};
+
+constexpr int SEG_LDS = 1024;
+
+// segment of row r (binary search over the bases); -1: r is past the last row
+__device__ __forceinline__ int segment_of(const Segments& sg, const int32_t* sbase,
+                                          const int32_t* sn, int r) {
+  if (sg.n == nullptr) return r < sg.rows ? 0 : -1;
+  int lo = 0, hi = sg.n_seg - 1;
+  while (lo < hi) {  // last segment with base <= r
+    const int mid = (lo + hi + 1) >> 1;
+    if (sbase[mid] <= r) lo = mid;
+    else hi = mid - 1;
+  }
+  // (empty segments share their base with the next one: step to the one that holds r)
+  while (lo < sg.n_seg && r >= sbase[lo] + sn[lo]) ++lo;
+  return lo < sg.n_seg ? lo : -1;
+}
+
+template <int STAGE>  // 0: mark bits, 1: place rows
+__global__ __launch_bounds__(BLOCK) void k_restore_rows(
+    Segments sg, const int32_t* __restrict__ ray_id, const int32_t* __restrict__ perm, int n_src,
+    int wn, uint2* __restrict__ words, const unsigned* __restrict__ totals, int nchunks,
+    int32_t* __restrict__ inv, int32_t* __restrict__ dest_of, int32_t* __restrict__ id_out) {
+  extern __shared__ unsigned lds[];
+  __shared__ unsigned wsum[WAVES];
+  __shared__ int32_t sbase[SEG_LDS], sn[SEG_LDS];
+  const int nseg = sg.n == nullptr ? 0 : min(sg.n_seg, SEG_LDS);
+  for (int k = threadIdx.x; k < nseg; k += BLOCK) {
+    sbase[k] = sg.base[(int64_t)k * sg.stride];
+    sn[k] = sg.n[(int64_t)k * sg.stride];
+  }
+  if constexpr (STAGE == 1) lds_exclusive_from(totals, nchunks, lds, wsum);
+  else __syncthreads();
+  const int rows = sg.total != nullptr ? *sg.total : sg.rows;
+  const int r = blockIdx.x * BLOCK + threadIdx.x;
+  if (r >= rows) return;
+  Segments s2 = sg;
+  s2.n_seg = nseg;
+  const int p = segment_of(s2, sbase, sn, r);
+  if (p < 0) return;
+  const int id = ray_id[r];
+  const int orig = perm != nullptr ? perm[id] : id;
+  const int64_t w = (int64_t)p * wn + (orig >> 5);
+  const unsigned bit = 1u << (orig & 31);
+  if constexpr (STAGE == 0) {
+    atomicOr(&words[w].x, bit);
+  } else {
+    const uint2 wd = words[w];
+    const int dest = (int)(lds[w / SCAN_CHUNK] + wd.y + (unsigned)__popc(wd.x & (bit - 1u)));
+    if (inv != nullptr) inv[dest] = r;
+    if (dest_of != nullptr) dest_of[r] = dest;
+    if (id_out != nullptr) id_out[dest] = orig;
+  }
+}
+
+// words[i].y <- popcounts of words[chunk start .. i).x, totals[chunk] <- the chunk's popcount
+__global__ __launch_bounds__(BLOCK) void k_restore_scan(uint2* __restrict__ words, int64_t len,
+                                                        unsigned* __restrict__ totals) {
+  __shared__ unsigned wsum[WAVES];
+  constexpr int PER = SCAN_CHUNK / BLOCK;
+  const int64_t i0 = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * PER;
+  unsigned v[PER];
+  unsigned sum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const unsigned c = (i0 + q < len) ? (unsigned)__popc(words[i0 + q].x) : 0u;
+    v[q] = sum;
+    sum += c;
+  }
+  unsigned total;
+  const unsigned base = block_exclusive(sum, wsum, &total);
+#pragma unroll
+  for (int q = 0; q < PER; ++q)
+    if (i0 + q < len) words[i0 + q].y = v[q] + base;
+  if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------ host side
+
+static int order_bits(int64_t n) {
+  int lg = 0;
+  while ((1ll << lg) < n) ++lg;       // ceil(log2 n)
+  int b = (lg + 2 + 1) / 2;           // about four cells per ray
+  if (b < 4) b = 4;
+  if (b > 13) b = 13;
+  return b;
+}
+static int order_items(int64_t n) { return n < (300 << 10) ? 4 : (n < (3 << 20) ? 8 : 16); }
+
+struct OrderLayout {
+  size_t head, xy, keys_a, keys_b, vals_a, hist, totals, total;
+  int bits, items, nblk, nchunks;
+};
+
+static OrderLayout order_layout(int64_t n) {
+  OrderLayout L;
+  const size_t m = n > 0 ? (size_t)n : 1;
+  L.bits = order_bits(n);
+  L.items = order_items(n);
+  L.nblk = cdiv((int64_t)m, (int64_t)BLOCK * L.items);
+  const int64_t hlen = (int64_t)(1 << L.bits) * L.nblk;
+  L.nchunks = cdiv(hlen, SCAN_CHUNK);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes);
+    return at;
+  };
+  L.head = take(64);
+  L.xy = take(m * sizeof(float2));
+  L.keys_a = take(m * sizeof(unsigned));
+  L.keys_b = take(m * sizeof(unsigned));
+  L.vals_a = take(m * sizeof(int32_t));
+  L.hist = take((size_t)hlen * sizeof(unsigned));
+  L.totals = take((size_t)L.nchunks * sizeof(unsigned));
+  L.total = o;
+  return L;
+}
+
+static size_t scatter_lds_bytes(int bits, int items, int nchunks) {
+  const size_t bins = (size_t)1 << bits;
+  return (WAVES * bins) * 2 + bins * 4 + (size_t)BLOCK * items * 8 + (size_t)nchunks * 4;
+}
+
+template <int ITEMS>
+static int sort_passes(const OrderLayout& L, char* ws, int n, int32_t* perm, unsigned* keys_nat,
+                       hipStream_t st) {
+  unsigned* keys_b = reinterpret_cast<unsigned*>(ws + L.keys_b);
+  int32_t* vals_a = reinterpret_cast<int32_t*>(ws + L.vals_a);
+  unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
+  unsigned* totals = reinterpret_cast<unsigned*>(ws + L.totals);
+  const int bins = 1 << L.bits;
+  const int64_t hlen = (int64_t)bins * L.nblk;
+  const size_t lds = scatter_lds_bytes(L.bits, ITEMS, L.nchunks);
+  if (lds > 160 * 1024) return TFRT_E_UNSUPPORTED;
+  // pass 0 (its histogram came with the keys)
+  hipLaunchKernelGGL(k_scan_chunks, dim3(L.nchunks), dim3(BLOCK), 0, st, hist, hlen, totals);
+  hipLaunchKernelGGL((k_sort_scatter<ITEMS, true, false>), dim3(L.nblk), dim3(BLOCK), lds, st,
+                     keys_nat, static_cast<const int32_t*>(nullptr), n, 0, L.bits, hist, L.nblk,
+                     totals, L.nchunks, keys_b, vals_a);
+  // pass 1
+  hipLaunchKernelGGL((k_sort_hist<ITEMS>), dim3(L.nblk), dim3(BLOCK), bins * sizeof(unsigned), st,
+                     keys_b, n, L.bits, L.bits, hist, L.nblk);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(L.nchunks), dim3(BLOCK), 0, st, hist, hlen, totals);
+  hipLaunchKernelGGL((k_sort_scatter<ITEMS, false, true>), dim3(L.nblk), dim3(BLOCK), lds, st,
+                     keys_b, vals_a, n, L.bits, L.bits, hist, L.nblk, totals, L.nchunks,
+                     static_cast<unsigned*>(nullptr), perm);
+  return 0;
+}
+
+template <typename T>
+static int ray_order_t(const void* rays, int64_t stride, int64_t N, const double* fverts,
+                       int64_t M, const double* axis, int32_t* perm, uint32_t* keys_out,
+                       char* ws, const OrderLayout& L, hipStream_t st) {
+  const int n = (int)N;
+  unsigned* mm = reinterpret_cast<unsigned*>(ws + L.head);
+  float2* xy = reinterpret_cast<float2*>(ws + L.xy);
+  unsigned* keys = keys_out != nullptr ? keys_out : reinterpret_cast<unsigned*>(ws + L.keys_a);
+  unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
+  (void)hipMemsetAsync(mm, 0xFF, 16, st);
+  hipLaunchKernelGGL((k_order_xy<T>), dim3(cdiv(N, BLOCK)), dim3(BLOCK), 0, st,
+                     static_cast<const T*>(rays), stride, n, fverts, (int)M,
+                     axis ? axis[0] : 0.0, axis ? axis[1] : 0.0, axis ? axis[2] : 0.0,
+                     axis ? 1 : 0, xy, mm);
+  const size_t hl = ((size_t)1 << L.bits) * sizeof(unsigned);
+  int rc = 0;
+#define TFRT_ORDER_ITEMS(I)                                                                       \
+  {                                                                                               \
+    hipLaunchKernelGGL((k_order_key<I>), dim3(L.nblk), dim3(BLOCK), hl, st, xy, n, mm, L.bits,    \
+                       keys, hist, L.nblk);                                                       \
+    rc = sort_passes<I>(L, ws, n, perm, keys, st);                                                \
+  }
+  if (L.items == 4) TFRT_ORDER_ITEMS(4)
+  else if (L.items == 8) TFRT_ORDER_ITEMS(8)
+  else TFRT_ORDER_ITEMS(16)
+#undef TFRT_ORDER_ITEMS
+  return rc;
+}
+
+template <typename T>
+static void permute_rays_t(const void* src, int64_t sstride, int64_t n, const int32_t* perm,
+                           void* dst, int64_t dstride, void* ws, hipStream_t st) {
+  T* rec = static_cast<T*>(ws);
+  hipLaunchKernelGGL((k_rays_to_records<T>), dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, st,
+                     static_cast<const T*>(src), sstride, (int)n, rec);
+  hipLaunchKernelGGL((k_records_to_rays<T>), dim3(cdiv(n, BLOCK)), dim3(BLOCK), 0, st, rec, perm,
+                     (int)n, static_cast<T*>(dst), dstride);
+}
+
+struct RestoreLayout {
+  size_t words, totals, total;
+  int wn, nchunks;
+  int64_t len;
+};
+static RestoreLayout restore_layout(int64_t n_src, int64_t n_seg) {
+  RestoreLayout L;
+  L.wn = (int)((n_src + 31) / 32);
+  if (L.wn < 1) L.wn = 1;
+  L.len = (int64_t)L.wn * (n_seg > 0 ? n_seg : 1);
+  L.nchunks = cdiv(L.len, SCAN_CHUNK);
+  L.words = 0;
+  L.totals = align_up((size_t)L.len * sizeof(uint2));
+  L.total = L.totals + align_up((size_t)L.nchunks * sizeof(unsigned));
+  return L;
+}
+
+}  // namespace tfrt
+
+// ================================================================================ C ABI
+using namespace tfrt;
+
+extern "C" {
+
+size_t tfrt_ray_order_workspace_bytes(int64_t n_rays) { return order_layout(n_rays).total; }
+
+int tfrt_ray_order(const void* rays, int64_t stride, int64_t n_rays, int32_t state_dtype,
+                   const double* face_verts, int64_t n_faces, const double* axis, int32_t* perm,
+                   uint32_t* keys_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_rays < 0 || n_rays >= (1ll << 31) || n_faces < 0 || n_faces >= (1ll << 31))
+    return TFRT_E_BADARG;
+  if (n_rays == 0) return 0;
+  if (!rays || !perm || !workspace || stride < n_rays) return TFRT_E_BADARG;
+  const OrderLayout L = order_layout(n_rays);
+  if (workspace_bytes < L.total) return TFRT_E_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  int rc;
+  switch (state_dtype) {
+    case TFRT_F32:
+      rc = ray_order_t<float>(rays, stride, n_rays, face_verts, n_faces, axis, perm, keys_out, ws, L, st);
+      break;
+    case TFRT_F64:
+      rc = ray_order_t<double>(rays, stride, n_rays, face_verts, n_faces, axis, perm, keys_out, ws, L, st);
+      break;
+    case TFRT_F16:
+      rc = ray_order_t<_Float16>(rays, stride, n_rays, face_verts, n_faces, axis, perm, keys_out, ws, L, st);
+      break;
+    default:
+      return TFRT_E_BADARG;
+  }
+  if (rc != 0) return rc;
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+size_t tfrt_permute_rays_workspace_bytes(int64_t n_rays, int32_t state_dtype) {
+  const size_t esz = state_dtype == TFRT_F64 ? 8 : (state_dtype == TFRT_F16 ? 2 : 4);
+  return align_up((size_t)(n_rays > 0 ? n_rays : 1) * 8 * esz);
+}
+
+int tfrt_permute_rays(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                      int32_t state_dtype, const int32_t* index, void* dst_rays,
+                      int64_t dst_stride, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_rays < 0 || n_rays >= (1ll << 31)) return TFRT_E_BADARG;
+  if (n_rays == 0) return 0;
+  if (!src_rays || !dst_rays || !index || !workspace || src_stride < n_rays || dst_stride < n_rays)
+    return TFRT_E_BADARG;
+  if (workspace_bytes < tfrt_permute_rays_workspace_bytes(n_rays, state_dtype))
+    return TFRT_E_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (state_dtype) {
+    case TFRT_F32:
+      permute_rays_t<float>(src_rays, src_stride, n_rays, index, dst_rays, dst_stride, workspace, st);
+      break;
+    case TFRT_F64:
+      permute_rays_t<double>(src_rays, src_stride, n_rays, index, dst_rays, dst_stride, workspace, st);
+      break;
+    case TFRT_F16:
+      permute_rays_t<_Float16>(src_rays, src_stride, n_rays, index, dst_rays, dst_stride, workspace, st);
+      break;
+    default:
+      return TFRT_E_BADARG;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_gather_rows(const void* src, int64_t src_stride, int32_t n_rows, int32_t elem_bytes,
+                     const int32_t* index, int64_t n, void* dst, int64_t dst_stride,
+                     void* stream) {
+  if (n < 0 || n_rows < 0) return TFRT_E_BADARG;
+  if (n == 0 || n_rows == 0) return 0;
+  if (!src || !dst || !index) return TFRT_E_BADARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid(cdiv(n, BLOCK));
+  switch (elem_bytes) {
+    case 1:
+      hipLaunchKernelGGL((k_gather_rows<uint8_t>), grid, dim3(BLOCK), 0, st,
+                         static_cast<const uint8_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<uint8_t*>(dst), dst_stride);
+      break;
+    case 2:
+      hipLaunchKernelGGL((k_gather_rows<uint16_t>), grid, dim3(BLOCK), 0, st,
+                         static_cast<const uint16_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<uint16_t*>(dst), dst_stride);
+      break;
+    case 4:
+      hipLaunchKernelGGL((k_gather_rows<uint32_t>), grid, dim3(BLOCK), 0, st,
+                         static_cast<const uint32_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<uint32_t*>(dst), dst_stride);
+      break;
+    case 8:
+      hipLaunchKernelGGL((k_gather_rows<uint64_t>), grid, dim3(BLOCK), 0, st,
+                         static_cast<const uint64_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<uint64_t*>(dst), dst_stride);
+      break;
+    default:
+      return TFRT_E_BADARG;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+size_t tfrt_restore_order_workspace_bytes(int64_t n_src, int32_t n_segments) {
+  return restore_layout(n_src, n_segments).total;
+}
+
+int tfrt_restore_order(const int32_t* ray_id, int64_t n_rows, const int32_t* seg_n,
+                       const int32_t* seg_base, int32_t seg_stride, int32_t n_segments,
+                       const int32_t* total_rows, const int32_t* perm, int64_t n_src,
+                       int32_t* inv, int32_t* dest_of, int32_t* ray_id_out, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  if (n_rows < 0 || n_rows >= (1ll << 31) || n_src < 0 || n_src >= (1ll << 31))
+    return TFRT_E_BADARG;
+  if (n_rows == 0) return 0;
+  if (!ray_id || !workspace) return TFRT_E_BADARG;
+  const bool segs = seg_n != nullptr && seg_base != nullptr;
+  if (segs && (n_segments < 1 || n_segments > SEG_LDS || seg_stride < 1)) return TFRT_E_UNSUPPORTED;
+  const RestoreLayout L = restore_layout(n_src, segs ? n_segments : 1);
+  if (workspace_bytes < L.total) return TFRT_E_WORKSPACE;
+  if ((size_t)L.nchunks * 4 > 96 * 1024) return TFRT_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  uint2* words = reinterpret_cast<uint2*>(ws + L.words);
+  unsigned* totals = reinterpret_cast<unsigned*>(ws + L.totals);
+  Segments sg;
+  sg.n = segs ? seg_n : nullptr;
+  sg.base = segs ? seg_base : nullptr;
+  sg.stride = seg_stride;
+  sg.n_seg = segs ? n_segments : 1;
+  sg.total = total_rows;
+  sg.rows = (int32_t)n_rows;
+  (void)hipMemsetAsync(words, 0, (size_t)L.len * sizeof(uint2), st);
+  const dim3 grid(cdiv(n_rows, BLOCK));
+  hipLaunchKernelGGL((k_restore_rows<0>), grid, dim3(BLOCK), 0, st, sg, ray_id, perm, (int)n_src,
+                     L.wn, words, totals, L.nchunks, inv, dest_of, ray_id_out);
+  hipLaunchKernelGGL(k_restore_scan, dim3(L.nchunks), dim3(BLOCK), 0, st, words, L.len, totals);
+  hipLaunchKernelGGL((k_restore_rows<1>), grid, dim3(BLOCK), (size_t)L.nchunks * 4, st, sg, ray_id,
+                     perm, (int)n_src, L.wn, words, totals, L.nchunks, inv, dest_of, ray_id_out);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+}  // extern "C"

@@ -728,13 +728,6 @@ __device__ __forceinline__ double dkey_inv(unsigned long long k) {
   const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
   return __longlong_as_double((long long)b);
 }
-// Ordering point between LDS accesses of ONE wave that communicate across lanes.  The LDS
-// executes a wave's instructions in issue order, so no wait is needed; this only keeps the
-// compiler from moving memory accesses across it.
-__device__ __forceinline__ void wave_fence() {
-  __asm__ volatile("" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // class byte of the tape: bits 0-1 the ray class, bits 2-3 the branches of the forward reaction
 constexpr int TAPE_INTERNAL = 4, TAPE_REFLECT = 8;
@@ -758,8 +751,10 @@ __device__ __forceinline__ void shift_in_le(unsigned& acc, const float q, const 
 // larger share of a wave's life, 0.809 ms against 0.826 (the four-wave configuration kept a copy of
 // the rays in LDS and a 1024-entry list).
 // (only the shipped one-ray-per-lane instantiation: 2 or 4 rays per lane need more LDS than that)
-#define TFRT_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(R == 1 ? 5 : 1, R == 1 ? 5 : 8)))
-template <typename T, int R>
+#define TFRT_GROUP_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
+// ORD: the wave does one wavefront that k_intersect_beam has left (k_intersect_group_left); a
+// compile-time switch, so that the natural-order kernel keeps its register budget
+template <typename T, int R, bool ORD>
 __device__ __forceinline__ void group_walk(
     const T* __restrict__ rays, int64_t stride, const int n,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
@@ -779,7 +774,7 @@ __device__ __forceinline__ void group_walk(
   // Coherent-ray traces (R == 1 only): this wave does wavefront `qwave` -- one that
   // k_intersect_beam has left to this kernel -- i.e. rays 64 qwave ... 64 qwave + 63.  qwave < 0:
   // nothing; the wave still walks the tiles with its block (the staging barriers), without tests.
-  const bool ordered = hist != nullptr;
+  constexpr bool ordered = ORD;
   const bool idle_wave = ordered && qwave < 0;
   if (!ordered && base >= n) return;  // block-uniform
   // ray of slot r * 64 + lane of this wave (-1: none)
@@ -1285,7 +1280,7 @@ __device__ __forceinline__ void group_walk(
   }
 }
 
-template <typename T, int R>
+template <typename T>
 __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
@@ -1296,26 +1291,39 @@ __global__ __launch_bounds__(BLOCK) TFRT_GROUP_ATTR void k_intersect_group(
     double eps_int, double eps_size, double eps_start, double* __restrict__ part_t,
     int32_t* __restrict__ part_i, int64_t part_stride, const int32_t* __restrict__ catagory,
     int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
-    int32_t* __restrict__ blockcnt, const int32_t* __restrict__ left_list,
-    const int32_t* __restrict__ left_count, int32_t* __restrict__ hist) {
+    int32_t* __restrict__ blockcnt) {
+  // one workgroup per 256 rays
+  group_walk<T, 1, false>(rays, stride, *n_ptr, last_tri, susphere, clsphere, csphere, crec, cface,
+                          fverts, c0, prep, pstride, n_clusters, chunk_clusters, eps_int, eps_size,
+                          eps_start, part_t, part_i, part_stride, catagory, rec_tri, rec_t, rec_cls,
+                          blockcnt, nullptr, (int)blockIdx.x * BLOCK, -1);
+}
+
+// Coherent-ray traces: the wavefronts k_intersect_beam has left (usually none: the workgroups read
+// one counter and retire), four per workgroup and round.  A kernel of its own: the loop and the
+// list arguments cost the natural-order kernel 25 vector and 78 scalar register spills at its five
+// waves per SIMD when both lived in one body.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_intersect_group_left(
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
+    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
+    const float4* __restrict__ crec, const int32_t* __restrict__ cface,
+    const double* __restrict__ fverts, const double* __restrict__ c0, int n_clusters,
+    int chunk_clusters, double eps_int, double eps_size, double eps_start,
+    const int32_t* __restrict__ catagory, int32_t* __restrict__ rec_tri,
+    double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
+    const int32_t* __restrict__ left_list, const int32_t* __restrict__ left_count,
+    int32_t* __restrict__ hist) {
   const int n = *n_ptr;
-  if (hist == nullptr) {  // one workgroup per 256 R rays
-    group_walk<T, R>(rays, stride, n, last_tri, susphere, clsphere, csphere, crec, cface, fverts,
-                     c0, prep, pstride, n_clusters, chunk_clusters, eps_int, eps_size, eps_start,
-                     part_t, part_i, part_stride, catagory, rec_tri, rec_t, rec_cls, blockcnt,
-                     nullptr, (int)blockIdx.x * (BLOCK * R), -1);
-    return;
-  }
-  // coherent-ray traces: the wavefronts k_intersect_beam has left (usually none: the workgroups
-  // read one counter and retire), four per workgroup and round
   const int total = *left_count;
   for (int item = blockIdx.x; item * WAVES < total; item += gridDim.x) {
     const int k = item * WAVES + (int)(threadIdx.x >> 6);
     const int qwave = k < total ? left_list[k] : -1;
-    group_walk<T, R>(rays, stride, n, last_tri, susphere, clsphere, csphere, crec, cface, fverts,
-                     c0, prep, pstride, n_clusters, chunk_clusters, eps_int, eps_size, eps_start,
-                     part_t, part_i, part_stride, catagory, rec_tri, rec_t, rec_cls, blockcnt,
-                     hist, 0, qwave);
+    group_walk<T, 1, true>(rays, stride, n, last_tri, susphere, clsphere, csphere, crec, cface,
+                           fverts, c0, nullptr, 0, n_clusters, chunk_clusters, eps_int, eps_size,
+                           eps_start, nullptr, nullptr, 0, catagory, rec_tri, rec_t, rec_cls,
+                           nullptr, hist, 0, qwave);
     __syncthreads();  // (the next round reuses the LDS tile and lists)
   }
 }
@@ -2823,8 +2831,8 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_seam(
 
 struct Plan3 {
   int R, ray_blocks, chunks, chunk_faces, nblk;
-  // grouped (two-level) kernel: rays per lane, grid and clusters per chunk
-  int gR, g_blocks, g_chunks, g_chunk_clusters;
+  // grouped (two-level) kernel: grid and clusters per chunk
+  int g_blocks, g_chunks, g_chunk_clusters;
 };
 
 // device buffers of the hierarchy for one trace (order == nullptr: all-pairs filter)
@@ -2841,13 +2849,8 @@ struct Accel3 {
 static Plan3 make_plan(int64_t N, int64_t M) {
   Plan3 p;
   p.R = (N >= 32768) ? 4 : (N >= 8192 ? 2 : 1);
-  if (const char* env = getenv("TFRT_RAYS_PER_LANE")) {
-    const int r = atoi(env);
-    if (r == 1 || r == 2 || r == 4) p.R = r;
-  }
   p.ray_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.R);
   int target = 4096;  // ~16 workgroups per CU on 256 CUs (measured best: finer tail)
-  if (const char* env = getenv("TFRT_TARGET_BLOCKS")) target = atoi(env) > 0 ? atoi(env) : target;
   int chunks = cdiv(target, p.ray_blocks);
   const int max_chunks = cdiv(M > 0 ? M : 1, 256);
   if (chunks > max_chunks) chunks = max_chunks;
@@ -2857,19 +2860,14 @@ static Plan3 make_plan(int64_t N, int64_t M) {
   p.nblk = cdiv(N > 0 ? N : 1, BLOCK);
   // grouped kernel: level 1 is 16x shorter, so favour more workgroups over rays per lane
   const int n_clusters = cdiv(M > 0 ? M : 1, 16);
-  p.gR = 1;  // measured: one ray per lane wins at every size (16M rays: 11.9 vs 17.7 ms for 2;
-             // more rays per lane cost LDS, i.e. workgroups per CU); 2 / 4 stay selectable
-  if (const char* env = getenv("TFRT_GROUP_RAYS_PER_LANE")) {
-    const int r = atoi(env);
-    if (r == 1 || r == 2 || r == 4) p.gR = r;
-  }
-  p.g_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK * p.gR);
+  // (one ray per lane: measured to win at every size -- 16M rays: 11.9 vs 17.7 ms for 2; more rays
+  // per lane cost LDS, i.e. workgroups per CU)
+  p.g_blocks = cdiv(N > 0 ? N : 1, (int64_t)BLOCK);
   // One cluster chunk (classification then happens in the kernel's epilogue: one launch less per
   // pass) from a few dozen ray blocks on; measured on the 10,574-face scene, optimiser step with
   // 1 chunk / 2048-workgroup target: 15k rays 0.255 / 0.261 ms, 60k 0.255 / 0.263, 125k 0.263 /
   // 0.263, 250k 0.307 / 0.333.  Only tiny launches spread the scene over more workgroups.
   int gtarget = 64;
-  if (const char* env = getenv("TFRT_GROUP_TARGET_BLOCKS")) gtarget = atoi(env) > 0 ? atoi(env) : gtarget;
   int gch = cdiv(gtarget, p.g_blocks);
   const int gmax = cdiv(n_clusters, 64);       // at least 64 clusters (1024 faces) per chunk
   if (gch > gmax) gch = gmax;
@@ -3009,7 +3007,6 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     // (half-size wavefronts while the launch would leave the chip half empty: §3.6)
     int bundle = 64;
     if (od->coherent_only && od->nq <= 160 * 1024) bundle = 32;  // (125k rays: 0.191 against 0.200 ms per step; 250k: 0.223 against 0.211)
-    if (const char* env = getenv("TFRT_BEAM_BUNDLE")) bundle = atoi(env) == 32 && od->coherent_only ? 32 : (atoi(env) == 64 ? 64 : bundle);
     hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, WAVES * bundle)), dim3(BLOCK), 0,
                        st, rays, stride, n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere,
                        ac->crec, fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
@@ -3018,29 +3015,29 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     // (enough workgroups to fill the chip when every wavefront is left over; they loop)
     grid = dim3(min(cdiv(od->nq, BLOCK), 1280), 1);
   }
-  const int32_t* g_left = od != nullptr ? od->left_list : nullptr;
-  const int32_t* g_nleft = od != nullptr ? od->left_count : nullptr;
-  int32_t* g_hist = od != nullptr ? od->hist : nullptr;
+  if (grouped && od != nullptr) {
+    // (every wavefront was finished by k_intersect_beam: no launch)
+    if (!od->coherent_only)
+      hipLaunchKernelGGL((k_intersect_group_left<T>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,
+                         last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec, ac->cface,
+                         fverts, c0, ac->n_clusters, pl.g_chunk_clusters, ei, es, er, fz.catagory,
+                         fz.rec_tri, fz.rec_t, fz.rec_cls, od->left_list, od->left_count, od->hist);
+  } else if (grouped) {
+    hipLaunchKernelGGL((k_intersect_group<T>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,
+                       last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec, ac->cface,
+                       fverts, c0, prep_inline ? nullptr : prep, pstride, ac->n_clusters,
+                       pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride, fz.catagory,
+                       fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt);
+  } else {
 #define TFRT_LAUNCH_R(RR)                                                                      \
-  if (grouped)                                                                                 \
-    hipLaunchKernelGGL((k_intersect_group<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride,     \
-                       n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere, ac->crec,     \
-                       ac->cface, fverts, c0, prep_inline ? nullptr : prep, pstride,           \
-                       ac->n_clusters,                                                         \
-                       pl.g_chunk_clusters, ei, es, er, part_t, part_i, part_stride,           \
-                       fz.catagory, fz.rec_tri, fz.rec_t, fz.rec_cls, fz.blockcnt, g_left,     \
-                       g_nleft, g_hist);                                                       \
-  else                                                                                         \
     hipLaunchKernelGGL((k_intersect3d<T, RR>), grid, dim3(BLOCK), 0, st, rays, stride, n_ptr,  \
                        last_tri, sphere, fverts, prep, pstride, M, pl.chunk_faces, ei, es, er, \
                        part_t, part_i, part_stride)
-  const int Ruse = grouped ? pl.gR : pl.R;
-  if (grouped && od != nullptr && od->coherent_only) {
-    // (every wavefront was finished by k_intersect_beam)
-  } else if (Ruse == 1) { TFRT_LAUNCH_R(1); }
-  else if (Ruse == 4) { TFRT_LAUNCH_R(4); }
-  else { TFRT_LAUNCH_R(2); }
+    if (pl.R == 1) { TFRT_LAUNCH_R(1); }
+    else if (pl.R == 4) { TFRT_LAUNCH_R(4); }
+    else { TFRT_LAUNCH_R(2); }
 #undef TFRT_LAUNCH_R
+  }
   return 0;
 }
 
@@ -3102,7 +3099,6 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* hist_ab[2] = {reinterpret_cast<int32_t*>(ws + lay.hist_a),
                          reinterpret_cast<int32_t*>(ws + lay.hist_b)};
   if (coherent) {
-    pl.gR = 1;
     pl.g_blocks = cdiv(N, (int64_t)BLOCK);
     pl.g_chunks = 1;
     pl.g_chunk_clusters = (ac.n_clusters + 7) / 8 * 8;
@@ -3249,7 +3245,6 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // (one launch sums all passes now: a block per CU is enough -- 125k rays x 11 windows, step time
   // with 1024 / 2048 / 4096 / 8192 slots per block: 0.302 / 0.278 / 0.265 / 0.268 ms)
   while (acc_chunk > 1024 && (int64_t)cdiv(N, acc_chunk) * windows < 256) acc_chunk /= 2;
-  if (const char* env = getenv("TFRT_ACC_CHUNK")) acc_chunk = atoi(env) > 0 ? atoi(env) : acc_chunk;
   for (int p = P - 1; p >= 0; --p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
     const int64_t sin = p == 0 ? src_stride : (int64_t)n;

@@ -457,16 +457,14 @@ def test_soup_matches_oracle_in_default_mode():
         _compare_sets(out[cls], out[cls + "_id"], ref[cls], 1e-9, cls)
 
 
-@pytest.mark.parametrize("rays_per_lane", ["2", "4"])
-def test_grouped_kernel_with_several_rays_per_lane(rays_per_lane, monkeypatch):
-    """k_intersect_group<T,2> / <T,4> are chosen only beyond 4M rays; force them on a small
-    scene (TFRT_GROUP_RAYS_PER_LANE) and require the all-pairs result bit for bit."""
+def test_grouped_kernel_with_several_cluster_chunks():
+    """A small launch spreads the scene over several cluster chunks (here 36 ray blocks x 2
+    chunks of the 125 clusters; k_classify3d then merges the partial results): the all-pairs
+    result bit for bit."""
     from tensorflowraytrace_amd import ops, _lib
     rays, fv, scene = _soup_scene(21, 2000, 9000)
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
     ref = ops.trace3d(rays, fv, scene(False), max_passes=3, flags=flags)
-    monkeypatch.setenv("TFRT_GROUP_RAYS_PER_LANE", rays_per_lane)
-    monkeypatch.setenv("TFRT_GROUP_TARGET_BLOCKS", "64")      # several cluster chunks as well
     out = ops.trace3d(rays, fv, scene("group"), max_passes=3, flags=flags)
     assert np.array_equal(out["counts"], ref["counts"])
     for cls in ("finished", "active", "stopped", "dead"):
@@ -474,21 +472,17 @@ def test_grouped_kernel_with_several_rays_per_lane(rays_per_lane, monkeypatch):
         assert torch.equal(out[cls], ref[cls]), cls
 
 
-@pytest.mark.parametrize("rays_per_lane", ["1", "2", "4"])
 @pytest.mark.parametrize("n_rays", [1, 255, 257, 9001])
-def test_grouped_kernel_classifies_in_its_epilogue_when_it_runs_as_one_chunk(rays_per_lane, n_rays,
-                                                                            monkeypatch):
-    """With a single cluster chunk (big traces; forced here with TFRT_GROUP_TARGET_BLOCKS=1)
-    k_intersect_group writes the hit records, classes and block histograms itself instead of
-    k_classify3d: counts, order and rays must equal the all-pairs path, also for ray counts
+def test_grouped_kernel_classifies_in_its_epilogue_when_it_runs_as_one_chunk(n_rays):
+    """With a single cluster chunk (big traces; here a scene of 63 clusters, which is never
+    split) k_intersect_group writes the hit records, classes and block histograms itself instead
+    of k_classify3d: counts, order and rays must equal the all-pairs path, also for ray counts
     that leave the last 256-ray slice partly or wholly empty."""
     from tensorflowraytrace_amd import ops, _lib
-    rays, fv, scene = _soup_scene(77, 1500, 9001)
+    rays, fv, scene = _soup_scene(77, 1000, 9001)
     rays = rays[:, :n_rays].contiguous()
     flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
     ref = ops.trace3d(rays, fv, scene(False), max_passes=3, flags=flags)
-    monkeypatch.setenv("TFRT_GROUP_RAYS_PER_LANE", rays_per_lane)
-    monkeypatch.setenv("TFRT_GROUP_TARGET_BLOCKS", "1")
     out = ops.trace3d(rays, fv, scene("group"), max_passes=3, flags=flags)
     assert np.array_equal(out["counts"], ref["counts"])
     assert out["n_tests"] == ref["n_tests"]
