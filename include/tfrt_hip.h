@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFRT_VERSION 102 /* 0.1.0 */
+#define TFRT_VERSION 103 /* 0.1.0 */
 
 #define TFRT_F32 0
 #define TFRT_F64 1
@@ -536,6 +536,136 @@ int tfrt_trace2d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
                           const double* grad_dead, int64_t cap_dead, double* grad_seg,
                           double* grad_arc, double* grad_src_rays, const int32_t* counts,
                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray order.  The reference's ray sets are ORDERED: every class lists, pass after pass, its rays
+ * in the order of the source set (OpticalEngine.ray_trace / single_pass own both: tfrt/engine.py:
+ * 2311-2330, the per-pass boolean_mask of :2069-2111, the ray-set properties :1379-1403).  The
+ * trace is fastest over rays in a COHERENT order (tfrt_scene3d.coherent_rays).  These four entry
+ * points give a caller both: order the source, trace the permuted block, put every class back.
+ * Nothing synchronises and every launch has data-independent arguments: a source whose rays are
+ * re-drawn every optimiser step (dev/hexalens.py:36-48 builds its source from RandomUniformCircle,
+ * tfrt/distributions.py:1590-1592) is ordered inside the step's launch graph.
+ *
+ * tfrt_ray_order: index[j] = the ray that comes j-th along a Hilbert curve through the points where
+ * the rays' lines pass the middle of the scene (foot of the perpendicular from the mean centroid of
+ * 64 sampled faces -- or, face_verts == NULL, from the mean end point of 256 sampled rays -- in the
+ * plane perpendicular to `axis`, 3 doubles on the HOST, or NULL: the mean direction of the sampled
+ * rays; rays without a common direction, |mean| <= 1/2: octahedral map of the directions).  The
+ * key has 2 b bits, b = ceil((log2 n + 2) / 2) in [4, 13]; ties keep the source order (a stable
+ * radix sort), so index == argsort(keys, stable).  keys_out (n_rays u32, natural order) or NULL. */
+size_t tfrt_ray_order_workspace_bytes(int64_t n_rays);
+int tfrt_ray_order(const void* rays, int64_t stride, int64_t n_rays, int32_t state_dtype,
+                   const double* face_verts, int64_t n_faces, const double* axis, int32_t* index,
+                   uint32_t* keys_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dst[:, j] = src[:, index[j]] for a 6-row ray block (through 8-element records: one random
+ * access per ray instead of six).  src and dst must not overlap. */
+size_t tfrt_permute_rays_workspace_bytes(int64_t n_rays, int32_t state_dtype);
+int tfrt_permute_rays(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                      int32_t state_dtype, const int32_t* index, void* dst_rays,
+                      int64_t dst_stride, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dst[k * dst_stride + j] = src[k * src_stride + index[j]], k < n_rows, j < min(n, *n_valid):
+ * per-ray rows of any element size (1, 2, 4 or 8 bytes) through an index -- the n(lambda) table
+ * and goal rows of an ordered source, the rows of an output class on their way back.  n_valid: a
+ * count on the device (entries of `index` beyond it are not read) or NULL. */
+int tfrt_gather_rows(const void* src, int64_t src_stride, int32_t n_rows, int32_t elem_bytes,
+                     const int32_t* index, int64_t n, const int32_t* n_valid, void* dst,
+                     int64_t dst_stride, void* stream);
+
+/* One output class of a trace over permuted rays (source ray j of the trace = original ray
+ * index[j]) back in the reference's order: inside every pass by original ray index.
+ *   ray_id      the class's tfrt_ray_out.ray_id (ids in the trace's numbering), n_rows rows at most
+ *   seg_n / seg_base / seg_stride / n_segments   rows and first row of the class in pass p at
+ *               seg_n[p * seg_stride] / seg_base[...]: counts + TFRT_CLS_x and counts + 4 +
+ *               TFRT_CLS_x with stride TFRT_COUNTS_PER_PASS, max_passes segments (<= 1024).
+ *               Both NULL: one segment of n_rows rows (the unfinished set).
+ *   total_rows  device count of the class's rows (counts + 8 max_passes + TFRT_CLS_x) or NULL: n_rows
+ *   index       the permutation the trace ran over, or NULL (identity: the rows only get ranked)
+ *   inv         out, row j of the restored class = row inv[j] of the trace's output   (or NULL)
+ *   dest_of     out, the inverse: row r of the output goes to row dest_of[r]          (or NULL)
+ *   ray_id_out  out, original ray index of restored row j                             (or NULL)
+ * Rows of the restored class: gather with tfrt_gather_rows(.., inv, ..); gradients w.r.t. restored
+ * rows on their way into tfrt_trace3d_backward: gather with dest_of. */
+size_t tfrt_restore_order_workspace_bytes(int64_t n_src, int32_t n_segments);
+int tfrt_restore_order(const int32_t* ray_id, int64_t n_rows, const int32_t* seg_n,
+                       const int32_t* seg_base, int32_t seg_stride, int32_t n_segments,
+                       const int32_t* total_rows, const int32_t* index, int64_t n_src,
+                       int32_t* inv, int32_t* dest_of, int32_t* ray_id_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Source rays made on the device, in place.  Replaces, for sources that re-draw their rays at
+ * every update (dev/hexalens.py:36-48; SGD_Optimizer.single_step calls optical_system.update()
+ * first, tfrt/optimizer.py:217): the Random* distributions' _update (tfrt/distributions.py:
+ * 1375-1393 square, 1586-1598 circle, 1751-1775 / 1814-1850 spherical caps: tf.random.uniform
+ * pushed through the distribution's formula), BasePointTransformation (:2014-2120) and the
+ * assembly of the rays by AperatureSource / PointSource / AngularSource._update
+ * (tfrt/sources.py:464-1095, undense sources: sample i of every input makes ray i).
+ *
+ * Random numbers come from a counter-based generator (Philox4x32-10): sample i of a distribution
+ * at epoch e is a pure function of (seed, stream, e, i), so rays and points can be written into
+ * the caller's persistent buffers by one launch, in any order (through `index`), any number of
+ * times, and only the epoch counters -- on the device, advanced by tfrt_epoch_advance -- change
+ * from one optimiser step to the next.  The stream of numbers differs from TensorFlow's (whose
+ * generator the reference leaves unseeded): parity here is the distribution, not the sequence. */
+#define TFRT_PTS_TABLE 0          /* row i of `table` (a static distribution, already transformed) */
+#define TFRT_PTS_CIRCLE 1         /* r = sqrt(u0), theta = theta_mod(2 pi u1): (0, R r cos, R r sin) */
+#define TFRT_PTS_SQUARE 2         /* (0, -xs + 2 xs u0, -ys + 2 ys u1) */
+#define TFRT_PTS_SPHERE_UNIFORM 3 /* phi = acos(lo + (1 - lo) u0), theta = theta_mod(pi (1 + sqrt 5) u1) */
+#define TFRT_PTS_SPHERE_LAMBERT 4 /* phi = acos(sqrt(lo + (1 - lo) u0)), lo = cos^2(angular_size) */
+typedef struct tfrt_points_program {
+  int32_t kind;          /* TFRT_PTS_* */
+  int32_t stream;        /* distinguishes the distributions that share a seed */
+  int64_t count;         /* samples of the distribution */
+  const double* table;   /* TFRT_PTS_TABLE: (count, 3) f64 */
+  /* circle: {radius, theta_start, theta_end, -}; square: {x_size, -, -, y_size} (centre to
+   * edge); spheres: {radius, theta_start, theta_end, lo}, lo = cos(angular_size) [uniform] or its
+   * square [Lambertian] */
+  double p[4];
+  double scale[3], quat[4], shift[3]; /* BasePointTransformation: scale, unit quaternion (w, x, y, z), translation */
+  int32_t has_scale, has_quat, has_shift;
+  int32_t reserved0;
+  uint64_t seed;
+  const int64_t* epoch;  /* device counter (one int64): the number of updates so far */
+} tfrt_points_program;
+
+#define TFRT_SRC_APERTURE 0 /* start = a[i], end = b[i]                                      sources.py:918-1095 */
+#define TFRT_SRC_POINT 1    /* start = center, end = center + L rot(b[i])                    sources.py:464-675 */
+#define TFRT_SRC_ANGULAR 2  /* start = center + rot(a[i]), end = start + L rot(b[i])         sources.py:678-915 */
+typedef struct tfrt_source3d_program {
+  int32_t kind;          /* TFRT_SRC_* */
+  int32_t swap;          /* start and end exchanged (start_on_center / start_on_base false) */
+  tfrt_points_program a; /* start points / base points (unused by TFRT_SRC_POINT) */
+  tfrt_points_program b; /* end points / direction vectors */
+  double center[3];
+  double quat[4];        /* central angle as a unit quaternion */
+  int32_t has_quat, reserved0;
+  double ray_length;
+  int64_t n_rays;        /* every input has 1 or n_rays samples */
+} tfrt_source3d_program;
+
+/* epochs[k][0] += 1 for k < n (n <= 8 distinct device counters, host array of pointers): one
+ * launch for all the distributions a source draws from. */
+int tfrt_epoch_advance(int64_t* const* epochs, int32_t n, void* stream);
+
+/* Samples first + index[j] (NULL: first + j), j < n, of one distribution at its current epoch: the points after
+ * the transformation as (n, 3) f64 rows (point_columns 3) or the distribution's own plane as
+ * (n, 2) rows (point_columns 2: components y, z), and the two numbers its rank properties are made
+ * of (circle: r in [0, 1] and theta; spheres: phi and theta; square: the point before the
+ * transformation) -- each output may be NULL. */
+int tfrt_points_generate(const tfrt_points_program* program, const int32_t* index,
+                         int64_t first, int64_t n, double* points, int32_t point_columns, double* aux0, double* aux1,
+                         void* stream);
+
+/* Rays first + index[j] (NULL: first + j), j < n (`first`: a rank's shard of the source), of the
+ * source at the current epochs of its distributions:
+ * `rays` a 6 x stride block of the state dtype and / or `fields` a 6 x field_stride f64 block
+ * (x_start ... z_end: the source's field columns); either may be NULL. */
+int tfrt_source3d_generate(const tfrt_source3d_program* program, const int32_t* index,
+                           int64_t first, int64_t n, int32_t state_dtype, void* rays, int64_t stride, double* fields,
+                           int64_t field_stride, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,24 @@ class RayOut(ctypes.Structure):
     _fields_ = [("rays", c_vp), ("ray_id", c_vp), ("face", c_vp), ("capacity", c_i64)]
 
 
+class PointsProgram(ctypes.Structure):
+    """tfrt_points_program (include/tfrt_hip.h)."""
+    _fields_ = [("kind", c_i32), ("stream", c_i32), ("count", c_i64), ("table", c_vp),
+                ("p", c_f64 * 4), ("scale", c_f64 * 3), ("quat", c_f64 * 4), ("shift", c_f64 * 3),
+                ("has_scale", c_i32), ("has_quat", c_i32), ("has_shift", c_i32),
+                ("reserved0", c_i32), ("seed", ctypes.c_uint64), ("epoch", c_vp)]
+
+
+class Source3DProgram(ctypes.Structure):
+    """tfrt_source3d_program (include/tfrt_hip.h)."""
+    _fields_ = [("kind", c_i32), ("swap", c_i32), ("a", PointsProgram), ("b", PointsProgram),
+                ("center", c_f64 * 3), ("quat", c_f64 * 4), ("has_quat", c_i32),
+                ("reserved0", c_i32), ("ray_length", c_f64), ("n_rays", c_i64)]
+
+
+PTS_TABLE, PTS_CIRCLE, PTS_SQUARE, PTS_SPHERE_UNIFORM, PTS_SPHERE_LAMBERT = 0, 1, 2, 3, 4
+SRC_APERTURE, SRC_POINT, SRC_ANGULAR = 0, 1, 2
+
 _P = ctypes.POINTER
 
 # name -> (restype, argtypes); must list every symbol include/tfrt_hip.h declares
@@ -143,6 +161,20 @@ SIGNATURES = {
         c_vp, c_i64, c_i64, _P(Scene2D), c_f64, c_f64, c_i32, c_i32,
         c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
         c_vp]),
+    "tfrt_ray_order_workspace_bytes": (c_sz, [c_i64]),
+    "tfrt_ray_order": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz,
+                               c_vp]),
+    "tfrt_permute_rays_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "tfrt_permute_rays": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "tfrt_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "tfrt_restore_order_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "tfrt_restore_order": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp,
+                                   c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_epoch_advance": (c_i32, [c_vp, c_i32, c_vp]),
+    "tfrt_points_generate": (c_i32, [_P(PointsProgram), c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp,
+                                     c_vp]),
+    "tfrt_source3d_generate": (c_i32, [_P(Source3DProgram), c_vp, c_i64, c_i64, c_i32, c_vp, c_i64,
+                                       c_vp, c_i64, c_vp]),
 }
 
 _lib = None

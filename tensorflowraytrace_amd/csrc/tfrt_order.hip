@@ -58,21 +58,21 @@ struct OrderFrame {
   int planar;
 };
 
-// Per ray: where its line passes the middle of the scene, as two coordinates (x, y) -- in the
-// plane perpendicular to the bundle's mean direction when the rays mostly share one, else the
-// octahedral map of its direction (an isotropic point source).  Every block derives the same
-// frame from the same samples (64 faces, 256 rays): no launch of its own, no atomics, the same
-// result on every run.  mm[0..3]: running minima of enc(x), ~enc(x), enc(y), ~enc(y).
+// The frame in which the rays' lines are compared: the middle of the scene (mean centroid of 64
+// sampled faces, or the mean end point of 256 sampled rays) and the plane perpendicular to the
+// bundle's mean direction (that of 256 sampled rays unless the caller gives an axis); rays without
+// a common direction, |mean| <= 1/2 (an isotropic point source): no plane -- octahedral map of the
+// directions.  One workgroup, a fixed reduction tree: the same frame on every run.  Also arms the
+// extents mm[0..3] (running minima of enc(x), ~enc(x), enc(y), ~enc(y)).
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, int64_t stride,
-                                                    int n, const double* __restrict__ fverts,
-                                                    int M, double ax0, double ax1, double ax2,
-                                                    int has_axis, float2* __restrict__ xy,
-                                                    unsigned* __restrict__ mm) {
+__global__ __launch_bounds__(BLOCK) void k_order_frame(const T* __restrict__ rays, int64_t stride,
+                                                       int n, const double* __restrict__ fverts,
+                                                       int M, double ax0, double ax1, double ax2,
+                                                       int has_axis, OrderFrame* __restrict__ frame,
+                                                       unsigned* __restrict__ mm) {
   __shared__ double red[BLOCK][4];
-  __shared__ OrderFrame fr;
-  __shared__ unsigned wmm[WAVES][4];
   const int tid = threadIdx.x;
+  if (tid < 4) mm[tid] = 0xFFFFFFFFu;
   const int64_t is = n > 0 ? (int64_t)tid * n / BLOCK : 0;  // this thread's sample ray
   double ss[3] = {0, 0, 0}, se[3] = {0, 0, 0};
   if (n > 0) load_ray3(rays, stride, is, ss, se);
@@ -108,20 +108,22 @@ __global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, 
   }
   block_sum4(dir, red);
   if (tid == 0) {
+    OrderFrame fr;
     double w[3] = {dir[0], dir[1], dir[2]};
     double ng = dir[3] > 0.0 ? dir[3] : 1.0;
     if (has_axis) {
       w[0] = ax0;
       w[1] = ax1;
       w[2] = ax2;
-      ng = 1.0;
     }
-    double wl = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-    if (has_axis && wl > 0.0) ng = wl;  // (any length of a given axis counts as "one direction")
+    const double wl = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (has_axis) ng = wl;  // (any length of a given axis counts as "one direction")
     fr.c[0] = cx;
     fr.c[1] = cy;
     fr.c[2] = cz;
-    fr.planar = (wl > 0.5 * ng) ? 1 : 0;
+    fr.planar = (wl > 0.5 * ng && wl > 0.0) ? 1 : 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fr.w[q] = fr.a[q] = fr.b[q] = 0.0;
     if (fr.planar) {
       w[0] /= wl;
       w[1] /= wl;
@@ -144,35 +146,42 @@ __global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, 
         fr.a[q] = a[q];
       }
     }
+    *frame = fr;
   }
-  __syncthreads();
-  const int i = blockIdx.x * BLOCK + tid;
+}
+
+// where a ray's line passes the middle of the scene, as two coordinates of the frame (NaN: no line)
+__device__ __forceinline__ void order_coords(const OrderFrame& fr, const double s[3],
+                                             const double e[3], float* xo, float* yo) {
   float x = __builtin_nanf(""), y = __builtin_nanf("");
-  if (i < n) {
-    double s[3], e[3];
-    load_ray3(rays, stride, i, s, e);
-    const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
-    const double len = sqrt(dx * dx + dy * dy + dz * dz);
-    if (isfinite(len) && len > 0.0) {
-      const double u[3] = {dx / len, dy / len, dz / len};
-      if (fr.planar) {
-        // foot of the perpendicular from the centre to the line, relative to the centre
-        const double t = (fr.c[0] - s[0]) * u[0] + (fr.c[1] - s[1]) * u[1] + (fr.c[2] - s[2]) * u[2];
-        const double p[3] = {s[0] + t * u[0] - fr.c[0], s[1] + t * u[1] - fr.c[1],
-                             s[2] + t * u[2] - fr.c[2]};
-        x = (float)(p[0] * fr.a[0] + p[1] * fr.a[1] + p[2] * fr.a[2]);
-        y = (float)(p[0] * fr.b[0] + p[1] * fr.b[1] + p[2] * fr.b[2]);
-      } else {
-        const double l1 = fabs(u[0]) + fabs(u[1]) + fabs(u[2]);
-        const double ox = u[0] / l1, oy = u[1] / l1, oz = u[2] / l1;
-        x = (float)(oz < 0.0 ? (1.0 - fabs(oy)) * (ox >= 0.0 ? 1.0 : -1.0) : ox);
-        y = (float)(oz < 0.0 ? (1.0 - fabs(ox)) * (oy >= 0.0 ? 1.0 : -1.0) : oy);
-      }
-      if (!(isfinite(x) && isfinite(y))) x = y = __builtin_nanf("");
+  const double dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
+  const double len = sqrt(dx * dx + dy * dy + dz * dz);
+  if (isfinite(len) && len > 0.0) {
+    const double u[3] = {dx / len, dy / len, dz / len};
+    if (fr.planar) {
+      // foot of the perpendicular from the centre to the line, relative to the centre
+      const double t = (fr.c[0] - s[0]) * u[0] + (fr.c[1] - s[1]) * u[1] + (fr.c[2] - s[2]) * u[2];
+      const double p[3] = {s[0] + t * u[0] - fr.c[0], s[1] + t * u[1] - fr.c[1],
+                           s[2] + t * u[2] - fr.c[2]};
+      x = (float)(p[0] * fr.a[0] + p[1] * fr.a[1] + p[2] * fr.a[2]);
+      y = (float)(p[0] * fr.b[0] + p[1] * fr.b[1] + p[2] * fr.b[2]);
+    } else {
+      const double l1 = fabs(u[0]) + fabs(u[1]) + fabs(u[2]);
+      const double ox = u[0] / l1, oy = u[1] / l1, oz = u[2] / l1;
+      x = (float)(oz < 0.0 ? (1.0 - fabs(oy)) * (ox >= 0.0 ? 1.0 : -1.0) : ox);
+      y = (float)(oz < 0.0 ? (1.0 - fabs(ox)) * (oy >= 0.0 ? 1.0 : -1.0) : oy);
     }
-    xy[i] = make_float2(x, y);
+    if (!(isfinite(x) && isfinite(y))) x = y = __builtin_nanf("");
   }
-  // extents of the finite coordinates: wave minima by shuffles, then one atomic per block and value
+  *xo = x;
+  *yo = y;
+}
+
+// extents of the block's finite coordinates into mm: wave minima by shuffles, one atomic per
+// block and value
+__device__ __forceinline__ void order_extents(float x, float y, unsigned (*wmm)[4],
+                                              unsigned* __restrict__ mm) {
+  const int tid = threadIdx.x;
   const bool ok = x == x;
   unsigned v[4] = {ok ? enc_f(x) : 0xFFFFFFFFu, ok ? ~enc_f(x) : 0xFFFFFFFFu,
                    ok ? enc_f(y) : 0xFFFFFFFFu, ok ? ~enc_f(y) : 0xFFFFFFFFu};
@@ -191,6 +200,24 @@ __global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, 
     for (int w = 1; w < WAVES; ++w) m = min(m, wmm[w][tid]);
     if (m != 0xFFFFFFFFu) atomicMin(&mm[tid], m);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, int64_t stride,
+                                                    int n, const OrderFrame* __restrict__ frame,
+                                                    float2* __restrict__ xy,
+                                                    unsigned* __restrict__ mm) {
+  __shared__ unsigned wmm[WAVES][4];
+  const OrderFrame fr = *frame;
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  float x = __builtin_nanf(""), y = __builtin_nanf("");
+  if (i < n) {
+    double s[3], e[3];
+    load_ray3(rays, stride, i, s, e);
+    order_coords(fr, s, e, &x, &y);
+    xy[i] = make_float2(x, y);
+  }
+  order_extents(x, y, wmm, mm);
 }
 
 // Index of grid point (x, y), 0 <= x, y < 2^bits, along the Hilbert curve: unlike a Morton code
@@ -247,18 +274,92 @@ __global__ __launch_bounds__(BLOCK) void k_order_key(const float2* __restrict__ 
     }
   }
   __syncthreads();
-  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)d * nblk + blockIdx.x] = h_lds[d];
+  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
 }
 
 // ------------------------------------------------------------------------------ radix sort
 //
 // Stable LSD radix sort of (key, value) pairs, two passes with digits of `bits` bits each
-// (bits <= 13: 8192 bins).  Per pass: tile histograms (digit-major: hist[d * nblk + tile]), an
-// exclusive scan of that array in chunks of 4096 + chunk totals, and the scatter: every tile ranks
-// its items (wave-wide match of the digit by ballots, a counter per wave and digit in LDS), sorts
-// them by digit in LDS and writes runs of equal digits to consecutive addresses.
+// (bits <= 13: 8192 bins).  Per pass: tile histograms hist[tile][digit] (rows written and read
+// whole: a digit-major matrix meant a million scattered 4-byte accesses per pass), their prefix
+// down the columns in two steps (k_colscan_rows: segments of 32 tiles; k_colscan_finish: the
+// segments' bases and the digits' bases, one workgroup), and the scatter: every tile ranks its
+// items (wave-wide match of the digit by ballots, a counter per wave and digit in LDS), sorts them
+// by digit in LDS and writes runs of equal digits to consecutive addresses.
+constexpr int COL_SEG = 32;   // tiles per column segment
+constexpr int SCAN_CHUNK = 4096;  // words per block of the restore scan
 
-constexpr int SCAN_CHUNK = 4096;
+// hist[r][d] <- sum of hist[segment start .. r)[d];  seg[s][d] <- the segment's sum
+__global__ __launch_bounds__(BLOCK) void k_colscan_rows(unsigned* __restrict__ hist, int nblk,
+                                                        int bins, unsigned* __restrict__ seg) {
+  const int d = blockIdx.x * BLOCK + threadIdx.x;
+  if (d >= bins) return;
+  const int r0 = blockIdx.y * COL_SEG, r1 = min(nblk, r0 + COL_SEG);
+  unsigned run = 0;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    unsigned v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = hist[(int64_t)(r + q) * bins + d];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      hist[(int64_t)(r + q) * bins + d] = run;
+      run += v[q];
+    }
+  }
+  for (; r < r1; ++r) {
+    const unsigned v = hist[(int64_t)r * bins + d];
+    hist[(int64_t)r * bins + d] = run;
+    run += v;
+  }
+  seg[(int64_t)blockIdx.y * bins + d] = run;
+}
+
+// seg[s][d] <- (items with a smaller digit) + sum of seg[0 .. s)[d]: what a tile of segment s adds
+// to its own row of hist to know where its items of digit d go.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void k_colscan_finish(unsigned* __restrict__ seg, int nseg,
+                                                         int bins) {
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = bins >= 1024 ? bins / 1024 : 1;   // <= 8 (bins <= 8192)
+  const int d0 = tid * per;
+  unsigned dtot[8];
+  unsigned tsum = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    dtot[q] = 0;
+    const int d = d0 + q;
+    if (q < per && d < bins) {
+      unsigned run = 0;
+      for (int s = 0; s < nseg; ++s) {
+        const unsigned t = seg[(int64_t)s * bins + d];
+        seg[(int64_t)s * bins + d] = run;
+        run += t;
+      }
+      dtot[q] = run;
+      tsum += run;
+    }
+  }
+  // exclusive prefix of tsum over the 1024 threads
+  unsigned x = tsum;
+#pragma unroll
+  for (int k = 1; k < 64; k <<= 1) {
+    const unsigned o = (unsigned)__shfl_up((int)x, k, 64);
+    if (lane >= k) x += o;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  unsigned base = x - tsum;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int d = d0 + q;
+    if (q < per && d < bins) {
+      for (int s = 0; s < nseg; ++s) seg[(int64_t)s * bins + d] += base;
+      base += dtot[q];
+    }
+  }
+}
 
 template <int ITEMS>
 __global__ __launch_bounds__(BLOCK) void k_sort_hist(const unsigned* __restrict__ keys, int n,
@@ -276,7 +377,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(const unsigned* __restrict_
     if (i < n) atomicAdd(&h_lds[(keys[i] >> shift) & (unsigned)(bins - 1)], 1u);
   }
   __syncthreads();
-  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)d * nblk + blockIdx.x] = h_lds[d];
+  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
 }
 
 // exclusive prefix of `v` over the 256 threads of the block (wave scan + one LDS exchange);
@@ -303,49 +404,6 @@ __device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned* wsum, 
   return base + x - v;
 }
 
-// in place: data[i] <- sum of data[chunk start .. i), totals[chunk] <- the chunk's sum
-__global__ __launch_bounds__(BLOCK) void k_scan_chunks(unsigned* __restrict__ data, int64_t len,
-                                                       unsigned* __restrict__ totals) {
-  __shared__ unsigned wsum[WAVES];
-  constexpr int PER = SCAN_CHUNK / BLOCK;  // 16
-  const int64_t i0 = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * PER;
-  unsigned v[PER];
-  unsigned sum = 0;
-  if (i0 + PER <= len) {
-    const uint4* p = reinterpret_cast<const uint4*>(data + i0);
-#pragma unroll
-    for (int q = 0; q < PER / 4; ++q) {
-      const uint4 x = p[q];
-      v[4 * q] = x.x;
-      v[4 * q + 1] = x.y;
-      v[4 * q + 2] = x.z;
-      v[4 * q + 3] = x.w;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < PER; ++q) v[q] = (i0 + q < len) ? data[i0 + q] : 0u;
-  }
-#pragma unroll
-  for (int q = 0; q < PER; ++q) {
-    const unsigned t = v[q];
-    v[q] = sum;
-    sum += t;
-  }
-  unsigned total;
-  const unsigned base = block_exclusive(sum, wsum, &total);
-  if (i0 + PER <= len) {
-    uint4* p = reinterpret_cast<uint4*>(data + i0);
-#pragma unroll
-    for (int q = 0; q < PER / 4; ++q)
-      p[q] = make_uint4(v[4 * q] + base, v[4 * q + 1] + base, v[4 * q + 2] + base, v[4 * q + 3] + base);
-  } else {
-#pragma unroll
-    for (int q = 0; q < PER; ++q)
-      if (i0 + q < len) data[i0 + q] = v[q] + base;
-  }
-  if (threadIdx.x == 0) totals[blockIdx.x] = total;
-}
-
 // exclusive scan, in LDS, of `cnt` values loaded from `src` (every block does this for the chunk
 // totals: a few hundred values; saves a launch).  All 256 threads take part.
 __device__ __forceinline__ void lds_exclusive_from(const unsigned* __restrict__ src, int cnt,
@@ -370,12 +428,12 @@ __device__ __forceinline__ void lds_exclusive_from(const unsigned* __restrict__ 
 
 // One pass of the sort for one tile.  FIRST: the values are the items' own indices (not read);
 // LAST: keys are not written.  Dynamic LDS: cnt u16 [WAVES][bins] | delta i32 [bins] |
-// stage_k u32 [TILE] | stage_v i32 [TILE] | cbase u32 [nchunks].
+// stage_k u32 [TILE] | stage_v i32 [TILE].
 template <int ITEMS, bool FIRST, bool LAST>
 __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
     const unsigned* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int n, int shift,
-    int bits, const unsigned* __restrict__ hist, int nblk, const unsigned* __restrict__ totals,
-    int nchunks, unsigned* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+    int bits, const unsigned* __restrict__ hist, const unsigned* __restrict__ seg,
+    unsigned* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
   constexpr int TILE = BLOCK * ITEMS;
   extern __shared__ unsigned lds[];
   __shared__ unsigned wsum[WAVES];
@@ -384,7 +442,6 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
   int32_t* delta = reinterpret_cast<int32_t*>(lds + (WAVES * bins) / 2);  // [bins]
   unsigned* stage_k = lds + (WAVES * bins) / 2 + bins;
   int32_t* stage_v = reinterpret_cast<int32_t*>(stage_k + TILE);
-  unsigned* cbase = stage_k + 2 * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int base = blockIdx.x * TILE;
   const int wbase = base + wave * (64 * ITEMS);
@@ -405,7 +462,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
     dr[r] = ok ? ((key[r] >> shift) & dmask) : dmask;
   }
   for (int w = tid; w < (WAVES * bins) / 2; w += BLOCK) lds[w] = 0u;
-  lds_exclusive_from(totals, nchunks, cbase, wsum);  // (ends with a barrier)
+  __syncthreads();
 
   // rank of every item among the items of its wave with the same digit (stable: rounds in
   // order, lanes in order)
@@ -456,8 +513,8 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
         const unsigned c = (unsigned)delta[d];
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) cnt[w * bins + d] = (uint16_t)(cnt[w * bins + d] + dbase);
-        const int64_t at = (int64_t)d * nblk + blockIdx.x;
-        const unsigned goff = cbase[at / SCAN_CHUNK] + hist[at];
+        const unsigned goff = seg[(int64_t)(blockIdx.x / COL_SEG) * bins + d] +
+                              hist[(int64_t)blockIdx.x * bins + d];
         delta[d] = (int32_t)goff - (int32_t)dbase;
         dbase += c;
       }
@@ -529,10 +586,11 @@ __global__ __launch_bounds__(BLOCK) void k_records_to_rays(const T* __restrict__
 template <typename E>
 __global__ __launch_bounds__(BLOCK) void k_gather_rows(const E* __restrict__ src, int64_t sstride,
                                                        int rows, const int32_t* __restrict__ index,
-                                                       int64_t n, E* __restrict__ dst,
-                                                       int64_t dstride) {
+                                                       int64_t n,
+                                                       const int32_t* __restrict__ n_valid,
+                                                       E* __restrict__ dst, int64_t dstride) {
   const int64_t j = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (j >= n) return;
+  if (j >= n || (n_valid != nullptr && j >= *n_valid)) return;
   const int64_t i = index[j];
   for (int k = 0; k < rows; ++k) dst[k * dstride + j] = src[k * sstride + i];
 }
@@ -641,8 +699,8 @@ static int order_bits(int64_t n) {
 static int order_items(int64_t n) { return n < (300 << 10) ? 4 : (n < (3 << 20) ? 8 : 16); }
 
 struct OrderLayout {
-  size_t head, xy, keys_a, keys_b, vals_a, hist, totals, total;
-  int bits, items, nblk, nchunks;
+  size_t head, xy, keys_a, keys_b, vals_a, hist, seg, total;
+  int bits, items, nblk, nseg;
 };
 
 static OrderLayout order_layout(int64_t n) {
@@ -652,27 +710,27 @@ static OrderLayout order_layout(int64_t n) {
   L.items = order_items(n);
   L.nblk = cdiv((int64_t)m, (int64_t)BLOCK * L.items);
   const int64_t hlen = (int64_t)(1 << L.bits) * L.nblk;
-  L.nchunks = cdiv(hlen, SCAN_CHUNK);
+  L.nseg = cdiv(L.nblk, COL_SEG);
   size_t o = 0;
   auto take = [&](size_t bytes) {
     size_t at = o;
     o = align_up(o + bytes);
     return at;
   };
-  L.head = take(64);
+  L.head = take(64 + sizeof(OrderFrame));   // extents (4 u32) | frame
   L.xy = take(m * sizeof(float2));
   L.keys_a = take(m * sizeof(unsigned));
   L.keys_b = take(m * sizeof(unsigned));
   L.vals_a = take(m * sizeof(int32_t));
   L.hist = take((size_t)hlen * sizeof(unsigned));
-  L.totals = take((size_t)L.nchunks * sizeof(unsigned));
+  L.seg = take((size_t)L.nseg * ((size_t)1 << L.bits) * sizeof(unsigned));
   L.total = o;
   return L;
 }
 
-static size_t scatter_lds_bytes(int bits, int items, int nchunks) {
+static size_t scatter_lds_bytes(int bits, int items) {
   const size_t bins = (size_t)1 << bits;
-  return (WAVES * bins) * 2 + bins * 4 + (size_t)BLOCK * items * 8 + (size_t)nchunks * 4;
+  return (WAVES * bins) * 2 + bins * 4 + (size_t)BLOCK * items * 8;
 }
 
 template <int ITEMS>
@@ -681,22 +739,24 @@ static int sort_passes(const OrderLayout& L, char* ws, int n, int32_t* perm, uns
   unsigned* keys_b = reinterpret_cast<unsigned*>(ws + L.keys_b);
   int32_t* vals_a = reinterpret_cast<int32_t*>(ws + L.vals_a);
   unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
-  unsigned* totals = reinterpret_cast<unsigned*>(ws + L.totals);
+  unsigned* seg = reinterpret_cast<unsigned*>(ws + L.seg);
   const int bins = 1 << L.bits;
-  const int64_t hlen = (int64_t)bins * L.nblk;
-  const size_t lds = scatter_lds_bytes(L.bits, ITEMS, L.nchunks);
+  const size_t lds = scatter_lds_bytes(L.bits, ITEMS);
   if (lds > 160 * 1024) return TFRT_E_UNSUPPORTED;
+  const dim3 cgrid(cdiv(bins, BLOCK), L.nseg);
   // pass 0 (its histogram came with the keys)
-  hipLaunchKernelGGL(k_scan_chunks, dim3(L.nchunks), dim3(BLOCK), 0, st, hist, hlen, totals);
+  hipLaunchKernelGGL(k_colscan_rows, cgrid, dim3(BLOCK), 0, st, hist, L.nblk, bins, seg);
+  hipLaunchKernelGGL(k_colscan_finish, dim3(1), dim3(1024), 0, st, seg, L.nseg, bins);
   hipLaunchKernelGGL((k_sort_scatter<ITEMS, true, false>), dim3(L.nblk), dim3(BLOCK), lds, st,
-                     keys_nat, static_cast<const int32_t*>(nullptr), n, 0, L.bits, hist, L.nblk,
-                     totals, L.nchunks, keys_b, vals_a);
+                     keys_nat, static_cast<const int32_t*>(nullptr), n, 0, L.bits, hist, seg,
+                     keys_b, vals_a);
   // pass 1
   hipLaunchKernelGGL((k_sort_hist<ITEMS>), dim3(L.nblk), dim3(BLOCK), bins * sizeof(unsigned), st,
                      keys_b, n, L.bits, L.bits, hist, L.nblk);
-  hipLaunchKernelGGL(k_scan_chunks, dim3(L.nchunks), dim3(BLOCK), 0, st, hist, hlen, totals);
+  hipLaunchKernelGGL(k_colscan_rows, cgrid, dim3(BLOCK), 0, st, hist, L.nblk, bins, seg);
+  hipLaunchKernelGGL(k_colscan_finish, dim3(1), dim3(1024), 0, st, seg, L.nseg, bins);
   hipLaunchKernelGGL((k_sort_scatter<ITEMS, false, true>), dim3(L.nblk), dim3(BLOCK), lds, st,
-                     keys_b, vals_a, n, L.bits, L.bits, hist, L.nblk, totals, L.nchunks,
+                     keys_b, vals_a, n, L.bits, L.bits, hist, seg,
                      static_cast<unsigned*>(nullptr), perm);
   return 0;
 }
@@ -707,14 +767,15 @@ static int ray_order_t(const void* rays, int64_t stride, int64_t N, const double
                        char* ws, const OrderLayout& L, hipStream_t st) {
   const int n = (int)N;
   unsigned* mm = reinterpret_cast<unsigned*>(ws + L.head);
+  OrderFrame* frame = reinterpret_cast<OrderFrame*>(ws + L.head + 64);
   float2* xy = reinterpret_cast<float2*>(ws + L.xy);
   unsigned* keys = keys_out != nullptr ? keys_out : reinterpret_cast<unsigned*>(ws + L.keys_a);
   unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
-  (void)hipMemsetAsync(mm, 0xFF, 16, st);
+  hipLaunchKernelGGL((k_order_frame<T>), dim3(1), dim3(BLOCK), 0, st, static_cast<const T*>(rays),
+                     stride, n, fverts, (int)M, axis ? axis[0] : 0.0, axis ? axis[1] : 0.0,
+                     axis ? axis[2] : 0.0, axis ? 1 : 0, frame, mm);
   hipLaunchKernelGGL((k_order_xy<T>), dim3(cdiv(N, BLOCK)), dim3(BLOCK), 0, st,
-                     static_cast<const T*>(rays), stride, n, fverts, (int)M,
-                     axis ? axis[0] : 0.0, axis ? axis[1] : 0.0, axis ? axis[2] : 0.0,
-                     axis ? 1 : 0, xy, mm);
+                     static_cast<const T*>(rays), stride, n, frame, xy, mm);
   const size_t hl = ((size_t)1 << L.bits) * sizeof(unsigned);
   int rc = 0;
 #define TFRT_ORDER_ITEMS(I)                                                                       \
@@ -827,8 +888,8 @@ int tfrt_permute_rays(const void* src_rays, int64_t src_stride, int64_t n_rays,
 }
 
 int tfrt_gather_rows(const void* src, int64_t src_stride, int32_t n_rows, int32_t elem_bytes,
-                     const int32_t* index, int64_t n, void* dst, int64_t dst_stride,
-                     void* stream) {
+                     const int32_t* index, int64_t n, const int32_t* n_valid, void* dst,
+                     int64_t dst_stride, void* stream) {
   if (n < 0 || n_rows < 0) return TFRT_E_BADARG;
   if (n == 0 || n_rows == 0) return 0;
   if (!src || !dst || !index) return TFRT_E_BADARG;
@@ -837,22 +898,22 @@ int tfrt_gather_rows(const void* src, int64_t src_stride, int32_t n_rows, int32_
   switch (elem_bytes) {
     case 1:
       hipLaunchKernelGGL((k_gather_rows<uint8_t>), grid, dim3(BLOCK), 0, st,
-                         static_cast<const uint8_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<const uint8_t*>(src), src_stride, n_rows, index, n, n_valid,
                          static_cast<uint8_t*>(dst), dst_stride);
       break;
     case 2:
       hipLaunchKernelGGL((k_gather_rows<uint16_t>), grid, dim3(BLOCK), 0, st,
-                         static_cast<const uint16_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<const uint16_t*>(src), src_stride, n_rows, index, n, n_valid,
                          static_cast<uint16_t*>(dst), dst_stride);
       break;
     case 4:
       hipLaunchKernelGGL((k_gather_rows<uint32_t>), grid, dim3(BLOCK), 0, st,
-                         static_cast<const uint32_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<const uint32_t*>(src), src_stride, n_rows, index, n, n_valid,
                          static_cast<uint32_t*>(dst), dst_stride);
       break;
     case 8:
       hipLaunchKernelGGL((k_gather_rows<uint64_t>), grid, dim3(BLOCK), 0, st,
-                         static_cast<const uint64_t*>(src), src_stride, n_rows, index, n,
+                         static_cast<const uint64_t*>(src), src_stride, n_rows, index, n, n_valid,
                          static_cast<uint64_t*>(dst), dst_stride);
       break;
     default:

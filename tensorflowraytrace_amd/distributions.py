@@ -30,6 +30,7 @@ def seed(value):
     global _seed
     _seed = int(value)
     _generators.clear()
+    _streams[0] = 0       # (distributions made after this call draw the same streams again)
 
 
 def _generator_for(dev):
@@ -55,6 +56,160 @@ def _uniform(n, low=0.0, high=1.0):
 
 def _f64(x):
     return config.as_f64(x)
+
+
+# ------------------------------------------------------- random distributions on the device
+#
+# On a HIP device the Random* point distributions do not draw with stock tensor ops: a
+# distribution is a small *program* (csrc/tfrt_source.hip, tfrt_points_program) whose sample i at
+# update e is a pure function of (seed, stream, e, i) -- a counter-based generator.  ``update()``
+# only steps the distribution's epoch counter (on the device); ``points`` / ``ranks`` / ...
+# are made by one kernel when somebody asks, and a source made of such distributions writes its
+# rays straight into persistent buffers (sources.DeviceRaySet), in any order.  The numbers differ
+# from the torch generator's stream; the distributions are the same (tests/test_gpu_source_programs.py).
+
+_device_random = True
+_streams = [0]
+
+
+def set_device_random(on):
+    """False: the Random* distributions draw with torch ops again (new tensors per update)."""
+    global _device_random
+    _device_random = bool(on)
+
+
+class _Drawn:
+    """Attribute that is a stored tensor in the torch path and a kernel's output, made on first
+    use after every update, in the device path."""
+
+    def __init__(self, what):
+        self.what = what
+
+    def __set_name__(self, owner, name):
+        self.name = name
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        if obj.__dict__.get("_device_active"):
+            return obj._draw(self.what)
+        try:
+            return obj.__dict__[self.name]
+        except KeyError:
+            raise AttributeError(self.name) from None
+
+    def __set__(self, obj, val):
+        obj.__dict__[self.name] = val
+
+
+class _DeviceRandom:
+    """Mixin of the Random* base point / direction distributions (see above)."""
+
+    _kind = None          # _lib.PTS_*
+
+    def _device_mode(self):
+        return (_device_random and config.get_device().type == "cuda"
+                and len(self.__dict__.get("_transformations", ())) <= 1)
+
+    def _device_update(self):
+        from . import _lib
+        dev = config.get_device()
+        ep = self.__dict__.get("_epoch_dev")
+        if ep is None or ep.device != dev:
+            self._epoch_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            _streams[0] += 1
+            self._stream_id = _streams[0]
+        self._device_active = True
+        # (the device counter is stepped when somebody draws -- a source does it for all of its
+        # distributions in one launch)
+        self._epoch_pending = self.__dict__.get("_epoch_pending", 0) + 1
+        self.epoch = self.__dict__.get("epoch", 0) + 1
+        self._drawn = {}
+        # (a transformation takes effect with the update after it was attached, like the
+        # reference's post-update handle)
+        self._active_transformations = list(self.__dict__.get("_transformations", ()))
+        assert self._kind in (_lib.PTS_CIRCLE, _lib.PTS_SQUARE, _lib.PTS_SPHERE_UNIFORM,
+                              _lib.PTS_SPHERE_LAMBERT)
+
+    def _leave_device_mode(self):
+        self.__dict__["_device_active"] = False
+
+    def pending_epochs(self):
+        """[(device counter, steps it is behind)] -- consumed by whoever flushes."""
+        n, self._epoch_pending = self.__dict__.get("_epoch_pending", 0), 0
+        return [(self._epoch_dev, n)] if n else []
+
+    def flush_epoch(self):
+        from . import ops
+        for counter, n in self.pending_epochs():
+            for _ in range(n):
+                ops.epoch_advance([counter])
+
+    def _program_parameters(self):
+        raise NotImplementedError
+
+    def program(self):
+        """The distribution as a tfrt_points_program (with its BasePointTransformation).  Built
+        once per set of parameters (reading the transformation's tensors back costs a host sync,
+        which a captured launch sequence must not contain)."""
+        from . import _lib
+        tr = self.__dict__.get("_active_transformations", [])
+        tensors = []
+        if tr:
+            tensors = [tr[0].scale, tr[0].rotation, tr[0].translation]
+        key = (self._kind, self._stream_id, self._sample_total(),
+               tuple(float(v) for v in self._program_parameters()), _seed,
+               self._epoch_dev.data_ptr(),
+               tuple((id(t), getattr(t, "_version", None)) for t in tensors))
+        cached = self.__dict__.get("_program_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        pg = _lib.PointsProgram()
+        pg.kind = self._kind
+        pg.stream = self._stream_id
+        pg.count = self._sample_total()
+        pg.table = None
+        for k, v in enumerate(self._program_parameters()):
+            pg.p[k] = float(v)
+        pg.has_scale = pg.has_quat = pg.has_shift = 0
+        if tr:
+            t = tr[0]
+            if t.scale is not None:
+                sc = t.scale.detach().cpu().reshape(-1).tolist()
+                sc = sc * 3 if len(sc) == 1 else sc
+                pg.has_scale = 1
+                for k in range(3):
+                    pg.scale[k] = sc[k]
+            if t.rotation is not None:
+                q = t.rotation.detach().cpu().double()
+                q = (q / torch.linalg.norm(q)).tolist()
+                pg.has_quat = 1
+                for k in range(4):
+                    pg.quat[k] = q[k]
+            if t.translation is not None:
+                sh = t.translation.detach().cpu().reshape(-1).tolist()
+                pg.has_shift = 1
+                for k in range(3):
+                    pg.shift[k] = sh[k]
+        pg.seed = _seed & 0xFFFFFFFFFFFFFFFF
+        pg.epoch = self._epoch_dev.data_ptr()
+        self._program_cache = (key, pg, tensors)
+        return pg
+
+    def _transformed(self):
+        return bool(self.__dict__.get("_active_transformations"))
+
+    def _draw(self, what):
+        from . import ops, _lib
+        d = self._drawn
+        if what not in d:
+            self.flush_epoch()
+            cols = 3 if (self._transformed() or self._kind in (_lib.PTS_SPHERE_UNIFORM,
+                                                               _lib.PTS_SPHERE_LAMBERT)) else 2
+            pts, a0, a1 = ops.points_generate(self.program(), self._sample_total(), columns=cols,
+                                              want_aux=True, device=self._epoch_dev.device)
+            d["points"], d["aux0"], d["aux1"] = pts, a0, a1
+        return d[what]
 
 
 # ------------------------------------------------------------------------- quaternions
@@ -363,12 +518,31 @@ class StaticUniformSquare(SquareBase):
         self._ranks = self._points / max(self.x_size, self.y_size)
 
 
-class RandomUniformSquare(SquareBase):
+class RandomUniformSquare(_DeviceRandom, SquareBase):
+    _kind = 2     # _lib.PTS_SQUARE
+    _points = _Drawn("points")
+
+    def _sample_total(self):
+        return self.x_res * self.y_res
+
+    def _program_parameters(self):
+        return (self.x_size, 0.0, 0.0, self.y_size)
+
     def _update(self):
+        if self._device_mode():
+            self._device_update()
+            return
+        self._leave_device_mode()
         n = self.x_res * self.y_res
         self._points = torch.stack([_uniform(n, -self.x_size, self.x_size),
                                     _uniform(n, -self.y_size, self.y_size)], dim=1)
         self._ranks = self._points / max(self.x_size, self.y_size)
+
+    @property
+    def ranks(self):
+        if self.__dict__.get("_device_active"):
+            return torch.stack([self._draw("aux0"), self._draw("aux1")], dim=1) / max(self.x_size, self.y_size)
+        return self._ranks
 
 
 class ThetaMod:
@@ -436,8 +610,23 @@ class StaticUniformCircle(CircleBase):
         self._finish()
 
 
-class RandomUniformCircle(CircleBase):
+class RandomUniformCircle(_DeviceRandom, CircleBase):
+    _kind = 1     # _lib.PTS_CIRCLE
+    _points = _Drawn("points")
+    _r = _Drawn("aux0")
+    _theta = _Drawn("aux1")
+
+    def _sample_total(self):
+        return self.sample_count
+
+    def _program_parameters(self):
+        return (self.radius, self.theta_start, self.theta_end, 0.0)
+
     def _update(self):
+        if self._device_mode():
+            self._device_update()
+            return
+        self._leave_device_mode()
         self._r = torch.sqrt(_uniform(self.sample_count))
         self._theta = self._theta_mod(2 * PI * _uniform(self.sample_count))
         self._finish()
@@ -483,8 +672,23 @@ class StaticUniformSphere(SphereBase):
         self._finish()
 
 
-class RandomUniformSphere(SphereBase):
+class RandomUniformSphere(_DeviceRandom, SphereBase):
+    _kind = 3     # _lib.PTS_SPHERE_UNIFORM
+    _points = _Drawn("points")
+    _phi = _Drawn("aux0")
+    _theta = _Drawn("aux1")
+
+    def _sample_total(self):
+        return self.sample_count
+
+    def _program_parameters(self):
+        return (self.radius, self.theta_start, self.theta_end, math.cos(self.angular_size))
+
     def _update(self):
+        if self._device_mode():
+            self._device_update()
+            return
+        self._leave_device_mode()
         c = _uniform(self.sample_count, math.cos(self.angular_size), 1.0)
         self._phi = torch.acos(c)
         self._theta = self._theta_mod(PI * (1 + 5 ** 0.5) * _uniform(self.sample_count))
@@ -505,10 +709,24 @@ class StaticLambertianSphere(SphereBase):
         self._finish()
 
 
-class RandomLambertianSphere(SphereBase):
+class RandomLambertianSphere(_DeviceRandom, SphereBase):
     """distributions.py:1814-1850."""
+    _kind = 4     # _lib.PTS_SPHERE_LAMBERT
+    _points = _Drawn("points")
+    _phi = _Drawn("aux0")
+    _theta = _Drawn("aux1")
+
+    def _sample_total(self):
+        return self.sample_count
+
+    def _program_parameters(self):
+        return (self.radius, self.theta_start, self.theta_end, math.cos(self.angular_size) ** 2)
 
     def _update(self):
+        if self._device_mode():
+            self._device_update()
+            return
+        self._leave_device_mode()
         c2 = _uniform(self.sample_count, math.cos(self.angular_size) ** 2, 1.0)
         self._phi = torch.acos(torch.sqrt(c2))
         self._theta = self._theta_mod(PI * (1 + 5 ** 0.5) * _uniform(self.sample_count))
@@ -1012,8 +1230,14 @@ class BasePointTransformation:
         self.translation = translation
         self.scale = scale
         self._base.post_update_handles.append(self._apply_transformation)
+        if isinstance(base, _DeviceRandom):
+            # the program of a device-random distribution carries ONE transformation; with a
+            # second one the distribution goes back to drawing with torch ops
+            base.__dict__.setdefault("_transformations", []).append(self)
 
     def _apply_transformation(self):
+        if self._base.__dict__.get("_device_active"):
+            return                    # (part of the distribution's program)
         pts = self._base._points
         key = (id(pts), pts._version, id(self._scale), id(self._rotation), id(self._translation))
         if getattr(self, "_memo_key", None) == key:

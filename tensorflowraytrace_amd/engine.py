@@ -107,6 +107,9 @@ def amalgamate(stuff, signature=None):
     if len(items) == 1 and not signature:
         if isinstance(items[0], LazyFields):
             return items[0]
+        lazy = getattr(items[0], "_fields", None)
+        if hasattr(lazy, "ray_block"):      # a source made by a device program (sources.DeviceRaySet)
+            return lazy
         return {f: items[0][f] for f in items[0].keys()}
     return _amalgamate_plain(stuff, signature)
 
@@ -630,13 +633,13 @@ class OpticalEngine:
         # 3-D hierarchy mode: trace the rays in a coherent order (ops.ray_order: a Hilbert-curve
         # order of their lines, computed once per source on the device) so that wavefronts of 64
         # neighbouring rays share one walk of the face hierarchy, and bring every ray set back to
-        # the reference's order afterwards (ops.restore_order) -- invisible to the caller.  "auto"
-        # (default): in the fused optimiser step (fused_step.FusedStep, which needs no ray set in
-        # the reference's order to form error and gradient), from the second step with the same
-        # source rays on (a static source pays the sort once; a source that changes every step
-        # never does); plain ray_trace() stays in natural order, because restoring a million rows
-        # costs about what the coherent kernels save.  True: always, ray_trace() included; False:
-        # never.
+        # the reference's order afterwards (tfrt_restore_order) -- invisible to the caller.  The
+        # order is made on the device (tfrt_ray_order: ~0.1 ms per million rays, no host sync), so
+        # a source re-drawn every step is ordered every step; a static source once.  "auto"
+        # (default): every trace of >= 4096 rays, ray_trace() included, until a source shows that
+        # its wavefronts are no narrow bundles (more than 5 % of the wavefront-passes left to the
+        # grouped kernel: a light guide after a few bounces) -- that source then goes back to
+        # natural order.  True: always; False: never.
         if coherent not in ("auto", True, False):
             raise ValueError(f"OpticalEngine: coherent must be 'auto', True or False, got {coherent!r}")
         self.coherent = coherent
@@ -868,18 +871,30 @@ class OpticalEngine:
         geo = _GEO3 if self.dimension == 3 else _GEO2
         dt = self.ray_dtype or config.get_ray_dtype()
         index_mode, ghost = self._reaction()
-        # the ray block and the n(lambda) table depend only on the input tensors: reuse them
-        # while the caller hands in the very same tensors (static sources between steps)
-        key = tuple((id(rays[f]), rays[f]._version) for f in geo) + (dt,)
-        cache = getattr(self, "_input_cache", None)
-        repeated = False
-        if (cache is not None and cache[0] == key
-                and not any(rays[f].requires_grad for f in geo)):
-            block = cache[1]
-            repeated = True
+        device_set = hasattr(rays, "ray_block")     # sources.DeviceRaySet: rays made in place
+        if device_set:
+            # (the buffers are persistent; ``cache_key`` changes with every update of the source)
+            key = rays.cache_key + (dt,)
+            needs_grad = False
+            cache = getattr(self, "_input_cache", None)
+            if cache is not None and cache[0] == key:
+                block = cache[1]
+            else:
+                block = rays.ray_block(dt)
+                self._input_cache = (key, block, [rays])
         else:
-            block = torch.stack([rays[f] for f in geo]).to(dt)
-            self._input_cache = (key, block, [rays[f] for f in geo])
+            # the ray block and the n(lambda) table depend only on the input tensors: reuse them
+            # while the caller hands in the very same tensors (static sources between steps).  The
+            # cache holds the tensors, so their ids cannot be recycled under the key.
+            needs_grad = any(rays[f].requires_grad for f in geo)
+            key = tuple((id(rays[f]), rays[f]._version) for f in geo) + (dt,)
+            cache = getattr(self, "_input_cache", None)
+            if (cache is not None and cache[0] == key and not needs_grad
+                    and all(a is rays[f] for a, f in zip(cache[2], geo))):
+                block = cache[1]
+            else:
+                block = torch.stack([rays[f] for f in geo]).to(dt)
+                self._input_cache = (key, block, [rays[f] for f in geo])
         n_table = None
         if index_mode:
             # keyed by the wavelengths' memory, not by the tensor object: a random source makes a
@@ -893,21 +908,22 @@ class OpticalEngine:
                 n_table = tcache[1]
             else:
                 n_table = system.material_table(wl)
-                self._table_cache = (wkey, n_table, wl)
+                self._table_cache = (wkey, n_table, wl, wl.dim() > 0 and wl.stride(0) == 0)
         mode = self._trace_mode(system)
         if self.dimension == 3:
             perm = None
-            if coherent_ok and not any(rays[f].requires_grad for f in geo):
-                perm = self._coherent_order(block, n_table, key, repeated, mode, system)
+            if coherent_ok and not needs_grad:
+                perm = self._coherent_order(rays, block, n_table, key, mode, system)
             if perm is not None:
-                _, perm, block, n_table = self._order_cache[:4]
+                block, n_table = self._order_cache[2:4]
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       deterministic=self.deterministic)
             scene.coherent_rays = perm is not None
             # a source that left no wavefront to the grouped kernel last time: no such launch
+            ident = self._source_identity(rays, key)
             scene.coherent_only = (perm is not None
-                                   and getattr(self, "_visit_all_key", None) == key)
-            self._visit_key = key if perm is not None else None
+                                   and getattr(self, "_visit_all_key", None) == ident)
+            self._visit_key = ident if perm is not None else None
             self._trace_perm = perm
         else:
             scene = system.scene_args(n_table, index_mode, ghost,
@@ -919,32 +935,55 @@ class OpticalEngine:
                 fv = torch.zeros((0, 9), dtype=torch.float64, device=block.device)
         return block, scene, fv
 
-    def _coherent_order(self, block, n_table, key, repeated, mode, system):
-        """The coherent order of the source block (see ``coherent``), cached with the permuted
-        block and n(lambda) table: ``self._order_cache = (key, perm, block_p, n_table_p, ...)``."""
+    @staticmethod
+    def _source_identity(rays, key):
+        """What names a SOURCE across its updates: a device-made source keeps its identity when
+        its rays are re-drawn (what the engine learns about its coherence stays valid), a set of
+        plain tensors is its tensors."""
+        return rays.identity if hasattr(rays, "identity") else key
+
+    def _coherent_order(self, rays, block, n_table, key, mode, system):
+        """The coherent order of the source block (see ``coherent``), with the permuted block and
+        n(lambda) table: ``self._order_cache = (key, perm, block_p, n_table_p, n_table, held)``.
+        A static source is ordered once (the cache holds its tensors and is honoured only for the
+        very same ones); a source re-drawn in place is ordered after every update, into the same
+        persistent buffers."""
         if (mode == "all-pairs" or self.coherent is False or block.shape[1] < 4096
                 or not block.is_cuda):
             return None
-        if self.coherent == "auto" and getattr(self, "_incoherent_key", None) == key:
+        ident = self._source_identity(rays, key)
+        if self.coherent == "auto" and getattr(self, "_incoherent_key", None) == ident:
             return None                      # (tried: this source's wavefronts are no bundles)
         cached = getattr(self, "_order_cache", None)
-        if cached is not None and cached[0] == key:
-            if cached[4] != id(n_table):     # (other materials / wavelengths: same order)
-                cached = cached[:3] + (
-                    None if n_table is None else n_table[:, cached[1].long()].contiguous(),
-                    id(n_table), n_table)
+        if cached is not None and cached[0] == key and cached[5][0] is block:
+            if cached[4] is not n_table:     # (other materials / wavelengths: same order)
+                cached = cached[:3] + (self._permuted_table(n_table, cached[1]), n_table, cached[5])
                 self._order_cache = cached
             return cached[1]
-        if self.coherent == "auto" and not repeated:
-            return None
         fv = system._merged_face_verts
-        centre = fv.detach().reshape(-1, 3).mean(dim=0) if fv is not None and fv.shape[0] else None
-        perm = ops.ray_order(block, centre)
-        p64 = perm.long()
-        self._order_cache = (key, perm, block[:, p64].contiguous(),
-                             None if n_table is None else n_table[:, p64].contiguous(),
-                             id(n_table), n_table)      # (the table is held: its id stays its own)
+        device_set = hasattr(rays, "permuted")
+        bufs = None
+        if cached is not None and device_set and cached[5][1] == ident and cached[1].numel() == block.shape[1]:
+            bufs = cached       # (same source, new draw: the same perm buffer, so that a captured
+            #                      launch sequence of the step stays valid)
+        perm = bufs[1] if bufs is not None else None
+        axis = rays._src.axis_hint() if (device_set and hasattr(rays._src, "axis_hint")) else None
+        perm = ops.ray_order(block, fv if fv is not None and fv.shape[0] else None, axis, out=perm)
+        if device_set:
+            block_p = rays.permuted(perm).ray_block(block.dtype)
+        else:
+            block_p = ops.permute_rays(block, perm)
+        self._order_cache = (key, perm, block_p, self._permuted_table(n_table, perm), n_table,
+                             (block, ident))
         return perm
+
+    def _permuted_table(self, n_table, perm):
+        if n_table is None:
+            return None
+        tc = getattr(self, "_table_cache", None)
+        if tc is not None and tc[1] is n_table and tc[3]:
+            return n_table                   # (one wavelength for every ray: the rows are constant)
+        return ops.gather_rows(n_table, perm)
 
     def _note_left_over(self, left_over, passes=1):
         """Coherent-ray trace: remember whether the source left wavefronts to the grouped kernel
@@ -963,14 +1002,12 @@ class OpticalEngine:
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
         # (a speculative trace cuts its outputs before the counts are known: natural order only)
-        block, scene, fv = self._trace_inputs(
-            rays, coherent_ok=predicted is None and self.coherent is True)
+        block, scene, fv = self._trace_inputs(rays, coherent_ok=predicted is None)
         if self.dimension == 3:
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
-                              self.dead_ray_length, flags, predicted_counts=predicted)
+                              self.dead_ray_length, flags, predicted_counts=predicted,
+                              perm=self._trace_perm)
             self._note_left_over(out.get("left_over", 0), max_passes)
-            if self._trace_perm is not None:
-                out = ops.restore_order(out, self._trace_perm)
             return out
         return ops.trace2d(block, scene, max_passes, self.new_ray_length,
                            self.dead_ray_length, flags, predicted_counts=predicted)
@@ -1038,6 +1075,9 @@ class OpticalEngine:
         if shard == "auto":
             shard = (tdist.rank(), tdist.world_size()) if tdist.is_distributed() else None
         if shard is not None:
+            if hasattr(src, "shard"):       # rays made in place: the rank makes its own block
+                lo, hi = tdist.shard_bounds(src.n_rays, *shard)
+                return src.shard(lo, hi)
             n = src["x_start"].shape[0]
             lo, hi = tdist.shard_bounds(n, *shard)
             # the same views for the same source tensors: everything cached per input tensor

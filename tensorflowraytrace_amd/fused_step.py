@@ -59,8 +59,15 @@ class GoalError:
         erf = GoalError(("y_end", "z_end"), lambda src: -m * src["object_coords"][:, 1:])
     """
 
-    def __init__(self, fields=("y_end", "z_end"), goal=None):
+    def __init__(self, fields=("y_end", "z_end"), goal=None, rowwise=False):
         self.fields = tuple(fields)
+        # ``rowwise=True`` states that a callable ``goal`` computes row i from ray i's fields alone
+        # (dev/hexalens.py:154-157 does: a multiple of the ray's object coordinates).  The fused
+        # step may then evaluate it on the source in whatever order it traces the rays, instead of
+        # permuting a table made in source order -- for a source re-drawn every step that saves a
+        # random gather per step.  Leave it False for goals that depend on a ray's POSITION in the
+        # source (a table closed over by the callable, a linspace over the rays, ...).
+        self.rowwise = bool(rowwise)
         if not self.fields or any(f not in _GEO3 for f in self.fields):
             raise ValueError(f"GoalError: fields must be taken from {_GEO3}, got {fields!r}")
         if goal is None:
@@ -73,8 +80,11 @@ class GoalError:
 
     def table(self, src):
         """(len(fields), N) contiguous float64 goal table of the source set ``src``."""
-        vals = list(src.values()) if hasattr(src, "values") else [src[k] for k in src.keys()]
-        key = tuple((id(v), getattr(v, "_version", None)) for v in vals)
+        if hasattr(src, "cache_key"):      # rays made in place (sources.DeviceRaySet): lazy fields
+            vals, key = [src], src.cache_key
+        else:
+            vals = list(src.values()) if hasattr(src, "values") else [src[k] for k in src.keys()]
+            key = tuple((id(v), getattr(v, "_version", None)) for v in vals)
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         g = self.goal(src) if callable(self.goal) else self.goal
@@ -221,16 +231,21 @@ class FusedStep:
         if not src:
             raise RuntimeError("FusedStep: the optical system has no source rays")
         erf = opt.error_function
-        goal = erf.table(src)
         block, scene, fv = eng._trace_inputs(src)
         perm = eng._trace_perm
-        if perm is not None:
+        if perm is None:
+            goal = erf.table(src)
+        else:
             # coherent order: the trace runs over src[perm] (its ray ids are positions in that
             # order), so the goal rows go along; the ray sets are restored when somebody asks
-            gkey = (id(goal), id(perm))
+            gkey = (id(erf), eng._order_cache[0], id(perm))
             cached = getattr(self, "_goal_perm", None)
             if cached is None or cached[0] != gkey:
-                cached = self._goal_perm = (gkey, goal[:, perm.long()].contiguous(), goal, perm)
+                if erf.rowwise and callable(erf.goal) and hasattr(src, "permuted"):
+                    rows = erf.table(src.permuted(perm))      # made in the trace's order
+                else:
+                    rows = ops.gather_rows(erf.table(src), perm)
+                cached = self._goal_perm = (gkey, rows, perm)
             goal = cached[1]
         P, flags = int(opt.trace_depth), eng._flags() | _lib.COMPILE_FINISHED
         dt = ops._DT[block.dtype]
@@ -430,12 +445,16 @@ class FusedStep:
         """Everything a captured graph has baked in and the caller could have changed."""
         opt, eng = self.opt, self.opt.engine
         src = eng.optical_system._amalgamated_sources
+        if src and hasattr(src, "identity"):
+            src_id = src.identity        # (rays re-drawn in place: the buffers stay)
+        else:
+            src_id = tuple(id(src[f]) for f in _GEO3) if src else ()
         return (tuple(id(a) for a in accumulators), tuple(p.data_ptr() for p in opt.parameters),
-                tuple(id(src[f]) for f in _GEO3) if src else (), int(opt.trace_depth),
+                src_id, int(opt.trace_depth),
                 eng._flags(), eng.new_ray_length, eng.dead_ray_length, eng._trace_mode(),
                 id(opt.error_function), id(opt.error_function.goal), opt.error_function.fields,
                 tdist.world_size(), eng.optical_system.scene_signature(), bool(eng.deterministic),
-                id((getattr(eng, "_order_cache", None) or (None, None))[1]),
+                id((getattr(eng, "_order_cache", None) or (None, None, None))[2]),
                 getattr(eng, "_visit_all_key", None) is not None)
 
     def step(self, accumulators, lr_scale):
@@ -482,6 +501,12 @@ class FusedStep:
             torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
             gb.replay()
         self.graph_replays += 1
+        # (a replay re-draws a device-made source behind Python's back: what the source and its
+        # distributions had materialised for an earlier draw is stale now)
+        for source in getattr(self.opt.engine.optical_system, "_sources", ()):
+            note = getattr(source, "note_external_update", None)
+            if note is not None:
+                note()
         self._republish()
         return self._err_view
 

@@ -692,6 +692,31 @@ class _Trace3D(torch.autograd.Function):
         tape.src, tape.face_verts, tape.scene, tape.opts = src, face_verts, scene, dict(opts)
         tape.ws, tape.wsb, tape.counts, tape.dt = ws, wsb, counts, dt
         tape.caps = [o[0].shape[1] if o[0] is not None else 0 for o in (fin, act, stp, dead)]
+        tape.dest = None
+        perm = opts.get("perm")
+        if perm is not None and N:
+            # `src` is a permuted source (src = natural[:, perm], e.g. perm = ray_order(natural)):
+            # hand every class back in the reference's order, ids in the natural numbering; the
+            # reverse sweep takes the gradients back through `dest`
+            tape.dest = []
+            restored = []
+            for o, col in zip((fin, act, stp, dead),
+                              (_lib.CLS_FINISHED, _lib.CLS_ACTIVE, _lib.CLS_STOPPED, _lib.CLS_DEAD)):
+                if o[0] is None:
+                    tape.dest.append(None)
+                    restored.append(o)
+                    continue
+                at = _lib.COUNTS_PER_PASS * P + col
+                total = counts[at:at + 1]
+                inv, dest, ids_o = restore_plan(o[1], counts, P, col, perm, N, o[0].shape[1])
+                restored.append((gather_rows(o[0], inv, total), ids_o, gather_rows(o[2], inv, total)))
+                tape.dest.append((dest, total))
+            fin, act, stp, dead = restored
+            if P > 0:
+                at = _lib.COUNTS_PER_PASS * (P - 1) + _lib.CLS_ACTIVE
+                total = counts[at:at + 1]
+                inv, _, ids_o = restore_plan(unf_id, None, 0, None, perm, N, capN, total)
+                unf, unf_id = gather_rows(unf, inv, total), ids_o
         ctx.tape = tape
         aux = {
             "counts": counts, "unfinished": unf, "unfinished_id": unf_id,
@@ -716,6 +741,9 @@ class _Trace3D(torch.autograd.Function):
         need_src = ctx.needs_input_grad[0]
         g_src = torch.zeros((6, t.src.shape[1]), dtype=torch.float64, device=dev) if need_src else None
         gs = _class_grads(ctx.present, t.caps, 6, dev, grads)
+        if t.dest is not None:      # (restored classes: gradients back into the trace's row order)
+            gs = [g if (g is None or d is None) else gather_rows(g, d[0], d[1])
+                  for g, d in zip(gs, t.dest)]
         sc = t.scene.struct(t.face_verts)
         want_n = (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and M > 0
         g_n = torch.zeros((2, M), dtype=torch.float64, device=dev) if want_n else None
@@ -765,6 +793,7 @@ def _slice_outputs(full, aux, counts, P, ncols_prefix=None):
         raise TfrtError("trace forward: output capacity exceeded (internal error)")
     out = {
         "counts": counts[:P * 8].reshape(P, 8).copy(),
+        "counts_dev": aux["counts"],
         "n_tests": int(np.uint32(tail[4])) | (int(np.uint32(tail[5])) << 32),
         # visiting-order traces: wavefronts that were no narrow bundles (done by the grouped kernel)
         "left_over": int(tail[7]),
@@ -822,7 +851,7 @@ def _finish_trace(full, aux, P, predicted_counts):
 
 
 def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
-            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED, predicted_counts=None):
+            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED, predicted_counts=None, perm=None):
     """Run the whole 3-D trace.  ``src`` is a (6,N) ray block (f32 or f64) on the GPU.
 
     Returns a dict: for each class c in finished/active/stopped/dead (when compiled) the ray
@@ -831,10 +860,15 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     ``counts`` (host numpy, per pass) and ``n_tests``.  One host sync (to read the counts),
     unless ``predicted_counts`` (the ``raw_counts`` of an earlier, identical-shape trace) is
     given: then nothing blocks and ``out["pending"].resolve()`` checks the prediction.
+
+    ``perm`` (int32, N): ``src`` is ``natural[:, perm]`` -- a source handed over in a coherent
+    order (``ray_order`` / ``permute_rays``; set ``scene.coherent_rays``).  Every output then comes
+    back as the trace of ``natural`` itself gives it: ids in the natural numbering, every class in
+    the reference's order (restored on the device inside the autograd node, gradients included).
     """
     opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
                 dead_ray_length=dead_ray_length, flags=flags,
-                zero_init=predicted_counts is not None)
+                zero_init=predicted_counts is not None, perm=perm)
     grad_n = lambda t: t if (isinstance(t, torch.Tensor) and t.requires_grad) else None
     outs = _Trace3D.apply(src, face_verts, grad_n(scene.n_in_arg), grad_n(scene.n_out_arg),
                           scene, opts)
@@ -871,142 +905,206 @@ def intersect3d(rays, face_verts, intersect_epsilion=1e-10, size_epsilion=1e-10,
     return x, y, z, valid.bool(), ray_u, trig_u, trig_v, gather
 
 
-def hilbert_key(x, y, bits=16):
-    """Index along the Hilbert curve of the integer grid points (x, y), 0 <= x, y < 2**bits
-    (int64 tensors).  Unlike a Morton code the curve has no jumps: points with neighbouring
-    indices are neighbouring cells."""
-    x, y = x.clone(), y.clone()
-    d = torch.zeros_like(x)
-    n = 1 << bits
-    s = n >> 1
-    while s > 0:
-        rx = ((x & s) > 0).to(torch.int64)
-        ry = ((y & s) > 0).to(torch.int64)
-        d += s * s * ((3 * rx) ^ ry)
-        swap = ry == 0
-        flip = swap & (rx == 1)
-        x = torch.where(flip, n - 1 - x, x)
-        y = torch.where(flip, n - 1 - y, y)
-        x, y = torch.where(swap, y, x), torch.where(swap, x, y)
-        s >>= 1
-    return d
-
-
-def ray_order(rays, centre=None):
+def ray_order(rays, face_verts=None, axis=None, return_keys=False, out=None):
     """A coherent visiting order of the rays of a (6, N) block: int32 permutation in which rays
     whose lines run close together are neighbours, so that 64 consecutive entries form a narrow
-    bundle.  Trace ``rays[:, order]`` (and per-ray tables in the same order) with
-    ``Scene3DArgs.coherent_rays`` / ``tfrt_scene3d.coherent_rays`` set: coherent wavefronts share one
-    walk of the face hierarchy (k_intersect_beam); ``restore_order(out, order)`` gives the ray sets
-    of ``rays`` itself.
+    bundle (tfrt_ray_order: Hilbert keys + a stable radix sort on the device, no host sync,
+    capturable).  Trace ``permute_rays(rays, order)`` (and per-ray tables in the same order) with
+    ``Scene3DArgs.coherent_rays`` / ``tfrt_scene3d.coherent_rays`` set: coherent wavefronts share
+    one walk of the face hierarchy (k_intersect_beam); ``restore_order(out, order)`` gives the ray
+    sets of ``rays`` itself.
 
     Rays that mostly share a direction are ordered along a Hilbert curve through the points where
-    their lines pass ``centre`` (default: the mean of their end points), in the plane perpendicular
-    to the mean direction; a bundle without a common direction (an isotropic point source) along a
-    Hilbert curve over the octahedral map of the directions.  Device-side torch ops, O(N log N)
-    once per source."""
-    r = rays.detach().to(torch.float64)
-    s, e = r[:3], r[3:]
-    d = e - s
-    length = torch.linalg.norm(d, dim=0)
-    good = torch.isfinite(length) & (length > 0)
-    u = torch.where(good, d / torch.clamp(length, min=1e-300), torch.zeros_like(d))
-    n_good = torch.clamp(good.sum(), min=1)
-    w = u.sum(dim=1)
-    wl = torch.linalg.norm(w)
-    if centre is None:
-        centre = torch.where(good, e, torch.zeros_like(e)).sum(dim=1) / n_good
-    centre = torch.as_tensor(centre, dtype=torch.float64, device=r.device).reshape(3, 1)
-    if float(wl) > 0.5 * float(n_good):
-        w = (w / wl).reshape(3, 1)
-        # foot of the perpendicular from the centre to every line, in a basis (a, b) _|_ w
-        p = s + ((centre - s) * u).sum(dim=0, keepdim=True) * u - centre
-        k = int(torch.argmin(w.abs().reshape(-1)))
-        ek = torch.zeros(3, 1, dtype=torch.float64, device=r.device)
-        ek[k] = 1.0
-        a = torch.linalg.cross(w, ek, dim=0)
-        a = a / torch.linalg.norm(a)
-        b = torch.linalg.cross(w, a, dim=0)
-        x, y = (p * a).sum(dim=0), (p * b).sum(dim=0)
+    their lines pass the middle of the scene (``face_verts`` (M, 9): the mean centroid of 64
+    sampled faces; None: the mean end point of 256 sampled rays), in the plane perpendicular to
+    ``axis`` (3 numbers; None: the mean direction of the sampled rays); rays without a common
+    direction (an isotropic point source) along a Hilbert curve over the octahedral map of their
+    directions.  ``return_keys``: also the uint32 keys (natural order, as int32 bits); the order
+    equals ``argsort(keys, stable=True)``.  ``out``: an int32 tensor of N entries to write into."""
+    _need_gpu(rays, face_verts)
+    if rays.dtype not in _DT:
+        raise TfrtError(f"ray state dtype must be float32, float64 or float16, got {rays.dtype}")
+    rays = rays.detach()
+    if rays.stride(1) != 1:
+        rays = rays.contiguous()
+    N = rays.shape[1]
+    dev = rays.device
+    L = _lib.lib()
+    perm = out if out is not None else torch.empty(N, dtype=torch.int32, device=dev)
+    if perm.dtype != torch.int32 or perm.numel() != N or not perm.is_contiguous():
+        raise TfrtError("ray_order: `out` must be a contiguous int32 tensor of N entries")
+    keys = torch.empty(N, dtype=torch.int32, device=dev) if return_keys else None
+    if N:
+        fv = None if face_verts is None else _c(face_verts.detach(), torch.float64)
+        wsb = L.tfrt_ray_order_workspace_bytes(N)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        ax = None if axis is None else (ctypes.c_double * 3)(*[float(v) for v in axis])
+        check(L.tfrt_ray_order(_p(rays), rays.stride(0), N, _DT[rays.dtype], _p(fv),
+                               0 if fv is None else fv.shape[0], ax, _p(perm), _p(keys), _p(ws),
+                               wsb, _stream(rays)), "tfrt_ray_order")
+    return (perm, keys) if return_keys else perm
+
+
+def permute_rays(rays, index, out=None):
+    """``rays[:, index]`` of a (6, N) ray block (tfrt_permute_rays)."""
+    _need_gpu(rays, index)
+    rays = rays.detach()
+    if rays.stride(1) != 1:
+        rays = rays.contiguous()
+    N = rays.shape[1]
+    if index.dtype != torch.int32 or index.numel() != N:
+        raise TfrtError("permute_rays: index must be an int32 permutation of the N rays")
+    if out is None:
+        out = torch.empty((6, N), dtype=rays.dtype, device=rays.device)
+    if N:
+        L = _lib.lib()
+        wsb = L.tfrt_permute_rays_workspace_bytes(N, _DT[rays.dtype])
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=rays.device)
+        check(L.tfrt_permute_rays(_p(rays), rays.stride(0), N, _DT[rays.dtype], _p(index), _p(out),
+                                  out.stride(0), _p(ws), wsb, _stream(rays)), "tfrt_permute_rays")
+    return out
+
+
+def gather_rows(src, index, n_valid=None, out=None):
+    """``src[..., index]`` for a (k, n) or (n,) tensor of 1/2/4/8-byte elements through an int32
+    index (tfrt_gather_rows); ``n_valid``: int32 device scalar, entries beyond it are left alone."""
+    _need_gpu(src, index)
+    src = src.detach()
+    one = src.dim() == 1
+    s2 = src.reshape(1, -1) if one else src
+    if s2.stride(1) != 1:
+        s2 = s2.contiguous()
+    k, n = s2.shape[0], index.numel()
+    if out is None:
+        out = torch.empty((k, n), dtype=src.dtype, device=src.device)
+    o2 = out.reshape(1, -1) if out.dim() == 1 else out
+    if n and k:
+        check(_lib.lib().tfrt_gather_rows(_p(s2), s2.stride(0), k, s2.element_size(), _p(index), n,
+                                          _p(n_valid), _p(o2), o2.stride(0), _stream(src)),
+              "tfrt_gather_rows")
+    return out.reshape(-1) if (one and out.dim() == 2) else out
+
+
+def restore_plan(ids, counts_dev, P, cls_col, perm, n_src, n_rows=None, total=None):
+    """(inv, dest_of, original ids) of one output class of a trace over permuted rays
+    (tfrt_restore_order): row j of the class in the reference's order = row ``inv[j]`` of the
+    trace's output, ``dest_of`` is the inverse.  ``cls_col``: the class's TFRT_CLS_* column of
+    ``counts_dev`` (the device counts of the trace), or None: ``ids`` is one segment (the
+    unfinished set; ``total``: its row count as an int32 device scalar, default all of ``ids``).
+    Entries beyond the class's row count are not written."""
+    cap = ids.numel() if n_rows is None else int(n_rows)
+    dev = ids.device
+    inv = torch.empty(cap, dtype=torch.int32, device=dev)
+    dest = torch.empty(cap, dtype=torch.int32, device=dev)
+    ids_o = torch.empty(cap, dtype=torch.int32, device=dev)
+    if cap == 0:
+        return inv, dest, ids_o
+    L = _lib.lib()
+    nseg = int(P) if cls_col is not None else 1
+    wsb = L.tfrt_restore_order_workspace_bytes(int(n_src), nseg)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    if cls_col is not None:
+        base = counts_dev.data_ptr()
+        seg_n = ctypes.c_void_p(base + 4 * cls_col)
+        seg_b = ctypes.c_void_p(base + 4 * (4 + cls_col))
+        total = ctypes.c_void_p(base + 4 * (_lib.COUNTS_PER_PASS * int(P) + cls_col))
+        check(L.tfrt_restore_order(_p(ids), cap, seg_n, seg_b, _lib.COUNTS_PER_PASS, nseg, total,
+                                   _p(perm), int(n_src), _p(inv), _p(dest), _p(ids_o), _p(ws), wsb,
+                                   _stream(ids)), "tfrt_restore_order")
     else:
-        # octahedral map of the unit directions onto [-1, 1]^2
-        l1 = torch.clamp(u.abs().sum(dim=0), min=1e-300)
-        ox, oy, oz = u[0] / l1, u[1] / l1, u[2] / l1
-        fx = torch.where(oz < 0, (1 - oy.abs()) * torch.sign(ox + 1e-300), ox)
-        fy = torch.where(oz < 0, (1 - ox.abs()) * torch.sign(oy + 1e-300), oy)
-        x, y = fx, fy
-
-    def grid(v):
-        v = torch.where(good & torch.isfinite(v), v, torch.zeros_like(v))
-        lo, hi = v.min(), v.max()
-        return ((v - lo) / torch.clamp(hi - lo, min=1e-300) * 65535.0).clamp(0, 65535).to(torch.int64)
-
-    key = hilbert_key(grid(x), grid(y))
-    key = torch.where(good, key, torch.full_like(key, 1 << 40))     # rays that can hit nothing: last
-    return torch.argsort(key, stable=True).to(torch.int32).contiguous()
+        check(L.tfrt_restore_order(_p(ids), cap, None, None, 1, 1, _p(total), _p(perm), int(n_src),
+                                   _p(inv), _p(dest), _p(ids_o), _p(ws), wsb, _stream(ids)),
+              "tfrt_restore_order")
+    return inv, dest, ids_o
 
 
 def restore_order(out, perm):
-    """Outputs of a trace over PERMUTED rays (``src[:, perm]``, e.g. ``perm = ray_order(src)``, the
-    form tfrt_scene3d.coherent_rays wants) brought back to what the trace of ``src`` itself gives:
-    ray ids mapped through ``perm``, and inside every class the rays of one pass sorted by ray id
-    again (the reference's per-pass boolean_mask order, engine.py:2069-2111).  ``out``: the dict of
-    trace3d(); returns a new dict.  O(N) per class and pass (a rank by prefix sum, no sort)."""
-    perm = perm.to(torch.int64)
+    """Outputs of a trace over PERMUTED rays (``permute_rays(src, perm)``, e.g. ``perm =
+    ray_order(src)``, the form tfrt_scene3d.coherent_rays wants) brought back to what the trace of
+    ``src`` itself gives: ray ids mapped through ``perm``, and inside every class the rays of one
+    pass sorted by ray id again (the reference's per-pass boolean_mask order,
+    engine.py:2069-2111).  ``out``: the dict of trace3d(); returns a new dict.  Device kernels
+    (tfrt_restore_order, tfrt_gather_rows): a counting sort by (pass, original id), no host sync."""
     n_src = perm.numel()
-    dev = perm.device
-    counts = out["counts"]
+    counts_dev = out["counts_dev"]
+    P = out["counts"].shape[0]
     new = dict(out)
 
-    def reorder(ids_p, segments):
-        """inv such that rows[inv] is in reference order; ids in original numbering.  The key
-        (pass, original id) of a row is unique: rows are scattered into a table indexed by the key
-        and read back in key order (a counting sort: no comparison sort, no host sync)."""
-        ids_o = perm[ids_p.long()]
-        n = ids_o.numel()
-        live = [k for k, c in enumerate(segments) if c > 0]
-        row = torch.arange(1, n + 1, dtype=torch.int32, device=dev)
-        if len(live) * n_src <= (1 << 26):
-            if len(live) == 1:
-                key = ids_o
-            else:
-                slot = {k: j for j, k in enumerate(live)}
-                seg_of = torch.repeat_interleave(
-                    torch.tensor([slot[k] for k in live], dtype=torch.int64, device=dev),
-                    torch.tensor([segments[k] for k in live], dtype=torch.int64, device=dev),
-                    output_size=n)
-                key = seg_of * n_src + ids_o
-            table = torch.zeros(len(live) * n_src, dtype=torch.int32, device=dev)
-            table[key] = row
-            at = torch.nonzero_static(table, size=n).reshape(-1)      # ascending keys
-            return table[at].long() - 1, ids_o
-        inv = torch.empty(n, dtype=torch.int64, device=dev)         # (huge P x N: pass by pass)
-        base = 0
-        for n_seg in segments:
-            if n_seg == 0:
-                continue
-            table = torch.zeros(n_src, dtype=torch.int32, device=dev)
-            table[ids_o[base:base + n_seg]] = row[base:base + n_seg]
-            at = torch.nonzero_static(table, size=n_seg).reshape(-1)
-            inv[base:base + n_seg] = table[at].long() - 1
-            base += n_seg
-        return inv, ids_o
+    def rows(t, inv):
+        if t.requires_grad:
+            return t.index_select(t.dim() - 1, inv.long())
+        return gather_rows(t, inv)
 
     for col, cls in enumerate(_CLASS_NAMES_BY_COUNT_COLUMN):
         if cls not in out or out[cls].shape[1] == 0 or out.get(cls + "_id") is None:
             continue
-        inv, ids_o = reorder(out[cls + "_id"], [int(c) for c in counts[:, col]])
-        new[cls] = out[cls].index_select(1, inv)
-        new[cls + "_id"] = ids_o[inv].to(out[cls + "_id"].dtype)
+        n = out[cls].shape[1]
+        inv, _, ids_o = restore_plan(out[cls + "_id"], counts_dev, P, col, perm, n_src, n)
+        new[cls] = rows(out[cls], inv)
+        new[cls + "_id"] = ids_o
         if out.get(cls + "_face") is not None:
-            new[cls + "_face"] = out[cls + "_face"][inv]
+            new[cls + "_face"] = gather_rows(out[cls + "_face"], inv)
         new.pop(cls + "_rows", None)
     if "unfinished" in out and out["unfinished"].shape[1]:
         n_u = out["unfinished"].shape[1]
-        inv, ids_o = reorder(out["unfinished_id"], [n_u])
-        new["unfinished"] = out["unfinished"].index_select(1, inv)
-        new["unfinished_id"] = ids_o[inv].to(out["unfinished_id"].dtype)
+        inv, _, ids_o = restore_plan(out["unfinished_id"], None, 0, None, perm, n_src, n_u)
+        new["unfinished"] = rows(out["unfinished"], inv)
+        new["unfinished_id"] = ids_o
     return new
+
+
+def epoch_advance(counters):
+    """``c[0] += 1`` for up to 8 distinct int64 device counters in one launch (tfrt_epoch_advance):
+    the distributions of a source step to their next draw."""
+    counters = [c for c in counters if c is not None]
+    if not counters:
+        return
+    _need_gpu(*counters)
+    for at in range(0, len(counters), 8):
+        part = counters[at:at + 8]
+        arr = (ctypes.c_void_p * len(part))(*[c.data_ptr() for c in part])
+        check(_lib.lib().tfrt_epoch_advance(arr, len(part), _stream(part[0])), "tfrt_epoch_advance")
+
+
+def points_generate(program, n, first=0, index=None, columns=3, want_points=True, want_aux=False,
+                    device=None):
+    """Samples of one distribution (a ``_lib.PointsProgram``) at its current epoch
+    (tfrt_points_generate): (points (n, columns) f64 or None, aux0, aux1 (n,) f64 or None)."""
+    dev = device if device is not None else (index.device if index is not None else None)
+    n = int(n)
+    pts = torch.empty((n, columns), dtype=torch.float64, device=dev) if want_points else None
+    a0 = torch.empty(n, dtype=torch.float64, device=dev) if want_aux else None
+    a1 = torch.empty(n, dtype=torch.float64, device=dev) if want_aux else None
+    ref = pts if pts is not None else a0
+    if n and ref is not None:
+        _need_gpu(ref)
+        check(_lib.lib().tfrt_points_generate(ctypes.byref(program), _p(index), int(first), n,
+                                              _p(pts), int(columns), _p(a0), _p(a1), _stream(ref)),
+              "tfrt_points_generate")
+    return pts, a0, a1
+
+
+def source3d_generate(program, n, dtype=None, first=0, index=None, rays_out=None, fields=False,
+                      device=None):
+    """Rays of a source program (``_lib.Source3DProgram``) at the current epochs of its
+    distributions (tfrt_source3d_generate): (ray block (6, n) of ``dtype`` or None, fields (6, n)
+    f64 or None); ``index``: the rays ``first + index[j]`` instead of ``first + j``."""
+    n = int(n)
+    dev = device if device is not None else (index.device if index is not None else
+                                             (rays_out.device if rays_out is not None else None))
+    rays = rays_out
+    if rays is None and dtype is not None:
+        rays = torch.empty((6, n), dtype=dtype, device=dev)
+    fl = torch.empty((6, n), dtype=torch.float64, device=dev) if fields else None
+    ref = rays if rays is not None else fl
+    if n and ref is not None:
+        _need_gpu(ref)
+        dt = _DT[rays.dtype] if rays is not None else _lib.F64
+        check(_lib.lib().tfrt_source3d_generate(
+            ctypes.byref(program), _p(index), int(first), n, dt, _p(rays),
+            rays.stride(0) if rays is not None else 0, _p(fl), n if fl is not None else 0,
+            _stream(ref)), "tfrt_source3d_generate")
+    return rays, fl
 
 
 def morton_order(face_verts):

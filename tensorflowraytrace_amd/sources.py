@@ -30,6 +30,114 @@ def _f64(x):
     return config.as_f64(x)
 
 
+def _lib_kinds():
+    from . import _lib
+    return _lib.SRC_APERTURE, _lib.SRC_POINT, _lib.SRC_ANGULAR
+
+
+_GEO3 = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
+
+
+class DeviceRaySet:
+    """The field set of a source whose rays are made by a device program (csrc/tfrt_source.hip):
+    a read-only mapping like the reference's source dict (``x_start`` ... ``z_end``,
+    ``wavelength``, the extra fields), but nothing is computed until somebody asks -- the trace
+    takes ``ray_block(dtype)`` (one launch into a persistent buffer, no float64 field columns, no
+    stack / cast), a field is one more launch on first use.  ``permuted(index)`` is the same set
+    with ray j = ray ``index[j]`` (a coherent order), made by the same programs: an ordered copy
+    of a re-drawn source costs a second launch, not a gather."""
+
+    def __init__(self, source, first=0, count=None, index=None):
+        self._src = source
+        self._first = int(first)
+        self._n = int(source._dev_n if count is None else count)
+        self._index = index
+        self._index_id = None if index is None else (id(index), index._version)
+
+    # ------------------------------------------------------------------ identity for caches
+    @property
+    def epoch(self):
+        return self._src._dev_epoch
+
+    @property
+    def cache_key(self):
+        """Changes whenever the rays do (an update of the source re-draws them in place)."""
+        return ("device-source", id(self._src), self._src._dev_epoch, self._first, self._n,
+                self._index_id)
+
+    @property
+    def identity(self):
+        """What stays the same from update to update (the buffers are persistent)."""
+        return ("device-source", id(self._src), self._first, self._n, self._src._dev_program_key)
+
+    n_rays = property(lambda self: self._n)
+    device = property(lambda self: self._src._dev_device)
+
+    def shard(self, lo, hi):
+        return self._src._device_view(self._first + int(lo), int(hi) - int(lo), None)
+
+    def permuted(self, index):
+        return self._src._device_view(self._first, self._n, index)
+
+    # ------------------------------------------------------------------------- mapping
+    def keys(self):
+        ks = list(_GEO3)
+        if self._src._wavelengths is not None:
+            ks.append("wavelength")
+        return ks + [f for f in self._src._extra_fields if f not in ks]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def __contains__(self, key):
+        return key in self.keys()
+
+    def __bool__(self):
+        return True
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def _memo(self, name, make):
+        cache = self._src._dev_cache
+        k = (self._first, self._n, self._index_id, name)
+        if k not in cache:
+            cache[k] = make()
+        return cache[k]
+
+    def __getitem__(self, key):
+        src = self._src
+        if key in _GEO3:
+            block = self._memo("__fields__", lambda: src._device_rays(
+                self._first, self._n, self._index, None, fields=True)[1])
+            return block[_GEO3.index(key)]
+        if key == "wavelength" and src._wavelengths is not None:
+            return self._memo(key, lambda: self._cut(src._wavelength_column()))
+        if key in src._extra_fields:
+            return self._memo(key, lambda: src._device_extra(key, self._first, self._n, self._index))
+        raise KeyError(key)
+
+    def _cut(self, column):
+        """rows [first, first + n) of a natural-order column, through the index if there is one."""
+        if column.stride(0) == 0 or column.shape[0] == 1:       # one value for every ray
+            return column.expand(self._n, *column.shape[1:]) if column.shape[0] == 1 else \
+                column[:self._n]
+        part = column[self._first:self._first + self._n]
+        if self._index is None:
+            return part
+        return part.index_select(0, self._index.long())
+
+    def ray_block(self, dtype):
+        """(6, n) block of the ray-state dtype: a persistent buffer, filled once per update."""
+        return self._src._device_rays(self._first, self._n, self._index, dtype)[0]
+
+
 class SourceBase(RecursivelyUpdatable, ABC):
     def __init__(self, extra_fields={}, standard_domains=set(), dense=True,
                  always_resize=False, **kwargs):
@@ -165,7 +273,197 @@ class SourceBase(RecursivelyUpdatable, ABC):
                 value = value[self._domain_gathers[domain]]
             self[field] = value
 
+    # --------------------------------------------------------------- device programs
+    def _device_inputs(self):
+        """(kind, a, b, extra) of tfrt_source3d_program for this source, ``a`` / ``b`` the input
+        distributions' point tensors or device-random distributions; None: no device form."""
+        return None
+
+    def _device_program(self):
+        """The source as a tfrt_source3d_program when that is possible: 3-D, undense, on a HIP
+        device, at least one input a device-random distribution (a source of static inputs keeps
+        its tensors: they are computed once anyway)."""
+        from . import _lib
+        if (getattr(self, "_dimension", None) != 3 or self.dense or not dist._device_random
+                or config.get_device().type != "cuda"):
+            return None
+        spec = self._device_inputs()
+        if spec is None:
+            return None
+        kind, a, b, extra = spec
+        live = [d for d in (a, b) if isinstance(d, dist._DeviceRandom)
+                and d.__dict__.get("_device_active")]
+        if not live:
+            return None
+        counts, parts, keep, key = [], [], [], [kind]
+        for d in (a, b):
+            if d is None:
+                parts.append(None)
+                key.append(None)
+                continue
+            if isinstance(d, dist._DeviceRandom) and d.__dict__.get("_device_active"):
+                pg = d.program()
+                parts.append(pg)
+                counts.append(int(pg.count))
+                key.append(("program", id(d), id(pg)))
+                continue
+            pts = d if isinstance(d, torch.Tensor) else None
+            if pts is None or pts.dim() != 2 or pts.shape[1] not in (2, 3):
+                return None
+            tkey = (id(pts), pts._version)
+            memo = self.__dict__.setdefault("_dev_tables", {})
+            hit = memo.get(tkey)
+            if hit is None:
+                t = _f64(pts.detach())
+                if t.shape[1] == 2:
+                    t = torch.cat([torch.zeros_like(t[:, :1]), t], dim=1)
+                if len(memo) > 8:
+                    memo.clear()
+                hit = memo[tkey] = (pts, t.contiguous())
+            pg = _lib.PointsProgram()
+            pg.kind, pg.count, pg.table = _lib.PTS_TABLE, hit[1].shape[0], hit[1].data_ptr()
+            keep.append(hit[1])
+            parts.append(pg)
+            counts.append(int(pg.count))
+            key.append(("table", tkey))
+        n = max(counts)
+        if any(c not in (1, n) for c in counts):
+            return None
+        if self._wavelengths is not None and self._wavelengths.numel() not in (1, n):
+            return None
+        key.append(extra["key"])
+        key = tuple(key)
+        cached = self.__dict__.get("_dev_program")
+        if cached is not None and cached[0] == key:
+            return cached[1], n, key
+        sp = _lib.Source3DProgram()
+        sp.kind = kind
+        sp.swap = 1 if extra.get("swap") else 0
+        if parts[0] is not None:
+            sp.a = parts[0]
+        sp.b = parts[1]
+        c = extra.get("center")
+        for k in range(3):
+            sp.center[k] = 0.0 if c is None else c[k]
+        q = extra.get("quat")
+        sp.has_quat = 0 if q is None else 1
+        for k in range(4):
+            sp.quat[k] = 0.0 if q is None else q[k]
+        sp.ray_length = float(extra.get("ray_length", 1.0))
+        sp.n_rays = n
+        self._dev_program = (key, sp, keep, live)
+        return sp, n, key
+
+    def _host_values(self, name, tensor, normalise=False):
+        """A small tensor's values as python floats, read back once per tensor version."""
+        memo = self.__dict__.setdefault("_dev_host", {})
+        key = (id(tensor), tensor._version)
+        hit = memo.get(name)
+        if hit is None or hit[0] != key:
+            t = tensor.detach().cpu().double().reshape(-1)
+            if normalise:
+                t = t / torch.linalg.norm(t)
+            hit = memo[name] = (key, t.tolist(), tensor)
+        return hit[1]
+
+    def _enter_device(self, sp, n, key):
+        from . import ops
+        # step the distributions that were updated since they last drew: one launch for all
+        pending = []
+        for d in self._dev_program[3]:
+            pending.extend(d.pending_epochs())
+        while pending:
+            ops.epoch_advance([c for c, _ in pending])
+            pending = [(c, k - 1) for c, k in pending if k > 1]
+        self._dev_n, self._dev_program_key = n, key
+        self._dev_device = config.get_device()
+        self._dev_epoch = self.__dict__.get("_dev_epoch", 0) + 1
+        self._dev_cache = {}
+        self._domain_sizes = {"whole": n}
+        self._domain_gathers = {}
+        self._needs_resize = False
+        self._fields = self._device_view(0, n, None)
+        self._memo_key = None
+
+    def note_external_update(self):
+        """The distributions' device counters were stepped without Python (a replayed launch
+        graph of an optimiser step): forget what was materialised for earlier draws."""
+        if isinstance(self._fields, DeviceRaySet):
+            self._dev_epoch += 1
+            self._dev_cache = {}
+            for d in self._dev_program[3]:
+                d._drawn = {}
+                d.epoch = d.__dict__.get("epoch", 0) + 1
+
+    def _device_view(self, first, n, index):
+        views = self.__dict__.setdefault("_dev_views", {})
+        k = (first, n, None if index is None else id(index))
+        v = views.get(k)
+        if v is None or (index is not None and v._index is not index):
+            if len(views) > 16:
+                views.clear()
+            v = views[k] = DeviceRaySet(self, first, n, index)
+        return v
+
+    def _device_rays(self, first, n, index, dtype, fields=False):
+        """Generate (once per update and destination) the ray block of ``dtype`` and / or the
+        float64 field columns of rays ``first + index[j]``."""
+        from . import ops
+        sp = self._dev_program[1]
+        bufs = self.__dict__.setdefault("_dev_buffers", {})
+        ik = None if index is None else (id(index), index._version)
+        rays = fl = None
+        if dtype is not None:
+            bk = (first, n, None if index is None else "index", dtype)
+            ent = bufs.get(bk)
+            if ent is None or ent[0].device != self._dev_device:
+                ent = bufs[bk] = [torch.empty((6, n), dtype=dtype, device=self._dev_device), None, None]
+            if ent[1] != (self._dev_epoch, ik):
+                ops.source3d_generate(sp, n, first=first, index=index, rays_out=ent[0])
+                ent[1], ent[2] = (self._dev_epoch, ik), index
+            rays = ent[0]
+        if fields:
+            _, fl = ops.source3d_generate(sp, n, first=first, index=index, fields=True,
+                                          device=self._dev_device)
+        return rays, fl
+
+    def _wavelength_column(self):
+        w = self._wavelengths
+        return w if w.numel() != 1 else w.reshape(1).expand(self._dev_n)
+
+    def _device_extra(self, field, first, n, index):
+        """An extra field of rays ``first + index[j]``, resolved when somebody asks."""
+        from . import ops
+        items = self._extra_fields[field]
+        if len(items) == 3 and items[2] == "points" and isinstance(items[1], dist._DeviceRandom) \
+                and items[1].__dict__.get("_device_active") and items[1]._sample_total() == self._dev_n:
+            # the points of one of the source's own distributions: made in the asked order
+            d = items[1]
+            if index is None and first == 0 and n == self._dev_n:
+                return d._draw("points")
+            from . import _lib
+            cols = 3 if (d._transformed() or d._kind in (_lib.PTS_SPHERE_UNIFORM,
+                                                         _lib.PTS_SPHERE_LAMBERT)) else 2
+            d.flush_epoch()
+            return ops.points_generate(d.program(), n, first=first, index=index, columns=cols,
+                                       device=self._dev_device)[0]
+        domain, value = self._resolve_extra(items)
+        value = value if isinstance(value, torch.Tensor) else torch.as_tensor(np.asarray(value))
+        value = value.to(self._dev_device)
+        if value.dim() < 2 and value.shape[:1] != (self._dev_n,):
+            value = value.expand(self._dev_n)
+        part = value[first:first + n]
+        return part if index is None else part.index_select(0, index.long())
+
     def _update(self):
+        prog = self._device_program()
+        if prog is not None:
+            self._enter_device(*prog)
+            return
+        if isinstance(self._fields, DeviceRaySet):
+            self._fields = {}
+            self._memo_key = None
+            self._needs_resize = True
         if self._needs_resize or self.always_resize:
             self._resize()
         ivars = self._internal_vars()
@@ -342,6 +640,15 @@ class PointSource(SourceBase, RotationBase):
         self.ray_length = ray_length
         SourceBase.__init__(self, standard_domains={"angle"}, **kwargs)
 
+    def _device_inputs(self):
+        ad = self._angular_distribution
+        b = ad if isinstance(ad, dist._DeviceRandom) else (ad.angles if hasattr(ad, "angles") else ad.points)
+        c = self._host_values("center", self._center)
+        q = self._host_values("quat", self._central_angle, normalise=True)
+        return _lib_kinds()[1], None, b, dict(
+            center=c, quat=q, ray_length=float(self.ray_length), swap=not self.start_on_center,
+            key=("point", tuple(c), tuple(q), float(self.ray_length), bool(self.start_on_center)))
+
     def _internal_update(self, ev):
         angles = self._rotate_angles(ev["angles"])
         if self.dimension == 2:
@@ -388,6 +695,16 @@ class AngularSource(SourceBase, RotationBase):
         self.ray_length = ray_length
         SourceBase.__init__(self, standard_domains={"base_point", "angle"}, **kwargs)
 
+    def _device_inputs(self):
+        ad, bd = self._angular_distribution, self._base_point_distribution
+        b = ad if isinstance(ad, dist._DeviceRandom) else (ad.angles if hasattr(ad, "angles") else ad.points)
+        a = bd if isinstance(bd, dist._DeviceRandom) else bd.points
+        c = self._host_values("center", self._center)
+        q = self._host_values("quat", self._central_angle, normalise=True)
+        return _lib_kinds()[2], a, b, dict(
+            center=c, quat=q, ray_length=float(self.ray_length), swap=not self.start_on_base,
+            key=("angular", tuple(c), tuple(q), float(self.ray_length), bool(self.start_on_base)))
+
     def _internal_update(self, ev):
         angles = self._rotate_angles(ev["angles"])
         base = self._rotate_points(ev["base_points"])
@@ -430,6 +747,27 @@ class AperatureSource(SourceBase):
         self._end_point_distribution = end_point_distribution
         self._wavelengths = None if wavelengths is None else _f64(wavelengths).reshape(-1)
         super().__init__(standard_domains={"start_point", "end_point"}, **kwargs)
+
+    def _device_inputs(self):
+        sd, ed = self._start_point_distribution, self._end_point_distribution
+        a = sd if isinstance(sd, dist._DeviceRandom) else sd.points
+        b = ed if isinstance(ed, dist._DeviceRandom) else ed.points
+        return _lib_kinds()[0], a, b, dict(key=("aperture",))
+
+    def axis_hint(self):
+        """Direction the rays mostly share, when the programs tell (two shifted planar
+        distributions): from the middle of the start points to the middle of the end points."""
+        prog = self.__dict__.get("_dev_program")
+        if prog is None:
+            return None
+        sp = prog[1]
+        if sp.a.kind in (1, 2) and sp.b.kind in (1, 2):
+            sa = [sp.a.shift[k] if sp.a.has_shift else 0.0 for k in range(3)]
+            sb = [sp.b.shift[k] if sp.b.has_shift else 0.0 for k in range(3)]
+            ax = [sb[k] - sa[k] for k in range(3)]
+            if sum(v * v for v in ax) > 0.0:
+                return ax
+        return None
 
     def _internal_update(self, ev):
         self._set_ray_fields(ev["start_points"], ev["end_points"], ev.get("wavelengths"))

@@ -31,7 +31,7 @@ def _oracle_surface(surface, params):
     return f
 
 
-def _build_lens(n_rays, k=4, ray_dtype=torch.float64):
+def _build_lens(n_rays, k=4, ray_dtype=torch.float64, random_rays=False, **engine_kw):
     import tfrt.boundaries as boundaries
     import tfrt.distributions as distributions
     import tfrt.drawing as drawing
@@ -41,9 +41,10 @@ def _build_lens(n_rays, k=4, ray_dtype=torch.float64):
     import tfrt.operation as operation
     import tfrt.sources as sources
 
-    start_points = distributions.StaticUniformCircle(n_rays, 0.2)
+    circle = distributions.RandomUniformCircle if random_rays else distributions.StaticUniformCircle
+    start_points = circle(n_rays, 0.2)
     distributions.BasePointTransformation(start_points, translation=(-10, 0, 0))
-    end_points = distributions.StaticUniformCircle(n_rays, 0.8)
+    end_points = circle(n_rays, 0.8)
     distributions.BasePointTransformation(end_points)
     source = sources.AperatureSource(
         3, start_points, end_points, [drawing.YELLOW], dense=False,
@@ -74,7 +75,7 @@ def _build_lens(n_rays, k=4, ray_dtype=torch.float64):
     system.update()
     eng = engine.OpticalEngine(
         3, [operation.StandardReaction()],
-        simple_ray_inheritance={"wavelength", "object_coords"}, ray_dtype=ray_dtype)
+        simple_ray_inheritance={"wavelength", "object_coords"}, ray_dtype=ray_dtype, **engine_kw)
     eng.optical_system = system
     eng.validate_system()
     return eng, system, lens, target, source
