@@ -175,14 +175,16 @@ def test_goal_error_kernel_sum_is_reproducible_and_matches_torch():
 
 
 def test_fused_step_in_coherent_order_equals_the_generic_path():
-    """From 4096 rays on the fused step sorts a static source along a Hilbert curve (engine
-    ``coherent='auto'``: k_intersect_beam, per-wavefront face sums) from its second step on.  The
+    """From 4096 rays on the engine sorts the source along a Hilbert curve (``coherent='auto'``:
+    tfrt_ray_order, k_intersect_beam, per-wavefront face sums).  The
     sorted trace must be invisible: same errors and parameters as the generic natural-order path,
     and the lazily cut ray sets come back in the reference's order."""
     steps = 8
     runs = {}
     for mode in ("generic", "graph"):
         opt, eng, system, lens, *_rest, acc = _make(20000, mode, k=6, ray_dtype=torch.float64)
+        if mode == "generic":
+            eng.coherent = False              # (the reference's order all the way: the yardstick)
         errs = _run(opt, None, steps)
         runs[mode] = (errs, _params(lens), opt, eng)
     g = runs["graph"][2]._fused_step

@@ -756,9 +756,9 @@ def test_coherent_order_with_unusual_epsilons(eps):
 
 
 def test_engine_coherent_order_is_invisible():
-    """OpticalEngine(coherent=True): ray_trace() runs over the sorted source and hands back the
-    same ray sets, inherited fields included; 'auto' keeps plain ray_trace() in natural order (the
-    fused optimiser step is where 'auto' sorts: tests/test_gpu_fused_step.py)."""
+    """OpticalEngine(coherent=True / "auto"): ray_trace() runs over the sorted source (ordered on
+    the device, restored inside the trace's autograd node) and hands back the same ray sets as the
+    natural-order trace, inherited fields included."""
     import bench
     outs = {}
     for mode in (False, True, "auto"):
@@ -766,7 +766,7 @@ def test_engine_coherent_order_is_invisible():
         eng.coherent = mode
         eng.ray_trace(3)
         eng.ray_trace(3)
-        assert (getattr(eng, "_order_cache", None) is not None) == (mode is True)
+        assert (getattr(eng, "_order_cache", None) is not None) == (mode is not False)
         fin = eng.finished_rays
         outs[mode] = (torch.stack([fin[f] for f in ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")]),
                       fin["wavelength"], fin["object_coords"], eng.last_trace["finished_id"])
