@@ -49,7 +49,8 @@ BYTES_PER_RAY_BWD = 116    # tape 32 + upstream 24 + downs
 BYTES_PER_FACE = 48
 
 
-def build_scene(n_rays, k_front, k_back, ray_dtype, accelerate="auto"):
+def build_scene(n_rays, k_front, k_back, ray_dtype, accelerate="auto", random_rays=False,
+                coherent="auto"):
     import tensorflowraytrace_amd as tfa
     import tfrt.boundaries as boundaries
     import tfrt.distributions as distributions
@@ -60,9 +61,12 @@ def build_scene(n_rays, k_front, k_back, ray_dtype, accelerate="auto"):
     import tfrt.operation as operation
     import tfrt.sources as sources
 
-    start_points = distributions.StaticUniformCircle(n_rays, 0.2)
+    # random_rays: the source of dev/hexalens.py:36-48 -- RandomUniformCircle distributions, re-drawn
+    # by every optical_system.update(), i.e. every optimiser step
+    circle = distributions.RandomUniformCircle if random_rays else distributions.StaticUniformCircle
+    start_points = circle(n_rays, 0.2)
     distributions.BasePointTransformation(start_points, translation=(-10, 0, 0))
-    end_points = distributions.StaticUniformCircle(n_rays, 0.98)
+    end_points = circle(n_rays, 0.98)
     distributions.BasePointTransformation(end_points)
     source = sources.AperatureSource(
         3, start_points, end_points, [drawing.YELLOW], dense=False,
@@ -92,7 +96,7 @@ def build_scene(n_rays, k_front, k_back, ray_dtype, accelerate="auto"):
     eng = engine.OpticalEngine(
         3, [operation.StandardReaction()], compile_active_rays=False,
         simple_ray_inheritance={"wavelength", "object_coords"}, ray_dtype=ray_dtype,
-        accelerate=accelerate)
+        accelerate=accelerate, coherent=coherent)
     eng.optical_system = system
     eng.validate_system()
     return eng, system, [front.parameters, back.parameters]
@@ -107,9 +111,10 @@ def goal(src):
 def make_error_function():
     """error = squared_difference(stack(finished y_end, z_end), goal) (dev/hexalens.py:144-168),
     stated as a GoalError so the optimiser can run the step as one fixed launch sequence; it is
-    also an ordinary error_function(engine) (``--generic-step`` times that path)."""
+    also an ordinary error_function(engine) (``--generic-step`` times that path).  The goal of a
+    ray is a function of that ray's own fields (rowwise)."""
     import tfrt.optimizer as optimizer
-    return optimizer.GoalError(("y_end", "z_end"), goal)
+    return optimizer.GoalError(("y_end", "z_end"), goal, rowwise=True)
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -254,14 +259,16 @@ def main(argv=None):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed_leg(global_rays, trace_mode, step_mode, dtype, profile=False):
+    def timed_leg(global_rays, trace_mode, step_mode, dtype, profile=False, random_rays=False,
+                  coherent="auto"):
         """Build the scene with `global_rays` source rays (each rank traces its contiguous
         shard), run warmup + exactly `steps` optimiser steps between barriers.  Returns a dict:
         seconds (max over ranks), tests (sum over ranks), per-launch ms of the dominant kernel
         (only with `profile`, which needs eagerly launched kernels), pass counts, faces, mode."""
         ray_dtype = torch.float32 if dtype == "f32" else torch.float64
         eng, system, params = build_scene(global_rays, args.k_front, args.k_back, ray_dtype,
-                                          accelerate=trace_mode)
+                                          accelerate=trace_mode, random_rays=random_rays,
+                                          coherent=coherent)
         opt = optimizer.SGD_Optimizer(
             eng, params, make_error_function(), trace_depth=3, learning_rate=1e-6, grad_clip=1e-3,
             fused=False if step_mode == "generic" else "auto",
@@ -547,7 +554,26 @@ def main(argv=None):
             leg = timed_leg(args.rays, args.trace_mode, "generic", args.dtype)
             legs["generic_step"] = {"ms_per_step": leg["dt"] / leg["steps"] * 1e3,
                                     "tests_per_s": leg["tests"] / leg["dt"],
-                                    "note": "same error function as arbitrary torch code"}
+                                    "note": "same error function as arbitrary torch code (rays "
+                                            "ordered on the device, every ray set handed back in "
+                                            "the reference's order)"}
+            # the reference's own optimisation workload: the source is re-drawn at every step
+            # (dev/hexalens.py:36-48 RandomUniformCircle, optimizer.py:217 update() per step)
+            leg = timed_leg(args.rays, args.trace_mode, args.step_mode, args.dtype,
+                            random_rays=True)
+            legs["random_source"] = {
+                "ms_per_step": leg["dt"] / leg["steps"] * 1e3,
+                "tests_per_s": leg["tests"] / leg["dt"],
+                "graph_replays": leg["graph_replays"], "capture_error": leg["capture_error"],
+                "ordered": bool(leg["visiting"]),
+                "note": "source rays drawn in place every step (tfrt_source3d_generate), ordered "
+                        "every step (tfrt_ray_order), same launch graph"}
+            leg = timed_leg(args.rays, args.trace_mode, args.step_mode, args.dtype,
+                            coherent=False)
+            legs["natural_order"] = {"ms_per_step": leg["dt"] / leg["steps"] * 1e3,
+                                     "tests_per_s": leg["tests"] / leg["dt"],
+                                     "note": "the headline step with the rays in source order "
+                                             "(k_intersect_group, stash + k_face_accumulate)"}
         line["other_legs"] = legs
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

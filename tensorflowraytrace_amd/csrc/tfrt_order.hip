@@ -72,7 +72,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_frame(const T* __restrict__ ray
                                                        unsigned* __restrict__ mm) {
   __shared__ double red[BLOCK][4];
   const int tid = threadIdx.x;
-  if (tid < 4) mm[tid] = 0xFFFFFFFFu;
+  mm[tid] = 0xFFFFFFFFu;      // (MM_SLOTS * 4 == BLOCK values)
   const int64_t is = n > 0 ? (int64_t)tid * n / BLOCK : 0;  // this thread's sample ray
   double ss[3] = {0, 0, 0}, se[3] = {0, 0, 0};
   if (n > 0) load_ray3(rays, stride, is, ss, se);
@@ -178,7 +178,9 @@ __device__ __forceinline__ void order_coords(const OrderFrame& fr, const double 
 }
 
 // extents of the block's finite coordinates into mm: wave minima by shuffles, one atomic per
-// block and value
+// block and value -- spread over MM_SLOTS copies of the four values (thousands of atomics on ONE
+// address are served one after the other: 47 us of a 50 us kernel at a million rays)
+constexpr int MM_SLOTS = 64;
 __device__ __forceinline__ void order_extents(float x, float y, unsigned (*wmm)[4],
                                               unsigned* __restrict__ mm) {
   const int tid = threadIdx.x;
@@ -198,8 +200,26 @@ __device__ __forceinline__ void order_extents(float x, float y, unsigned (*wmm)[
   if (tid < 4) {
     unsigned m = wmm[0][tid];
     for (int w = 1; w < WAVES; ++w) m = min(m, wmm[w][tid]);
-    if (m != 0xFFFFFFFFu) atomicMin(&mm[tid], m);
+    if (m != 0xFFFFFFFFu) atomicMin(&mm[(blockIdx.x % MM_SLOTS) * 4 + tid], m);
   }
+}
+
+// the four extents from their MM_SLOTS copies (every lane of a wave gets them)
+__device__ __forceinline__ void order_extents_read(const unsigned* __restrict__ mm, float* xlo,
+                                                   float* xhi, float* ylo, float* yhi) {
+  const int lane = threadIdx.x & 63;
+  uint4 v = reinterpret_cast<const uint4*>(mm)[lane];     // (MM_SLOTS == 64: one slot per lane)
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    v.x = min(v.x, (unsigned)__shfl_xor((int)v.x, d, 64));
+    v.y = min(v.y, (unsigned)__shfl_xor((int)v.y, d, 64));
+    v.z = min(v.z, (unsigned)__shfl_xor((int)v.z, d, 64));
+    v.w = min(v.w, (unsigned)__shfl_xor((int)v.w, d, 64));
+  }
+  *xlo = dec_f(v.x);
+  *xhi = dec_f(~v.y);
+  *ylo = dec_f(v.z);
+  *yhi = dec_f(~v.w);
 }
 
 template <typename T>
@@ -253,7 +273,8 @@ __global__ __launch_bounds__(BLOCK) void k_order_key(const float2* __restrict__ 
   const int bins = 1 << bits;
   for (int d = tid; d < bins; d += BLOCK) h_lds[d] = 0u;
   __syncthreads();
-  const float xlo = dec_f(mm[0]), xhi = dec_f(~mm[1]), ylo = dec_f(mm[2]), yhi = dec_f(~mm[3]);
+  float xlo, xhi, ylo, yhi;
+  order_extents_read(mm, &xlo, &xhi, &ylo, &yhi);
   const float g1 = (float)(bins - 1);
   const float sx = xhi > xlo ? g1 / (xhi - xlo) : 0.f, sy = yhi > ylo ? g1 / (yhi - ylo) : 0.f;
   const unsigned kmax = (bits >= 16) ? 0xFFFFFFFFu : ((1u << (2 * bits)) - 1u);
@@ -282,8 +303,8 @@ __global__ __launch_bounds__(BLOCK) void k_order_key(const float2* __restrict__ 
 // Stable LSD radix sort of (key, value) pairs, two passes with digits of `bits` bits each
 // (bits <= 13: 8192 bins).  Per pass: tile histograms hist[tile][digit] (rows written and read
 // whole: a digit-major matrix meant a million scattered 4-byte accesses per pass), their prefix
-// down the columns in two steps (k_colscan_rows: segments of 32 tiles; k_colscan_finish: the
-// segments' bases and the digits' bases, one workgroup), and the scatter: every tile ranks its
+// down the columns (k_colscan_rows: within segments of 32 tiles; k_colscan_segs: the segments'
+// bases and the digits' totals, whose scan every tile does for itself), and the scatter: every tile ranks its
 // items (wave-wide match of the digit by ballots, a counter per wave and digit in LDS), sorts them
 // by digit in LDS and writes runs of equal digits to consecutive addresses.
 constexpr int COL_SEG = 32;   // tiles per column segment
@@ -315,50 +336,29 @@ __global__ __launch_bounds__(BLOCK) void k_colscan_rows(unsigned* __restrict__ h
   seg[(int64_t)blockIdx.y * bins + d] = run;
 }
 
-// seg[s][d] <- (items with a smaller digit) + sum of seg[0 .. s)[d]: what a tile of segment s adds
-// to its own row of hist to know where its items of digit d go.  One workgroup of 1024 threads.
-__global__ __launch_bounds__(1024) void k_colscan_finish(unsigned* __restrict__ seg, int nseg,
-                                                         int bins) {
-  __shared__ unsigned wsum[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = bins >= 1024 ? bins / 1024 : 1;   // <= 8 (bins <= 8192)
-  const int d0 = tid * per;
-  unsigned dtot[8];
-  unsigned tsum = 0;
+// seg[s][d] <- sum of seg[0 .. s)[d];  total[d] <- the digit's items in all tiles
+__global__ __launch_bounds__(BLOCK) void k_colscan_segs(unsigned* __restrict__ seg, int nseg,
+                                                        int bins, unsigned* __restrict__ total) {
+  const int d = blockIdx.x * BLOCK + threadIdx.x;
+  if (d >= bins) return;
+  unsigned run = 0;
+  int s = 0;
+  for (; s + 8 <= nseg; s += 8) {
+    unsigned v[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    dtot[q] = 0;
-    const int d = d0 + q;
-    if (q < per && d < bins) {
-      unsigned run = 0;
-      for (int s = 0; s < nseg; ++s) {
-        const unsigned t = seg[(int64_t)s * bins + d];
-        seg[(int64_t)s * bins + d] = run;
-        run += t;
-      }
-      dtot[q] = run;
-      tsum += run;
+    for (int q = 0; q < 8; ++q) v[q] = seg[(int64_t)(s + q) * bins + d];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      seg[(int64_t)(s + q) * bins + d] = run;
+      run += v[q];
     }
   }
-  // exclusive prefix of tsum over the 1024 threads
-  unsigned x = tsum;
-#pragma unroll
-  for (int k = 1; k < 64; k <<= 1) {
-    const unsigned o = (unsigned)__shfl_up((int)x, k, 64);
-    if (lane >= k) x += o;
+  for (; s < nseg; ++s) {
+    const unsigned v = seg[(int64_t)s * bins + d];
+    seg[(int64_t)s * bins + d] = run;
+    run += v;
   }
-  if (lane == 63) wsum[wave] = x;
-  __syncthreads();
-  unsigned base = x - tsum;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int d = d0 + q;
-    if (q < per && d < bins) {
-      for (int s = 0; s < nseg; ++s) seg[(int64_t)s * bins + d] += base;
-      base += dtot[q];
-    }
-  }
+  total[d] = run;
 }
 
 template <int ITEMS>
@@ -433,7 +433,8 @@ template <int ITEMS, bool FIRST, bool LAST>
 __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
     const unsigned* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int n, int shift,
     int bits, const unsigned* __restrict__ hist, const unsigned* __restrict__ seg,
-    unsigned* __restrict__ keys_out, int32_t* __restrict__ vals_out) {
+    const unsigned* __restrict__ dtotal, unsigned* __restrict__ keys_out,
+    int32_t* __restrict__ vals_out) {
   constexpr int TILE = BLOCK * ITEMS;
   extern __shared__ unsigned lds[];
   __shared__ unsigned wsum[WAVES];
@@ -486,14 +487,19 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
   __syncthreads();
 
   // start of every (digit, wave) run within the tile, and the digit's distance to its place in
-  // the output
+  // the output: (items of smaller digits in all tiles: a scan of the digits' totals, which every
+  // tile does for itself) + (items of this digit in the tiles before: the column segments before
+  // this tile's + its row of hist)
   {
     const int per = bins >= BLOCK ? bins / BLOCK : 1;
     const int d0 = tid * per;
-    unsigned tsum = 0;
+    const int myseg = blockIdx.x / COL_SEG;
+    unsigned tsum = 0, gsum = 0;
     if (d0 < bins) {
       for (int q = 0; q < per; ++q) {
         const int d = d0 + q;
+        // wave w's start within the digit's run: exclusive prefixes in cnt[1..3]; cnt[0] (always
+        // 0) keeps the digit's count in this tile until the second loop
         unsigned run = 0;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
@@ -501,21 +507,25 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
           cnt[w * bins + d] = (uint16_t)run;
           run += c;
         }
-        delta[d] = (int32_t)run;  // (the digit's count, for now)
+        cnt[d] = (uint16_t)run;
         tsum += run;
+        // (for now: items of this thread's smaller digits + of this digit in the tiles before)
+        delta[d] = (int32_t)(gsum + seg[(int64_t)myseg * bins + d] +
+                             hist[(int64_t)blockIdx.x * bins + d]);
+        gsum += dtotal[d];
       }
     }
     unsigned total;
     unsigned dbase = block_exclusive(tsum, wsum, &total);
+    const unsigned gbase = block_exclusive(gsum, wsum, &total);
     if (d0 < bins) {
       for (int q = 0; q < per; ++q) {
         const int d = d0 + q;
-        const unsigned c = (unsigned)delta[d];
+        const unsigned c = cnt[d];
+        cnt[d] = (uint16_t)dbase;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) cnt[w * bins + d] = (uint16_t)(cnt[w * bins + d] + dbase);
-        const unsigned goff = seg[(int64_t)(blockIdx.x / COL_SEG) * bins + d] +
-                              hist[(int64_t)blockIdx.x * bins + d];
-        delta[d] = (int32_t)goff - (int32_t)dbase;
+        for (int w = 1; w < WAVES; ++w) cnt[w * bins + d] = (uint16_t)(cnt[w * bins + d] + dbase);
+        delta[d] = (int32_t)(gbase + (unsigned)delta[d]) - (int32_t)dbase;
         dbase += c;
       }
     }
@@ -699,7 +709,7 @@ static int order_bits(int64_t n) {
 static int order_items(int64_t n) { return n < (300 << 10) ? 4 : (n < (3 << 20) ? 8 : 16); }
 
 struct OrderLayout {
-  size_t head, xy, keys_a, keys_b, vals_a, hist, seg, total;
+  size_t head, xy, keys_a, keys_b, vals_a, hist, seg, dtotal, total;
   int bits, items, nblk, nseg;
 };
 
@@ -717,13 +727,14 @@ static OrderLayout order_layout(int64_t n) {
     o = align_up(o + bytes);
     return at;
   };
-  L.head = take(64 + sizeof(OrderFrame));   // extents (4 u32) | frame
+  L.head = take(MM_SLOTS * 16 + sizeof(OrderFrame));   // extents (MM_SLOTS x 4 u32) | frame
   L.xy = take(m * sizeof(float2));
   L.keys_a = take(m * sizeof(unsigned));
   L.keys_b = take(m * sizeof(unsigned));
   L.vals_a = take(m * sizeof(int32_t));
   L.hist = take((size_t)hlen * sizeof(unsigned));
   L.seg = take((size_t)L.nseg * ((size_t)1 << L.bits) * sizeof(unsigned));
+  L.dtotal = take(((size_t)1 << L.bits) * sizeof(unsigned));
   L.total = o;
   return L;
 }
@@ -740,23 +751,24 @@ static int sort_passes(const OrderLayout& L, char* ws, int n, int32_t* perm, uns
   int32_t* vals_a = reinterpret_cast<int32_t*>(ws + L.vals_a);
   unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
   unsigned* seg = reinterpret_cast<unsigned*>(ws + L.seg);
+  unsigned* dtotal = reinterpret_cast<unsigned*>(ws + L.dtotal);
   const int bins = 1 << L.bits;
   const size_t lds = scatter_lds_bytes(L.bits, ITEMS);
   if (lds > 160 * 1024) return TFRT_E_UNSUPPORTED;
   const dim3 cgrid(cdiv(bins, BLOCK), L.nseg);
   // pass 0 (its histogram came with the keys)
   hipLaunchKernelGGL(k_colscan_rows, cgrid, dim3(BLOCK), 0, st, hist, L.nblk, bins, seg);
-  hipLaunchKernelGGL(k_colscan_finish, dim3(1), dim3(1024), 0, st, seg, L.nseg, bins);
+  hipLaunchKernelGGL(k_colscan_segs, dim3(cgrid.x), dim3(BLOCK), 0, st, seg, L.nseg, bins, dtotal);
   hipLaunchKernelGGL((k_sort_scatter<ITEMS, true, false>), dim3(L.nblk), dim3(BLOCK), lds, st,
                      keys_nat, static_cast<const int32_t*>(nullptr), n, 0, L.bits, hist, seg,
-                     keys_b, vals_a);
+                     dtotal, keys_b, vals_a);
   // pass 1
   hipLaunchKernelGGL((k_sort_hist<ITEMS>), dim3(L.nblk), dim3(BLOCK), bins * sizeof(unsigned), st,
                      keys_b, n, L.bits, L.bits, hist, L.nblk);
   hipLaunchKernelGGL(k_colscan_rows, cgrid, dim3(BLOCK), 0, st, hist, L.nblk, bins, seg);
-  hipLaunchKernelGGL(k_colscan_finish, dim3(1), dim3(1024), 0, st, seg, L.nseg, bins);
+  hipLaunchKernelGGL(k_colscan_segs, dim3(cgrid.x), dim3(BLOCK), 0, st, seg, L.nseg, bins, dtotal);
   hipLaunchKernelGGL((k_sort_scatter<ITEMS, false, true>), dim3(L.nblk), dim3(BLOCK), lds, st,
-                     keys_b, vals_a, n, L.bits, L.bits, hist, seg,
+                     keys_b, vals_a, n, L.bits, L.bits, hist, seg, dtotal,
                      static_cast<unsigned*>(nullptr), perm);
   return 0;
 }
@@ -767,7 +779,7 @@ static int ray_order_t(const void* rays, int64_t stride, int64_t N, const double
                        char* ws, const OrderLayout& L, hipStream_t st) {
   const int n = (int)N;
   unsigned* mm = reinterpret_cast<unsigned*>(ws + L.head);
-  OrderFrame* frame = reinterpret_cast<OrderFrame*>(ws + L.head + 64);
+  OrderFrame* frame = reinterpret_cast<OrderFrame*>(ws + L.head + MM_SLOTS * 16);
   float2* xy = reinterpret_cast<float2*>(ws + L.xy);
   unsigned* keys = keys_out != nullptr ? keys_out : reinterpret_cast<unsigned*>(ws + L.keys_a);
   unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);

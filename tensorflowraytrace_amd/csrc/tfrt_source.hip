@@ -92,8 +92,10 @@ __device__ __forceinline__ void eval_points(const tfrt_points_program& pg, int64
     if (pg.kind == TFRT_PTS_CIRCLE) {            // p = {radius, theta_start, theta_end}
       const double r = sqrt(u0);
       const double th = theta_mod(TWO_PI * u1);
-      p[1] = pg.p[0] * (r * cos(th));
-      p[2] = pg.p[0] * (r * sin(th));
+      double sn, cs;
+      sincos(th, &sn, &cs);
+      p[1] = pg.p[0] * (r * cs);
+      p[2] = pg.p[0] * (r * sn);
       aux[0] = r;
       aux[1] = th;
     } else if (pg.kind == TFRT_PTS_SQUARE) {     // p = {x_size, -, -, y_size}
@@ -105,10 +107,12 @@ __device__ __forceinline__ void eval_points(const tfrt_points_program& pg, int64
       const double c = pg.p[3] + (1.0 - pg.p[3]) * u0;
       const double phi = acos(pg.kind == TFRT_PTS_SPHERE_LAMBERT ? sqrt(c) : c);
       const double th = theta_mod(GOLDEN_TURN * u1);
-      const double sp = sin(phi);
-      p[0] = pg.p[0] * cos(phi);
-      p[1] = pg.p[0] * (sp * cos(th));
-      p[2] = pg.p[0] * (sp * sin(th));
+      double sp, cp, sn, cs;
+      sincos(phi, &sp, &cp);
+      sincos(th, &sn, &cs);
+      p[0] = pg.p[0] * cp;
+      p[1] = pg.p[0] * (sp * cs);
+      p[2] = pg.p[0] * (sp * sn);
       aux[0] = phi;
       aux[1] = th;
     }

@@ -1733,12 +1733,36 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
         Perr = 2e-5f * (fabsf(p1) + fabsf(p2) + fabsf(ts) * (fabsf(Mx) + fabsf(My)) + rabs +
                         fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz));
       }
+      // The bound R0 + S |t| is tightest when t counts from the bundle's WAIST, not from the mean
+      // start: rays sorted by where they cross the scene but coming from all over an extended
+      // object (a source re-drawn at random every step, dev/hexalens.py:36-48) are a double cone
+      // whose narrow part is at the lens -- measured from their starts ten units away, the bundle
+      // looked as wide there as the object.  t0 = the least-squares point where the images A + M t
+      // are closest to the axis; the origin moves along the axis by t0, which changes no line.
+      float sam = sel ? Ax * Mx + Ay * My : 0.f, smm = sel ? Mx * Mx + My * My : 0.f;
+      float Lw = sel ? rabs : 0.f, pad2 = 0.f, pad4 = 0.f;
+      wave_sum4(sam, smm, pad2, pad4);
+      Lw = wave_max_f(Lw);
+      Lw += fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz);
+      float t0 = smm > 1e-30f ? -sam * __builtin_amdgcn_rcpf(smm) : 0.f;
+      // (a far waist would cost the origin its float32 digits: the bound below allows 4e-6 Lw)
+      t0 = fminf(fmaxf(t0, -8.f * Lw), 8.f * Lw);
+      if (!(t0 == t0)) t0 = 0.f;
+      bm.ox += t0 * bm.wx; bm.oy += t0 * bm.wy; bm.oz += t0 * bm.wz;
+      Ax += Mx * t0;
+      Ay += My * t0;
+      ray_t -= t0;
+      {
+        const float at0 = fabsf(t0);
+        ray_terr += 1e-5f * at0;
+        Perr += 2e-5f * at0 * (1.f + fabsf(Mx) + fabsf(My));
+        Lw += at0;
+      }
       // (offset and slope of the ray's line from the axis are those of its image: e1, e2, w are
       // orthonormal to rounding, which the inflation below covers many times over)
       float R0 = sel ? __builtin_amdgcn_sqrtf(Ax * Ax + Ay * Ay) : 0.f, S = sel ? Mlen : 0.f;
-      float Lw = sel ? rabs : 0.f, tmin = sel ? ts : INFINITY;
-      wave_max3_min(R0, S, Lw, tmin);
-      Lw += fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz);
+      float tmin = sel ? ray_t : INFINITY, pad3 = 0.f;
+      wave_max3_min(R0, S, pad3, tmin);
       // bounds inflated far beyond their float32 rounding (offsets ~ 2^-23 Lw, slopes ~ 2^-23)
       bm.R0 = R0 * 1.001f + 4e-6f * Lw;
       bm.S = S * 1.001f + 2e-6f;

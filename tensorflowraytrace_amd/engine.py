@@ -1001,8 +1001,7 @@ class OpticalEngine:
 
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
-        # (a speculative trace cuts its outputs before the counts are known: natural order only)
-        block, scene, fv = self._trace_inputs(rays, coherent_ok=predicted is None)
+        block, scene, fv = self._trace_inputs(rays)
         if self.dimension == 3:
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
                               self.dead_ray_length, flags, predicted_counts=predicted,
@@ -1056,7 +1055,8 @@ class OpticalEngine:
             self._unfinished_rays = rays if bool(rays) else {}
             return
         predicted = None
-        sig = (src["x_start"].shape[0], int(max_iterations), self._flags())
+        sig = (src.n_rays if hasattr(src, "n_rays") else src["x_start"].shape[0],
+               int(max_iterations), self._flags())
         if self.speculative_counts and self._predicted is not None and self._predicted[0] == sig:
             predicted = self._predicted[1]
         out = self._run(src, int(max_iterations), self._flags(), predicted)

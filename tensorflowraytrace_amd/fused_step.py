@@ -88,8 +88,11 @@ class GoalError:
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         g = self.goal(src) if callable(self.goal) else self.goal
-        n = src["x_start"].shape[0]
-        g = torch.as_tensor(g, dtype=torch.float64, device=src["x_start"].device).detach()
+        if hasattr(src, "n_rays"):
+            n, dev = src.n_rays, src.device
+        else:
+            n, dev = src["x_start"].shape[0], src["x_start"].device
+        g = torch.as_tensor(g, dtype=torch.float64, device=dev).detach()
         if g.dim() == 1:
             g = g.reshape(-1, 1)
         if tuple(g.shape) != (n, len(self.fields)):
@@ -335,7 +338,7 @@ class FusedStep:
     def _publish_lazily(self, st, src, P, flags, perm=None):
         eng = self.opt.engine
         eng._trace_src = src
-        eng._trace_sig = (src["x_start"].shape[0], P, flags)
+        eng._trace_sig = (src.n_rays if hasattr(src, "n_rays") else src["x_start"].shape[0], P, flags)
         full, aux = st["full"], st["aux"]
         self._last_perm = perm
 

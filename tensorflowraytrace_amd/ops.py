@@ -700,6 +700,7 @@ class _Trace3D(torch.autograd.Function):
             # reverse sweep takes the gradients back through `dest`
             tape.dest = []
             restored = []
+            zero = bool(opts.get("zero_init"))
             for o, col in zip((fin, act, stp, dead),
                               (_lib.CLS_FINISHED, _lib.CLS_ACTIVE, _lib.CLS_STOPPED, _lib.CLS_DEAD)):
                 if o[0] is None:
@@ -708,14 +709,17 @@ class _Trace3D(torch.autograd.Function):
                     continue
                 at = _lib.COUNTS_PER_PASS * P + col
                 total = counts[at:at + 1]
-                inv, dest, ids_o = restore_plan(o[1], counts, P, col, perm, N, o[0].shape[1])
-                restored.append((gather_rows(o[0], inv, total), ids_o, gather_rows(o[2], inv, total)))
+                inv, dest, ids_o = restore_plan(o[1], counts, P, col, perm, N, o[0].shape[1],
+                                                zero=zero)
+                face = torch.zeros_like(o[2]) if zero else None
+                restored.append((gather_rows(o[0], inv, total), ids_o,
+                                 gather_rows(o[2], inv, total, out=face)))
                 tape.dest.append((dest, total))
             fin, act, stp, dead = restored
             if P > 0:
                 at = _lib.COUNTS_PER_PASS * (P - 1) + _lib.CLS_ACTIVE
                 total = counts[at:at + 1]
-                inv, _, ids_o = restore_plan(unf_id, None, 0, None, perm, N, capN, total)
+                inv, _, ids_o = restore_plan(unf_id, None, 0, None, perm, N, capN, total, zero=zero)
                 unf, unf_id = gather_rows(unf, inv, total), ids_o
         ctx.tape = tape
         aux = {
@@ -985,7 +989,7 @@ def gather_rows(src, index, n_valid=None, out=None):
     return out.reshape(-1) if (one and out.dim() == 2) else out
 
 
-def restore_plan(ids, counts_dev, P, cls_col, perm, n_src, n_rows=None, total=None):
+def restore_plan(ids, counts_dev, P, cls_col, perm, n_src, n_rows=None, total=None, zero=False):
     """(inv, dest_of, original ids) of one output class of a trace over permuted rays
     (tfrt_restore_order): row j of the class in the reference's order = row ``inv[j]`` of the
     trace's output, ``dest_of`` is the inverse.  ``cls_col``: the class's TFRT_CLS_* column of
@@ -994,9 +998,10 @@ def restore_plan(ids, counts_dev, P, cls_col, perm, n_src, n_rows=None, total=No
     Entries beyond the class's row count are not written."""
     cap = ids.numel() if n_rows is None else int(n_rows)
     dev = ids.device
-    inv = torch.empty(cap, dtype=torch.int32, device=dev)
-    dest = torch.empty(cap, dtype=torch.int32, device=dev)
-    ids_o = torch.empty(cap, dtype=torch.int32, device=dev)
+    new = torch.zeros if zero else torch.empty    # (zero: rows past the count must be valid indices)
+    inv = new(cap, dtype=torch.int32, device=dev)
+    dest = new(cap, dtype=torch.int32, device=dev)
+    ids_o = new(cap, dtype=torch.int32, device=dev)
     if cap == 0:
         return inv, dest, ids_o
     L = _lib.lib()
