@@ -552,7 +552,7 @@ int tfrt_trace2d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
  * 64 sampled faces -- or, face_verts == NULL, from the mean end point of 256 sampled rays -- in the
  * plane perpendicular to `axis`, 3 doubles on the HOST, or NULL: the mean direction of the sampled
  * rays; rays without a common direction, |mean| <= 1/2: octahedral map of the directions).  The
- * key has 2 b bits, b = ceil((log2 n + 2) / 2) in [4, 13]; ties keep the source order (a stable
+ * key has 2 b bits, b = ceil(log2(n) / 2) in [4, 13]; ties keep the source order (a stable
  * radix sort), so index == argsort(keys, stable).  keys_out (n_rays u32, natural order) or NULL. */
 size_t tfrt_ray_order_workspace_bytes(int64_t n_rays);
 int tfrt_ray_order(const void* rays, int64_t stride, int64_t n_rays, int32_t state_dtype,
@@ -645,6 +645,15 @@ typedef struct tfrt_source3d_program {
   double ray_length;
   int64_t n_rays;        /* every input has 1 or n_rays samples */
 } tfrt_source3d_program;
+
+/* tfrt_ray_order for rays first .. first + n_rays of a source program, without the rays ever being
+ * written in source order: index[j] = the j-th ray (counted from `first`) in the coherent order.
+ * Workspace: tfrt_ray_order_workspace_bytes(n_rays).  tfrt_source3d_generate(program, index, first,
+ * ...) then makes the ordered block. */
+int tfrt_source3d_order(const tfrt_source3d_program* program, int64_t first, int64_t n_rays,
+                        const double* face_verts, int64_t n_faces, const double* axis,
+                        int32_t* index, uint32_t* keys_out, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* epochs[k][0] += 1 for k < n (n <= 8 distinct device counters, host array of pointers): one
  * launch for all the distributions a source draws from. */

@@ -170,6 +170,8 @@ SIGNATURES = {
     "tfrt_restore_order_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "tfrt_restore_order": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp,
                                    c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_source3d_order": (c_i32, [_P(Source3DProgram), c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
+                                    c_vp, c_sz, c_vp]),
     "tfrt_epoch_advance": (c_i32, [c_vp, c_i32, c_vp]),
     "tfrt_points_generate": (c_i32, [_P(PointsProgram), c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp,
                                      c_vp]),

@@ -20,8 +20,27 @@
 // calls can be captured into the graph of an optimiser step (a source re-drawn every step is
 // ordered every step).
 #include "tfrt_common.h"
+#include "source_programs.h"
 
 namespace tfrt {
+
+// where the rays to be ordered come from: a ray block, or a source program (then they are never
+// written in source order at all)
+template <typename T>
+struct BlockRays {
+  const T* rays;
+  int64_t stride;
+  __device__ __forceinline__ void load(int64_t i, double s[3], double e[3]) const {
+    load_ray3(rays, stride, i, s, e);
+  }
+};
+struct ProgramRays {
+  tfrt_source3d_program sp;
+  int64_t first;
+  __device__ __forceinline__ void load(int64_t i, double s[3], double e[3]) const {
+    eval_ray(sp, first + i, s, e);
+  }
+};
 
 // ------------------------------------------------------------------------------ order keys
 
@@ -64,8 +83,8 @@ struct OrderFrame {
 // a common direction, |mean| <= 1/2 (an isotropic point source): no plane -- octahedral map of the
 // directions.  One workgroup, a fixed reduction tree: the same frame on every run.  Also arms the
 // extents mm[0..3] (running minima of enc(x), ~enc(x), enc(y), ~enc(y)).
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_order_frame(const T* __restrict__ rays, int64_t stride,
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_order_frame(const R src,
                                                        int n, const double* __restrict__ fverts,
                                                        int M, double ax0, double ax1, double ax2,
                                                        int has_axis, OrderFrame* __restrict__ frame,
@@ -75,7 +94,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_frame(const T* __restrict__ ray
   mm[tid] = 0xFFFFFFFFu;      // (MM_SLOTS * 4 == BLOCK values)
   const int64_t is = n > 0 ? (int64_t)tid * n / BLOCK : 0;  // this thread's sample ray
   double ss[3] = {0, 0, 0}, se[3] = {0, 0, 0};
-  if (n > 0) load_ray3(rays, stride, is, ss, se);
+  if (n > 0) src.load(is, ss, se);
   double acc[4] = {0, 0, 0, 0};
   if (fverts != nullptr && M > 0) {
     if (tid < ORD_FACE_SAMPLES) {
@@ -222,8 +241,8 @@ __device__ __forceinline__ void order_extents_read(const unsigned* __restrict__ 
   *yhi = dec_f(~v.w);
 }
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, int64_t stride,
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_order_xy(const R src,
                                                     int n, const OrderFrame* __restrict__ frame,
                                                     float2* __restrict__ xy,
                                                     unsigned* __restrict__ mm) {
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_xy(const T* __restrict__ rays, 
   float x = __builtin_nanf(""), y = __builtin_nanf("");
   if (i < n) {
     double s[3], e[3];
-    load_ray3(rays, stride, i, s, e);
+    src.load(i, s, e);
     order_coords(fr, s, e, &x, &y);
     xy[i] = make_float2(x, y);
   }
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(BLOCK) void k_colscan_segs(unsigned* __restrict__ s
 }
 
 template <int ITEMS>
-__global__ __launch_bounds__(BLOCK) void k_sort_hist(const unsigned* __restrict__ keys, int n,
+__global__ __launch_bounds__(BLOCK) void k_sort_hist(const uint2* __restrict__ pairs, int n,
                                                      int shift, int bits,
                                                      unsigned* __restrict__ hist, int nblk) {
   extern __shared__ unsigned h_lds[];
@@ -374,7 +393,7 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(const unsigned* __restrict_
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const int i = base + r * BLOCK + tid;
-    if (i < n) atomicAdd(&h_lds[(keys[i] >> shift) & (unsigned)(bins - 1)], 1u);
+    if (i < n) atomicAdd(&h_lds[(pairs[i].x >> shift) & (unsigned)(bins - 1)], 1u);
   }
   __syncthreads();
   for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
@@ -426,14 +445,14 @@ __device__ __forceinline__ void lds_exclusive_from(const unsigned* __restrict__ 
   __syncthreads();
 }
 
-// One pass of the sort for one tile.  FIRST: the values are the items' own indices (not read);
-// LAST: keys are not written.  Dynamic LDS: cnt u16 [WAVES][bins] | delta i32 [bins] |
+// One pass of the sort for one tile.  FIRST: keys from `keys_in`, the values are the items' own
+// indices; otherwise (key, value) pairs from `pairs_in`.  LAST: only the values are written.  Dynamic LDS: cnt u16 [WAVES][bins] | delta i32 [bins] |
 // stage_k u32 [TILE] | stage_v i32 [TILE].
 template <int ITEMS, bool FIRST, bool LAST>
 __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
-    const unsigned* __restrict__ keys_in, const int32_t* __restrict__ vals_in, int n, int shift,
+    const unsigned* __restrict__ keys_in, const uint2* __restrict__ pairs_in, int n, int shift,
     int bits, const unsigned* __restrict__ hist, const unsigned* __restrict__ seg,
-    const unsigned* __restrict__ dtotal, unsigned* __restrict__ keys_out,
+    const unsigned* __restrict__ dtotal, uint2* __restrict__ pairs_out,
     int32_t* __restrict__ vals_out) {
   constexpr int TILE = BLOCK * ITEMS;
   extern __shared__ unsigned lds[];
@@ -455,9 +474,14 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
   for (int r = 0; r < ITEMS; ++r) {
     const int i = wbase + r * 64 + lane;
     const bool ok = i < n;
-    key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
-    if constexpr (FIRST) val[r] = i;
-    else val[r] = ok ? vals_in[i] : 0;
+    if constexpr (FIRST) {
+      key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
+      val[r] = i;
+    } else {
+      const uint2 kv = ok ? pairs_in[i] : make_uint2(0xFFFFFFFFu, 0u);
+      key[r] = kv.x;
+      val[r] = (int32_t)kv.y;
+    }
     // (a slot past the end ranks as the largest digit: it is also last by position, so it ends
     // up behind every item of the tile and is simply not written)
     dr[r] = ok ? ((key[r] >> shift) & dmask) : dmask;
@@ -543,8 +567,10 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
   for (int p = tid; p < nvalid; p += BLOCK) {
     const unsigned k = stage_k[p];
     const int dest = p + delta[(k >> shift) & dmask];
-    if constexpr (!LAST) keys_out[dest] = k;
-    vals_out[dest] = stage_v[p];
+    // (key and value travel as one 8-byte store: the writes are scattered, and their number is
+    // what this kernel costs)
+    if constexpr (!LAST) pairs_out[dest] = make_uint2(k, (unsigned)stage_v[p]);
+    else vals_out[dest] = stage_v[p];
   }
 }
 
@@ -701,15 +727,17 @@ __global__ __launch_bounds__(BLOCK) void k_restore_scan(uint2* __restrict__ word
 static int order_bits(int64_t n) {
   int lg = 0;
   while ((1ll << lg) < n) ++lg;       // ceil(log2 n)
-  int b = (lg + 2 + 1) / 2;           // about four cells per ray
+  int b = (lg + 1) / 2;               // about one cell per ray
   if (b < 4) b = 4;
   if (b > 13) b = 13;
   return b;
 }
-static int order_items(int64_t n) { return n < (300 << 10) ? 4 : (n < (3 << 20) ? 8 : 16); }
+// items per thread of a sort tile: big tiles make long runs of equal digits (the scatter's writes
+// are what it costs), small ones fill the chip when the rays are few
+static int order_items(int64_t n) { return n < (128 << 10) ? 4 : (n < (512 << 10) ? 8 : 16); }
 
 struct OrderLayout {
-  size_t head, xy, keys_a, keys_b, vals_a, hist, seg, dtotal, total;
+  size_t head, xy, keys_a, pairs, hist, seg, dtotal, total;
   int bits, items, nblk, nseg;
 };
 
@@ -730,8 +758,7 @@ static OrderLayout order_layout(int64_t n) {
   L.head = take(MM_SLOTS * 16 + sizeof(OrderFrame));   // extents (MM_SLOTS x 4 u32) | frame
   L.xy = take(m * sizeof(float2));
   L.keys_a = take(m * sizeof(unsigned));
-  L.keys_b = take(m * sizeof(unsigned));
-  L.vals_a = take(m * sizeof(int32_t));
+  L.pairs = take(m * sizeof(uint2));
   L.hist = take((size_t)hlen * sizeof(unsigned));
   L.seg = take((size_t)L.nseg * ((size_t)1 << L.bits) * sizeof(unsigned));
   L.dtotal = take(((size_t)1 << L.bits) * sizeof(unsigned));
@@ -747,8 +774,7 @@ static size_t scatter_lds_bytes(int bits, int items) {
 template <int ITEMS>
 static int sort_passes(const OrderLayout& L, char* ws, int n, int32_t* perm, unsigned* keys_nat,
                        hipStream_t st) {
-  unsigned* keys_b = reinterpret_cast<unsigned*>(ws + L.keys_b);
-  int32_t* vals_a = reinterpret_cast<int32_t*>(ws + L.vals_a);
+  uint2* pairs = reinterpret_cast<uint2*>(ws + L.pairs);
   unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
   unsigned* seg = reinterpret_cast<unsigned*>(ws + L.seg);
   unsigned* dtotal = reinterpret_cast<unsigned*>(ws + L.dtotal);
@@ -760,34 +786,34 @@ static int sort_passes(const OrderLayout& L, char* ws, int n, int32_t* perm, uns
   hipLaunchKernelGGL(k_colscan_rows, cgrid, dim3(BLOCK), 0, st, hist, L.nblk, bins, seg);
   hipLaunchKernelGGL(k_colscan_segs, dim3(cgrid.x), dim3(BLOCK), 0, st, seg, L.nseg, bins, dtotal);
   hipLaunchKernelGGL((k_sort_scatter<ITEMS, true, false>), dim3(L.nblk), dim3(BLOCK), lds, st,
-                     keys_nat, static_cast<const int32_t*>(nullptr), n, 0, L.bits, hist, seg,
-                     dtotal, keys_b, vals_a);
+                     keys_nat, static_cast<const uint2*>(nullptr), n, 0, L.bits, hist, seg,
+                     dtotal, pairs, static_cast<int32_t*>(nullptr));
   // pass 1
   hipLaunchKernelGGL((k_sort_hist<ITEMS>), dim3(L.nblk), dim3(BLOCK), bins * sizeof(unsigned), st,
-                     keys_b, n, L.bits, L.bits, hist, L.nblk);
+                     pairs, n, L.bits, L.bits, hist, L.nblk);
   hipLaunchKernelGGL(k_colscan_rows, cgrid, dim3(BLOCK), 0, st, hist, L.nblk, bins, seg);
   hipLaunchKernelGGL(k_colscan_segs, dim3(cgrid.x), dim3(BLOCK), 0, st, seg, L.nseg, bins, dtotal);
   hipLaunchKernelGGL((k_sort_scatter<ITEMS, false, true>), dim3(L.nblk), dim3(BLOCK), lds, st,
-                     keys_b, vals_a, n, L.bits, L.bits, hist, seg, dtotal,
-                     static_cast<unsigned*>(nullptr), perm);
+                     static_cast<const unsigned*>(nullptr), pairs, n, L.bits, L.bits, hist, seg,
+                     dtotal, static_cast<uint2*>(nullptr), perm);
   return 0;
 }
 
-template <typename T>
-static int ray_order_t(const void* rays, int64_t stride, int64_t N, const double* fverts,
-                       int64_t M, const double* axis, int32_t* perm, uint32_t* keys_out,
-                       char* ws, const OrderLayout& L, hipStream_t st) {
+template <typename R>
+static int ray_order_t(const R& src, int64_t N, const double* fverts, int64_t M,
+                       const double* axis, int32_t* perm, uint32_t* keys_out, char* ws,
+                       const OrderLayout& L, hipStream_t st) {
   const int n = (int)N;
   unsigned* mm = reinterpret_cast<unsigned*>(ws + L.head);
   OrderFrame* frame = reinterpret_cast<OrderFrame*>(ws + L.head + MM_SLOTS * 16);
   float2* xy = reinterpret_cast<float2*>(ws + L.xy);
   unsigned* keys = keys_out != nullptr ? keys_out : reinterpret_cast<unsigned*>(ws + L.keys_a);
   unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
-  hipLaunchKernelGGL((k_order_frame<T>), dim3(1), dim3(BLOCK), 0, st, static_cast<const T*>(rays),
-                     stride, n, fverts, (int)M, axis ? axis[0] : 0.0, axis ? axis[1] : 0.0,
-                     axis ? axis[2] : 0.0, axis ? 1 : 0, frame, mm);
-  hipLaunchKernelGGL((k_order_xy<T>), dim3(cdiv(N, BLOCK)), dim3(BLOCK), 0, st,
-                     static_cast<const T*>(rays), stride, n, frame, xy, mm);
+  hipLaunchKernelGGL((k_order_frame<R>), dim3(1), dim3(BLOCK), 0, st, src, n, fverts, (int)M,
+                     axis ? axis[0] : 0.0, axis ? axis[1] : 0.0, axis ? axis[2] : 0.0,
+                     axis ? 1 : 0, frame, mm);
+  hipLaunchKernelGGL((k_order_xy<R>), dim3(cdiv(N, BLOCK)), dim3(BLOCK), 0, st, src, n, frame, xy,
+                     mm);
   const size_t hl = ((size_t)1 << L.bits) * sizeof(unsigned);
   int rc = 0;
 #define TFRT_ORDER_ITEMS(I)                                                                       \
@@ -853,17 +879,40 @@ int tfrt_ray_order(const void* rays, int64_t stride, int64_t n_rays, int32_t sta
   int rc;
   switch (state_dtype) {
     case TFRT_F32:
-      rc = ray_order_t<float>(rays, stride, n_rays, face_verts, n_faces, axis, perm, keys_out, ws, L, st);
+      rc = ray_order_t(BlockRays<float>{static_cast<const float*>(rays), stride}, n_rays,
+                       face_verts, n_faces, axis, perm, keys_out, ws, L, st);
       break;
     case TFRT_F64:
-      rc = ray_order_t<double>(rays, stride, n_rays, face_verts, n_faces, axis, perm, keys_out, ws, L, st);
+      rc = ray_order_t(BlockRays<double>{static_cast<const double*>(rays), stride}, n_rays,
+                       face_verts, n_faces, axis, perm, keys_out, ws, L, st);
       break;
     case TFRT_F16:
-      rc = ray_order_t<_Float16>(rays, stride, n_rays, face_verts, n_faces, axis, perm, keys_out, ws, L, st);
+      rc = ray_order_t(BlockRays<_Float16>{static_cast<const _Float16*>(rays), stride}, n_rays,
+                       face_verts, n_faces, axis, perm, keys_out, ws, L, st);
       break;
     default:
       return TFRT_E_BADARG;
   }
+  if (rc != 0) return rc;
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_source3d_order(const tfrt_source3d_program* program, int64_t first, int64_t n_rays,
+                        const double* face_verts, int64_t n_faces, const double* axis,
+                        int32_t* perm, uint32_t* keys_out, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (!program || n_rays < 0 || n_rays >= (1ll << 31) || n_faces < 0 || n_faces >= (1ll << 31) ||
+      first < 0 || first + n_rays > program->n_rays)
+    return TFRT_E_BADARG;
+  if (n_rays == 0) return 0;
+  if (!perm || !workspace) return TFRT_E_BADARG;
+  const OrderLayout L = order_layout(n_rays);
+  if (workspace_bytes < L.total) return TFRT_E_WORKSPACE;
+  ProgramRays src;
+  src.sp = *program;
+  src.first = first;
+  const int rc = ray_order_t(src, n_rays, face_verts, n_faces, axis, perm, keys_out,
+                             static_cast<char*>(workspace), L, static_cast<hipStream_t>(stream));
   if (rc != 0) return rc;
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }

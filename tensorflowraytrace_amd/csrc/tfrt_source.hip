@@ -21,118 +21,9 @@
 // an ordered source, a field somebody asks for after the step), and nothing but the device-side
 // epoch counters changes from step to step, so the step stays one launch graph.
 #include "tfrt_common.h"
+#include "source_programs.h"
 
 namespace tfrt {
-
-__device__ __forceinline__ void philox_round(uint32_t c[4], const uint32_t k[2]) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
-  c[0] = n0;
-  c[1] = (uint32_t)p1;
-  c[2] = n2;
-  c[3] = (uint32_t)p0;
-}
-
-// two uniform float64 in [0, 1) (53 bits each) for (seed, stream, epoch, sample)
-__device__ __forceinline__ void uniform2(uint64_t seed, uint32_t stream, uint64_t epoch,
-                                         uint64_t sample, double* u0, double* u1) {
-  uint32_t c[4] = {(uint32_t)sample, (uint32_t)(sample >> 32), (uint32_t)epoch,
-                   (uint32_t)(epoch >> 32)};
-  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32) ^ stream};
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    philox_round(c, k);
-    k[0] += 0x9E3779B9u;
-    k[1] += 0xBB67AE85u;
-  }
-  const uint64_t a = ((uint64_t)c[0] << 32) | c[1], b = ((uint64_t)c[2] << 32) | c[3];
-  *u0 = (double)(a >> 11) * 0x1.0p-53;
-  *u1 = (double)(b >> 11) * 0x1.0p-53;
-}
-
-__device__ __forceinline__ void quat_rotate(const double q[4], double v[3]) {
-  // v' = v + w t + u x t, t = 2 u x v   (q = (w, u) a unit quaternion)
-  const double t0 = 2.0 * (q[2] * v[2] - q[3] * v[1]);
-  const double t1 = 2.0 * (q[3] * v[0] - q[1] * v[2]);
-  const double t2 = 2.0 * (q[1] * v[1] - q[2] * v[0]);
-  const double r0 = v[0] + q[0] * t0 + (q[2] * t2 - q[3] * t1);
-  const double r1 = v[1] + q[0] * t1 + (q[3] * t0 - q[1] * t2);
-  const double r2 = v[2] + q[0] * t2 + (q[1] * t1 - q[2] * t0);
-  v[0] = r0;
-  v[1] = r1;
-  v[2] = r2;
-}
-
-constexpr double TWO_PI = 6.283185307179586476925286766559;
-constexpr double GOLDEN_TURN = 3.14159265358979323846 * (1.0 + 2.2360679774997896964);  // pi (1 + sqrt 5)
-
-// Sample `i` of a points program: the 3-D point (after the transformation) and the two numbers the
-// distribution's rank properties are made of (circle: r in [0, 1], theta; sphere: phi, theta).
-__device__ __forceinline__ void eval_points(const tfrt_points_program& pg, int64_t i,
-                                            double out[3], double aux[2]) {
-  double p[3] = {0.0, 0.0, 0.0};
-  aux[0] = aux[1] = 0.0;
-  if (pg.kind == TFRT_PTS_TABLE) {
-    const double* row = pg.table + 3 * i;
-    p[0] = row[0];
-    p[1] = row[1];
-    p[2] = row[2];
-  } else {
-    double u0, u1;
-    uniform2(pg.seed, pg.stream, (uint64_t)*pg.epoch, (uint64_t)i, &u0, &u1);
-    auto theta_mod = [&](double th) {
-      if (pg.p[1] == 0.0 && pg.p[2] == TWO_PI) return th;
-      const double span = pg.p[2] - pg.p[1];
-      double m = fmod(th, span);
-      if (m != 0.0 && ((m < 0.0) != (span < 0.0))) m += span;   // (sign of the divisor)
-      return m + pg.p[1];
-    };
-    if (pg.kind == TFRT_PTS_CIRCLE) {            // p = {radius, theta_start, theta_end}
-      const double r = sqrt(u0);
-      const double th = theta_mod(TWO_PI * u1);
-      double sn, cs;
-      sincos(th, &sn, &cs);
-      p[1] = pg.p[0] * (r * cs);
-      p[2] = pg.p[0] * (r * sn);
-      aux[0] = r;
-      aux[1] = th;
-    } else if (pg.kind == TFRT_PTS_SQUARE) {     // p = {x_size, -, -, y_size}
-      p[1] = -pg.p[0] + (2.0 * pg.p[0]) * u0;
-      p[2] = -pg.p[3] + (2.0 * pg.p[3]) * u1;
-      aux[0] = p[1];
-      aux[1] = p[2];
-    } else {                                     // p = {radius, theta_start, theta_end, lower bound}
-      const double c = pg.p[3] + (1.0 - pg.p[3]) * u0;
-      const double phi = acos(pg.kind == TFRT_PTS_SPHERE_LAMBERT ? sqrt(c) : c);
-      const double th = theta_mod(GOLDEN_TURN * u1);
-      double sp, cp, sn, cs;
-      sincos(phi, &sp, &cp);
-      sincos(th, &sn, &cs);
-      p[0] = pg.p[0] * cp;
-      p[1] = pg.p[0] * (sp * cs);
-      p[2] = pg.p[0] * (sp * sn);
-      aux[0] = phi;
-      aux[1] = th;
-    }
-    // BasePointTransformation (distributions.py:2014-2120): scale, rotate, translate
-    if (pg.has_scale) {
-      p[0] *= pg.scale[0];
-      p[1] *= pg.scale[1];
-      p[2] *= pg.scale[2];
-    }
-    if (pg.has_quat) quat_rotate(pg.quat, p);
-    if (pg.has_shift) {
-      p[0] += pg.shift[0];
-      p[1] += pg.shift[1];
-      p[2] += pg.shift[2];
-    }
-  }
-  out[0] = p[0];
-  out[1] = p[1];
-  out[2] = p[2];
-}
 
 __global__ __launch_bounds__(BLOCK) void k_points(tfrt_points_program pg, const int32_t* index,
                                                   int64_t first, int64_t n,
@@ -156,35 +47,6 @@ __global__ __launch_bounds__(BLOCK) void k_points(tfrt_points_program pg, const 
   }
   if (aux0 != nullptr) aux0[j] = aux[0];
   if (aux1 != nullptr) aux1[j] = aux[1];
-}
-
-// ray i of the source (natural numbering)
-__device__ __forceinline__ void eval_ray(const tfrt_source3d_program& sp, int64_t i, double s[3],
-                                         double e[3]) {
-  double a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, aux[2];
-  const int64_t ia = sp.a.count == 1 ? 0 : i, ib = sp.b.count == 1 ? 0 : i;
-  if (sp.kind == TFRT_SRC_APERTURE) {
-    eval_points(sp.a, ia, s, aux);
-    eval_points(sp.b, ib, e, aux);
-    return;
-  }
-  eval_points(sp.b, ib, b, aux);   // the direction vectors
-  if (sp.has_quat) quat_rotate(sp.quat, b);
-  if (sp.kind == TFRT_SRC_ANGULAR) {
-    eval_points(sp.a, ia, a, aux);
-    if (sp.has_quat) quat_rotate(sp.quat, a);
-  }
-  double st[3], en[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    st[q] = sp.center[q] + a[q];
-    en[q] = st[q] + sp.ray_length * b[q];
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    s[q] = sp.swap ? en[q] : st[q];
-    e[q] = sp.swap ? st[q] : en[q];
-  }
 }
 
 template <typename T>

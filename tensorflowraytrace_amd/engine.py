@@ -873,15 +873,11 @@ class OpticalEngine:
         index_mode, ghost = self._reaction()
         device_set = hasattr(rays, "ray_block")     # sources.DeviceRaySet: rays made in place
         if device_set:
-            # (the buffers are persistent; ``cache_key`` changes with every update of the source)
+            # (the buffers are persistent; ``cache_key`` changes with every update of the source;
+            # the block in source order is only made when the trace runs in that order)
             key = rays.cache_key + (dt,)
             needs_grad = False
-            cache = getattr(self, "_input_cache", None)
-            if cache is not None and cache[0] == key:
-                block = cache[1]
-            else:
-                block = rays.ray_block(dt)
-                self._input_cache = (key, block, [rays])
+            block = None
         else:
             # the ray block and the n(lambda) table depend only on the input tensors: reuse them
             # while the caller hands in the very same tensors (static sources between steps).  The
@@ -913,9 +909,11 @@ class OpticalEngine:
         if self.dimension == 3:
             perm = None
             if coherent_ok and not needs_grad:
-                perm = self._coherent_order(rays, block, n_table, key, mode, system)
+                perm = self._coherent_order(rays, block, n_table, key, mode, system, dt)
             if perm is not None:
                 block, n_table = self._order_cache[2:4]
+            elif block is None:
+                block = rays.ray_block(dt)
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       deterministic=self.deterministic)
             scene.coherent_rays = perm is not None
@@ -926,6 +924,8 @@ class OpticalEngine:
             self._visit_key = ident if perm is not None else None
             self._trace_perm = perm
         else:
+            if block is None:
+                block = rays.ray_block(dt)
             scene = system.scene_args(n_table, index_mode, ghost,
                                       finite_tir_gradient=self.finite_tir_gradient)
         fv = None
@@ -942,36 +942,38 @@ class OpticalEngine:
         plain tensors is its tensors."""
         return rays.identity if hasattr(rays, "identity") else key
 
-    def _coherent_order(self, rays, block, n_table, key, mode, system):
-        """The coherent order of the source block (see ``coherent``), with the permuted block and
+    def _coherent_order(self, rays, block, n_table, key, mode, system, dt):
+        """The coherent order of the source (see ``coherent``), with the permuted block and
         n(lambda) table: ``self._order_cache = (key, perm, block_p, n_table_p, n_table, held)``.
-        A static source is ordered once (the cache holds its tensors and is honoured only for the
-        very same ones); a source re-drawn in place is ordered after every update, into the same
-        persistent buffers."""
-        if (mode == "all-pairs" or self.coherent is False or block.shape[1] < 4096
-                or not block.is_cuda):
+        A static source is ordered once (the cache holds its block and is honoured only for the
+        very same one); a source re-drawn in place (``block`` is None: sources.DeviceRaySet) is
+        ordered after every update, straight from its program, into the same persistent buffers."""
+        device_set = block is None
+        n = rays.n_rays if device_set else block.shape[1]
+        on_gpu = rays.device.type == "cuda" if device_set else block.is_cuda
+        if mode == "all-pairs" or self.coherent is False or n < 4096 or not on_gpu:
             return None
         ident = self._source_identity(rays, key)
         if self.coherent == "auto" and getattr(self, "_incoherent_key", None) == ident:
             return None                      # (tried: this source's wavefronts are no bundles)
         cached = getattr(self, "_order_cache", None)
-        if cached is not None and cached[0] == key and cached[5][0] is block:
+        if cached is not None and cached[0] == key and (device_set or cached[5][0] is block):
             if cached[4] is not n_table:     # (other materials / wavelengths: same order)
                 cached = cached[:3] + (self._permuted_table(n_table, cached[1]), n_table, cached[5])
                 self._order_cache = cached
             return cached[1]
         fv = system._merged_face_verts
-        device_set = hasattr(rays, "permuted")
-        bufs = None
-        if cached is not None and device_set and cached[5][1] == ident and cached[1].numel() == block.shape[1]:
-            bufs = cached       # (same source, new draw: the same perm buffer, so that a captured
-            #                      launch sequence of the step stays valid)
-        perm = bufs[1] if bufs is not None else None
-        axis = rays._src.axis_hint() if (device_set and hasattr(rays._src, "axis_hint")) else None
-        perm = ops.ray_order(block, fv if fv is not None and fv.shape[0] else None, axis, out=perm)
+        fv = fv if fv is not None and fv.shape[0] else None
         if device_set:
-            block_p = rays.permuted(perm).ray_block(block.dtype)
+            # (same source, new draw: the same perm buffer, so that a captured launch sequence of
+            # the step stays valid)
+            perm = None
+            if cached is not None and cached[5][1] == ident and cached[1].numel() == n:
+                perm = cached[1]
+            perm = rays.order(fv, out=perm)
+            block_p = rays.permuted(perm).ray_block(dt)
         else:
+            perm = ops.ray_order(block, fv)
             block_p = ops.permute_rays(block, perm)
         self._order_cache = (key, perm, block_p, self._permuted_table(n_table, perm), n_table,
                              (block, ident))

@@ -1058,6 +1058,27 @@ def restore_order(out, perm):
     return new
 
 
+def source3d_order(program, n, first=0, face_verts=None, axis=None, out=None, device=None):
+    """``ray_order`` of rays ``first .. first + n`` of a source program (tfrt_source3d_order): the
+    rays are never written in source order."""
+    n = int(n)
+    dev = device if device is not None else (out.device if out is not None else face_verts.device)
+    perm = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
+    if perm.dtype != torch.int32 or perm.numel() != n or not perm.is_contiguous():
+        raise TfrtError("source3d_order: `out` must be a contiguous int32 tensor of n entries")
+    _need_gpu(perm, face_verts)
+    if n:
+        L = _lib.lib()
+        fv = None if face_verts is None else _c(face_verts.detach(), torch.float64)
+        wsb = L.tfrt_ray_order_workspace_bytes(n)
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        ax = None if axis is None else (ctypes.c_double * 3)(*[float(v) for v in axis])
+        check(L.tfrt_source3d_order(ctypes.byref(program), int(first), n, _p(fv),
+                                    0 if fv is None else fv.shape[0], ax, _p(perm), None, _p(ws),
+                                    wsb, _stream(perm)), "tfrt_source3d_order")
+    return perm
+
+
 def epoch_advance(counters):
     """``c[0] += 1`` for up to 8 distinct int64 device counters in one launch (tfrt_epoch_advance):
     the distributions of a source step to their next draw."""

@@ -10,7 +10,7 @@ def order_bits(n):
     lg = 0
     while (1 << lg) < n:
         lg += 1
-    return min(13, max(4, (lg + 3) // 2))
+    return min(13, max(4, (lg + 1) // 2))
 
 
 def hilbert_index(x, y, bits):

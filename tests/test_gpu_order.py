@@ -21,7 +21,7 @@ def _lens_rays(n, dtype=torch.float32, seed=None):
     return torch.tensor(scene["rays"], dtype=dtype, device=DEV)
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 4097, 70001, 300 * 1024 + 5, 1000000, 3 * 2 ** 20 + 77])
+@pytest.mark.parametrize("n", [1, 63, 64, 4097, 70001, 300 * 1024 + 5, 1000000, 4 * 2 ** 20 + 77])
 def test_order_is_the_stable_argsort_of_its_keys(n):
     """Every tile size of the radix sort (4, 8 and 16 items per thread), partial tiles, one ray."""
     from tensorflowraytrace_amd import ops
