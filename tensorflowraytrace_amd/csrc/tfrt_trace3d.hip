@@ -1366,6 +1366,11 @@ constexpr int BEAM_WIDE = 48;     // candidate faces beyond which a bundle of mo
 struct Beam {  // wave-uniform
   float ox, oy, oz, wx, wy, wz, R0, S, tmin;      // axis, bounds (see k_intersect_beam)
   float e1x, e1y, e1z, e2x, e2y, e2z;             // image plane (see face_frame)
+  float R0b, tb;                                  // the bundle's radius in a second plane, t = tb
+  // radius bound of the bundle at axial coordinate t (+ pad on |t|): the smaller of the two
+  __device__ __forceinline__ float radius(float t, float pad) const {
+    return fminf(R0 + S * (fabsf(t) + pad), R0b + S * (fabsf(t - tb) + pad));
+  }
 };
 
 __device__ __forceinline__ bool beam_touch(const Beam& b, const float4 sp) {
@@ -1376,7 +1381,7 @@ __device__ __forceinline__ bool beam_touch(const Beam& b, const float4 sp) {
   const float vx = sp.x - b.ox, vy = sp.y - b.oy, vz = sp.z - b.oz;
   const float t = vx * b.wx + vy * b.wy + vz * b.wz;
   const float v2 = vx * vx + vy * vy + vz * vz;
-  const float B = r + b.R0 + b.S * (fabsf(t) + r);
+  const float B = r + b.radius(t, r);
   // (2e-6 v2: ten times the rounding error of v2 - t^2 and of a not exactly unit w)
   return (v2 - t * t <= B * B + 2e-6f * v2) && !(t + r < b.tmin);
 }
@@ -1440,7 +1445,9 @@ __device__ __forceinline__ bool face_frame(const Beam& b, const float4 r0, const
   rec[1] = make_float4(nx1, ny1, c1, thi);
   rec[2] = make_float4(nx2, ny2, c2, 0.5f * (tlo + thi));
   rec[3] = make_float4(0.5001f * (thi - tlo), slack2, r0.w, 0.f);
-  const float rho = (b.R0 + b.S * fmaxf(fabsf(tlo), fabsf(thi)) + slack2) * 1.0001f;
+  const float rho = (fminf(b.R0 + b.S * fmaxf(fabsf(tlo), fabsf(thi)),
+                           b.R0b + b.S * fmaxf(fabsf(tlo - b.tb), fabsf(thi - b.tb))) +
+                     slack2) * 1.0001f;
   return !(c0 > rho) && !(c1 > rho) && !(c2 > rho) && !(thi < b.tmin);
 }
 
@@ -1682,7 +1689,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
     const float cnt = (float)__popcll(__ballot(sel));
     bool narrow = true, brute = false;
     int ns = 0, nc = 0, nf = 0;
-    Beam bm = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, -INFINITY, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    Beam bm = {0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, -INFINITY, 1.f, 0.f, 0.f, 0.f, 1.f, 0.f,
+               INFINITY, 0.f};
     float ray_t = 0.f, ray_dt = 0.f, ray_terr = 0.f;  // this lane's ray along the axis: start, d . w
     float Ax = 0.f, Ay = 0.f, Mx = 0.f, My = 0.f, Mlen = 0.f, Perr = 0.f, Pm = 0.f;  // ... its image
     if (cnt > 0.f) {
@@ -1733,39 +1741,34 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
         Perr = 2e-5f * (fabsf(p1) + fabsf(p2) + fabsf(ts) * (fabsf(Mx) + fabsf(My)) + rabs +
                         fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz));
       }
-      // The bound R0 + S |t| is tightest when t counts from the bundle's WAIST, not from the mean
-      // start: rays sorted by where they cross the scene but coming from all over an extended
-      // object (a source re-drawn at random every step, dev/hexalens.py:36-48) are a double cone
-      // whose narrow part is at the lens -- measured from their starts ten units away, the bundle
-      // looked as wide there as the object.  t0 = the least-squares point where the images A + M t
-      // are closest to the axis; the origin moves along the axis by t0, which changes no line.
-      float sam = sel ? Ax * Mx + Ay * My : 0.f, smm = sel ? Mx * Mx + My * My : 0.f;
-      float Lw = sel ? rabs : 0.f, pad2 = 0.f, pad4 = 0.f;
-      wave_sum4(sam, smm, pad2, pad4);
-      Lw = wave_max_f(Lw);
-      Lw += fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz);
-      float t0 = smm > 1e-30f ? -sam * __builtin_amdgcn_rcpf(smm) : 0.f;
-      // (a far waist would cost the origin its float32 digits: the bound below allows 4e-6 Lw)
-      t0 = fminf(fmaxf(t0, -8.f * Lw), 8.f * Lw);
-      if (!(t0 == t0)) t0 = 0.f;
-      bm.ox += t0 * bm.wx; bm.oy += t0 * bm.wy; bm.oz += t0 * bm.wz;
-      Ax += Mx * t0;
-      Ay += My * t0;
-      ray_t -= t0;
-      {
-        const float at0 = fabsf(t0);
-        ray_terr += 1e-5f * at0;
-        Perr += 2e-5f * at0 * (1.f + fabsf(Mx) + fabsf(My));
-        Lw += at0;
-      }
       // (offset and slope of the ray's line from the axis are those of its image: e1, e2, w are
       // orthonormal to rounding, which the inflation below covers many times over)
       float R0 = sel ? __builtin_amdgcn_sqrtf(Ax * Ax + Ay * Ay) : 0.f, S = sel ? Mlen : 0.f;
-      float tmin = sel ? ray_t : INFINITY, pad3 = 0.f;
-      wave_max3_min(R0, S, pad3, tmin);
+      float Lw = sel ? rabs : 0.f, tmin = sel ? ts : INFINITY;
+      wave_max3_min(R0, S, Lw, tmin);
+      Lw += fabsf(bm.ox) + fabsf(bm.oy) + fabsf(bm.oz);
+      // A second anchor of the same bound: R0 + S |t| is tight near the plane where R0 was taken
+      // and loosens with the distance from it, because S is the largest slope, not the spread.
+      // The starts' plane is the right one once the rays are inside the scene -- but rays sorted
+      // by where they cross the scene and coming from all over an extended object ten units away
+      // (a source re-drawn at random every step, dev/hexalens.py:36-48) are a double cone whose
+      // narrow part is at the lens: measured from their starts the bundle looked as wide there as
+      // the object.  So the bundle's radius is also taken in the plane through the frame origin
+      // c0 (which lies in the mesh), at axial coordinate tb, and a node is tested against the
+      // smaller of the two bounds.
+      const float tb = -(bm.ox * bm.wx + bm.oy * bm.wy + bm.oz * bm.wz);
+      float R0b = 0.f;
+      if (sel) {
+        const float bx = Ax + Mx * tb, by = Ay + My * tb;
+        R0b = __builtin_amdgcn_sqrtf(bx * bx + by * by);
+      }
+      R0b = wave_max_f(R0b);
       // bounds inflated far beyond their float32 rounding (offsets ~ 2^-23 Lw, slopes ~ 2^-23)
       bm.R0 = R0 * 1.001f + 4e-6f * Lw;
       bm.S = S * 1.001f + 2e-6f;
+      bm.tb = tb;
+      bm.R0b = R0b * 1.001f + 4e-6f * (Lw + fabsf(tb)) + 2e-6f * fabsf(tb) * S;
+      if (!(bm.R0b < 3.0e38f)) bm.R0b = INFINITY;   // (NaN or overflow: the first bound alone)
       // (first pass of a trace: sources normally sit outside the scene, nothing lies behind
       // them; and only while hits must lie ahead of the start: ray_start_epsilion >= 0)
       bm.tmin = (!first_pass && eps_start >= 0.0) ? tmin - 1e-5f * Lw - 1e-5f * fabsf(tmin)
@@ -1775,6 +1778,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
       bm.ox = uniform_f(bm.ox); bm.oy = uniform_f(bm.oy); bm.oz = uniform_f(bm.oz);
       bm.wx = uniform_f(bm.wx); bm.wy = uniform_f(bm.wy); bm.wz = uniform_f(bm.wz);
       bm.R0 = uniform_f(bm.R0); bm.S = uniform_f(bm.S); bm.tmin = uniform_f(bm.tmin);
+      bm.R0b = uniform_f(bm.R0b); bm.tb = uniform_f(bm.tb);
       bm.e1x = uniform_f(bm.e1x); bm.e1y = uniform_f(bm.e1y); bm.e1z = uniform_f(bm.e1z);
       bm.e2x = uniform_f(bm.e2x); bm.e2y = uniform_f(bm.e2y); bm.e2z = uniform_f(bm.e2z);
       TFRT_TICK(1);
@@ -1931,7 +1935,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
         const float vx = sp.x - bm.ox, vy = sp.y - bm.oy, vz = sp.z - bm.oz;
         const float vu = vx * bm.wx + vy * bm.wy + vz * bm.wz;
         const float v2 = vx * vx + vy * vy + vz * vz;
-        const float rr = __builtin_amdgcn_sqrtf(sp.w) * 1.000002f + bm.R0 + bm.S * fabsf(vu);
+        const float rr = __builtin_amdgcn_sqrtf(sp.w) * 1.000002f + bm.radius(vu, 0.f);
         cand = v2 - vu * vu <= rr * rr + 4e-6f * v2;  // (padding: w < 0, NaN, never)
       }
       if (cand) {
