@@ -226,6 +226,9 @@ def main(argv=None):
                          "are identical in every mode): all-pairs = float32 bounding-sphere "
                          "filter on every pair; group = sphere hierarchy over k-d face "
                          "clusters; auto = the engine's default (group)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5a", "cfg5b"], default="cfg4",
+                    help="BASELINE.json configuration: cfg4 (default) is the headline; the others "
+                         "emit a line of the same shape for their workload (bench_configs.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the separately reported legs (all-pairs mode, float64 state, ...)")
@@ -238,6 +241,12 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the tfrt hot path has no CPU fallback")
+    if args.config != "cfg4":
+        if args.gpus != 1:
+            raise SystemExit("--config other than cfg4 is a single-GPU measurement")
+        import bench_configs
+        bench_configs.run(args.config, args)
+        return
 
     import tensorflowraytrace_amd as tfa
     from tensorflowraytrace_amd import _lib, distributed as tdist

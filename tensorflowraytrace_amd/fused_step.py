@@ -325,10 +325,20 @@ class FusedStep:
                 else:
                     grads[i] = g if grads[i] is None else grads[i] + g
             for i, g in total.items():
-                if (not self.untapped and self._tap_checks < self.graph_warmup
-                        and not (grads[i] is not None and
-                                 torch.allclose(grads[i], g, rtol=1e-12, atol=0.0, equal_nan=True))):
-                    self.untapped = True      # (one host read per parameter, first steps only)
+                if not self.untapped and self._tap_checks < self.graph_warmup:
+                    # (one host read per parameter, first steps only.  Relative to the gradient's
+                    # largest entry: the aliases are summed in another order than autograd's own
+                    # accumulation, entries near zero may differ by more than any relative bound)
+                    same = grads[i] is not None and bool(
+                        torch.isfinite(g).eq(torch.isfinite(grads[i])).all()) and float(
+                        (torch.nan_to_num(grads[i] - g, nan=0.0, posinf=0.0, neginf=0.0)).abs().max()
+                    ) <= 1e-9 * float(torch.nan_to_num(g, nan=0.0, posinf=0.0, neginf=0.0).abs().max())
+                    if not same:
+                        self.untapped = True
+                        self.capture_error = RuntimeError(
+                            f"FusedStep: parameter {i} reaches the faces without boundaries.tap "
+                            "(its leaf gradient differs from the sum over its aliases): the step "
+                            "is never captured in a launch graph")
                 grads[i] = g
             if not capturing:
                 self._tap_checks += 1

@@ -310,7 +310,12 @@ class ParamFacesBatch:
                     layout.append(("param", r))
                     continue
                 fv = b.__dict__.get("_face_verts_value")
-                if (fv is None or fv.requires_grad or not fv.is_cuda or fv.dtype != torch.float64
+                # (a boundary whose xp .. z2 fields were assigned by hand no longer shows its raw
+                # vertex block: its face_verts property stacks the fields -- not copyable)
+                overridden = any(k in getattr(b, "_fields", {}) for k in
+                                 ("xp", "yp", "zp", "x1", "y1", "z1", "x2", "y2", "z2"))
+                if (fv is None or overridden or fv.requires_grad or not fv.is_cuda
+                        or fv.dtype != torch.float64
                         or not fv.is_contiguous() or fv.dim() != 2 or fv.shape[1] != 9):
                     layout = None   # (something the block cannot hold: faces only, then cat)
                     break

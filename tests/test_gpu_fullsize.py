@@ -20,6 +20,7 @@ import oracle_util
 import scene_util
 from oracle import tracer
 from test_gpu_trace3d import _gpu_scene
+from scene_configs import _build_5a, _oracle_5a, _scene_5b, N_5A, PASSES_5A
 
 pytestmark = pytest.mark.gpu
 
@@ -194,31 +195,6 @@ def test_full_size_permutation_invariance(full):
 # ------------------------------------------------------------------------------------------
 # 2-D at cfg5b's size: 4,000,000 rays x (256 segments + 64 arcs), 4 passes
 
-def _scene_5b(n_rays, seed=0):
-    import math
-    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
-    na = 64
-    xc = np.linspace(-16, 16, na)
-    xs = np.linspace(-18, 18, 256)
-    ys = 6.0 + 0.3 * np.sin(xs)
-    sets = {
-        "optical_arcs": dict(x_center=t(xc), y_center=t(np.full(na, 3.0)),
-                             angle_start=t(np.full(na, -math.pi + 0.3)), angle_end=t(np.full(na, -0.3)),
-                             radius=t(np.full(na, 0.6)), mat_in=torch.ones(na, dtype=torch.int64),
-                             mat_out=torch.zeros(na, dtype=torch.int64)),
-        "optical_segments": dict(x_start=t(xs[:-1]), y_start=t(ys[:-1]), x_end=t(xs[1:]), y_end=t(ys[1:]),
-                                 mat_in=torch.full((255,), 2, dtype=torch.int64),
-                                 mat_out=torch.zeros(255, dtype=torch.int64)),
-        "target_segments": dict(x_start=t([20.0]), y_start=t([-1.0]), x_end=t([20.0]), y_end=t([9.0])),
-    }
-    rng = np.random.default_rng(seed)
-    ang = rng.uniform(0.3 * math.pi, 0.7 * math.pi, n_rays)
-    x0 = rng.uniform(-15, 15, n_rays)
-    rays = np.stack([x0, np.zeros(n_rays), x0 + np.cos(ang), np.sin(ang)])
-    wl = np.full(n_rays, 550.0)
-    return sets, rays, wl
-
-
 def test_full_size_2d_conservation_sample_and_shards():
     from tensorflowraytrace_amd import ops, _lib
     import test_gpu_trace2d as t2
@@ -381,58 +357,6 @@ def test_cfg2_cfg3_stated_size_sample_and_gradients():
 # cfg5a: hex lens H(24) x 2 + ParametricCylindricalGuide(64, 64) + target,
 # 4,000,000 rays, 8 passes, through the public API; float32 vs float16 vs float64 ray state
 
-N_5A, PASSES_5A = 4_000_000, 8
-
-
-def _build_5a(ray_dtype, n_rays=N_5A, accelerate="auto", ray_shard=None, compile_all=True):
-    import tfrt.boundaries as boundaries
-    import tfrt.distributions as distributions
-    import tfrt.drawing as drawing
-    import tfrt.engine as engine
-    import tfrt.materials as materials
-    import tfrt.mesh_tools as mt
-    import tfrt.operation as operation
-    import tfrt.sources as sources
-
-    def surface(k, flip, sign, z):
-        zp = mt.hexagonal_mesh(0.45, k)                 # in the x-y plane
-        zp.points[:, 2] = z
-        r2 = (zp.points[:, 0] ** 2 + zp.points[:, 1] ** 2) / 0.45 ** 2
-        return boundaries.ParametricTriangleBoundary(
-            zp, boundaries.FromVectorVG((0, 0, 1)), flip_norm=flip,
-            initial_parameters=sign * (0.02 + 0.05 * (1 - r2)),
-            material_dict={"mat_in": 1, "mat_out": 0})
-
-    front, back = surface(24, True, -1.0, 0.3), surface(24, False, +1.0, 0.5)
-    guide = boundaries.ParametricCylindricalGuide(
-        (0, 0, 1.0), (0, 0, 7.0), 0.5, theta_res=64, z_res=64, initial_taper=(0.0, 0.15),
-        material_dict={"mat_in": 1, "mat_out": 0})
-    target = boundaries.ManualTriangleBoundary(
-        mesh=mt.plane(center=(0, 0, 6.9), direction=(0, 0, 1), i_size=3, j_size=3))
-    start = distributions.StaticUniformCircle(n_rays, 0.05)
-    end = distributions.StaticUniformCircle(n_rays, 0.42)
-    start.update()
-    end.update()
-    sp, ep = start.points, end.points
-    z0 = torch.full((n_rays,), -1.0, dtype=torch.float64, device=sp.device)
-    src = sources.ManualSource(3)
-    src["x_start"], src["y_start"], src["z_start"] = sp[:, 0], sp[:, 1], z0
-    src["x_end"], src["y_end"], src["z_end"] = ep[:, 0], ep[:, 1], z0 + 1.2
-    src["wavelength"] = torch.full((n_rays,), float(drawing.YELLOW), dtype=torch.float64,
-                                   device=sp.device)
-    system = engine.OpticalSystem3D()
-    system.optical = [front, back, guide]
-    system.targets = [target]
-    system.sources = [src]
-    system.materials = [{"n": materials.vacuum}, {"n": materials.acrylic}]
-    system.update()
-    eng = engine.OpticalEngine(
-        3, [operation.StandardReaction()], ray_dtype=ray_dtype, accelerate=accelerate,
-        compile_dead_rays=compile_all, compile_stopped_rays=compile_all,
-        compile_active_rays=compile_all, simple_ray_inheritance={"wavelength"},
-        ray_shard=ray_shard)
-    eng.optical_system = system
-    return eng, system, (front, back, guide, target)
 
 
 @pytest.fixture(scope="module")
@@ -493,21 +417,6 @@ def test_cfg5a_coherent_order_changes_nothing(cfg5a):
         assert torch.equal(got[cls].detach(), out[cls].detach()), cls
     print(f"cfg5a coherent order: {got['left_over']} wavefront-passes left to the grouped kernel "
           f"of {PASSES_5A * N_5A // 64}")
-
-
-def _oracle_5a(parts):
-    front, back, guide, target = parts
-    cpu = lambda t: t.detach().cpu()
-    sets = []
-    for b in (front, back, guide):
-        f = tracer.faces_from_vertices(cpu(b.vertices), b.faces[:, 1:])
-        n = f["xp"].shape[0]
-        f["mat_in"] = torch.ones(n, dtype=torch.int64)
-        f["mat_out"] = torch.zeros(n, dtype=torch.int64)
-        sets.append(f)
-    tgt = tracer.faces_from_vertices(cpu(target.vertices), target.faces[:, 1:])
-    return tracer.System(3, materials=[tracer.MATERIALS["vacuum"], tracer.MATERIALS["acrylic"]],
-                         optical=tracer.amalgamate(sets), target=tgt)
 
 
 def test_cfg5a_sample_against_the_oracle(cfg5a):
@@ -698,3 +607,68 @@ def test_scene_with_122882_faces_hierarchy_equals_all_pairs_and_the_oracle():
             acc += g
     for s_, g in zip(g_sum, grads):
         assert float((s_ - g).abs().max()) <= 1e-10 * float(g.abs().max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.float64, 1e-8)])
+def test_full_size_coherent_gradients_against_oracle_autograd(full, dtype, tol):
+    """optimizer.py:216-220 at cfg4's size on the COHERENT path (k_intersect_beam + the reverse
+    sweep's per-wavefront face sums in LDS, several copies per sum folded by DPP): contiguous
+    512-ray slices of the SORTED 1M-ray source against the whole 10,574-face scene.
+    (i) three slices: parameter gradients against torch.autograd through the oracle;
+    (ii) the 64 slices traced as one coherent run give the sum of the 64 slice gradients;
+    (iii) the whole source in coherent order gives the natural-order run's gradients."""
+    from tensorflowraytrace_amd import ops
+    scene = full["scene"]
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster="group")
+    perm = ops.ray_order(src, fv)
+    goal_all = torch.tensor(scene["goal"], dtype=torch.float64, device=src.device)
+    slices = [perm[k * (N_FULL // 64):k * (N_FULL // 64) + 512] for k in range(64)]
+
+    def run(index):
+        """coherent trace of the rays `index` (already in sorted order) -> parameter gradients"""
+        i64 = index.long()
+        sc2 = ops.Scene3DArgs(fv, sc.catagory, mat_in=sc.mat_in, mat_out=sc.mat_out,
+                              n_table=sc.n_table[:, i64].contiguous(), face_grad_mask=sc.face_grad_mask,
+                              cluster_order=sc.cluster_order, coherent_rays=True)
+        out = ops.trace3d(src[:, i64].contiguous(), fv, sc2, max_passes=PASSES)
+        fin = out["finished"]
+        goal = goal_all[i64][out["finished_id"].long()]
+        loss = ((fin[4].double() - goal[:, 0]) ** 2 + (fin[5].double() - goal[:, 1]) ** 2).sum()
+        return [g.clone() for g in torch.autograd.grad(loss, [p_f, p_b], retain_graph=True)], out
+
+    # (i) against oracle autograd
+    for k in (0, 29, 63):
+        (g_f, g_b), out = run(slices[k])
+        pick = slices[k].long().cpu().numpy()
+        system, (q_f, q_b), _ = oracle_util.lens_oracle(scene)
+        rays = scene["rays"][:, pick]
+        ref = tracer.ray_trace(
+            system, oracle_util.source_dict(rays, scene["wavelength"][pick],
+                                            np.float32 if dtype == torch.float32 else np.float64),
+            max_iterations=PASSES, inherit=("wavelength", "ray_id"), chunk=256)
+        rf = ref["finished"]
+        assert np.array_equal(out["finished_id"].cpu().numpy(), rf["ray_id"].numpy().astype(np.int32))
+        rgoal = torch.tensor(scene["goal"][pick], dtype=torch.float64)[rf["ray_id"].long()]
+        rerr = ((rf["y_end"] - rgoal[:, 0]) ** 2 + (rf["z_end"] - rgoal[:, 1]) ** 2).sum()
+        r_f, r_b = torch.autograd.grad(rerr, [q_f, q_b])
+        for g, r in ((g_f, r_f), (g_b, r_b)):
+            rel = float((g.cpu() - r).abs().max() / r.abs().max())
+            assert rel < tol, f"slice {k}: gradient rel err {rel:.2e}"
+    # (ii) the slices as one coherent run (32,768 rays: full wavefronts, 64-ray bundles)
+    total = [torch.zeros_like(p_f), torch.zeros_like(p_b)]
+    for sl in slices:
+        g, _ = run(sl)
+        total[0] += g[0]
+        total[1] += g[1]
+    union, _ = run(torch.cat(slices))
+    add_tol = 1e-11 if dtype == torch.float64 else 1e-6
+    for a, b in zip(union, total):
+        assert float((a - b).abs().max()) <= add_tol * float(b.abs().max())
+    # (iii) the whole source, coherent against natural order
+    whole, out = run(perm)
+    assert out["left_over"] == 0
+    nat_src, nat_fv, nat_sc, nat_p = _gpu_scene(scene, dtype, cluster="group")
+    nat = ops.trace3d(nat_src, nat_fv, nat_sc, max_passes=PASSES)
+    _, nat_g = _loss_and_grads(nat, scene, list(nat_p))
+    for a, b in zip(whole, nat_g):
+        assert float((a - b).abs().max()) <= (1e-10 if dtype == torch.float64 else 2e-6) * float(b.abs().max())
