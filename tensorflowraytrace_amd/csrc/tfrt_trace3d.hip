@@ -1575,8 +1575,11 @@ __device__ __forceinline__ void beam_decide(const int nb, const int lane, LdsPtr
   wave_fence();
 }
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_intersect_beam(
+// BW wavefronts per workgroup.  The wavefronts of a workgroup share nothing and never meet at a
+// barrier, so one per workgroup (BW = 1) lets the dispatcher hand out work wavefront by wavefront:
+// a four-wavefront workgroup holds its LDS and its wave slots until the slowest of the four is done.
+template <typename T, int BW>
+__global__ __launch_bounds__(64 * BW) void k_intersect_beam(
     const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
     const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
@@ -1592,7 +1595,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
   // steps then, not as the work.  (32 only with coherent_only: the grouped kernel takes whole
   // 64-ray wavefronts.)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qwave = blockIdx.x * WAVES + wave;
+  const int qwave = blockIdx.x * BW + wave;
   const int q = qwave * bundle + lane;
   const int n = *n_ptr;
   if (qwave * bundle >= n) return;  // (whole wave; no block-level synchronisation in this kernel)
@@ -1611,15 +1614,15 @@ __global__ __launch_bounds__(BLOCK) void k_intersect_beam(
   const int skip = (live && last_tri != nullptr) ? last_tri[ii] : -1;
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
 
-  __shared__ uint16_t slist[WAVES][BEAM_SLIST];
-  __shared__ uint16_t clist[WAVES][BEAM_CLIST];
-  __shared__ uint32_t flist[WAVES][BEAM_FLIST];
-  __shared__ uint32_t x_pair[WAVES][192];  // face << 6 | lane of the ray (faces < 2^24)
+  __shared__ uint16_t slist[BW][BEAM_SLIST];
+  __shared__ uint16_t clist[BW][BEAM_CLIST];
+  __shared__ uint32_t flist[BW][BEAM_FLIST];
+  __shared__ uint32_t x_pair[BW][192];  // face << 6 | lane of the ray (faces < 2^24)
   // records of a chunk's faces, nearest first (face_frame)
-  __shared__ float4 ftab[WAVES][64][4];
-  __shared__ RT rtab[WAVES][6][64];  // the wave's rays as stored (the exact test reads them by slot)
-  __shared__ unsigned long long best_k[WAVES][64];
-  __shared__ int32_t best_i[WAVES][64];
+  __shared__ float4 ftab[BW][64][4];
+  __shared__ RT rtab[BW][6][64];  // the wave's rays as stored (the exact test reads them by slot)
+  __shared__ unsigned long long best_k[BW][64];
+  __shared__ int32_t best_i[BW][64];
 #pragma unroll
   for (int k = 0; k < 6; ++k) rtab[wave][k][lane] = own0[k];
   best_k[wave][lane] = dkey(INFINITY);
@@ -3035,8 +3038,9 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     // (half-size wavefronts while the launch would leave the chip half empty: §3.6)
     int bundle = 64;
     if (od->coherent_only && od->nq <= 160 * 1024) bundle = 32;  // (125k rays: 0.191 against 0.200 ms per step; 250k: 0.223 against 0.211)
-    hipLaunchKernelGGL((k_intersect_beam<T>), dim3(cdiv(od->nq, WAVES * bundle)), dim3(BLOCK), 0,
-                       st, rays, stride, n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere,
+    constexpr int BEAM_BW = 1;
+    hipLaunchKernelGGL((k_intersect_beam<T, BEAM_BW>), dim3(cdiv(od->nq, BEAM_BW * bundle)),
+                       dim3(64 * BEAM_BW), 0, st, rays, stride, n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere,
                        ac->crec, fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
                        fz.rec_tri, fz.rec_t, fz.rec_cls, od->hist, od->left_list,
                        od->left_count, od->left_total, od->coherent_only, bundle);
