@@ -256,6 +256,9 @@ class FusedStep:
         if fvc.dtype != torch.float64 or not fvc.is_contiguous():
             raise RuntimeError("FusedStep: merged faces must be contiguous float64")
         st = self._buffers(block, fvc, P, flags, dt)
+        sink = getattr(self, "_err_sink", None)
+        if tdist.is_distributed() and sink is not None and st["err"].data_ptr() != sink.data_ptr():
+            st["err"] = sink             # (the error sums land in the collective's buffer)
         L = _lib.lib()
         stream = ops._stream(block)
         sc = scene.struct(fvc)
@@ -423,20 +426,43 @@ class FusedStep:
 
     def _sequence(self, accumulators, world):
         """The whole step; with several ranks the collective sits between the two halves."""
+        if world > 1:
+            # one persistent buffer [grad p_0 ... grad p_k, sum of errors, terms, -]: the face
+            # updates' reverse kernels write the parameter gradients straight into it (ops.GradSink)
+            # and the error kernel its sums, so the collective needs no concatenation before and
+            # no slicing after
+            opt = self.opt
+            n = sum(p.numel() for p in opt.parameters)
+            flat = getattr(self, "_flat_buf", None)
+            if flat is None or flat.numel() != n + 3 or flat.device != opt.parameters[0].device:
+                flat = self._flat_buf = torch.zeros(n + 3, dtype=torch.float64,
+                                                    device=opt.parameters[0].device)
+            self._err_sink = flat[n:]
+            with ops.GradSink(flat[:n]) as sink:
+                grads, err = self._enqueue_gradient()
+            fixed = self._fix_grads(grads)
+            if (err.data_ptr() == flat[n:].data_ptr() and sink.at == n
+                    and all(sink.holds(g) for g in fixed)):
+                self._flat, self._flat_views = flat, True
+            else:       # (a gradient from somewhere else: a parameter with several aliases, ...)
+                self._flat = torch.cat([g.reshape(-1) for g in fixed] + [err[:2]])
+                self._flat_views = False
+            return fixed
         grads, err = self._enqueue_gradient()
         grads = self._fix_grads(grads)
-        if world > 1:
-            self._flat = torch.cat([g.reshape(-1) for g in grads] + [err[:2]])
-            return grads
         self._enqueue_apply(grads, accumulators)
         self._err_view = err
         return grads
 
     def _after_reduce(self, grads, accumulators):
-        flat, o, red = self._flat, 0, []
-        for g in grads:
-            red.append(flat[o:o + g.numel()].reshape(g.shape))
-            o += g.numel()
+        flat = self._flat
+        if self._flat_views:             # the gradients ARE slices of the reduced buffer
+            red, o = grads, flat.numel() - 3
+        else:
+            o, red = 0, []
+            for g in grads:
+                red.append(flat[o:o + g.numel()].reshape(g.shape))
+                o += g.numel()
         self._enqueue_apply(red, accumulators)
         mean = torch.where(flat[o + 1] > 0, flat[o] / torch.clamp(flat[o + 1], min=1.0),
                            torch.full_like(flat[o], float("nan")))
@@ -561,14 +587,31 @@ class FusedStep:
                 self.opt.engine._note_left_over(int(self._state["counts"][-1]), self._state["P"])
             sig = self._signature(accumulators)
             pool = torch.cuda.graph_pool_handle()
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga, pool=pool, stream=side):
-                grads = self._sequence(accumulators, world)
-            gb = None
-            if world > 1:
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=pool, stream=side):
-                    self._after_reduce(grads, accumulators)
+            ga, gb, grads = None, None, None
+            if world > 1 and torch.distributed.get_backend() == "nccl":
+                # RCCL collectives can be captured: update ... gradients | all-reduce | apply as ONE
+                # graph, one launch per step (two graphs with an eager collective between them
+                # otherwise: gloo, or a runtime that refuses the capture)
+                try:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, pool=pool, stream=side):
+                        grads = self._sequence(accumulators, world)
+                        torch.distributed.all_reduce(self._flat, op=torch.distributed.ReduceOp.SUM)
+                        self._after_reduce(grads, accumulators)
+                    ga, self.collective_in_graph = g1, True
+                except Exception as e:       # noqa: BLE001  (fall back to the split form)
+                    self.collective_capture_error = e
+                    torch.cuda.synchronize(dev)
+                    ga = None
+            if ga is None:
+                self.collective_in_graph = False
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, pool=pool, stream=side):
+                    grads = self._sequence(accumulators, world)
+                if world > 1:
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, pool=pool, stream=side):
+                        self._after_reduce(grads, accumulators)
             self._graphs = (sig, ga, gb, grads)
         except Exception as e:
             self.capture_error = e

@@ -234,7 +234,10 @@ class _ParamFacesMulti(torch.autograd.Function):
             if (g_fv is None and g_norm is None) or F == 0:
                 out.append(torch.zeros(shape, dtype=torch.float64, device=fv.device))
                 continue
-            gp = torch.empty(shape, dtype=torch.float64, device=fv.device)
+            sink = GradSink._active
+            gp = sink.take(shape) if sink is not None else None
+            if gp is None:
+                gp = torch.empty(shape, dtype=torch.float64, device=fv.device)
             d = _lib.FaceSurfaceGrad()
             d.grad_face_verts = g_fv.data_ptr() + at * 72 if g_fv is not None else None
             d.grad_norm = g_norm.data_ptr() + na * 24 if g_norm is not None else None
@@ -254,6 +257,41 @@ class _ParamFacesMulti(torch.autograd.Function):
 
 
 _faces_batch = None   # the batch parametric boundaries hand their update to (see ParamFacesBatch)
+
+
+class GradSink:
+    """While active (``with GradSink(flat):``) the parameter gradients of the face updates are
+    written into consecutive slices of ``flat`` (a persistent float64 buffer) instead of fresh
+    tensors: a sharded optimiser step then all-reduces ``flat`` as it is -- no concatenation
+    before the collective, no slicing after it."""
+
+    _active = None
+
+    def __init__(self, flat):
+        self.flat, self.at, self.taken = flat, 0, []
+
+    def __enter__(self):
+        self._prev, GradSink._active = GradSink._active, self
+        return self
+
+    def __exit__(self, *exc):
+        GradSink._active = self._prev
+        return False
+
+    def take(self, shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.at + n > self.flat.numel():
+            return None
+        view = self.flat[self.at:self.at + n].view(shape)
+        self.at += n
+        self.taken.append(view)
+        return view
+
+    def holds(self, t):
+        """True if ``t`` is one of the slices handed out (same memory, same size)."""
+        return any(v.data_ptr() == t.data_ptr() and v.numel() == t.numel() for v in self.taken)
 
 
 def current_faces_batch():

@@ -28,12 +28,15 @@ def test_sharded_step_through_rccl_with_one_rank(monkeypatch):
     if not dist.is_nccl_available() or dist.is_initialized():
         pytest.skip("needs a fresh process without a default process group and the nccl backend")
 
+    info = {}
+
     def run(steps):
         eng, system, params = bench.build_scene(60_000, 9, 5, torch.float32)
         opt = optimizer.SGD_Optimizer(eng, params, bench.make_error_function(), trace_depth=3,
                                       learning_rate=1e-5, grad_clip=1e-3)
         opt.suppress_warnings = True
         errs = [float(opt.single_step(None)) for _ in range(steps)]
+        info["fs"] = opt._fused_step
         return errs, [p.detach().clone() for p in params]
 
     plain_e, plain_p = run(8)      # 3 eager steps, capture, then HIP-graph replays
@@ -45,8 +48,15 @@ def test_sharded_step_through_rccl_with_one_rank(monkeypatch):
         pytest.skip(f"RCCL process group could not be created here: {exc}")
     try:
         monkeypatch.setattr(tdist, "is_distributed", lambda: True)     # force the N > 1 path
-        dist_e, dist_p = run(8)        # two graphs with the RCCL all-reduce between them
+        dist_e, dist_p = run(8)        # ONE graph with the RCCL all-reduce inside
         torch.cuda.synchronize()
+        fs = info["fs"]
+        assert fs.capture_error is None and fs.graph_replays >= 3
+        # the parameter gradients were written into the collective's buffer by the kernels (no
+        # concatenation), and the collective was captured with the rest of the step
+        assert fs._flat_views
+        assert fs.collective_in_graph, getattr(fs, "collective_capture_error", None)
+        assert fs._graphs[2] is None
     finally:
         dist.destroy_process_group()
     for a, b in zip(plain_e, dist_e):
