@@ -574,6 +574,17 @@ int tfrt_gather_rows(const void* src, int64_t src_stride, int32_t n_rows, int32_
                      const int32_t* index, int64_t n, const int32_t* n_valid, void* dst,
                      int64_t dst_stride, void* stream);
 
+/* tfrt_scene3d.cluster_order made on the device: the permutation of the faces that makes every
+ * aligned run of `leaf` (16: the trace kernels' clusters) and of `group` (128: their superclusters)
+ * consecutive entries a compact patch -- recursive median split of the face centroids along the
+ * longest axis of their bounding box, the left part a multiple of `group` (of `leaf` below that);
+ * faces eight times larger than the median face go last.  No counterpart in the reference (it
+ * tests every ray against every face, tfrt/engine.py:1103-1166); once per mesh topology.  No host
+ * sync.  group must be a multiple of leaf. */
+size_t tfrt_cluster_order_workspace_bytes(int64_t n_faces, int32_t leaf, int32_t group);
+int tfrt_cluster_order(const double* face_verts, int64_t n_faces, int32_t leaf, int32_t group,
+                       int32_t* order, void* workspace, size_t workspace_bytes, void* stream);
+
 /* One output class of a trace over permuted rays (source ray j of the trace = original ray
  * index[j]) back in the reference's order: inside every pass by original ray index.
  *   ray_id      the class's tfrt_ray_out.ray_id (ids in the trace's numbering), n_rows rows at most

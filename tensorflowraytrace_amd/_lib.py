@@ -167,6 +167,8 @@ SIGNATURES = {
     "tfrt_permute_rays_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "tfrt_permute_rays": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "tfrt_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "tfrt_cluster_order_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32]),
+    "tfrt_cluster_order": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_restore_order_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "tfrt_restore_order": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp,
                                    c_vp, c_vp, c_vp, c_sz, c_vp]),

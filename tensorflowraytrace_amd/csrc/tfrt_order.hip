@@ -399,6 +399,24 @@ __global__ __launch_bounds__(BLOCK) void k_sort_hist(const uint2* __restrict__ p
   for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
 }
 
+template <int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_sort_hist_keys(const unsigned* __restrict__ keys, int n,
+                                                          int bits, unsigned* __restrict__ hist) {
+  extern __shared__ unsigned h_lds[];
+  const int tid = threadIdx.x;
+  const int bins = 1 << bits;
+  for (int d = tid; d < bins; d += BLOCK) h_lds[d] = 0u;
+  __syncthreads();
+  const int base = blockIdx.x * (BLOCK * ITEMS);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const int i = base + r * BLOCK + tid;
+    if (i < n) atomicAdd(&h_lds[keys[i] & (unsigned)(bins - 1)], 1u);
+  }
+  __syncthreads();
+  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
+}
+
 // exclusive prefix of `v` over the 256 threads of the block (wave scan + one LDS exchange);
 // returns the block total in *total
 __device__ __forceinline__ unsigned block_exclusive(unsigned v, unsigned* wsum, unsigned* total) {
@@ -722,6 +740,195 @@ __global__ __launch_bounds__(BLOCK) void k_restore_scan(uint2* __restrict__ word
   if (threadIdx.x == 0) totals[blockIdx.x] = total;
 }
 
+// ------------------------------------------------------------------------------ face clusters
+//
+// tfrt_cluster_order: the permutation of the faces that makes every aligned run of `leaf`
+// consecutive entries (and of `group` entries: the trace kernels' clusters and superclusters) a
+// compact patch -- a k-d ordering: recursive median split of the face centroids along the longest
+// axis of their bounding box, the left part a multiple of `group` (of `leaf` below that), down to
+// parts of <= `leaf` faces; outsized faces (a target plane behind a fine lens mesh) go last, or
+// every ray would test the fifteen small faces that happen to share a huge one's cluster.
+// Level by level on the device: every position carries its segment (start, length, path in the
+// tree); per level the segments' bounding boxes (atomics), a key (path, quantised coordinate along
+// the segment's longest axis), the stable radix sort of those keys -- which sorts inside every
+// segment at once, because the path is monotone in the position --, and the split of every
+// segment at its aligned median.  The split sizes depend on the lengths alone, so nothing is read
+// back: no host sync.
+
+constexpr int CO_SIZE_BINS = 4096;   // positive float32 >> 19: exponent + 4 mantissa bits
+
+__global__ __launch_bounds__(BLOCK) void k_co_prepare(const double* __restrict__ fverts, int M,
+                                                      float4* __restrict__ cent,
+                                                      unsigned* __restrict__ size_hist) {
+  const int f = blockIdx.x * BLOCK + threadIdx.x;
+  if (f >= M) return;
+  const double* v = fverts + 9 * (int64_t)f;
+  const double cx = (v[0] + v[3] + v[6]) / 3.0, cy = (v[1] + v[4] + v[7]) / 3.0,
+               cz = (v[2] + v[5] + v[8]) / 3.0;
+  double r2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double dx = v[3 * k] - cx, dy = v[3 * k + 1] - cy, dz = v[3 * k + 2] - cz;
+    r2 = fmax(r2, dx * dx + dy * dy + dz * dz);
+  }
+  const float size = (float)sqrt(r2);
+  cent[f] = make_float4((float)cx, (float)cy, (float)cz, size);
+  unsigned bin = __float_as_uint(size) >> 19;
+  if (!(size >= 0.f) || bin >= CO_SIZE_BINS) bin = CO_SIZE_BINS - 1;   // (NaN / inf: the last bin)
+  atomicAdd(&size_hist[bin], 1u);
+}
+
+// thr[0] <- 8 x (upper edge of the bin that holds the median size); counters cleared
+__global__ __launch_bounds__(BLOCK) void k_co_threshold(const unsigned* __restrict__ size_hist,
+                                                        int M, float* __restrict__ thr,
+                                                        int32_t* __restrict__ n_big) {
+  __shared__ unsigned wsum[WAVES];
+  constexpr int PER = CO_SIZE_BINS / BLOCK;
+  unsigned v[PER], sum = 0;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    v[q] = size_hist[threadIdx.x * PER + q];
+    sum += v[q];
+  }
+  unsigned total;
+  unsigned run = block_exclusive(sum, wsum, &total);
+  const unsigned half = ((unsigned)M + 1u) / 2u;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    if (run < half && run + v[q] >= half) {
+      const unsigned bin = threadIdx.x * PER + q;
+      thr[0] = 8.0f * __uint_as_float((bin + 1u) << 19);
+    }
+    run += v[q];
+  }
+  if (threadIdx.x == 0) n_big[0] = 0;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_co_flag(const float4* __restrict__ cent, int M,
+                                                   const float* __restrict__ thr,
+                                                   unsigned* __restrict__ keys,
+                                                   int32_t* __restrict__ n_big) {
+  const int f = blockIdx.x * BLOCK + threadIdx.x;
+  bool big = false;
+  if (f < M) {
+    big = !(cent[f].w <= thr[0]);
+    keys[f] = big ? 1u : 0u;
+  }
+  const unsigned long long m = __ballot(big);
+  if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(n_big, __popcll(m));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_co_init(int M, const int32_t* __restrict__ n_big,
+                                                   int32_t* __restrict__ seg_start,
+                                                   int32_t* __restrict__ seg_len,
+                                                   unsigned* __restrict__ path) {
+  const int pos = blockIdx.x * BLOCK + threadIdx.x;
+  if (pos >= M) return;
+  const int n_small = M - *n_big;
+  const bool small = pos < n_small;
+  seg_start[pos] = small ? 0 : n_small;
+  seg_len[pos] = small ? n_small : 0;      // (0: never split)
+  path[pos] = small ? 0u : 1u;
+}
+
+// bounding boxes of the segments still to be split: bbox[6 * start + q], running minima of
+// enc(x), ~enc(x), enc(y), ...
+__global__ __launch_bounds__(BLOCK) void k_co_bbox(const float4* __restrict__ cent,
+                                                   const int32_t* __restrict__ idx,
+                                                   const int32_t* __restrict__ seg_start,
+                                                   const int32_t* __restrict__ seg_len, int leaf,
+                                                   int M, unsigned* __restrict__ bbox) {
+  const int pos = blockIdx.x * BLOCK + threadIdx.x;
+  const bool on = pos < M && seg_len[pos] > leaf;
+  const int start = on ? seg_start[pos] : -1;
+  unsigned v[6];
+  if (on) {
+    const float4 c = cent[idx[pos]];
+    v[0] = enc_f(c.x); v[1] = ~enc_f(c.x);
+    v[2] = enc_f(c.y); v[3] = ~enc_f(c.y);
+    v[4] = enc_f(c.z); v[5] = ~enc_f(c.z);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) v[q] = 0xFFFFFFFFu;
+  }
+  // a wave whose lanes all belong to one segment (the rule once segments are long) folds its
+  // minima first: six atomics per wave instead of six per lane on the same six addresses
+  const int first = __shfl(start, 0, 64);
+  const bool same = __all(start == first || !on) && first >= 0;
+  if (same) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v[q] = min(v[q], (unsigned)__shfl_xor((int)v[q], d, 64));
+    }
+    const int lane = threadIdx.x & 63;
+    unsigned mine = v[0];
+#pragma unroll
+    for (int q = 1; q < 6; ++q) mine = lane == q ? v[q] : mine;
+    if (lane < 6 && mine != 0xFFFFFFFFu) atomicMin(&bbox[6 * (int64_t)first + lane], mine);
+  } else if (on) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) atomicMin(&bbox[6 * (int64_t)start + q], v[q]);
+  }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_co_key(const float4* __restrict__ cent,
+                                                  const int32_t* __restrict__ idx,
+                                                  const int32_t* __restrict__ seg_start,
+                                                  const int32_t* __restrict__ seg_len,
+                                                  const unsigned* __restrict__ path,
+                                                  const unsigned* __restrict__ bbox, int leaf,
+                                                  int cbits, int M, unsigned* __restrict__ keys) {
+  const int pos = blockIdx.x * BLOCK + threadIdx.x;
+  if (pos >= M) return;
+  unsigned q = 0;
+  if (seg_len[pos] > leaf) {
+    const unsigned* b = bbox + 6 * (int64_t)seg_start[pos];
+    const float lo[3] = {dec_f(b[0]), dec_f(b[2]), dec_f(b[4])};
+    const float hi[3] = {dec_f(~b[1]), dec_f(~b[3]), dec_f(~b[5])};
+    int axis = 0;
+    float ext = hi[0] - lo[0];
+    if (hi[1] - lo[1] > ext) { axis = 1; ext = hi[1] - lo[1]; }
+    if (hi[2] - lo[2] > ext) { axis = 2; ext = hi[2] - lo[2]; }
+    const float4 c = cent[idx[pos]];
+    const float x = axis == 0 ? c.x : (axis == 1 ? c.y : c.z);
+    const float top = (float)((1u << cbits) - 1u);
+    const float t = ext > 0.f ? (x - lo[axis]) / ext * top : 0.f;
+    q = (unsigned)fminf(fmaxf(t, 0.f), top);      // (NaN: 0)
+  }
+  keys[pos] = (path[pos] << cbits) | q;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_co_apply(const int32_t* __restrict__ idx_in,
+                                                    const int32_t* __restrict__ perm, int M,
+                                                    int32_t* __restrict__ idx_out) {
+  const int pos = blockIdx.x * BLOCK + threadIdx.x;
+  if (pos < M) idx_out[pos] = idx_in != nullptr ? idx_in[perm[pos]] : perm[pos];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_co_split(int32_t* __restrict__ seg_start,
+                                                    int32_t* __restrict__ seg_len,
+                                                    unsigned* __restrict__ path, int leaf,
+                                                    int group, int M) {
+  const int pos = blockIdx.x * BLOCK + threadIdx.x;
+  if (pos >= M) return;
+  const int len = seg_len[pos];
+  unsigned p = path[pos] << 1;
+  if (len > leaf) {
+    const int start = seg_start[pos];
+    const int unit = len > group ? group : leaf;
+    const int n_left = unit * (((len + unit - 1) / unit) / 2);
+    if (pos - start < n_left) {
+      seg_len[pos] = n_left;
+    } else {
+      seg_start[pos] = start + n_left;
+      seg_len[pos] = len - n_left;
+      p |= 1u;
+    }
+  }
+  path[pos] = p;
+}
+
 // ------------------------------------------------------------------------------ host side
 
 static int order_bits(int64_t n) {
@@ -741,10 +948,10 @@ struct OrderLayout {
   int bits, items, nblk, nseg;
 };
 
-static OrderLayout order_layout(int64_t n) {
+static OrderLayout order_layout(int64_t n, int bits = -1) {
   OrderLayout L;
   const size_t m = n > 0 ? (size_t)n : 1;
-  L.bits = order_bits(n);
+  L.bits = bits > 0 ? bits : order_bits(n);
   L.items = order_items(n);
   L.nblk = cdiv((int64_t)m, (int64_t)BLOCK * L.items);
   const int64_t hlen = (int64_t)(1 << L.bits) * L.nblk;
@@ -797,6 +1004,23 @@ static int sort_passes(const OrderLayout& L, char* ws, int n, int32_t* perm, uns
                      static_cast<const unsigned*>(nullptr), pairs, n, L.bits, L.bits, hist, seg,
                      dtotal, static_cast<uint2*>(nullptr), perm);
   return 0;
+}
+
+// perm = argsort(keys, stable) for keys of 2 * L.bits bits
+static int sort_keys(const OrderLayout& L, char* ws, int n, unsigned* keys, int32_t* perm,
+                     hipStream_t st) {
+  unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
+  const size_t hl = ((size_t)1 << L.bits) * sizeof(unsigned);
+  if (L.items == 4) {
+    hipLaunchKernelGGL((k_sort_hist_keys<4>), dim3(L.nblk), dim3(BLOCK), hl, st, keys, n, L.bits, hist);
+    return sort_passes<4>(L, ws, n, perm, keys, st);
+  }
+  if (L.items == 8) {
+    hipLaunchKernelGGL((k_sort_hist_keys<8>), dim3(L.nblk), dim3(BLOCK), hl, st, keys, n, L.bits, hist);
+    return sort_passes<8>(L, ws, n, perm, keys, st);
+  }
+  hipLaunchKernelGGL((k_sort_hist_keys<16>), dim3(L.nblk), dim3(BLOCK), hl, st, keys, n, L.bits, hist);
+  return sort_passes<16>(L, ws, n, perm, keys, st);
 }
 
 template <typename R>
@@ -853,6 +1077,51 @@ static RestoreLayout restore_layout(int64_t n_src, int64_t n_seg) {
   L.words = 0;
   L.totals = align_up((size_t)L.len * sizeof(uint2));
   L.total = L.totals + align_up((size_t)L.nchunks * sizeof(unsigned));
+  return L;
+}
+
+static int cluster_levels(int64_t M, int leaf, int group) {
+  int L = 0;
+  int64_t m = M;
+  while (m > leaf) {
+    const int64_t unit = m > group ? group : leaf;
+    const int64_t n_left = unit * (((m + unit - 1) / unit) / 2);
+    m = n_left > m - n_left ? n_left : m - n_left;
+    ++L;
+  }
+  return L;
+}
+
+struct ClusterLayout {
+  size_t cent, size_hist, scalars, idx_a, idx_b, seg_start, seg_len, path, bbox, keys, perm, sort, total;
+  OrderLayout S;
+  int levels;
+};
+
+static ClusterLayout cluster_layout(int64_t M, int leaf, int group) {
+  ClusterLayout L;
+  const size_t m = M > 0 ? (size_t)M : 1;
+  L.levels = cluster_levels(M, leaf, group);
+  L.S = order_layout(M, 13);     // keys of 26 bits
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = o;
+    o = align_up(o + bytes);
+    return at;
+  };
+  L.cent = take(m * sizeof(float4));
+  L.size_hist = take(CO_SIZE_BINS * sizeof(unsigned));
+  L.scalars = take(64);            // thr (float) | n_big (int32)
+  L.idx_a = take(m * 4);
+  L.idx_b = take(m * 4);
+  L.seg_start = take(m * 4);
+  L.seg_len = take(m * 4);
+  L.path = take(m * 4);
+  L.bbox = take(m * 24);
+  L.keys = take(m * 4);
+  L.perm = take(m * 4);
+  L.sort = take(L.S.total);
+  L.total = o;
   return L;
 }
 
@@ -980,6 +1249,64 @@ int tfrt_gather_rows(const void* src, int64_t src_stride, int32_t n_rows, int32_
     default:
       return TFRT_E_BADARG;
   }
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+size_t tfrt_cluster_order_workspace_bytes(int64_t n_faces, int32_t leaf, int32_t group) {
+  if (leaf < 1 || group < leaf) return 0;
+  return cluster_layout(n_faces, leaf, group).total;
+}
+
+int tfrt_cluster_order(const double* face_verts, int64_t n_faces, int32_t leaf, int32_t group,
+                       int32_t* order, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_faces < 0 || n_faces >= (1ll << 31) || leaf < 1 || group < leaf || group % leaf != 0)
+    return TFRT_E_BADARG;
+  if (n_faces == 0) return 0;
+  if (!face_verts || !order || !workspace) return TFRT_E_BADARG;
+  const ClusterLayout L = cluster_layout(n_faces, leaf, group);
+  if (L.levels + 1 > 22) return TFRT_E_UNSUPPORTED;     // (the key keeps >= 4 coordinate bits)
+  if (workspace_bytes < L.total) return TFRT_E_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  const int M = (int)n_faces;
+  float4* cent = reinterpret_cast<float4*>(ws + L.cent);
+  unsigned* size_hist = reinterpret_cast<unsigned*>(ws + L.size_hist);
+  float* thr = reinterpret_cast<float*>(ws + L.scalars);
+  int32_t* n_big = reinterpret_cast<int32_t*>(ws + L.scalars + 16);
+  int32_t* idx[2] = {reinterpret_cast<int32_t*>(ws + L.idx_a), reinterpret_cast<int32_t*>(ws + L.idx_b)};
+  int32_t* seg_start = reinterpret_cast<int32_t*>(ws + L.seg_start);
+  int32_t* seg_len = reinterpret_cast<int32_t*>(ws + L.seg_len);
+  unsigned* path = reinterpret_cast<unsigned*>(ws + L.path);
+  unsigned* bbox = reinterpret_cast<unsigned*>(ws + L.bbox);
+  unsigned* keys = reinterpret_cast<unsigned*>(ws + L.keys);
+  int32_t* perm = reinterpret_cast<int32_t*>(ws + L.perm);
+  char* sort_ws = ws + L.sort;
+  const dim3 grid(cdiv(M, BLOCK)), block(BLOCK);
+  (void)hipMemsetAsync(size_hist, 0, CO_SIZE_BINS * sizeof(unsigned), st);
+  hipLaunchKernelGGL(k_co_prepare, grid, block, 0, st, face_verts, M, cent, size_hist);
+  hipLaunchKernelGGL(k_co_threshold, dim3(1), block, 0, st, size_hist, M, thr, n_big);
+  hipLaunchKernelGGL(k_co_flag, grid, block, 0, st, cent, M, thr, keys, n_big);
+  int rc = sort_keys(L.S, sort_ws, M, keys, perm, st);     // small faces first, outsized last
+  if (rc != 0) return rc;
+  int cur = 0;
+  hipLaunchKernelGGL(k_co_apply, grid, block, 0, st, static_cast<const int32_t*>(nullptr), perm, M,
+                     idx[cur]);
+  hipLaunchKernelGGL(k_co_init, grid, block, 0, st, M, n_big, seg_start, seg_len, path);
+  for (int lev = 0; lev < L.levels; ++lev) {
+    int cbits = 26 - (lev + 1);
+    if (cbits > 10) cbits = 10;
+    (void)hipMemsetAsync(bbox, 0xFF, (size_t)M * 24, st);
+    hipLaunchKernelGGL(k_co_bbox, grid, block, 0, st, cent, idx[cur], seg_start, seg_len, leaf, M,
+                       bbox);
+    hipLaunchKernelGGL(k_co_key, grid, block, 0, st, cent, idx[cur], seg_start, seg_len, path, bbox,
+                       leaf, cbits, M, keys);
+    rc = sort_keys(L.S, sort_ws, M, keys, perm, st);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(k_co_apply, grid, block, 0, st, idx[cur], perm, M, idx[cur ^ 1]);
+    cur ^= 1;
+    hipLaunchKernelGGL(k_co_split, grid, block, 0, st, seg_start, seg_len, path, leaf, group, M);
+  }
+  (void)hipMemcpyAsync(order, idx[cur], (size_t)M * 4, hipMemcpyDeviceToDevice, st);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 

@@ -167,3 +167,57 @@ def test_restore_order_of_rows_that_span_many_passes():
     for cls in ("finished", "active", "dead", "stopped", "unfinished"):
         assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), cls
         assert torch.equal(out[cls], ref[cls]), cls
+
+
+def _run_radius(cent, run):
+    n = cent.shape[0] // run * run
+    c = cent[:n].reshape(-1, run, 3)
+    return np.linalg.norm(c - c.mean(1, keepdims=True), axis=2).max(1)
+
+
+@pytest.mark.parametrize("k,extra", [(3, 0), (20, 2), (41, 2), (120, 0)])
+def test_device_cluster_order_against_the_numpy_kd_order(k, extra):
+    """tfrt_cluster_order: a permutation; aligned runs of 16 / 128 faces as compact as the host
+    k-d order's (mean bounding radius within 10 %); outsized faces (a target plane) last."""
+    from tensorflowraytrace_amd import ops
+    import cluster_reference
+    import tfrt.mesh_tools as mt
+    mesh = mt.hexagonal_mesh(1.0, k)
+    tri = np.asarray(mesh.points[mesh.triangles()].reshape(-1, 9), dtype=np.float64)
+    tri[:, 2::3] += 0.15 * (tri[:, 0::3] ** 2 + tri[:, 1::3] ** 2)          # a curved surface
+    if extra:
+        big = np.array([[-50, -50, 10, 50, -50, 10, 50, 50, 10], [-50, -50, 10, 50, 50, 10, -50, 50, 10.0]])
+        tri = np.concatenate([tri[:100], big, tri[100:]])                   # (in the middle of the list)
+    fv = torch.tensor(tri, device=DEV)
+    order = ops.cluster_order(fv)
+    assert order.dtype == torch.int32 and order.is_cuda
+    o = order.cpu().numpy()
+    M = tri.shape[0]
+    assert np.array_equal(np.sort(o), np.arange(M))
+    assert torch.equal(ops.cluster_order(fv), order)                        # the same on every run
+    if extra:
+        assert sorted(o[-2:].tolist()) == [100, 101]
+    ref = cluster_reference.cluster_order_numpy(torch.tensor(tri)).numpy()
+    cent = tri.reshape(-1, 3, 3).mean(1)
+    n_small = M - extra
+    for run in (16, 128):
+        if n_small < 4 * run:
+            continue
+        got, want = _run_radius(cent[o[:n_small]], run).mean(), _run_radius(cent[ref[:n_small]], run).mean()
+        assert got <= 1.10 * want, (run, got, want)
+
+
+def test_device_cluster_order_tiny_and_degenerate_inputs():
+    from tensorflowraytrace_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for M in (0, 1, 5, 16, 17, 129):
+        fv = torch.randn(M, 9, generator=g, dtype=torch.float64).to(DEV)
+        o = ops.cluster_order(fv).cpu().numpy()
+        assert np.array_equal(np.sort(o), np.arange(M))
+    same = torch.ones(1000, 9, dtype=torch.float64, device=DEV)            # every centroid equal
+    assert np.array_equal(np.sort(ops.cluster_order(same).cpu().numpy()), np.arange(1000))
+    bad = torch.randn(300, 9, generator=g, dtype=torch.float64)
+    bad[7] = float("nan")
+    bad[9, 0] = float("inf")
+    o = ops.cluster_order(bad.to(DEV)).cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(300))

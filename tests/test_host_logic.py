@@ -356,9 +356,11 @@ def test_sphere_mesh_is_closed_and_outward():
 
 
 def test_cluster_order_is_a_permutation_with_compact_aligned_runs():
-    """ops.cluster_order (host side of the sphere hierarchy): a permutation whose aligned runs
-    of 16 and 128 faces are spatially compact (k-d subtrees)."""
-    from tensorflowraytrace_amd import ops
+    """The numpy k-d face ordering (the yardstick of tfrt_cluster_order, tests/test_gpu_order.py):
+    a permutation whose aligned runs of 16 and 128 faces are spatially compact (k-d subtrees)."""
+    import types
+    import cluster_reference
+    ops = types.SimpleNamespace(cluster_order=cluster_reference.cluster_order_numpy)
     import tfrt.mesh_tools as mt
     mesh = mt.hexagonal_mesh(1.0, 20)                     # 2400 faces
     tri = torch.tensor(mesh.points[mesh.triangles()].reshape(-1, 9))
