@@ -787,10 +787,34 @@ class _Trace3D(torch.autograd.Function):
         g_fv = torch.zeros((M, 9), dtype=torch.float64, device=dev)
         need_src = ctx.needs_input_grad[0]
         g_src = torch.zeros((6, t.src.shape[1]), dtype=torch.float64, device=dev) if need_src else None
-        gs = _class_grads(ctx.present, t.caps, 6, dev, grads)
-        if t.dest is not None:      # (restored classes: gradients back into the trace's row order)
-            gs = [g if (g is None or d is None) else gather_rows(g, d[0], d[1])
-                  for g, d in zip(gs, t.dest)]
+        if t.dest is None:
+            gs = _class_grads(ctx.present, t.caps, 6, dev, grads)
+        else:
+            # restored classes: the gradients go back into the trace's row order, row by row --
+            # an error function usually touches one or two of a class's six rows (y_end, z_end),
+            # and a random gather of a million float64 costs 15 us per row
+            gs, at = [], 4
+            for k, present in enumerate(ctx.present):
+                if not present:
+                    gs.append(None)
+                    continue
+                gb, gr = grads[k], grads[at:at + 6]
+                at += 6
+                d = t.dest[k]
+                if gb is None and all(g is None for g in gr):
+                    gs.append(None)
+                    continue
+                blk = torch.zeros((6, t.caps[k]), dtype=torch.float64, device=dev)
+                if gb is not None:
+                    gather_rows(_c(gb, torch.float64), d[0], d[1], out=blk)
+                for i, g in enumerate(gr):
+                    if g is None:
+                        continue
+                    row = gather_rows(_c(g, torch.float64), d[0], d[1],
+                                      out=blk[i] if gb is None else None)
+                    if gb is not None:
+                        blk[i].add_(row)
+                gs.append(blk)
         sc = t.scene.struct(t.face_verts)
         want_n = (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and M > 0
         g_n = torch.zeros((2, M), dtype=torch.float64, device=dev) if want_n else None
