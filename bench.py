@@ -379,7 +379,7 @@ def main(argv=None):
         """Counters of one kernel from profiles/ (separate rocprofv3 --pmc runs of the same step,
         scratch/collect_profiles.sh) -- only for the kernel sources and workload they were
         collected on."""
-        path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % tag)
+        path = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % tag)
         if not (same_workload and os.path.exists(path)):
             return None, path
         doc = json.load(open(path))

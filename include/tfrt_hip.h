@@ -226,7 +226,10 @@ typedef struct tfrt_scene3d {
    * visits faces in clusters of 16 consecutive entries behind a bounding-sphere test (a
    * two-level conservative filter); results are identical to the all-pairs path (NULL). */
   const int32_t* cluster_order;
-  int32_t reserved0;  /* must be 0 */
+  /* 1: every source ray has the same wavelength -- n_table has ONE column, n_table[m *
+   * n_table_stride] = n_m(that wavelength), read by every ray (a source made from one wavelength,
+   * e.g. dev/hexalens.py:48 `[drawing.YELLOW]`).  0: one column per source ray. */
+  int32_t n_table_uniform;
   /* Reverse sweep only.  0 (default): the 9 face-gradient terms of every ray are summed with
    * float64 atomics (LDS windows, then global): fastest, but float64 addition is not
    * associative, so the last bits of a face's sum depend on the arrival order and differ from

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.inse
 import numpy as np, torch, bench
 from tensorflowraytrace_amd import _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-eng, system, params = bench.build_scene(N, 41, 9, torch.float32)
+RANDOM = len(sys.argv) > 2 and sys.argv[2] == "random"
+eng, system, params = bench.build_scene(N, 41, 9, torch.float32, random_rays=RANDOM)
 eng.coherent = True
 h = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 32)()

@@ -2,7 +2,7 @@
 # Collects the profile artefacts of the default bench into gpurun_out/profiles_new/ and installs the
 # PMC files under profiles/ (copy the rest by hand).  Run on the GPU box: bash scratch/collect_profiles.sh [ROUND]
 set -e
-RN=${1:-r03}
+RN=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles_new; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 STEP="python $R/scratch/prof_step.py 1000000 fused 30"

@@ -28,7 +28,7 @@ class Scene3D(ctypes.Structure):
         ("n_in", c_vp), ("n_out", c_vp), ("n_faces", c_i64),
         ("n_table", c_vp), ("n_table_stride", c_i64), ("n_materials", c_i32),
         ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
-        ("face_grad_mask", c_vp), ("cluster_order", c_vp), ("reserved0", c_i32),
+        ("face_grad_mask", c_vp), ("cluster_order", c_vp), ("n_table_uniform", c_i32),
         ("deterministic", c_i32), ("coherent_rays", c_i32), ("coherent_only", c_i32),
         ("grad_n_in", c_vp), ("grad_n_out", c_vp),
     ]

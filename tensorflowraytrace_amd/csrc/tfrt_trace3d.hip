@@ -2210,8 +2210,11 @@ __global__ __launch_bounds__(1024) void k_scan3d(const int32_t* __restrict__ n_p
 __device__ __forceinline__ void face_indices(const tfrt_scene3d& sc, int tri, int rid,
                                              double* n_in, double* n_out) {
   if (sc.n_table != nullptr && sc.mat_in != nullptr) {
-    *n_in = sc.n_table[(int64_t)sc.mat_in[tri] * sc.n_table_stride + rid];
-    *n_out = sc.n_table[(int64_t)sc.mat_out[tri] * sc.n_table_stride + rid];
+    // (one wavelength for every ray: one column, the same few values for every lane -- not
+    // sixteen bytes per ray and pass from a table as long as the source)
+    const int64_t col = sc.n_table_uniform ? 0 : rid;
+    *n_in = sc.n_table[(int64_t)sc.mat_in[tri] * sc.n_table_stride + col];
+    *n_out = sc.n_table[(int64_t)sc.mat_out[tri] * sc.n_table_stride + col];
   } else {
     *n_in = sc.n_in[tri];
     *n_out = sc.n_out[tri];

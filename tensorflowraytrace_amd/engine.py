@@ -903,8 +903,11 @@ class OpticalEngine:
             if tcache is not None and tcache[0] == wkey:
                 n_table = tcache[1]
             else:
-                n_table = system.material_table(wl)
-                self._table_cache = (wkey, n_table, wl, wl.dim() > 0 and wl.stride(0) == 0)
+                # (one wavelength for every ray -- an expanded scalar --: one column, read by all)
+                uniform = (self.dimension == 3 and wl.dim() == 1 and wl.shape[0] > 1
+                           and wl.stride(0) == 0)
+                n_table = system.material_table(wl[:1].contiguous() if uniform else wl)
+                self._table_cache = (wkey, n_table, wl, uniform)
         mode = self._trace_mode(system)
         if self.dimension == 3:
             perm = None
@@ -916,6 +919,8 @@ class OpticalEngine:
                 block = rays.ray_block(dt)
             scene = system.scene_args(n_table, index_mode, ghost, cluster=mode != "all-pairs",
                                       deterministic=self.deterministic)
+            tc = getattr(self, "_table_cache", None)
+            scene.n_table_uniform = bool(index_mode and tc is not None and tc[3])
             scene.coherent_rays = perm is not None
             # a source that left no wavefront to the grouped kernel last time: no such launch
             ident = self._source_identity(rays, key)

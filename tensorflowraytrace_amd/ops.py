@@ -540,6 +540,8 @@ class Scene3DArgs:
         self.n_in_arg = n_in if isinstance(n_in, torch.Tensor) else None
         self.n_out_arg = n_out if isinstance(n_out, torch.Tensor) else None
         self.n_table = _c(n_table, torch.float64)  # (n_materials, N)
+        # True: `n_table` has ONE column that holds for every ray (one wavelength)
+        self.n_table_uniform = False
         self.face_grad_mask = _c(face_grad_mask, torch.uint8)  # (M) or None
         self.cluster_order = _c(cluster_order, torch.int32)    # (M) or None: two-level filter
         self.deterministic = bool(deterministic)               # ordered reverse-sweep sums
@@ -561,6 +563,7 @@ class Scene3DArgs:
             sc.face_verts = face_verts.data_ptr() if M else None
             sc.coherent_rays = 1 if self.coherent_rays else 0
             sc.coherent_only = 1 if (self.coherent_only and self.coherent_rays) else 0
+            sc.n_table_uniform = 1 if self.n_table_uniform else 0
             return sc
         sc = Scene3D()
         sc.face_verts = face_verts.data_ptr() if M else None
@@ -582,7 +585,7 @@ class Scene3DArgs:
         if co is not None and co.numel() != M:
             raise TfrtError("cluster_order must be a permutation of the M face indices")
         sc.cluster_order = co.data_ptr() if (co is not None and M) else None
-        sc.reserved0 = 0
+        sc.n_table_uniform = 1 if self.n_table_uniform else 0
         sc.deterministic = 1 if self.deterministic else 0
         sc.coherent_rays = 1 if self.coherent_rays else 0
         sc.coherent_only = 1 if (self.coherent_only and self.coherent_rays) else 0

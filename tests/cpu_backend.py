@@ -48,7 +48,10 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     mats = []
     if index_mode:
         for row in scene.n_table:
-            mats.append(lambda rid, row=row: row[rid.long()])
+            if getattr(scene, "n_table_uniform", False):      # one column for every ray
+                mats.append(lambda rid, row=row: row[0].expand(rid.shape[0]))
+            else:
+                mats.append(lambda rid, row=row: row[rid.long()])
     ie, se, rse = scene.eps
     system = tracer.System(3, materials=mats, intersect_epsilion=ie, size_epsilion=se,
                            ray_start_epsilion=rse, **sets)
