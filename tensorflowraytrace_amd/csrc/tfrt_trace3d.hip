@@ -2453,8 +2453,9 @@ __device__ __forceinline__ double dpp_f64(const double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void k_backward3d(
+// BW wavefronts per workgroup (the wavefronts share nothing: see k_intersect_beam)
+template <typename T, int BW>
+__global__ __launch_bounds__(64 * BW) void k_backward3d(
     const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ n_ptr,
     const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
     const double* __restrict__ rec_t, const uint8_t* __restrict__ rec_cls,
@@ -2469,7 +2470,7 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     typename SweepStore<T>::type* __restrict__ stash_g, int32_t* __restrict__ stash_face,
     int wave_sums) {
   const int n = *n_ptr;
-  const int q0 = blockIdx.x * BLOCK + threadIdx.x;
+  const int q0 = blockIdx.x * (64 * BW) + threadIdx.x;
   const int i = q0;
   if (wave_sums) {
     // Coherent rays (tfrt_scene3d.coherent_rays): the 64 rays of a wavefront hit a handful of
@@ -2482,8 +2483,8 @@ __global__ __launch_bounds__(BLOCK) void k_backward3d(
     // neighbouring lanes are the ones that share a face.  Eight copies for up to 8 faces, four for
     // up to 16, two for up to 32: sparse rays share a face with few lanes anyway)
     constexpr int SLOTS = 32, CELLS = 576;
-    __shared__ double wacc[WAVES][CELLS];  // [slot][term][copy]
-    __shared__ int32_t wface[WAVES][SLOTS];
+    __shared__ double wacc[BW][CELLS];  // [slot][term][copy]
+    __shared__ int32_t wface[BW][SLOTS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double gP[9];
     int tri = -1;
@@ -3295,7 +3296,9 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     G* stash_g = stash_g_all + (size_t)p * 9 * n;
     int32_t* stash_face = stash_face_all + (size_t)p * n;
     ProfScope prof_bwd(TFRT_PROF_BACKWARD, st);
-    hipLaunchKernelGGL((k_backward3d<T>), dim3(pl.nblk), dim3(BLOCK), 0, st, rin, sin, nrays + p,
+    constexpr int BWD_BW = 1;
+    hipLaunchKernelGGL((k_backward3d<T, BWD_BW>), dim3(cdiv(N, 64 * BWD_BW)), dim3(64 * BWD_BW), 0,
+                       st, rin, sin, nrays + p,
                        idin, rec_tri + (size_t)p * n, rec_t + (size_t)p * n,
                        rec_cls + (size_t)p * n, rec_slot + (size_t)p * n,
                        counts + (size_t)p * TFRT_COUNTS_PER_PASS, *sc, L, dead_len, g_child,
