@@ -27,8 +27,9 @@ for d in sys.argv[4:]:
                     per_pass[n % passes][c].append(v)
 doc = {
     "kernel": kernel, "collected": time.strftime("%Y-%m-%d"), "source_hash": bench._source_hash(),
-    "workload": "bench.py default (cfg4: 1,000,000 rays x 10,574 faces, f32 state), eager fused step, "
-                "rocprofv3 --kernel-trace --pmc, one counter set per run",
+    "workload": os.environ.get("PMC_WORKLOAD") or
+    "bench.py default (cfg4: 1,000,000 rays x 10,574 faces, f32 state), eager fused step, "
+    "rocprofv3 --kernel-trace --pmc, one counter set per run",
     "launches_per_pass": launches // passes,
     "units": "per launch, summed over XCDs/SEs; medians over the launches of a pass; FETCH_SIZE / "
              "WRITE_SIZE in KB as reported (FETCH_SIZE counts half of wide reads on gfx950)",

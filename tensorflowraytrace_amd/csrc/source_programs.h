@@ -64,18 +64,27 @@ __device__ __forceinline__ void eval_points(const tfrt_points_program& pg, int64
   } else {
     double u0, u1;
     uniform2(pg.seed, pg.stream, (uint64_t)*pg.epoch, (uint64_t)i, &u0, &u1);
-    auto theta_mod = [&](double th) {
-      if (pg.p[1] == 0.0 && pg.p[2] == TWO_PI) return th;
-      const double span = pg.p[2] - pg.p[1];
-      double m = fmod(th, span);
-      if (m != 0.0 && ((m < 0.0) != (span < 0.0))) m += span;   // (sign of the divisor)
-      return m + pg.p[1];
+    // theta = turns * pi, folded into the wedge [theta_start, theta_end) when there is one
+    // (distributions.py:1396-1447); sine and cosine straight from the half-turns when there is
+    // none (sincospi: no range reduction against a rounded pi)
+    const bool wedge = !(pg.p[1] == 0.0 && pg.p[2] == TWO_PI);
+    auto angle = [&](double half_turns, double* th, double* sn, double* cs) {
+      double t = half_turns * 3.14159265358979323846;
+      if (wedge) {
+        const double span = pg.p[2] - pg.p[1];
+        double m = fmod(t, span);
+        if (m != 0.0 && ((m < 0.0) != (span < 0.0))) m += span;   // (sign of the divisor)
+        t = m + pg.p[1];
+        sincos(t, sn, cs);
+      } else {
+        sincospi(half_turns, sn, cs);
+      }
+      *th = t;
     };
     if (pg.kind == TFRT_PTS_CIRCLE) {            // p = {radius, theta_start, theta_end}
       const double r = sqrt(u0);
-      const double th = theta_mod(TWO_PI * u1);
-      double sn, cs;
-      sincos(th, &sn, &cs);
+      double th, sn, cs;
+      angle(2.0 * u1, &th, &sn, &cs);
       p[1] = pg.p[0] * (r * cs);
       p[2] = pg.p[0] * (r * sn);
       aux[0] = r;
@@ -87,15 +96,15 @@ __device__ __forceinline__ void eval_points(const tfrt_points_program& pg, int64
       aux[1] = p[2];
     } else {                                     // p = {radius, theta_start, theta_end, lower bound}
       const double c = pg.p[3] + (1.0 - pg.p[3]) * u0;
-      const double phi = acos(pg.kind == TFRT_PTS_SPHERE_LAMBERT ? sqrt(c) : c);
-      const double th = theta_mod(GOLDEN_TURN * u1);
-      double sp, cp, sn, cs;
-      sincos(phi, &sp, &cp);
-      sincos(th, &sn, &cs);
+      // cos(phi) = c (uniform cap) or sqrt(c) (Lambertian: cos^2 is uniform); sin from it
+      const double cp = pg.kind == TFRT_PTS_SPHERE_LAMBERT ? sqrt(c) : c;
+      const double sp = sqrt(fmax(0.0, (1.0 - cp) * (1.0 + cp)));
+      double th, sn, cs;
+      angle((1.0 + 2.2360679774997896964) * u1, &th, &sn, &cs);   // theta = pi (1 + sqrt 5) u
       p[0] = pg.p[0] * cp;
       p[1] = pg.p[0] * (sp * cs);
       p[2] = pg.p[0] * (sp * sn);
-      aux[0] = phi;
+      aux[0] = acos(cp);
       aux[1] = th;
     }
     // BasePointTransformation (distributions.py:2014-2120): scale, rotate, translate
