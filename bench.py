@@ -457,15 +457,22 @@ def main(argv=None):
         # every hot kernel of the step: live launch time, the roof that bounds it, SURVEY 8d's
         # algorithmic bytes beside the counter traffic
         n_fwd = float(np.mean(n_active))
+        # coherent rays: the reverse sweep is ONE launch per step (as many records as react has / P)
+        bwd_one = len(kms.get("backward") or []) * P <= len(kms.get("react") or []) + P - 1
         rows = [dict(name=kernel_name, kind="intersect", launches_per_step=P, bound="valu",
                      avg_ms=avg_ms, frac=roofline.get("frac"),
                      algorithmic_bytes=alg_bytes, traffic=roofline.get("traffic"))]
         for kind, kname, per_step, alg, note in (
                 ("react", "tfrt::k_react3d", P, n_fwd * BYTES_PER_RAY_FWD,
                  "SURVEY 8d forward bytes: 64 B per ray entering the pass"),
-                ("backward", "tfrt::k_backward3d", P, n_fwd * BYTES_PER_RAY_BWD,
-                 "SURVEY 8d backward bytes: 116 B per ray of the pass (coherent rays: the face-gradient "
-                 "terms are summed per wavefront in LDS and leave as one atomic per face and term)"),
+                ("backward", "tfrt::k_backward_chain" if bwd_one else "tfrt::k_backward3d",
+                 1 if bwd_one else P,
+                 (float(sum(n_active)) if bwd_one else n_fwd) * BYTES_PER_RAY_BWD,
+                 "SURVEY 8d backward bytes: 116 B per ray entering a pass" +
+                 (", all passes in the one launch (coherent rays: a lane walks its ray's chain of "
+                  "slots back with the child gradient in registers; the face-gradient terms are summed "
+                  "per wavefront in LDS and leave as one atomic per face and term)" if bwd_one else
+                  " (one launch per pass)")),
                 ("accumulate", "tfrt::k_face_accumulate", 1, float(sum(n_active)) * 40.0,
                  "the stash read once: 36 B of terms + 4 B face index per ray and pass")):
             v = np.asarray(kms.get(kind) or [], dtype=np.float64)

@@ -19,7 +19,7 @@ D="/tmp/pmc0 /tmp/pmc1 /tmp/pmc2 /tmp/pmc3 /tmp/pmc4"
 python $R/scratch/pmc_to_json.py $O/${RN}_pmc_beam.json k_intersect_beam 3 $D > /dev/null
 python $R/scratch/pmc_to_json.py $O/${RN}_pmc_group.json k_intersect_group 3 $D > /dev/null
 python $R/scratch/pmc_to_json.py $O/${RN}_pmc_react.json k_react3d 3 $D > /dev/null
-python $R/scratch/pmc_to_json.py $O/${RN}_pmc_backward.json k_backward3d 3 $D > /dev/null
+python $R/scratch/pmc_to_json.py $O/${RN}_pmc_backward.json k_backward_chain 1 $D > /dev/null
 python $R/scratch/pmc_to_json.py $O/${RN}_pmc_accumulate.json k_face_accumulate 1 $D > /dev/null
 # 3. the bench line itself, now that the PMC files exist (bench withholds the counter-derived
 #    fields when the kernel sources have changed since the counters were collected)

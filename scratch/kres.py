@@ -22,6 +22,7 @@ for line in out.splitlines():
         cur = {"name": t.split(":", 1)[1].strip()}; rows.append(cur)
     elif cur is not None and ":" in t:
         k, v = t.split(":", 1); cur[k.strip()] = v.strip()
+if not rows: sys.exit("no kernels found (compile error?)\n" + out[-2000:])
 dem = subprocess.run(["/usr/bin/c++filt"] + [r["name"] for r in rows], stdout=subprocess.PIPE).stdout.decode().splitlines()
 print(f"{'kernel':58s} {'SGPR':>4s} {'VGPR':>4s} {'AGPR':>4s} {'vspill':>6s} {'sspill':>6s} {'scr':>4s} {'occ':>3s} {'LDS':>6s}")
 for r, d in zip(rows, dem):

@@ -166,12 +166,19 @@ __device__ __forceinline__ float4 pack_sphere(const double cc[3], double reff) {
 __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fverts, int M,
                                                    const double* __restrict__ c0,
                                                    double size_eps,
-                                                   float4* __restrict__ sphere) {
+                                                   float4* __restrict__ sphere,
+                                                   double* __restrict__ fnorm) {
   const int j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= M) return;
   double cc[3], reff;
   face_sphere(fverts + 9 * (int64_t)j, c0, size_eps, cc, &reff);
   sphere[j] = pack_sphere(cc, reff);
+  if (fnorm != nullptr) {  // the reaction's unit normal, once per face (snell_normal)
+    double P[9], un[3];
+    for (int q = 0; q < 9; ++q) P[q] = fverts[9 * (int64_t)j + q];
+    snell_normal(P, un);
+    for (int q = 0; q < 3; ++q) fnorm[3 * (int64_t)j + q] = un[q];
+  }
 }
 
 // Hierarchy modes: faces are visited in `order` (spatially coherent groups of CLUSTER faces).
@@ -207,7 +214,7 @@ __device__ __forceinline__ void cluster_spheres_block(
     const int block, const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
     const double* __restrict__ c0, double size_eps, int n_clusters,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
-    float4* __restrict__ crec) {
+    float4* __restrict__ crec, double* __restrict__ fnorm) {
   const int k = block * BLOCK + threadIdx.x;  // member slot = cluster * CLUSTER + member
   const int c = k / CLUSTER;
   const bool in_range = c < n_clusters;            // uniform over the 16 lanes of a cluster
@@ -224,6 +231,12 @@ __device__ __forceinline__ void cluster_spheres_block(
       double e2 = 0;
       for (int q = 0; q < 3; ++q) e2 += (V[(v + 1) % 3][q] - V[v][q]) * (V[(v + 1) % 3][q] - V[v][q]);
       edge = fmax(edge, sqrt(e2));
+    }
+    if (fnorm != nullptr) {  // the reaction's unit normal, once per face (snell_normal)
+      double Pf[9], un[3];
+      for (int q = 0; q < 9; ++q) Pf[q] = P[q];
+      snell_normal(Pf, un);
+      for (int q = 0; q < 3; ++q) fnorm[3 * (int64_t)f + q] = un[q];
     }
   }
   if (in_range) {
@@ -401,7 +414,8 @@ __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     double* __restrict__ c0_out, double size_eps, int n_clusters, int n_super,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
     float4* __restrict__ crec, float4* __restrict__ susphere, int32_t* nrays0, int n,
-    int32_t* tail8, unsigned int* scan_ticket, int32_t* __restrict__ hist0, int hist_len) {
+    int32_t* tail8, unsigned int* scan_ticket, int32_t* __restrict__ hist0, int hist_len,
+    double* __restrict__ fnorm) {
   // (coherent-ray traces: the class histogram the first pass's intersect kernels add into)
   for (int k = blockIdx.x * BLOCK + threadIdx.x; k < hist_len; k += gridDim.x * BLOCK) hist0[k] = 0;
   __shared__ double c0[3];
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     super_spheres_block(blockIdx.x, fverts, M, order, c0, size_eps, susphere);
   } else {
     cluster_spheres_block(blockIdx.x - n_super, fverts, M, order, c0, size_eps, n_clusters,
-                          csphere, cface, clsphere, crec);
+                          csphere, cface, clsphere, crec, fnorm);
   }
 }
 
@@ -2262,7 +2276,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_
     int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_tri_out,
     int32_t* __restrict__ rec_slot, tfrt_ray_out fin, tfrt_ray_out act, tfrt_ray_out stp,
     tfrt_ray_out dead, int32_t* __restrict__ err, float* __restrict__ prep_next, int64_t pstride,
-    const double* __restrict__ c0, SelfScan ss) {
+    const double* __restrict__ c0, SelfScan ss, const double* __restrict__ fnorm) {
   const int n = *n_ptr;
   const int base = blockIdx.x * BLOCK;
   // Self-scan mode (few ray blocks): no scan launch ran.  Every block sums the class histograms
@@ -2367,13 +2381,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_
       rec_slot[i] = (int32_t)gslot;
     } else {  // ACTIVE
       if (flags & TFRT_COMPILE_ACTIVE) ok = emit<T>(act, gslot, s, h, rid, tri);
-      double P[9], N[3], C[3], clen, n_in, n_out;
-      const double* fp = sc.face_verts + 9 * (int64_t)tri;
+      // (the face's unit normal was formed once per face by the trace's set-up launch: the cross
+      // product, a square root and four divisions of float64 less per ray, 24 B gathered for 72)
+      double un[3], n_in, n_out;
+      const double* fp = fnorm + 3 * (int64_t)tri;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) P[q] = fp[q];
-      face_normal(P, N, C, &clen);
+      for (int q = 0; q < 3; ++q) un[q] = fp[q];
       face_indices(sc, tri, rid, &n_in, &n_out);
-      const Snell3 f = snell3d(s, h, N, n_in, n_out);
+      const Snell3 f = snell3d_unit(s, h, un, n_in, n_out);
       // the branches this reaction took go on the tape (bits 2, 3 of the class byte): the reverse
       // sweep re-derives everything else, but with other roundings (reciprocals instead of
       // quotients), and at grazing incidence or at the critical angle must not take another side
@@ -2453,6 +2468,64 @@ __device__ __forceinline__ double dpp_f64(const double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// Coherent rays (tfrt_scene3d.coherent_rays): the 64 rays of a wavefront hit a handful of
+// faces.  Their terms are summed per face in LDS first (one slot per distinct face of the
+// wavefront, LDS float64 adds), then every (face, term) sum goes to memory with ONE atomic:
+// no per-ray stash written and read back, no accumulate launch.
+// (several copies of every sum, taken by the lane's low bits: lanes that add to ONE LDS address
+// are served one after the other -- with a single copy a third of this kernel's time -- and
+// neighbouring lanes are the ones that share a face.  Eight copies for up to 8 faces, four for
+// up to 16, two for up to 32: sparse rays share a face with few lanes anyway)
+constexpr int WSUM_SLOTS = 32, WSUM_CELLS = 576;
+__device__ __forceinline__ void wave_face_sums(int tri, const double gP[9], double* wacc,
+                                               int32_t* wface, double* __restrict__ g_fverts) {
+  const int lane = threadIdx.x & 63;
+  int slot = -1, ns = 0;
+  unsigned long long todo = __ballot(tri >= 0);
+  if (todo == 0ull) return;  // (wave-uniform)
+  while (todo != 0ull && ns < WSUM_SLOTS) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int k = __builtin_amdgcn_readlane(tri, leader);
+    const bool mine = tri == k;
+    if (mine) slot = ns;
+    if (lane == leader) wface[ns] = k;
+    ++ns;
+    todo &= ~__ballot(mine);
+  }
+  const int copies = ns <= 8 ? 8 : (ns <= 16 ? 4 : 2);
+  const int cells = ns * 9 * copies;
+  for (int k = lane; k < cells; k += 64) wacc[k] = 0.0;
+  wave_fence();
+  if (tri >= 0) {
+    if (slot >= 0) {
+      double* w = &wacc[slot * 9 * copies + (lane & (copies - 1))];
+#pragma unroll
+      for (int c = 0; c < 9; ++c)
+        if (gP[c] != 0.0) unsafeAtomicAdd(w + c * copies, gP[c]);
+    } else {  // (more distinct faces than slots: rays that are not coherent after all)
+      double* gp = g_fverts + 9 * (int64_t)tri;
+#pragma unroll
+      for (int c = 0; c < 9; ++c)
+        if (gP[c] != 0.0) unsafeAtomicAdd(gp + c, gP[c]);
+    }
+  }
+  wave_fence();
+  // the copies of a sum lie in neighbouring lanes now: folded with DPP, then ONE atomic per
+  // (face, term) of the wavefront goes to memory
+  for (int k0 = 0; k0 < cells; k0 += 64) {
+    const int k = k0 + lane;
+    double v = k < cells ? wacc[k] : 0.0;
+    v += dpp_f64<0xB1>(v);                    // quad_perm [1,0,3,2]
+    if (copies >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    if (copies >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the eight
+    if ((lane & (copies - 1)) == 0 && k < cells && v != 0.0) {
+      const int term = k / copies;
+      unsafeAtomicAdd(g_fverts + 9 * (int64_t)wface[term / 9] + (term % 9), v);
+    }
+  }
+  wave_fence();  // (the next use of wacc / wface must not overtake these reads)
+}
+
 // BW wavefronts per workgroup (the wavefronts share nothing: see k_intersect_beam)
 template <typename T, int BW>
 __global__ __launch_bounds__(64 * BW) void k_backward3d(
@@ -2473,19 +2546,10 @@ __global__ __launch_bounds__(64 * BW) void k_backward3d(
   const int q0 = blockIdx.x * (64 * BW) + threadIdx.x;
   const int i = q0;
   if (wave_sums) {
-    // Coherent rays (tfrt_scene3d.coherent_rays): the 64 rays of a wavefront hit a handful of
-    // faces.  Their terms are summed per face in LDS first (one slot per distinct face of the
-    // wavefront, LDS float64 adds), then every (face, term) sum goes to memory with ONE atomic:
-    // no per-ray stash written and read back, no accumulate launch.
-    if ((q0 & ~63) >= n) return;  // (whole wave)
-    // (several copies of every sum, taken by the lane's low bits: lanes that add to ONE LDS address
-    // are served one after the other -- with a single copy a third of this kernel's time -- and
-    // neighbouring lanes are the ones that share a face.  Eight copies for up to 8 faces, four for
-    // up to 16, two for up to 32: sparse rays share a face with few lanes anyway)
-    constexpr int SLOTS = 32, CELLS = 576;
-    __shared__ double wacc[BW][CELLS];  // [slot][term][copy]
-    __shared__ int32_t wface[BW][SLOTS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((q0 & ~63) >= n) return;  // (whole wave; the sums: wave_face_sums)
+    __shared__ double wacc[BW][WSUM_CELLS];  // [slot][term][copy]
+    __shared__ int32_t wface[BW][WSUM_SLOTS];
+    const int wave = threadIdx.x >> 6;
     double gP[9];
     int tri = -1;
     if (i < n)
@@ -2493,48 +2557,7 @@ __global__ __launch_bounds__(64 * BW) void k_backward3d(
                             pass_counts, sc, L, dead_len, g_child, child_stride, g_fin, cap_fin,
                             g_act, cap_act, g_stp, cap_stp, g_dead, cap_dead, g_out, g_src_out,
                             out_stride, gP);
-    int slot = -1, ns = 0;
-    unsigned long long todo = __ballot(tri >= 0);
-    while (todo != 0ull && ns < SLOTS) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int k = __builtin_amdgcn_readlane(tri, leader);
-      const bool mine = tri == k;
-      if (mine) slot = ns;
-      if (lane == leader) wface[wave][ns] = k;
-      ++ns;
-      todo &= ~__ballot(mine);
-    }
-    const int copies = ns <= 8 ? 8 : (ns <= 16 ? 4 : 2);
-    const int cells = ns * 9 * copies;
-    for (int k = lane; k < cells; k += 64) wacc[wave][k] = 0.0;
-    wave_fence();
-    if (tri >= 0) {
-      if (slot >= 0) {
-        double* w = &wacc[wave][slot * 9 * copies + (lane & (copies - 1))];
-#pragma unroll
-        for (int c = 0; c < 9; ++c)
-          if (gP[c] != 0.0) unsafeAtomicAdd(w + c * copies, gP[c]);
-      } else {  // (more distinct faces than slots: rays that are not coherent after all)
-        double* gp = g_fverts + 9 * (int64_t)tri;
-#pragma unroll
-        for (int c = 0; c < 9; ++c)
-          if (gP[c] != 0.0) unsafeAtomicAdd(gp + c, gP[c]);
-      }
-    }
-    wave_fence();
-    // the copies of a sum lie in neighbouring lanes now: folded with DPP, then ONE atomic per
-    // (face, term) of the wavefront goes to memory
-    for (int k0 = 0; k0 < cells; k0 += 64) {
-      const int k = k0 + lane;
-      double v = k < cells ? wacc[wave][k] : 0.0;
-      v += dpp_f64<0xB1>(v);                    // quad_perm [1,0,3,2]
-      if (copies >= 4) v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
-      if (copies >= 8) v += dpp_f64<0x141>(v);  // row_half_mirror: the other quad of the eight
-      if ((lane & (copies - 1)) == 0 && k < cells && v != 0.0) {
-        const int term = k / copies;
-        unsafeAtomicAdd(g_fverts + 9 * (int64_t)wface[wave][term / 9] + (term % 9), v);
-      }
-    }
+    wave_face_sums(tri, gP, wacc[wave], wface[wave], g_fverts);
     return;
   }
   if (i >= n) return;
@@ -2721,27 +2744,24 @@ __global__ __launch_bounds__(BLOCK) void k_fixed_finish(int64_t m9,
   if (i == 0) *max_next = 0ull;
 }
 
-// Reverse of one ray slot of one pass.  Writes the gradient w.r.t. the slot's input ray to
-// g_out and returns the face whose gradient gP must be accumulated (-1: none).
+// Reverse of one ray slot of one pass, in registers: `child` holds the gradient w.r.t. the slot's
+// child ray (start, end) when it has one; gs / ge receive the gradient w.r.t. the slot's input
+// ray.  Returns the face whose gradient gP must be accumulated (-1: none).
 template <typename T>
-__device__ __forceinline__ int backward_ray(
-    int i, const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ ray_id_in,
-    const int32_t* __restrict__ rec_tri, const double* __restrict__ rec_t,
-    const uint8_t* __restrict__ rec_cls, const int32_t* __restrict__ rec_slot,
-    const int32_t* __restrict__ pass_counts, const tfrt_scene3d& sc, double L, double dead_len,
-    const typename SweepStore<T>::type* __restrict__ g_child, int64_t child_stride,
+__device__ __forceinline__ int backward_core(
+    int i, int tape, int slot, const T* __restrict__ rays_in, int64_t stride_in,
+    const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
+    const double* __restrict__ rec_t, const int32_t* __restrict__ pass_counts,
+    const tfrt_scene3d& sc, double L, double dead_len, bool child_pass, const double child[6],
     const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
     int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
-    const double* __restrict__ g_dead, int64_t cap_dead,
-    typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
-    int64_t out_stride, double gP[9]) {
+    const double* __restrict__ g_dead, int64_t cap_dead, double gs[3], double ge[3],
+    double gP[9]) {
   int face_out = -1;
-  const int tape = rec_cls[i];
   const int cls = tape & 3;
-  const int slot = rec_slot[i];
   double s[3], e[3];
   load_ray3(rays_in, stride_in, i, s, e);
-  double gs[3] = {0, 0, 0}, ge[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k) gs[k] = ge[k] = 0.0;
 
   if (cls == CLS_DEAD) {
     if (g_dead != nullptr) {
@@ -2762,9 +2782,12 @@ __device__ __forceinline__ int backward_ray(
       add6(g_stp, cap_stp, slot, g_s, g_h);
     } else {
       add6(g_act, cap_act, (int64_t)pass_counts[4 + CLS_ACTIVE] + slot, g_s, g_h);
-      if (g_child != nullptr) {
+      if (child_pass) {
         has_child = true;
-        add6(g_child, child_stride, slot, g_h, g_ce);
+        for (int k = 0; k < 3; ++k) {
+          g_h[k] += child[k];
+          g_ce[k] += child[3 + k];
+        }
       }
     }
     bool nz = has_child;
@@ -2788,7 +2811,35 @@ __device__ __forceinline__ int backward_ray(
       if (sc.face_grad_mask == nullptr || sc.face_grad_mask[tri] != 0) face_out = tri;
     }
   }
-  // (first pass: to the caller's source-ray gradient, or nowhere when nobody asked for it)
+  return face_out;
+}
+
+// The same with the child's gradient read from, and the slot's own written to, the sweep's
+// per-pass buffers (k_backward3d).  The first pass writes to the caller's g_src, or nowhere.
+template <typename T>
+__device__ __forceinline__ int backward_ray(
+    int i, const T* __restrict__ rays_in, int64_t stride_in, const int32_t* __restrict__ ray_id_in,
+    const int32_t* __restrict__ rec_tri, const double* __restrict__ rec_t,
+    const uint8_t* __restrict__ rec_cls, const int32_t* __restrict__ rec_slot,
+    const int32_t* __restrict__ pass_counts, const tfrt_scene3d& sc, double L, double dead_len,
+    const typename SweepStore<T>::type* __restrict__ g_child, int64_t child_stride,
+    const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
+    int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
+    const double* __restrict__ g_dead, int64_t cap_dead,
+    typename SweepStore<T>::type* __restrict__ g_out, double* __restrict__ g_src_out,
+    int64_t out_stride, double gP[9]) {
+  const int tape = rec_cls[i];
+  const int slot = rec_slot[i];
+  double child[6] = {0, 0, 0, 0, 0, 0};
+  const bool child_pass = g_child != nullptr;
+  if (child_pass && (tape & 3) == CLS_ACTIVE) {
+    for (int k = 0; k < 6; ++k) child[k] = static_cast<double>(g_child[k * child_stride + slot]);
+  }
+  double gs[3], ge[3];
+  const int face_out = backward_core<T>(i, tape, slot, rays_in, stride_in, ray_id_in, rec_tri,
+                                        rec_t, pass_counts, sc, L, dead_len, child_pass, child,
+                                        g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
+                                        cap_dead, gs, ge, gP);
   if (g_out != nullptr) {
     using G = typename SweepStore<T>::type;
     for (int k = 0; k < 3; ++k) {
@@ -2802,6 +2853,95 @@ __device__ __forceinline__ int backward_ray(
     }
   }
   return face_out;
+}
+
+// The whole reverse sweep of a coherent trace in ONE launch.  A ray's gradient only ever flows
+// along the ray's own chain of slots (pass p slot -> rec_slot -> pass p + 1 slot), so a lane takes a
+// SOURCE ray, follows its chain forward to the pass where the ray ended (finished / stopped / dead /
+// still active after the last pass), and walks back pass by pass with the gradient w.r.t. the
+// child ray in registers: the per-pass gradient blocks (2 x 24..48 B per ray and pass written
+// and read back) and P - 1 dependent launches are gone, and the intermediates stay float64.
+// Stable compaction keeps the slots of neighbouring lanes neighbours in every pass, so the tape
+// reads stay coalesced and a wavefront's rays still share their faces (wave_face_sums, once per
+// pass).  The slots of a chain wait in LDS (one column per lane) because P is not a constant.
+constexpr int CHAIN_MAXP = 8;
+
+template <typename T>
+struct ChainArgs {
+  const T* src;            // source rays (inputs of pass 1)
+  int64_t src_stride;
+  const T* rays_ws;        // inputs of pass 2..P, (P - 1) blocks of 6 x n
+  const int32_t* nrays;    // rays entering pass 1..P
+  const int32_t* rayid;    // per pass (from pass 2 on): source-ray index of a slot
+  const int32_t* rec_tri;
+  const int32_t* rec_slot;
+  const double* rec_t;
+  const uint8_t* rec_cls;
+  const int32_t* counts;
+  int64_t n;               // slot stride of the per-pass arrays
+  int32_t P;
+  double L, dead_len;
+  const double *g_fin, *g_act, *g_stp, *g_dead;
+  int64_t cap_fin, cap_act, cap_stp, cap_dead;
+  double* g_src;           // (6 x N) or null
+  int64_t N;
+  double* g_fverts;
+};
+
+template <typename T, int BW>
+__global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_backward_chain(
+    ChainArgs<T> a, tfrt_scene3d sc) {
+  const int n0 = a.nrays[0];
+  const int i0 = blockIdx.x * (64 * BW) + threadIdx.x;
+  if ((i0 & ~63) >= n0) return;  // (whole wave)
+  __shared__ double wacc[BW][WSUM_CELLS];
+  __shared__ int32_t wface[BW][WSUM_SLOTS];
+  __shared__ int32_t chain[BW][CHAIN_MAXP][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int P = a.P;
+  // forward: the slots of this ray's chain and the pass it ends in
+  int last = -1;
+  if (i0 < n0) {
+    int j = i0;
+    for (int p = 0; p < P; ++p) {
+      chain[wave][p][lane] = j;
+      last = p;
+      const size_t at = (size_t)p * a.n + j;
+      if ((a.rec_cls[at] & 3) != CLS_ACTIVE || p == P - 1) break;
+      j = a.rec_slot[at];
+    }
+  }
+  // (wave-uniform bound of the walk back)
+  int top = last;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) top = max(top, __shfl_xor(top, d, 64));
+  double child[6] = {0, 0, 0, 0, 0, 0};
+  for (int p = top; p >= 0; --p) {
+    double gP[9];
+    int tri = -1;
+    if (p <= last) {
+      const int j = chain[wave][p][lane];
+      const size_t off = (size_t)p * a.n;
+      const T* rin = p == 0 ? a.src : a.rays_ws + (size_t)(p - 1) * 6 * a.n;
+      const int64_t sin = p == 0 ? a.src_stride : a.n;
+      const int32_t* idin = p == 0 ? nullptr : a.rayid + (size_t)(p - 1) * a.n;
+      double gs[3], ge[3];
+      tri = backward_core<T>(j, a.rec_cls[off + j], a.rec_slot[off + j], rin, sin, idin,
+                             a.rec_tri + off, a.rec_t + off,
+                             a.counts + (size_t)p * TFRT_COUNTS_PER_PASS, sc, a.L, a.dead_len,
+                             p < P - 1, child, a.g_fin, a.cap_fin, a.g_act, a.cap_act, a.g_stp,
+                             a.cap_stp, a.g_dead, a.cap_dead, gs, ge, gP);
+      for (int k = 0; k < 3; ++k) {
+        child[k] = gs[k];
+        child[3 + k] = ge[k];
+      }
+    }
+    wave_face_sums(tri, gP, wacc[wave], wface[wave], a.g_fverts);
+  }
+  if (a.g_src != nullptr && i0 < n0) {
+    // (a ray without a chain cannot be: every source ray enters pass 1 when P > 0)
+    for (int k = 0; k < 6; ++k) a.g_src[k * a.N + i0] = child[k];
+  }
 }
 
 // ------------------------------------------------------------------------------ misc
@@ -2918,7 +3058,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec, hist_a, hist_b, left_list;
+  size_t csphere, cface, clsphere, susphere, crec, fnorm, hist_a, hist_b, left_list;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -2950,6 +3090,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.clsphere = take(ncl * sizeof(float4));
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
+  L.fnorm = take(m * 3 * sizeof(double));   // the reaction's unit normal per face (snell_normal)
   // coherent-ray traces (tfrt_scene3d.coherent_rays): two class histograms (one being read, one
   // being built with atomics by both intersect kernels), the wavefronts left to the grouped kernel
   L.hist_a = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   // (+ the count of wavefronts
@@ -3119,6 +3260,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* rec_slot = reinterpret_cast<int32_t*>(ws + lay.rec_slot);
   double* rec_t = reinterpret_cast<double*>(ws + lay.rec_t);
   uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
+  double* fnorm = reinterpret_cast<double*>(ws + lay.fnorm);
   int32_t* tail = counts + (size_t)P * TFRT_COUNTS_PER_PASS;
   const size_t n = N > 0 ? N : 1;
 
@@ -3149,12 +3291,12 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
-                         (int)N, tail, ticket, hist_ab[0], coherent ? pl.nblk * 4 + 1 : 0);
+                         (int)N, tail, ticket, hist_ab[0], coherent ? pl.nblk * 4 + 1 : 0, fnorm);
     } else {
       hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
                          (int)N, tail, ticket);
       hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,
-                         c0, sc->size_epsilion, sphere);
+                         c0, sc->size_epsilion, sphere, fnorm);
     }
   }
   const int chunks_used = ac.order == nullptr ? pl.chunks : pl.g_chunks;
@@ -3227,7 +3369,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                        rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
                        stp ? *stp : none, dead ? *dead : none, tail + 6,
                        (p + 1 < P && !coherent) ? prep : nullptr,
-                       (int64_t)n, c0, ss);
+                       (int64_t)n, c0, ss, fnorm);
   }
   if (unfinished != nullptr && P > 0) {
     hipLaunchKernelGGL((k_copy_rays<T>), dim3(pl.nblk), dim3(BLOCK), 0, st,
@@ -3284,6 +3426,39 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // (one launch sums all passes now: a block per CU is enough -- 125k rays x 11 windows, step time
   // with 1024 / 2048 / 4096 / 8192 slots per block: 0.302 / 0.278 / 0.265 / 0.268 ms)
   while (acc_chunk > 1024 && (int64_t)cdiv(N, acc_chunk) * windows < 256) acc_chunk /= 2;
+  if (wave_sums && P >= 1 && P <= CHAIN_MAXP) {
+    // coherent rays: the whole sweep in one launch (k_backward_chain)
+    ChainArgs<T> a;
+    a.src = static_cast<const T*>(src_rays);
+    a.src_stride = src_stride;
+    a.rays_ws = rays_ws;
+    a.nrays = nrays;
+    a.rayid = rayid;
+    a.rec_tri = rec_tri;
+    a.rec_slot = rec_slot;
+    a.rec_t = rec_t;
+    a.rec_cls = rec_cls;
+    a.counts = counts;
+    a.n = (int64_t)n;
+    a.P = P;
+    a.L = L;
+    a.dead_len = dead_len;
+    a.g_fin = g_fin;
+    a.g_act = g_act;
+    a.g_stp = g_stp;
+    a.g_dead = g_dead;
+    a.cap_fin = cap_fin;
+    a.cap_act = cap_act;
+    a.cap_stp = cap_stp;
+    a.cap_dead = cap_dead;
+    a.g_src = g_src;
+    a.N = N;
+    a.g_fverts = g_fverts;
+    ProfScope prof_bwd(TFRT_PROF_BACKWARD, st);
+    if (N > 0)
+      hipLaunchKernelGGL((k_backward_chain<T, 1>), dim3(cdiv(N, 64)), dim3(64), 0, st, a, *sc);
+    return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+  }
   for (int p = P - 1; p >= 0; --p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
     const int64_t sin = p == 0 ? src_stride : (int64_t)n;
@@ -3446,7 +3621,7 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
     hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, face_verts, M, c0, nptr, (int)n_rays,
                        nptr + 8, (unsigned int*)nullptr);
     hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, face_verts, M, c0,
-                       size_epsilion, sphere);
+                       size_epsilion, sphere, static_cast<double*>(nullptr));
   }
 #define TFRT_SEAM(TT)                                                                          \
   launch_intersect<TT>(pl, st, static_cast<const TT*>(rays), stride, nptr, nullptr, sphere,    \

@@ -132,14 +132,26 @@ struct Snell3 {
   double w[3];        // new direction
 };
 
-// geometry.py:715-753.  s = ray start, h = projected ray end (the hit), norm = face normal.
-TFRT_HD Snell3 snell3d(const double s[3], const double h[3], const double norm[3],
-                       double n_in, double n_out) {
+// The normal of a face as snell3d() uses it: boundaries.py:918-923 followed by the l2_normalize of
+// geometry.py:721 -- a function of the face alone, so a trace may form it once per face
+// (k_hierarchy_spheres / k_spheres) instead of once per ray and pass: the same operations in the
+// same order, hence the same bits.
+TFRT_HD void snell_normal(const double P[9], double n[3]) {
+  double N[3], C[3], clen;
+  face_normal(P, N, C, &clen);
+  l2_normalize3(N, n);
+}
+
+// geometry.py:715-753 from the normal on (un = snell_normal() of the face).
+TFRT_HD Snell3 snell3d_unit(const double s[3], const double h[3], const double un[3],
+                            double n_in, double n_out) {
 #pragma clang fp contract(off)
   Snell3 o;
   const double r[3] = {h[0] - s[0], h[1] - s[1], h[2] - s[2]};
   l2_normalize3(r, o.u);
-  l2_normalize3(norm, o.n);
+  o.n[0] = un[0];
+  o.n[1] = un[1];
+  o.n[2] = un[2];
   o.nu = dot3(o.n, o.u);
   const bool internal = o.nu > 0.0;
   const bool in_safe = n_in != 0.0, out_safe = n_out != 0.0;
@@ -159,6 +171,14 @@ TFRT_HD Snell3 snell3d(const double s[3], const double h[3], const double norm[3
     for (int i = 0; i < 3; ++i) o.w[i] = alpha * o.n[i] + o.eta * o.u[i];
   }
   return o;
+}
+
+// geometry.py:715-753.  s = ray start, h = projected ray end (the hit), norm = face normal.
+TFRT_HD Snell3 snell3d(const double s[3], const double h[3], const double norm[3],
+                       double n_in, double n_out) {
+  double un[3];
+  l2_normalize3(norm, un);
+  return snell3d_unit(s, h, un, n_in, n_out);
 }
 
 // floor-mod like tf.math.mod / python %
