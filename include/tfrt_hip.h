@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFRT_VERSION 103 /* 0.1.0 */
+#define TFRT_VERSION 104 /* 0.1.0 */
 
 #define TFRT_F32 0
 #define TFRT_F64 1
@@ -335,7 +335,9 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
  *   counts         the device-side counters of that trace (TFRT_COUNTS_LEN(max_passes) int32):
  *                  the number of finished rows and the trace's test count are read from its tail
  *   fields[c]      row of the ray block (0..5 = x_start..z_end) compared with goal column c
- *   goal           n_fields x goal_stride f64, goal[c * goal_stride + source_ray]
+ *   goal           f64 goal table, entry (c, source ray r) at goal[c * goal_stride +
+ *                  r * goal_ray_stride]: one contiguous column per field (goal_ray_stride 1) or
+ *                  one row per ray (goal_stride 1, goal_ray_stride n_fields)
  *   grad_finished  6 x capacity f64: rows fields[c] receive 2 * (output - goal) for the
  *                  finished rows; other rows and rows beyond n_finished are left untouched
  *                  (zero them once: tfrt_trace3d_backward reads finished rows only)
@@ -350,9 +352,10 @@ size_t tfrt_goal_error3d_workspace_bytes(int64_t capacity);
 int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
                       int32_t state_dtype, const int32_t* counts, int32_t max_passes,
                       const int32_t* fields, int32_t n_fields, const double* goal,
-                      int64_t goal_stride, double* grad_finished, double* error_out,
-                      double* zero_buffer, int64_t zero_count, int64_t* tests_total,
-                      void* workspace, size_t workspace_bytes, void* stream);
+                      int64_t goal_stride, int64_t goal_ray_stride, double* grad_finished,
+                      double* error_out, double* zero_buffer, int64_t zero_count,
+                      int64_t* tests_total, void* workspace, size_t workspace_bytes,
+                      void* stream);
 
 /* The same without the second stage of the sum: `pending` (host struct) is filled in and whoever
  * runs next finishes it -- tfrt_sgd_process_multi_finish in a spare workgroup of the parameter
@@ -361,9 +364,10 @@ int tfrt_goal_error3d_deferred(const void* finished_rays, int64_t capacity,
                                const int32_t* finished_id, int32_t state_dtype,
                                const int32_t* counts, int32_t max_passes, const int32_t* fields,
                                int32_t n_fields, const double* goal, int64_t goal_stride,
-                               double* grad_finished, double* error_out, double* zero_buffer,
-                               int64_t zero_count, int64_t* tests_total, void* workspace,
-                               size_t workspace_bytes, tfrt_goal_pending* pending, void* stream);
+                               int64_t goal_ray_stride, double* grad_finished, double* error_out,
+                               double* zero_buffer, int64_t zero_count, int64_t* tests_total,
+                               void* workspace, size_t workspace_bytes,
+                               tfrt_goal_pending* pending, void* stream);
 int tfrt_goal_finish(const tfrt_goal_pending* pending, void* stream);
 
 /* Benchmark instrumentation (the only global state in the library; not used by the product

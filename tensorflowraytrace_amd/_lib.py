@@ -136,9 +136,9 @@ SIGNATURES = {
         c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_goal_error3d_workspace_bytes": (c_sz, [c_i64]),
     "tfrt_goal_error3d": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64,
-                                  c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
+                                  c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_goal_error3d_deferred": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64,
-                                  c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp, c_vp]),
+                                  c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "tfrt_goal_finish": (c_i32, [c_vp, c_vp]),
     "tfrt_intersect3d_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "tfrt_intersect3d": (c_i32, [

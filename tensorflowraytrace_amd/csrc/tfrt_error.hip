@@ -33,7 +33,7 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_goal_error(
     const T* __restrict__ fin, int64_t cap, const int32_t* __restrict__ fin_id,
     const int32_t* __restrict__ n_ptr, GoalFields gf, const double* __restrict__ goal,
-    int64_t goal_stride, double* __restrict__ g_fin, double* __restrict__ partial,
+    int64_t goal_stride, int64_t goal_ray_stride, double* __restrict__ g_fin, double* __restrict__ partial,
     double* __restrict__ zero_buf, int64_t zero_n) {
   // the reference's squared_difference and reduce_sum are separate ops: no contraction
 #pragma clang fp contract(off)
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(BLOCK) void k_goal_error(
     const int64_t id = fin_id[i];
     for (int c = 0; c < gf.n; ++c) {
       const int64_t at = (int64_t)gf.row[c] * cap + i;
-      const double r = ldd(fin, at) - goal[(int64_t)c * goal_stride + id];
+      const double r = ldd(fin, at) - goal[(int64_t)c * goal_stride + id * goal_ray_stride];
       g_fin[at] = 2.0 * r;
       acc += r * r;
     }
@@ -87,12 +87,13 @@ static int goal_error_launch(const void* finished_rays, int64_t capacity,
                              const int32_t* finished_id, int32_t state_dtype,
                              const int32_t* counts, int32_t max_passes, const int32_t* fields,
                              int32_t n_fields, const double* goal, int64_t goal_stride,
-                             double* grad_finished, double* error_out, double* zero_buffer,
+                             int64_t goal_ray_stride, double* grad_finished, double* error_out,
+                             double* zero_buffer,
                              int64_t zero_count, int64_t* tests_total, void* workspace,
                              size_t workspace_bytes, tfrt_goal_pending* pending, void* stream) {
   if (capacity < 0 || n_fields < 1 || n_fields > 6 || !fields || !counts || max_passes < 0 ||
       !error_out || !workspace || workspace_bytes < tfrt_goal_error3d_workspace_bytes(capacity) ||
-      zero_count < 0 || (zero_count > 0 && !zero_buffer))
+      zero_count < 0 || (zero_count > 0 && !zero_buffer) || goal_stride < 0 || goal_ray_stride < 0)
     return TFRT_E_BADARG;
   if (capacity > 0 && (!finished_rays || !finished_id || !goal || !grad_finished))
     return TFRT_E_BADARG;
@@ -111,7 +112,8 @@ static int goal_error_launch(const void* finished_rays, int64_t capacity,
 #define TFRT_GOAL(T)                                                                           \
   hipLaunchKernelGGL((k_goal_error<T>), dim3(nblk), dim3(BLOCK), 0, st,                        \
                      static_cast<const T*>(finished_rays), capacity, finished_id, n_finished,  \
-                     gf, goal, goal_stride, grad_finished, partial, zero_buffer, zero_count)
+                     gf, goal, goal_stride, goal_ray_stride, grad_finished, partial, zero_buffer,   \
+                     zero_count)
   if (state_dtype == TFRT_F32) {
     TFRT_GOAL(float);
   } else if (state_dtype == TFRT_F64) {
@@ -141,11 +143,13 @@ static int goal_error_launch(const void* finished_rays, int64_t capacity,
 int tfrt_goal_error3d(const void* finished_rays, int64_t capacity, const int32_t* finished_id,
                       int32_t state_dtype, const int32_t* counts, int32_t max_passes,
                       const int32_t* fields, int32_t n_fields, const double* goal,
-                      int64_t goal_stride, double* grad_finished, double* error_out,
-                      double* zero_buffer, int64_t zero_count, int64_t* tests_total,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+                      int64_t goal_stride, int64_t goal_ray_stride, double* grad_finished,
+                      double* error_out, double* zero_buffer, int64_t zero_count,
+                      int64_t* tests_total, void* workspace, size_t workspace_bytes,
+                      void* stream) {
   return goal_error_launch(finished_rays, capacity, finished_id, state_dtype, counts, max_passes,
-                           fields, n_fields, goal, goal_stride, grad_finished, error_out,
+                           fields, n_fields, goal, goal_stride, goal_ray_stride, grad_finished,
+                           error_out,
                            zero_buffer, zero_count, tests_total, workspace, workspace_bytes,
                            nullptr, stream);
 }
@@ -154,12 +158,14 @@ int tfrt_goal_error3d_deferred(const void* finished_rays, int64_t capacity,
                                const int32_t* finished_id, int32_t state_dtype,
                                const int32_t* counts, int32_t max_passes, const int32_t* fields,
                                int32_t n_fields, const double* goal, int64_t goal_stride,
-                               double* grad_finished, double* error_out, double* zero_buffer,
-                               int64_t zero_count, int64_t* tests_total, void* workspace,
-                               size_t workspace_bytes, tfrt_goal_pending* pending, void* stream) {
+                               int64_t goal_ray_stride, double* grad_finished, double* error_out,
+                               double* zero_buffer, int64_t zero_count, int64_t* tests_total,
+                               void* workspace, size_t workspace_bytes,
+                               tfrt_goal_pending* pending, void* stream) {
   if (!pending) return TFRT_E_BADARG;
   return goal_error_launch(finished_rays, capacity, finished_id, state_dtype, counts, max_passes,
-                           fields, n_fields, goal, goal_stride, grad_finished, error_out,
+                           fields, n_fields, goal, goal_stride, goal_ray_stride, grad_finished,
+                           error_out,
                            zero_buffer, zero_count, tests_total, workspace, workspace_bytes,
                            pending, stream);
 }

@@ -28,6 +28,7 @@ namespace tfrt {
 // written in source order at all)
 template <typename T>
 struct BlockRays {
+  static constexpr bool HAS_F32 = false;
   const T* rays;
   int64_t stride;
   __device__ __forceinline__ void load(int64_t i, double s[3], double e[3]) const {
@@ -35,10 +36,15 @@ struct BlockRays {
   }
 };
 struct ProgramRays {
+  static constexpr bool HAS_F32 = true;
   tfrt_source3d_program sp;
   int64_t first;
   __device__ __forceinline__ void load(int64_t i, double s[3], double e[3]) const {
     eval_ray(sp, first + i, s, e);
+  }
+  // (float32 evaluation: enough for the order's keys, a fraction of the float64 one's time)
+  __device__ __forceinline__ void load_f(int64_t i, float s[3], float e[3]) const {
+    eval_ray<float>(sp, first + i, s, e);
   }
 };
 
@@ -77,24 +83,35 @@ struct OrderFrame {
   int planar;
 };
 
+__device__ __forceinline__ void order_coords_f(const OrderFrame& fr, const float s[3],
+                                               const float e[3], float* xo, float* yo);
+
 // The frame in which the rays' lines are compared: the middle of the scene (mean centroid of 64
 // sampled faces, or the mean end point of 256 sampled rays) and the plane perpendicular to the
 // bundle's mean direction (that of 256 sampled rays unless the caller gives an axis); rays without
 // a common direction, |mean| <= 1/2 (an isotropic point source): no plane -- octahedral map of the
 // directions.  One workgroup, a fixed reduction tree: the same frame on every run.  Also arms the
 // extents mm[0..3] (running minima of enc(x), ~enc(x), enc(y), ~enc(y)).
-template <typename R>
-__global__ __launch_bounds__(BLOCK) void k_order_frame(const R src,
-                                                       int n, const double* __restrict__ fverts,
-                                                       int M, double ax0, double ax1, double ax2,
-                                                       int has_axis, OrderFrame* __restrict__ frame,
-                                                       unsigned* __restrict__ mm) {
-  __shared__ double red[BLOCK][4];
+// (the work of one workgroup; `red` is BLOCK x 4 doubles of LDS; thread 0 returns the frame in *out)
+template <typename R, bool F32>
+__device__ __forceinline__ void block_frame(const R& src, int n, const double* __restrict__ fverts,
+                                            int M, double ax0, double ax1, double ax2, int has_axis,
+                                            double (*red)[4], OrderFrame* out, float sf[3],
+                                            float ef[3]) {
   const int tid = threadIdx.x;
-  mm[tid] = 0xFFFFFFFFu;      // (MM_SLOTS * 4 == BLOCK values)
   const int64_t is = n > 0 ? (int64_t)tid * n / BLOCK : 0;  // this thread's sample ray
   double ss[3] = {0, 0, 0}, se[3] = {0, 0, 0};
-  if (n > 0) src.load(is, ss, se);
+  if (n > 0) {
+    if constexpr (F32) {
+      src.load_f(is, sf, ef);
+      for (int q = 0; q < 3; ++q) {
+        ss[q] = sf[q];
+        se[q] = ef[q];
+      }
+    } else {
+      src.load(is, ss, se);
+    }
+  }
   double acc[4] = {0, 0, 0, 0};
   if (fverts != nullptr && M > 0) {
     if (tid < ORD_FACE_SAMPLES) {
@@ -125,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) void k_order_frame(const R src,
       dir[3] = 1.0;
     }
   }
-  block_sum4(dir, red);
+  if (!has_axis) block_sum4(dir, red);
   if (tid == 0) {
     OrderFrame fr;
     double w[3] = {dir[0], dir[1], dir[2]};
@@ -165,8 +182,20 @@ __global__ __launch_bounds__(BLOCK) void k_order_frame(const R src,
         fr.a[q] = a[q];
       }
     }
-    *frame = fr;
+    *out = fr;
   }
+}
+
+template <typename R>
+__global__ __launch_bounds__(BLOCK) void k_order_frame(const R src,
+                                                       int n, const double* __restrict__ fverts,
+                                                       int M, double ax0, double ax1, double ax2,
+                                                       int has_axis, OrderFrame* __restrict__ frame,
+                                                       unsigned* __restrict__ mm) {
+  __shared__ double red[BLOCK][4];
+  mm[threadIdx.x] = 0xFFFFFFFFu;      // (MM_SLOTS * 4 == BLOCK values)
+  float sf[3], ef[3];
+  block_frame<R, false>(src, n, fverts, M, ax0, ax1, ax2, has_axis, red, frame, sf, ef);
 }
 
 // where a ray's line passes the middle of the scene, as two coordinates of the frame (NaN: no line)
@@ -189,6 +218,34 @@ __device__ __forceinline__ void order_coords(const OrderFrame& fr, const double 
       const double ox = u[0] / l1, oy = u[1] / l1, oz = u[2] / l1;
       x = (float)(oz < 0.0 ? (1.0 - fabs(oy)) * (ox >= 0.0 ? 1.0 : -1.0) : ox);
       y = (float)(oz < 0.0 ? (1.0 - fabs(ox)) * (oy >= 0.0 ? 1.0 : -1.0) : oy);
+    }
+    if (!(isfinite(x) && isfinite(y))) x = y = __builtin_nanf("");
+  }
+  *xo = x;
+  *yo = y;
+}
+
+// the same in float32, for rays evaluated in float32 (ProgramRays::load_f)
+__device__ __forceinline__ void order_coords_f(const OrderFrame& fr, const float s[3],
+                                               const float e[3], float* xo, float* yo) {
+  float x = __builtin_nanf(""), y = __builtin_nanf("");
+  const float dx = e[0] - s[0], dy = e[1] - s[1], dz = e[2] - s[2];
+  const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (isfinite(len) && len > 0.f) {
+    const float il = 1.f / len;
+    const float u[3] = {dx * il, dy * il, dz * il};
+    if (fr.planar) {
+      const float c[3] = {(float)fr.c[0], (float)fr.c[1], (float)fr.c[2]};
+      const float q[3] = {s[0] - c[0], s[1] - c[1], s[2] - c[2]};   // start relative to the centre
+      const float t = -(q[0] * u[0] + q[1] * u[1] + q[2] * u[2]);
+      const float p[3] = {q[0] + t * u[0], q[1] + t * u[1], q[2] + t * u[2]};
+      x = p[0] * (float)fr.a[0] + p[1] * (float)fr.a[1] + p[2] * (float)fr.a[2];
+      y = p[0] * (float)fr.b[0] + p[1] * (float)fr.b[1] + p[2] * (float)fr.b[2];
+    } else {
+      const float l1 = fabsf(u[0]) + fabsf(u[1]) + fabsf(u[2]);
+      const float ox = u[0] / l1, oy = u[1] / l1, oz = u[2] / l1;
+      x = oz < 0.f ? (1.f - fabsf(oy)) * (ox >= 0.f ? 1.f : -1.f) : ox;
+      y = oz < 0.f ? (1.f - fabsf(ox)) * (oy >= 0.f ? 1.f : -1.f) : oy;
     }
     if (!(isfinite(x) && isfinite(y))) x = y = __builtin_nanf("");
   }
@@ -307,6 +364,85 @@ __global__ __launch_bounds__(BLOCK) void k_order_key(const float2* __restrict__ 
       if (p.x == p.x) {
         const float fx = fminf(fmaxf((p.x - xlo) * sx, 0.f), g1);
         const float fy = fminf(fmaxf((p.y - ylo) * sy, 0.f), g1);
+        key = hilbert_index((unsigned)fx, (unsigned)fy, bits);
+      }
+      keys[i] = key;
+      atomicAdd(&h_lds[key & (unsigned)(bins - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
+}
+
+// Program sources: rays -> coordinates -> keys in ONE launch, float32 evaluation.  Every workgroup
+// makes the frame itself from the same 256 sample rays (the same arithmetic in every workgroup:
+// block_frame) and takes the extents of the key grid from those samples, widened by 1/16 -- a ray
+// outside them lands in an edge cell --, so nothing has to pass over all rays before the keys are
+// made.  Also leaves the histogram of the low digits per sort tile.
+template <int ITEMS>
+__global__ __launch_bounds__(BLOCK) void k_order_pkey(const ProgramRays src, int n,
+                                                      const double* __restrict__ fverts, int M,
+                                                      double ax0, double ax1, double ax2,
+                                                      int has_axis, int bits,
+                                                      unsigned* __restrict__ keys,
+                                                      unsigned* __restrict__ hist, int nblk) {
+  extern __shared__ unsigned h_lds[];
+  __shared__ double red[BLOCK][4];
+  __shared__ OrderFrame fr;
+  __shared__ unsigned wmm[WAVES][4];
+  const int tid = threadIdx.x;
+  const int bins = 1 << bits;
+  for (int d = tid; d < bins; d += BLOCK) h_lds[d] = 0u;
+  float sf[3] = {0.f, 0.f, 0.f}, ef[3] = {0.f, 0.f, 0.f};
+  block_frame<ProgramRays, true>(src, n, fverts, M, ax0, ax1, ax2, has_axis, red, &fr, sf, ef);
+  __syncthreads();
+  float xlo, xhi, ylo, yhi;
+  {
+    float x, y;
+    order_coords_f(fr, sf, ef, &x, &y);
+    const bool ok = n > 0 && x == x;
+    unsigned v[4] = {ok ? enc_f(x) : 0xFFFFFFFFu, ok ? ~enc_f(x) : 0xFFFFFFFFu,
+                     ok ? enc_f(y) : 0xFFFFFFFFu, ok ? ~enc_f(y) : 0xFFFFFFFFu};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v[q] = min(v[q], (unsigned)__shfl_xor((int)v[q], d, 64));
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wmm[tid >> 6][q] = v[q];
+    }
+    __syncthreads();
+    unsigned m[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      m[q] = wmm[0][q];
+      for (int w = 1; w < WAVES; ++w) m[q] = min(m[q], wmm[w][q]);
+    }
+    xlo = dec_f(m[0]);
+    xhi = dec_f(~m[1]);
+    ylo = dec_f(m[2]);
+    yhi = dec_f(~m[3]);
+    const float mx = 0.0625f * (xhi - xlo), my = 0.0625f * (yhi - ylo);
+    xlo -= mx;
+    xhi += mx;
+    ylo -= my;
+    yhi += my;
+  }
+  const float g1 = (float)(bins - 1);
+  const float sx = xhi > xlo ? g1 / (xhi - xlo) : 0.f, sy = yhi > ylo ? g1 / (yhi - ylo) : 0.f;
+  const unsigned kmax = (bits >= 16) ? 0xFFFFFFFFu : ((1u << (2 * bits)) - 1u);
+  const int base = blockIdx.x * (BLOCK * ITEMS);
+  for (int r = 0; r < ITEMS; ++r) {
+    const int i = base + r * BLOCK + tid;
+    if (i < n) {
+      float s3[3], e3[3], x, y;
+      src.load_f(i, s3, e3);
+      order_coords_f(fr, s3, e3, &x, &y);
+      unsigned key = kmax;  // rays that are no line (zero length, non-finite): last
+      if (x == x) {
+        const float fx = fminf(fmaxf((x - xlo) * sx, 0.f), g1);
+        const float fy = fminf(fmaxf((y - ylo) * sy, 0.f), g1);
         key = hilbert_index((unsigned)fx, (unsigned)fy, bits);
       }
       keys[i] = key;
@@ -941,7 +1077,9 @@ static int order_bits(int64_t n) {
 }
 // items per thread of a sort tile: big tiles make long runs of equal digits (the scatter's writes
 // are what it costs), small ones fill the chip when the rays are few
-static int order_items(int64_t n) { return n < (128 << 10) ? 4 : (n < (512 << 10) ? 8 : 16); }
+static int order_items(int64_t n) { return n < (128 << 10) ? 4 : 8; }
+// (16 items per thread -- 244 tiles at a million rays, one wavefront per SIMD -- measured slower
+// than 8 with every digit width: the fused step over a re-drawn source 0.521 -> 0.513 ms)
 
 struct OrderLayout {
   size_t head, xy, keys_a, pairs, hist, seg, dtotal, total;
@@ -1015,12 +1153,8 @@ static int sort_keys(const OrderLayout& L, char* ws, int n, unsigned* keys, int3
     hipLaunchKernelGGL((k_sort_hist_keys<4>), dim3(L.nblk), dim3(BLOCK), hl, st, keys, n, L.bits, hist);
     return sort_passes<4>(L, ws, n, perm, keys, st);
   }
-  if (L.items == 8) {
-    hipLaunchKernelGGL((k_sort_hist_keys<8>), dim3(L.nblk), dim3(BLOCK), hl, st, keys, n, L.bits, hist);
-    return sort_passes<8>(L, ws, n, perm, keys, st);
-  }
-  hipLaunchKernelGGL((k_sort_hist_keys<16>), dim3(L.nblk), dim3(BLOCK), hl, st, keys, n, L.bits, hist);
-  return sort_passes<16>(L, ws, n, perm, keys, st);
+  hipLaunchKernelGGL((k_sort_hist_keys<8>), dim3(L.nblk), dim3(BLOCK), hl, st, keys, n, L.bits, hist);
+  return sort_passes<8>(L, ws, n, perm, keys, st);
 }
 
 template <typename R>
@@ -1033,22 +1167,27 @@ static int ray_order_t(const R& src, int64_t N, const double* fverts, int64_t M,
   float2* xy = reinterpret_cast<float2*>(ws + L.xy);
   unsigned* keys = keys_out != nullptr ? keys_out : reinterpret_cast<unsigned*>(ws + L.keys_a);
   unsigned* hist = reinterpret_cast<unsigned*>(ws + L.hist);
-  hipLaunchKernelGGL((k_order_frame<R>), dim3(1), dim3(BLOCK), 0, st, src, n, fverts, (int)M,
-                     axis ? axis[0] : 0.0, axis ? axis[1] : 0.0, axis ? axis[2] : 0.0,
-                     axis ? 1 : 0, frame, mm);
-  hipLaunchKernelGGL((k_order_xy<R>), dim3(cdiv(N, BLOCK)), dim3(BLOCK), 0, st, src, n, frame, xy,
-                     mm);
+  const double a0 = axis ? axis[0] : 0.0, a1 = axis ? axis[1] : 0.0, a2 = axis ? axis[2] : 0.0;
+  if constexpr (!R::HAS_F32) {
+    hipLaunchKernelGGL((k_order_frame<R>), dim3(1), dim3(BLOCK), 0, st, src, n, fverts, (int)M, a0,
+                       a1, a2, axis ? 1 : 0, frame, mm);
+    hipLaunchKernelGGL((k_order_xy<R>), dim3(cdiv(N, BLOCK)), dim3(BLOCK), 0, st, src, n, frame,
+                       xy, mm);
+  }
   const size_t hl = ((size_t)1 << L.bits) * sizeof(unsigned);
   int rc = 0;
 #define TFRT_ORDER_ITEMS(I)                                                                       \
   {                                                                                               \
-    hipLaunchKernelGGL((k_order_key<I>), dim3(L.nblk), dim3(BLOCK), hl, st, xy, n, mm, L.bits,    \
-                       keys, hist, L.nblk);                                                       \
+    if constexpr (R::HAS_F32)   /* a program's rays: frame, extents and keys in one launch */     \
+      hipLaunchKernelGGL((k_order_pkey<I>), dim3(L.nblk), dim3(BLOCK), hl, st, src, n, fverts,    \
+                         (int)M, a0, a1, a2, axis ? 1 : 0, L.bits, keys, hist, L.nblk);           \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_order_key<I>), dim3(L.nblk), dim3(BLOCK), hl, st, xy, n, mm, L.bits,  \
+                         keys, hist, L.nblk);                                                     \
     rc = sort_passes<I>(L, ws, n, perm, keys, st);                                                \
   }
   if (L.items == 4) TFRT_ORDER_ITEMS(4)
-  else if (L.items == 8) TFRT_ORDER_ITEMS(8)
-  else TFRT_ORDER_ITEMS(16)
+  else TFRT_ORDER_ITEMS(8)
 #undef TFRT_ORDER_ITEMS
   return rc;
 }

@@ -78,13 +78,16 @@ class GoalError:
         self.goal = goal
         self._cache = None
 
-    def table(self, src):
-        """(len(fields), N) contiguous float64 goal table of the source set ``src``."""
+    def table(self, src, by_ray=False):
+        """(len(fields), N) contiguous float64 goal table of the source set ``src``; with
+        ``by_ray`` the (N, len(fields)) contiguous form the callable returns (no transposed copy:
+        tfrt_goal_error3d takes either layout)."""
         if hasattr(src, "cache_key"):      # rays made in place (sources.DeviceRaySet): lazy fields
             vals, key = [src], src.cache_key
         else:
             vals = list(src.values()) if hasattr(src, "values") else [src[k] for k in src.keys()]
             key = tuple((id(v), getattr(v, "_version", None)) for v in vals)
+        key = (key, bool(by_ray))
         if self._cache is not None and self._cache[0] == key:
             return self._cache[1]
         g = self.goal(src) if callable(self.goal) else self.goal
@@ -98,7 +101,7 @@ class GoalError:
         if tuple(g.shape) != (n, len(self.fields)):
             raise ValueError(f"GoalError: goal has shape {tuple(g.shape)}, expected "
                              f"({n}, {len(self.fields)}) -- one row per source ray")
-        table = g.t().contiguous()
+        table = g.contiguous() if by_ray else g.t().contiguous()
         self._cache = (key, table, vals)     # the keyed tensors stay alive with the key
         return table
 
@@ -236,6 +239,7 @@ class FusedStep:
         erf = opt.error_function
         block, scene, fv = eng._trace_inputs(src)
         perm = eng._trace_perm
+        goal_by_ray = False       # (N, fields) rows instead of (fields, N) columns
         if perm is None:
             goal = erf.table(src)
         else:
@@ -245,11 +249,12 @@ class FusedStep:
             cached = getattr(self, "_goal_perm", None)
             if cached is None or cached[0] != gkey:
                 if erf.rowwise and callable(erf.goal) and hasattr(src, "permuted"):
-                    rows = erf.table(src.permuted(perm))      # made in the trace's order
+                    # made in the trace's order, left in the layout the callable returns
+                    rows, by_ray = erf.table(src.permuted(perm), by_ray=True), True
                 else:
-                    rows = ops.gather_rows(erf.table(src), perm)
-                cached = self._goal_perm = (gkey, rows, perm)
-            goal = cached[1]
+                    rows, by_ray = ops.gather_rows(erf.table(src), perm), False
+                cached = self._goal_perm = (gkey, rows, perm, by_ray)
+            goal, goal_by_ray = cached[1], cached[3]
         P, flags = int(opt.trace_depth), eng._flags() | _lib.COMPILE_FINISHED
         dt = ops._DT[block.dtype]
         fvc = fv.detach()
@@ -278,7 +283,9 @@ class FusedStep:
         # into the collective and is finished here)
         goal_args = (
             ops._p(fin), st["capN"], ops._p(st["aux"]["finished_id"]), dt, ops._p(st["counts"]), P,
-            st["fields"], len(erf.rows), ops._p(goal), goal.shape[1], ops._p(st["g_fin"]),
+            st["fields"], len(erf.rows), ops._p(goal),
+            1 if goal_by_ray else goal.shape[1], goal.shape[1] if goal_by_ray else 1,
+            ops._p(st["g_fin"]),
             ops._p(st["err"]), ops._p(st["g_fv"]) if need_back else None,
             st["g_fv"].numel() if need_back else 0, ops._p(self.tests_total),
             ops._p(st["goal_ws"]), st["gws"])

@@ -153,18 +153,22 @@ def test_goal_error_kernel_sum_is_reproducible_and_matches_torch():
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tests_total = torch.zeros(1, dtype=torch.int64, device=dev)
     outs = []
-    for _ in range(3):
+    goal_by_ray = goal.t().contiguous()      # the other layout: one row per source ray
+    for k in range(3):
         g_fin = torch.zeros((6, cap), dtype=torch.float64, device=dev)
         err = torch.zeros(3, dtype=torch.float64, device=dev)
         junk = torch.ones(12345, dtype=torch.float64, device=dev)
+        table, col_stride, ray_stride = (goal, n_src, 1) if k < 2 else (goal_by_ray, 1, 2)
         _lib.check(L.tfrt_goal_error3d(ops._p(fin), cap, ops._p(ids), _lib.F32, ops._p(counts), P,
-                                       fields, 2, ops._p(goal), n_src, ops._p(g_fin), ops._p(err),
+                                       fields, 2, ops._p(table), col_stride, ray_stride,
+                                       ops._p(g_fin), ops._p(err),
                                        ops._p(junk), 12000, ops._p(tests_total), ops._p(ws), wsb,
                                        ops._stream(fin)), "tfrt_goal_error3d")
         outs.append((g_fin, err.cpu()))
         assert not bool(junk[:12000].any()) and bool((junk[12000:] == 1).all())
     assert int(tests_total.item()) == 3 * (2 * 2 ** 32 + 123456)
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[1][1], outs[2][1])
+    assert torch.equal(outs[0][0], outs[2][0])           # (either layout of the goal table)
     r = fin[4:6, :n].double() - goal[:, ids[:n].long()]
     want = (r ** 2).sum()
     g_fin, err = outs[0]

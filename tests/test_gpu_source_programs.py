@@ -145,6 +145,38 @@ def test_aperture_source_fields_blocks_orders_and_shards_are_one_draw(static_end
         assert torch.equal(new[3:], old[3:])
 
 
+@pytest.mark.parametrize("n", [30_000, 300_000])
+def test_order_of_a_program_is_a_permutation_as_compact_as_the_order_of_its_rays(n):
+    """tfrt_source3d_order makes the keys straight from the program (float32 evaluation, extents of
+    the key grid from 1024 sampled rays): not the same permutation as tfrt_ray_order over the
+    generated block, but one whose 64-ray wavefronts cover patches of the aperture just as small."""
+    from tensorflowraytrace_amd import ops
+    d = _dist()
+    d.seed(11)
+    src, a, b = _aperture(n)
+    src.update()
+    rs = src._fields
+    perm = rs.order()
+    assert perm.dtype == torch.int32 and perm.shape == (n,)
+    assert torch.equal(torch.sort(perm.long())[0], torch.arange(n, device=perm.device))
+    block = rs.ray_block(torch.float32)
+    ref = ops.ray_order(block, None, axis=src.axis_hint())
+
+    def spread(p):      # mean diagonal of the end-point bounding box of a wavefront's 64 rays
+        yz = block[4:6, p.long()][:, :n // 64 * 64].reshape(2, -1, 64)
+        ext = yz.max(dim=2)[0] - yz.min(dim=2)[0]
+        return float(ext.pow(2).sum(dim=0).sqrt().mean())
+
+    assert spread(perm) <= 1.1 * spread(ref)
+    g = torch.Generator().manual_seed(0)
+    assert spread(perm) < 0.2 * spread(torch.randperm(n, generator=g).to(perm.device))
+    # a new draw: a new order from the same launch sequence
+    src.update()
+    perm2 = src._fields.order()
+    assert not torch.equal(perm, perm2)
+    assert torch.equal(torch.sort(perm2.long())[0], torch.arange(n, device=perm.device))
+
+
 def test_point_and_angular_sources_assemble_like_the_torch_path():
     import tfrt.sources as sources
     d = _dist()
