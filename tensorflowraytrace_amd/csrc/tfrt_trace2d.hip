@@ -160,16 +160,68 @@ __device__ __forceinline__ float4 filter_arc(const double* g) {
   return make_float4((float)cx, (float)cy, round_up2(r * r), round_up2(R * R));
 }
 
+// Two levels (round 4): the primitives of a tile, in the caller's order, form clusters of G2 = 8
+// consecutive ones -- the segments of a polyline and the arcs of a lens array are neighbours in
+// the tables the reference builds (boundaries.py: one row per segment along the curve) -- under a
+// bounding circle of their bounding circles.  A lane first collects the clusters its line touches
+// (Ms / 8 + Ma / 8 tests instead of Ms + Ma), then tests the members of ITS clusters, cluster by
+// cluster in ascending order: primitives still reach the exact test in ascending index, so ties
+// fall as before.  A line that passes a member's circle passes the cluster's:
+// |t_C - t_m| <= |C - c_m|, hence |t_C| <= |C - c_m| + r_m + sqrt(s_m) <= R_C + q, with
+// s_m = R_m^4 (2 w + w^2 R_m^2) the arc's tangent-snap term and
+// q = Rq sqrt(w1) + Rq^1.5 sqrt(w2) >= sqrt(s_max)   (Rq = the largest R^2 of the cluster).
+// Measured on cfg5b (4M rays x 320 primitives, random rays): 5,340 -> VALU instructions per
+// wavefront, k_intersect2d 627 us per pass -> see DESIGN.md 5.
+constexpr int G2 = 8;                     // primitives per cluster
+constexpr int NC2 = TILE2 / G2;           // clusters per tile
+
+// bounding circle (cx, cy, R, Rq) and Rq^1.5 of the filter entries f[0..G2) (z < 0: padding)
+__device__ __forceinline__ float4 cluster_filter(const float4* f, float* rq15) {
+  float sx = 0.f, sy = 0.f, rq = 0.f;
+  int m = 0;
+  bool always = false;
+#pragma unroll
+  for (int g = 0; g < G2; ++g) {
+    const float4 v = f[g];
+    if (v.z < 0.f) continue;
+    always = always || !(v.z < INFINITY);
+    sx += v.x;
+    sy += v.y;
+    rq = fmaxf(rq, v.w);
+    ++m;
+  }
+  *rq15 = 0.f;
+  if (m == 0) return make_float4(0.f, 0.f, -1.f, 0.f);          // never touched
+  if (always || !(rq < 1e30f)) return make_float4(0.f, 0.f, INFINITY, 0.f);  // always a candidate
+  const float cx = sx / (float)m, cy = sy / (float)m;
+  float R = 0.f;
+#pragma unroll
+  for (int g = 0; g < G2; ++g) {
+    const float4 v = f[g];
+    if (v.z < 0.f) continue;
+    const float dx = v.x - cx, dy = v.y - cy;
+    const float d = sqrtf(dx * dx + dy * dy) * (1.f + 1e-6f);
+    const float r = sqrtf(v.z) * (1.f + 1e-6f);
+    R = fmaxf(R, d + r);
+  }
+  // (the same allowance for the float32 evaluation of the line's offset as the members have)
+  R = R * (1.f + 1e-5f) + 64.f * 5.9604644775390625e-08f * (sqrtf(cx * cx + cy * cy) + R);
+  if (!(R < INFINITY)) return make_float4(0.f, 0.f, INFINITY, 0.f);
+  *rq15 = rq * sqrtf(rq) * (1.f + 1e-6f);
+  return make_float4(cx, cy, R, rq);
+}
+
 template <int STATE_BITS>
 __device__ __forceinline__ int nearest2d_filtered(const double s[2], const double e[2],
                                                   const double* __restrict__ seg, int Ms,
                                                   const double* __restrict__ arc, int Ma,
                                                   double ei, double es, double er, int last_prim,
                                                   double* lds, float4* filt, int32_t* queue,
+                                                  float4* cfilt, float* crq15, uint8_t* cqueue,
                                                   bool active, double* out_u, double* out_aux) {
   // float32 state of this lane's ray
   // sn = NaN: a lane without a (valid) ray never passes the test, whatever the radius
-  float nx = 0.f, ny = 0.f, sn = __builtin_nanf(""), w1 = 0.f, w2 = 0.f;
+  float nx = 0.f, ny = 0.f, sn = __builtin_nanf(""), w1 = 0.f, w2 = 0.f, k1 = 0.f, kw = 0.f;
   {
     const double dx = e[0] - s[0], dy = e[1] - s[1];
     const double l2 = dx * dx + dy * dy;
@@ -182,6 +234,8 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
       const double w = (ei > 0.0 ? ei : 0.0) / (8.0 * l2);
       w1 = round_up2(2.0 * w * (1.0 + 1e-5));
       w2 = round_up2(w * w * (1.0 + 1e-5));
+      k1 = round_up2(sqrt((double)w1) * (1.0 + 1e-6));
+      kw = round_up2(sqrt((double)w2) * (1.0 + 1e-6));
     }
   }
   auto touches = [&](const float4 f) {
@@ -189,19 +243,41 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
     const float lim = fmaf(f.w * f.w, fmaf(w2, f.w, w1), f.z);
     return t * t <= lim;
   };
+  auto touches_cluster = [&](const float4 c, const float rq15) {
+    const float t = fmaf(c.x, nx, fmaf(c.y, ny, -sn));
+    return fabsf(t) <= c.z + fmaf(c.w, k1, rq15 * kw);
+  };
   const int tid = threadIdx.x;
   int cnt = 0;
   double su = INFINITY, au = INFINITY, aang = 0.0;
   int sj = -1, aj = -1;
 
+  // the clusters of the tile in `filt` (nt primitives, padded to whole clusters)
+  auto build_clusters = [&](int nt) {
+    const int nc = (nt + G2 - 1) / G2;
+    for (int k = tid; k < nc; k += BLOCK) cfilt[k] = cluster_filter(filt + G2 * k, crq15 + k);
+    return nc;
+  };
+  // this lane's clusters, ascending (always store, count only hits: no branch per test)
+  auto collect = [&](int nc) {
+    int cc = 0;
+    for (int c = 0; c < nc; ++c) {
+      cqueue[cc * BLOCK + tid] = (uint8_t)c;
+      cc += touches_cluster(cfilt[c], crq15[c]) ? 1 : 0;
+    }
+    return cc;
+  };
+
   for (int t0 = 0; t0 < Ms; t0 += TILE2) {
     const int nt = min(TILE2, Ms - t0);
-    const int nt4 = (nt + 3) & ~3;
+    const int nt8 = (nt + G2 - 1) & ~(G2 - 1);
     __syncthreads();
     for (int k = tid; k < nt * 4; k += BLOCK) lds[k] = seg[(int64_t)t0 * 4 + k];
     __syncthreads();
-    for (int k = tid; k < nt4; k += BLOCK)
+    for (int k = tid; k < nt8; k += BLOCK)
       filt[k] = k < nt ? filter_segment(lds + 4 * k, es) : make_float4(0.f, 0.f, -1.f, 0.f);
+    __syncthreads();
+    const int nc = build_clusters(nt);
     __syncthreads();
     auto flush = [&]() {
       for (int k = 0; k < cnt; ++k) {
@@ -215,26 +291,30 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
       }
       cnt = 0;
     };
-    for (int j = 0; j < nt4; j += 4) {
+    const int cc = collect(nc);
+    for (int k = 0; __any(k < cc); ++k) {
+      if (k < cc) {
+        const int j0 = G2 * (int)cqueue[k * BLOCK + tid];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // always store, count only hits: no branch per test (the slot index stays below KQ2
-        // because the queue is drained whenever fewer than four slots are free)
-        queue[cnt * BLOCK + tid] = j + g;
-        cnt += touches(filt[j + g]) ? 1 : 0;
+        for (int g = 0; g < G2; ++g) {
+          queue[cnt * BLOCK + tid] = j0 + g;
+          cnt += touches(filt[j0 + g]) ? 1 : 0;
+        }
       }
-      if (__any(cnt > KQ2 - 4)) flush();
+      if (__any(cnt > KQ2 - G2)) flush();
     }
     flush();  // the queue refers to this tile's LDS copy
   }
   for (int t0 = 0; t0 < Ma; t0 += TILE2) {
     const int nt = min(TILE2, Ma - t0);
-    const int nt4 = (nt + 3) & ~3;
+    const int nt8 = (nt + G2 - 1) & ~(G2 - 1);
     __syncthreads();
     for (int k = tid; k < nt * 5; k += BLOCK) lds[k] = arc[(int64_t)t0 * 5 + k];
     __syncthreads();
-    for (int k = tid; k < nt4; k += BLOCK)
+    for (int k = tid; k < nt8; k += BLOCK)
       filt[k] = k < nt ? filter_arc(lds + 5 * k) : make_float4(0.f, 0.f, -1.f, 0.f);
+    __syncthreads();
+    const int nc = build_clusters(nt);
     __syncthreads();
     auto flush = [&]() {
       for (int k = 0; k < cnt; ++k) {
@@ -256,15 +336,17 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
       }
       cnt = 0;
     };
-    for (int j = 0; j < nt4; j += 4) {
+    const int cc = collect(nc);
+    for (int k = 0; __any(k < cc); ++k) {
+      if (k < cc) {
+        const int j0 = G2 * (int)cqueue[k * BLOCK + tid];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        // always store, count only hits: no branch per test (the slot index stays below KQ2
-        // because the queue is drained whenever fewer than four slots are free)
-        queue[cnt * BLOCK + tid] = j + g;
-        cnt += touches(filt[j + g]) ? 1 : 0;
+        for (int g = 0; g < G2; ++g) {
+          queue[cnt * BLOCK + tid] = j0 + g;
+          cnt += touches(filt[j0 + g]) ? 1 : 0;
+        }
       }
-      if (__any(cnt > KQ2 - 4)) flush();
+      if (__any(cnt > KQ2 - G2)) flush();
     }
     flush();
   }
@@ -299,6 +381,9 @@ __global__ __launch_bounds__(BLOCK) void k_intersect2d(
   __shared__ double lds[TILE2 * 5];
   __shared__ float4 filt[TILE2];
   __shared__ int32_t queue[KQ2 * BLOCK];
+  __shared__ float4 cfilt[NC2];
+  __shared__ float crq15[NC2];
+  __shared__ uint8_t cqueue[NC2 * BLOCK];
   __shared__ int wc[WAVES][NBIN];
   const int i = base + threadIdx.x;
   const bool active = i < n;
@@ -309,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect2d(
   double u, aux;
   const int prim = nearest2d_filtered<(sizeof(T) == 8 ? 53 : (sizeof(T) == 4 ? 24 : 11))>(
       s, e, sc.seg, Ms, sc.arc, Ma, sc.intersect_epsilion, sc.size_epsilion,
-      sc.ray_start_epsilion, lp, lds, filt, queue, active, &u, &aux);
+      sc.ray_start_epsilion, lp, lds, filt, queue, cfilt, crq15, cqueue, active, &u, &aux);
   int bin = -1;
   if (active) {
     if (prim < 0) {
