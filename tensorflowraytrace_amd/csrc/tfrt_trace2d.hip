@@ -327,7 +327,7 @@ __device__ __forceinline__ int nearest2d_filtered(const double s[2], const doubl
           const double mag = fabs(s[0]) + fabs(s[1]) + fabs(lds[5 * j + 4]);
           er_j = fmax(er, 64.0 * ldexp(1.0, -STATE_BITS) * mag / fmax(dl, 1e-300));
         }
-        const Hit2 h = exact_arc(s, e, lds + 5 * j, ei, er_j);
+        const Hit2 h = exact_arc_hit(s, e, lds + 5 * j, ei, er_j);
         if (h.valid && h.ray_u < au) {
           au = h.ray_u;
           aj = t0 + j;

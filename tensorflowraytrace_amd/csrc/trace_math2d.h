@@ -98,6 +98,65 @@ TFRT_HD Hit2 exact_arc(const double s[2], const double e[2], const double arc[5]
   return o;
 }
 
+// exact_arc() for callers that only use VALID hits (the trace kernels): the same roots, the same
+// atan2 of the same points and the same choice, but an angle is only computed for a root that can
+// be the answer -- the minus root when it lies in range, else the plus root; the plus root a
+// second time only when the minus root lay in range and missed the arc's interval.  (exact_arc
+// evaluates three atan2 -- ~100 float64 instructions each -- on nearly every call of a wavefront;
+// this one one, sometimes two.)  When !valid the other fields are unspecified.
+TFRT_HD Hit2 exact_arc_hit(const double s[2], const double e[2], const double arc[5],
+                           double eps_int, double eps_start) {
+#pragma clang fp contract(off)
+  const double xc = arc[0], yc = arc[1], a1 = arc[2], a2 = arc[3], r = arc[4];
+  const double inv_r = 1.0 / r;
+  const double xr = (s[0] - xc) * inv_r, yr = (s[1] - yc) * inv_r;
+  const double xd = (e[0] - s[0]) * inv_r, yd = (e[1] - s[1]) * inv_r;
+  const double a = xd * xd + yd * yd;
+  const double b = 2.0 * xr * xd + 2.0 * yr * yd;
+  const double c = xr * xr + yr * yr - 1.0;
+  double rad = b * b - 4.0 * a * c;
+  if (fabs(rad) < eps_int) rad = 0.0;
+  const bool rad_less = rad < 0.0;
+  const double sr = sqrt(rad_less ? 1.0 : rad);
+  double um = rad_less ? 1.0 : (-b - sr);
+  double up = rad_less ? 1.0 : (-b + sr);
+  const bool azero = fabs(a) < eps_int;
+  const double inv = 1.0 / (azero ? 1.0 : 2 * a);
+  um = azero ? 1.0 : um * inv;
+  up = azero ? 1.0 : up * inv;
+  const bool base = !rad_less && !azero;
+  const bool em = base && (um >= eps_start), ep = base && (up >= eps_start);
+  Hit2 o;
+  o.valid = false;
+  o.ray_u = up;
+  o.prim_u = o.x = o.y = 0.0;
+  if (em || ep) {
+    // (um <= up: when both are valid the minus root wins -- and when they coincide the two
+    // candidates are the same point with the same angle)
+    const double u1 = em ? um : up;
+    const double x1 = s[0] + (e[0] - s[0]) * u1, y1 = s[1] + (e[1] - s[1]) * u1;
+    const double ang1 = atan2(y1 - yc, x1 - xc);
+    if (angle_in_interval(ang1, a1, a2)) {
+      o.valid = true;
+      o.ray_u = u1;
+      o.prim_u = ang1;
+      o.x = x1;
+      o.y = y1;
+    } else if (em && ep) {
+      const double xp = s[0] + (e[0] - s[0]) * up, yp = s[1] + (e[1] - s[1]) * up;
+      const double angp = atan2(yp - yc, xp - xc);
+      if (angle_in_interval(angp, a1, a2)) {
+        o.valid = true;
+        o.ray_u = up;
+        o.prim_u = angp;
+        o.x = xp;
+        o.y = yp;
+      }
+    }
+  }
+  return o;
+}
+
 // engine.py:667-670
 TFRT_HD double arc_norm(double radius, double arc_u) {
 #pragma clang fp contract(off)

@@ -99,6 +99,16 @@ void hm_exact_arc(int64_t n, const double* s, const double* e, const double* arc
   }
 }
 
+// the trace kernels' variant (valid hits only)
+void hm_exact_arc_hit(int64_t n, const double* s, const double* e, const double* arc,
+                      double eps_int, double eps_start, double* ray_u, double* arc_u, double* xy,
+                      uint8_t* valid) {
+  for (int64_t i = 0; i < n; ++i) {
+    tfrt::Hit2 h = tfrt::exact_arc_hit(s + 2 * i, e + 2 * i, arc + 5 * i, eps_int, eps_start);
+    ray_u[i] = h.ray_u; arc_u[i] = h.prim_u; xy[2 * i] = h.x; xy[2 * i + 1] = h.y; valid[i] = h.valid;
+  }
+}
+
 void hm_adjoint2d(int64_t n, const double* s, const double* e, const double* prim, int prim_stride,
                   int is_arc, const double* u, const uint8_t* has_child, const double* n_in,
                   const double* n_out, double L, const double* g_s, const double* g_h,

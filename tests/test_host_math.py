@@ -180,6 +180,40 @@ def test_arc_exact_matches_oracle(host_math):
     assert 100 < seen < n
 
 
+def test_arc_hit_variant_equals_exact_arc_on_every_valid_hit(host_math):
+    """csrc/trace_math2d.h::exact_arc_hit (one atan2 where exact_arc takes three) against exact_arc
+    itself: the same validity everywhere, the same bits on every valid hit -- rays from outside
+    and inside the circles, tangents, short arcs the first root misses, negative radii."""
+    rng = np.random.default_rng(31)
+    n = 40_000
+    arc = np.stack([rng.normal(size=n) * 3, rng.normal(size=n) * 3, rng.uniform(-PI, PI, n),
+                    rng.uniform(-PI, PI, n), rng.uniform(0.3, 2, n) * rng.choice([-1, 1], n)], 1)
+    arc[:4000, 3] = arc[:4000, 2] + rng.uniform(0.05, 0.6, 4000)      # short arcs
+    ang = rng.uniform(-PI, PI, n)
+    hit = arc[:, :2] + np.abs(arc[:, 4:5]) * np.stack([np.cos(ang), np.sin(ang)], 1)
+    s = hit + rng.normal(size=(n, 2)) * 2
+    inside = rng.random(n) < 0.4                                         # start inside the circle
+    s[inside] = arc[inside, :2] + rng.uniform(-0.5, 0.5, (int(inside.sum()), 2)) * np.abs(arc[inside, 4:5])
+    e = s + (hit - s) * rng.uniform(0.3, 2.5, size=(n, 1))
+    tang = slice(n - 2000, n)                                            # tangent lines
+    tdir = np.stack([-np.sin(ang[tang]), np.cos(ang[tang])], 1)
+    s[tang] = hit[tang] - tdir * 1.5
+    e[tang] = hit[tang] + tdir * 0.5
+    out = []
+    for fn, extra in ((host_math.hm_exact_arc, True), (host_math.hm_exact_arc_hit, False)):
+        ru, au, xy = np.zeros(n), np.zeros(n), np.zeros((n, 2))
+        va, nm = np.zeros(n, np.uint8), np.zeros(n)
+        args = [I(n), P(s), P(e), P(arc), D(1e-10), D(1e-10), P(ru), P(au), P(xy), P(va)]
+        fn(*(args + ([P(nm)] if extra else [])))
+        out.append((ru, au, xy, va))
+    (ru0, au0, xy0, va0), (ru1, au1, xy1, va1) = out
+    assert np.array_equal(va0, va1)
+    v = va0.astype(bool)
+    assert 0.2 * n < v.sum() < 0.95 * n
+    assert np.array_equal(ru0[v], ru1[v]) and np.array_equal(au0[v], au1[v])
+    assert np.array_equal(xy0[v], xy1[v])
+
+
 def test_snell3d_restatement_is_bit_identical_to_the_oracle(host_math):
     """csrc/trace_math.h::snell3d + advance against oracle.geom.snells_law_3D (geometry.py:715-753)
     on 20,000 random rays incl. TIR, mirrors and n_out = 0: every bit equal.  (The same comparison
