@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFRT_VERSION 104 /* 0.1.0 */
+#define TFRT_VERSION 105 /* 0.1.0 */
 
 #define TFRT_F32 0
 #define TFRT_F64 1
@@ -261,6 +261,11 @@ typedef struct tfrt_scene3d {
    * two fields as ordinary tensors, which a tape can differentiate).  Both or neither. */
   double* grad_n_in;
   double* grad_n_out;
+  /* Forward only, optional: clear_count f64 at clear_buffer are set to zero by the trace's set-up
+   * launch -- the (M,9) block a reverse sweep will ACCUMULATE into (tfrt_trace3d_backward,
+   * tfrt_trace3d_backward_goal), cleared without a launch of its own.  NULL / 0: nothing. */
+  double* clear_buffer;
+  int64_t clear_count;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in
@@ -369,6 +374,38 @@ int tfrt_goal_error3d_deferred(const void* finished_rays, int64_t capacity,
                                void* workspace, size_t workspace_bytes,
                                tfrt_goal_pending* pending, void* stream);
 int tfrt_goal_finish(const tfrt_goal_pending* pending, void* stream);
+
+/* tfrt_goal_error3d_deferred and tfrt_trace3d_backward in ONE launch, for a trace over coherent
+ * rays (tfrt_scene3d.coherent_rays, not deterministic, max_passes <= 8; TFRT_E_UNSUPPORTED
+ * otherwise -- call the two entry points instead): the lane that walks a finished ray's chain of
+ * slots back forms that ray's residuals itself -- output row minus goal row, the output as stored
+ * in `finished` (state dtype) -- seeds the walk with 2 (output - goal) and leaves the squared
+ * residuals in per-wavefront partial sums (a fixed order: the error is bit-identical from run to
+ * run).  No seed block is written and read back, one dependent launch less per step.
+ *   finished        the finished-ray block tfrt_trace3d_forward wrote (rays + capacity; ids unused:
+ *                   a chain knows its source ray)
+ *   fields, goal    as for tfrt_goal_error3d; goal rows are indexed by the source ray in the
+ *                   trace's order
+ *   goal_workspace  tfrt_trace3d_backward_goal_workspace_bytes(n_rays) bytes (the partial sums)
+ *   pending         filled in like tfrt_goal_error3d_deferred's: finish with
+ *                   tfrt_sgd_process_multi_finish or tfrt_goal_finish
+ *   grad_face_verts (M,9) f64, ACCUMULATED into (cleared beforehand: tfrt_scene3d.clear_buffer)
+ * Everything else as for tfrt_trace3d_backward (grad_active / grad_stopped / grad_dead may be
+ * given as well; the finished rows' gradient is the goal's). */
+size_t tfrt_trace3d_backward_goal_workspace_bytes(int64_t n_rays);
+int tfrt_trace3d_backward_goal(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                               const tfrt_scene3d* scene, double new_ray_length,
+                               double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                               const tfrt_ray_out* finished, const int32_t* fields,
+                               int32_t n_fields, const double* goal, int64_t goal_stride,
+                               int64_t goal_ray_stride, double* error_out, int64_t* tests_total,
+                               void* goal_workspace, size_t goal_workspace_bytes,
+                               tfrt_goal_pending* pending, const double* grad_active,
+                               int64_t cap_active, const double* grad_stopped,
+                               int64_t cap_stopped, const double* grad_dead, int64_t cap_dead,
+                               double* grad_face_verts, double* grad_src_rays,
+                               const int32_t* counts, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* Benchmark instrumentation (the only global state in the library; not used by the product
  * path).  While enabled, the launches of the hot kernels made by tfrt_trace3d_forward /

@@ -30,7 +30,7 @@ class Scene3D(ctypes.Structure):
         ("intersect_epsilion", c_f64), ("size_epsilion", c_f64), ("ray_start_epsilion", c_f64),
         ("face_grad_mask", c_vp), ("cluster_order", c_vp), ("n_table_uniform", c_i32),
         ("deterministic", c_i32), ("coherent_rays", c_i32), ("coherent_only", c_i32),
-        ("grad_n_in", c_vp), ("grad_n_out", c_vp),
+        ("grad_n_in", c_vp), ("grad_n_out", c_vp), ("clear_buffer", c_vp), ("clear_count", c_i64),
     ]
 
 
@@ -140,6 +140,11 @@ SIGNATURES = {
     "tfrt_goal_error3d_deferred": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_vp, c_i64,
                                   c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "tfrt_goal_finish": (c_i32, [c_vp, c_vp]),
+    "tfrt_trace3d_backward_goal_workspace_bytes": (c_sz, [c_i64]),
+    "tfrt_trace3d_backward_goal": (c_i32, [
+        c_vp, c_i64, c_i64, c_vp, c_f64, c_f64, c_i32, c_i32,          # rays, scene, lengths, P, dtype
+        c_vp, c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_sz, c_vp,   # goal
+        c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_intersect3d_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "tfrt_intersect3d": (c_i32, [
         c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_f64, c_f64, c_f64,

@@ -24,11 +24,6 @@
 
 namespace tfrt {
 
-struct GoalFields {
-  int32_t n;
-  int32_t row[6];  // row of the ray block (0..5: x_start .. z_end) compared with goal column c
-};
-
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void k_goal_error(
     const T* __restrict__ fin, int64_t cap, const int32_t* __restrict__ fin_id,

@@ -42,6 +42,7 @@
 
 #include <type_traits>
 #include "tfrt_common.h"
+#include "goal_finish.h"
 
 namespace tfrt {
 
@@ -163,22 +164,61 @@ __device__ __forceinline__ float4 pack_sphere(const double cc[3], double reff) {
   return make_float4((float)cc[0], (float)cc[1], (float)cc[2], rf);
 }
 
+// What the reaction needs of a face besides the hit: the unit normal as snell3d uses it and,
+// when the refractive indices do not depend on the ray (one wavelength for every ray, or "value"
+// mode), the two index ratios and n_in -- formed ONCE per face by the trace's set-up launch
+// (the same operations in the same order as snell3d's, hence the same bits) instead of once per
+// ray and pass: a cross product, two square roots and six float64 divisions less per ray, 48 B
+// gathered for 72 + two dependent index loads.
+struct FaceTables {
+  double* fnorm = nullptr;           // (M, 3)
+  double* feta = nullptr;            // (M, 3): n1, n2, n_in -- or nullptr: indices per ray
+  const int32_t* mat_in = nullptr;
+  const int32_t* mat_out = nullptr;
+  const double* n_table = nullptr;   // (column 0: n_table_uniform)
+  int64_t n_table_stride = 0;
+  const double* n_in = nullptr;
+  const double* n_out = nullptr;
+};
+
+__device__ __forceinline__ void face_tables(const FaceTables& ft, const double* __restrict__ P9,
+                                            int f) {
+  if (ft.fnorm != nullptr) {
+    double P[9], un[3];
+    for (int q = 0; q < 9; ++q) P[q] = P9[q];
+    snell_normal(P, un);
+    for (int q = 0; q < 3; ++q) ft.fnorm[3 * (int64_t)f + q] = un[q];
+  }
+  if (ft.feta != nullptr) {
+    double ni, no, n1, n2;
+    if (ft.n_table != nullptr && ft.mat_in != nullptr) {
+      ni = ft.n_table[(int64_t)ft.mat_in[f] * ft.n_table_stride];
+      no = ft.n_table[(int64_t)ft.mat_out[f] * ft.n_table_stride];
+    } else {
+      ni = ft.n_in[f];
+      no = ft.n_out[f];
+    }
+    snell_ratios(ni, no, &n1, &n2);
+    ft.feta[3 * (int64_t)f] = n1;
+    ft.feta[3 * (int64_t)f + 1] = n2;
+    ft.feta[3 * (int64_t)f + 2] = ni;
+  }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_spheres(const double* __restrict__ fverts, int M,
                                                    const double* __restrict__ c0,
                                                    double size_eps,
                                                    float4* __restrict__ sphere,
-                                                   double* __restrict__ fnorm) {
+                                                   FaceTables ft,
+                                                   double* __restrict__ clear_buf,
+                                                   int64_t clear_n) {
   const int j = blockIdx.x * BLOCK + threadIdx.x;
+  for (int64_t k = j; k < clear_n; k += (int64_t)gridDim.x * BLOCK) clear_buf[k] = 0.0;
   if (j >= M) return;
   double cc[3], reff;
   face_sphere(fverts + 9 * (int64_t)j, c0, size_eps, cc, &reff);
   sphere[j] = pack_sphere(cc, reff);
-  if (fnorm != nullptr) {  // the reaction's unit normal, once per face (snell_normal)
-    double P[9], un[3];
-    for (int q = 0; q < 9; ++q) P[q] = fverts[9 * (int64_t)j + q];
-    snell_normal(P, un);
-    for (int q = 0; q < 3; ++q) fnorm[3 * (int64_t)j + q] = un[q];
-  }
+  face_tables(ft, fverts + 9 * (int64_t)j, j);
 }
 
 // Hierarchy modes: faces are visited in `order` (spatially coherent groups of CLUSTER faces).
@@ -214,7 +254,7 @@ __device__ __forceinline__ void cluster_spheres_block(
     const int block, const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
     const double* __restrict__ c0, double size_eps, int n_clusters,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
-    float4* __restrict__ crec, double* __restrict__ fnorm) {
+    float4* __restrict__ crec, const FaceTables& ft) {
   const int k = block * BLOCK + threadIdx.x;  // member slot = cluster * CLUSTER + member
   const int c = k / CLUSTER;
   const bool in_range = c < n_clusters;            // uniform over the 16 lanes of a cluster
@@ -232,12 +272,7 @@ __device__ __forceinline__ void cluster_spheres_block(
       for (int q = 0; q < 3; ++q) e2 += (V[(v + 1) % 3][q] - V[v][q]) * (V[(v + 1) % 3][q] - V[v][q]);
       edge = fmax(edge, sqrt(e2));
     }
-    if (fnorm != nullptr) {  // the reaction's unit normal, once per face (snell_normal)
-      double Pf[9], un[3];
-      for (int q = 0; q < 9; ++q) Pf[q] = P[q];
-      snell_normal(Pf, un);
-      for (int q = 0; q < 3; ++q) fnorm[3 * (int64_t)f + q] = un[q];
-    }
+    face_tables(ft, P, f);
   }
   if (in_range) {
     cface[k] = f;
@@ -415,9 +450,13 @@ __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
     float4* __restrict__ crec, float4* __restrict__ susphere, int32_t* nrays0, int n,
     int32_t* tail8, unsigned int* scan_ticket, int32_t* __restrict__ hist0, int hist_len,
-    double* __restrict__ fnorm) {
+    FaceTables ft, double* __restrict__ clear_buf, int64_t clear_n) {
   // (coherent-ray traces: the class histogram the first pass's intersect kernels add into)
   for (int k = blockIdx.x * BLOCK + threadIdx.x; k < hist_len; k += gridDim.x * BLOCK) hist0[k] = 0;
+  // (tfrt_scene3d.clear_buffer: the block a reverse sweep will accumulate into)
+  for (int64_t k = (int64_t)blockIdx.x * BLOCK + threadIdx.x; k < clear_n;
+       k += (int64_t)gridDim.x * BLOCK)
+    clear_buf[k] = 0.0;
   __shared__ double c0[3];
   if (threadIdx.x < 64) {
     const int step = M > 64 ? M / 64 : 1;
@@ -449,7 +488,7 @@ __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     super_spheres_block(blockIdx.x, fverts, M, order, c0, size_eps, susphere);
   } else {
     cluster_spheres_block(blockIdx.x - n_super, fverts, M, order, c0, size_eps, n_clusters,
-                          csphere, cface, clsphere, crec, fnorm);
+                          csphere, cface, clsphere, crec, ft);
   }
 }
 
@@ -2276,7 +2315,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_
     int64_t stride_out, int32_t* __restrict__ ray_id_out, int32_t* __restrict__ last_tri_out,
     int32_t* __restrict__ rec_slot, tfrt_ray_out fin, tfrt_ray_out act, tfrt_ray_out stp,
     tfrt_ray_out dead, int32_t* __restrict__ err, float* __restrict__ prep_next, int64_t pstride,
-    const double* __restrict__ c0, SelfScan ss, const double* __restrict__ fnorm) {
+    const double* __restrict__ c0, SelfScan ss, const double* __restrict__ fnorm,
+    const double* __restrict__ feta) {
   const int n = *n_ptr;
   const int base = blockIdx.x * BLOCK;
   // Self-scan mode (few ray blocks): no scan launch ran.  Every block sums the class histograms
@@ -2383,12 +2423,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_
       if (flags & TFRT_COMPILE_ACTIVE) ok = emit<T>(act, gslot, s, h, rid, tri);
       // (the face's unit normal was formed once per face by the trace's set-up launch: the cross
       // product, a square root and four divisions of float64 less per ray, 24 B gathered for 72)
-      double un[3], n_in, n_out;
+      double un[3], n1, n2, n_in;
       const double* fp = fnorm + 3 * (int64_t)tri;
 #pragma unroll
       for (int q = 0; q < 3; ++q) un[q] = fp[q];
-      face_indices(sc, tri, rid, &n_in, &n_out);
-      const Snell3 f = snell3d_unit(s, h, un, n_in, n_out);
+      if (feta != nullptr) {
+        const double* fe = feta + 3 * (int64_t)tri;
+        n1 = fe[0];
+        n2 = fe[1];
+        n_in = fe[2];
+      } else {
+        double n_out;
+        face_indices(sc, tri, rid, &n_in, &n_out);
+        snell_ratios(n_in, n_out, &n1, &n2);
+      }
+      const Snell3 f = snell3d_core(s, h, un, n1, n2, n_in == 0.0);
       // the branches this reaction took go on the tape (bits 2, 3 of the class byte): the reverse
       // sweep re-derives everything else, but with other roundings (reciprocals instead of
       // quotients), and at grazing incidence or at the critical angle must not take another side
@@ -2753,6 +2802,7 @@ __device__ __forceinline__ int backward_core(
     const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
     const double* __restrict__ rec_t, const int32_t* __restrict__ pass_counts,
     const tfrt_scene3d& sc, double L, double dead_len, bool child_pass, const double child[6],
+    const double* seed_fin,   // the finished row's gradient in registers (else read from g_fin)
     const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
     int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
     const double* __restrict__ g_dead, int64_t cap_dead, double gs[3], double ge[3],
@@ -2777,7 +2827,14 @@ __device__ __forceinline__ int backward_core(
     double g_s[3] = {0, 0, 0}, g_h[3] = {0, 0, 0}, g_ce[3] = {0, 0, 0};
     bool has_child = false;
     if (cls == CLS_FINISHED) {
-      add6(g_fin, cap_fin, slot, g_s, g_h);
+      if (seed_fin != nullptr) {
+        for (int k = 0; k < 3; ++k) {
+          g_s[k] += seed_fin[k];
+          g_h[k] += seed_fin[3 + k];
+        }
+      } else {
+        add6(g_fin, cap_fin, slot, g_s, g_h);
+      }
     } else if (cls == CLS_STOPPED) {
       add6(g_stp, cap_stp, slot, g_s, g_h);
     } else {
@@ -2838,7 +2895,7 @@ __device__ __forceinline__ int backward_ray(
   double gs[3], ge[3];
   const int face_out = backward_core<T>(i, tape, slot, rays_in, stride_in, ray_id_in, rec_tri,
                                         rec_t, pass_counts, sc, L, dead_len, child_pass, child,
-                                        g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
+                                        nullptr, g_fin, cap_fin, g_act, cap_act, g_stp, cap_stp, g_dead,
                                         cap_dead, gs, ge, gP);
   if (g_out != nullptr) {
     using G = typename SweepStore<T>::type;
@@ -2886,14 +2943,26 @@ struct ChainArgs {
   double* g_src;           // (6 x N) or null
   int64_t N;
   double* g_fverts;
+  // GOAL: the finished rows' gradient is that of the built-in goal error, formed here
+  const T* fin_rays;       // the finished-ray block of the forward (6 x fin_cap)
+  int64_t fin_cap;
+  GoalFields gf;
+  const double* goal;
+  int64_t goal_stride, goal_ray_stride;
+  double* partial;         // one partial error sum per wavefront of the launch
 };
 
-template <typename T, int BW>
+template <typename T, int BW, bool GOAL>
 __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_backward_chain(
     ChainArgs<T> a, tfrt_scene3d sc) {
+  // the reference's squared_difference and reduce_sum are separate ops: no contraction
+#pragma clang fp contract(off)
   const int n0 = a.nrays[0];
   const int i0 = blockIdx.x * (64 * BW) + threadIdx.x;
-  if ((i0 & ~63) >= n0) return;  // (whole wave)
+  if ((i0 & ~63) >= n0) {  // (whole wave)
+    if (GOAL && (threadIdx.x & 63) == 0) a.partial[i0 >> 6] = 0.0;
+    return;
+  }
   __shared__ double wacc[BW][WSUM_CELLS];
   __shared__ int32_t wface[BW][WSUM_SLOTS];
   __shared__ int32_t chain[BW][CHAIN_MAXP][64];
@@ -2916,6 +2985,7 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) top = max(top, __shfl_xor(top, d, 64));
   double child[6] = {0, 0, 0, 0, 0, 0};
+  double err = 0.0;
   for (int p = top; p >= 0; --p) {
     double gP[9];
     int tri = -1;
@@ -2925,12 +2995,27 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
       const T* rin = p == 0 ? a.src : a.rays_ws + (size_t)(p - 1) * 6 * a.n;
       const int64_t sin = p == 0 ? a.src_stride : a.n;
       const int32_t* idin = p == 0 ? nullptr : a.rayid + (size_t)(p - 1) * a.n;
+      const int tape = a.rec_cls[off + j], slot = a.rec_slot[off + j];
+      double seed[6] = {0, 0, 0, 0, 0, 0};
+      if (GOAL && p == last && (tape & 3) == CLS_FINISHED) {
+        // tfrt_goal_error3d's terms for this ray: the output AS STORED in the finished block
+        // minus the goal row of the source ray; d (sum of squares) = 2 (output - goal)
+        for (int c = 0; c < a.gf.n; ++c) {
+          const int row = a.gf.row[c];
+          const double r = ldd(a.fin_rays, (int64_t)row * a.fin_cap + slot) -
+                           a.goal[(int64_t)c * a.goal_stride + (int64_t)i0 * a.goal_ray_stride];
+          const double g = 2.0 * r;
+#pragma unroll
+          for (int q = 0; q < 6; ++q)   // (no dynamic register index)
+            if (q == row) seed[q] = g;
+          err += r * r;
+        }
+      }
       double gs[3], ge[3];
-      tri = backward_core<T>(j, a.rec_cls[off + j], a.rec_slot[off + j], rin, sin, idin,
-                             a.rec_tri + off, a.rec_t + off,
+      tri = backward_core<T>(j, tape, slot, rin, sin, idin, a.rec_tri + off, a.rec_t + off,
                              a.counts + (size_t)p * TFRT_COUNTS_PER_PASS, sc, a.L, a.dead_len,
-                             p < P - 1, child, a.g_fin, a.cap_fin, a.g_act, a.cap_act, a.g_stp,
-                             a.cap_stp, a.g_dead, a.cap_dead, gs, ge, gP);
+                             p < P - 1, child, GOAL ? seed : nullptr, a.g_fin, a.cap_fin, a.g_act,
+                             a.cap_act, a.g_stp, a.cap_stp, a.g_dead, a.cap_dead, gs, ge, gP);
       for (int k = 0; k < 3; ++k) {
         child[k] = gs[k];
         child[3 + k] = ge[k];
@@ -2941,6 +3026,12 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   if (a.g_src != nullptr && i0 < n0) {
     // (a ray without a chain cannot be: every source ray enters pass 1 when P > 0)
     for (int k = 0; k < 6; ++k) a.g_src[k * a.N + i0] = child[k];
+  }
+  if (GOAL) {
+    // fixed-shape reduction: xor butterflies inside the wave (k_goal_finish sums the partials)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) err += __shfl_xor(err, d, 64);
+    if (lane == 0) a.partial[i0 >> 6] = err;
   }
 }
 
@@ -3058,7 +3149,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec, fnorm, hist_a, hist_b, left_list;
+  size_t csphere, cface, clsphere, susphere, crec, fnorm, feta, hist_a, hist_b, left_list;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -3091,6 +3182,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
   L.fnorm = take(m * 3 * sizeof(double));   // the reaction's unit normal per face (snell_normal)
+  L.feta = take(m * 3 * sizeof(double));    // ... and its index ratios (FaceTables)
   // coherent-ray traces (tfrt_scene3d.coherent_rays): two class histograms (one being read, one
   // being built with atomics by both intersect kernels), the wavefronts left to the grouped kernel
   L.hist_a = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   // (+ the count of wavefronts
@@ -3260,11 +3352,24 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   int32_t* rec_slot = reinterpret_cast<int32_t*>(ws + lay.rec_slot);
   double* rec_t = reinterpret_cast<double*>(ws + lay.rec_t);
   uint8_t* rec_cls = reinterpret_cast<uint8_t*>(ws + lay.rec_cls);
-  double* fnorm = reinterpret_cast<double*>(ws + lay.fnorm);
+  FaceTables ft;
+  ft.fnorm = reinterpret_cast<double*>(ws + lay.fnorm);
+  // (the indices of a face do not depend on the ray: one table column, or "value" mode)
+  const bool index_mode = sc->n_table != nullptr && sc->mat_in != nullptr;
+  if (index_mode ? sc->n_table_uniform != 0 : (sc->n_in != nullptr && sc->n_out != nullptr))
+    ft.feta = reinterpret_cast<double*>(ws + lay.feta);
+  ft.mat_in = sc->mat_in;
+  ft.mat_out = sc->mat_out;
+  ft.n_table = sc->n_table;
+  ft.n_table_stride = sc->n_table_stride;
+  ft.n_in = sc->n_in;
+  ft.n_out = sc->n_out;
   int32_t* tail = counts + (size_t)P * TFRT_COUNTS_PER_PASS;
   const size_t n = N > 0 ? N : 1;
 
   if (M <= 0) hipLaunchKernelGGL(k_init, dim3(1), dim3(64), 0, st, nrays, (int)N, tail, ticket);
+  if (M <= 0 && sc->clear_buffer != nullptr && sc->clear_count > 0)   // (no set-up launch to do it)
+    (void)hipMemsetAsync(sc->clear_buffer, 0, (size_t)sc->clear_count * sizeof(double), st);
   Accel3 ac;
   // (the grouped kernel packs member slot and ray slot into 32 bits: member slots < 2^24)
   ac.order = (M >= 4 * CLUSTER && M < (1 << 24) - CLUSTER) ? sc->cluster_order : nullptr;
@@ -3291,12 +3396,14 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
-                         (int)N, tail, ticket, hist_ab[0], coherent ? pl.nblk * 4 + 1 : 0, fnorm);
+                         (int)N, tail, ticket, hist_ab[0], coherent ? pl.nblk * 4 + 1 : 0, ft,
+                         sc->clear_buffer, sc->clear_buffer ? sc->clear_count : 0);
     } else {
       hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
                          (int)N, tail, ticket);
       hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, sc->face_verts, M,
-                         c0, sc->size_epsilion, sphere, fnorm);
+                         c0, sc->size_epsilion, sphere, ft, sc->clear_buffer,
+                         sc->clear_buffer ? sc->clear_count : 0);
     }
   }
   const int chunks_used = ac.order == nullptr ? pl.chunks : pl.g_chunks;
@@ -3369,7 +3476,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                        rec_slot + (size_t)p * n, fin ? *fin : none, act ? *act : none,
                        stp ? *stp : none, dead ? *dead : none, tail + 6,
                        (p + 1 < P && !coherent) ? prep : nullptr,
-                       (int64_t)n, c0, ss, fnorm);
+                       (int64_t)n, c0, ss, ft.fnorm, ft.feta);
   }
   if (unfinished != nullptr && P > 0) {
     hipLaunchKernelGGL((k_copy_rays<T>), dim3(pl.nblk), dim3(BLOCK), 0, st,
@@ -3379,6 +3486,16 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 
+// the built-in goal error folded into the sweep (tfrt_trace3d_backward_goal)
+struct ChainGoal {
+  const void* fin_rays;
+  int64_t fin_cap;
+  GoalFields gf;
+  const double* goal;
+  int64_t goal_stride, goal_ray_stride;
+  double* partial;
+};
+
 template <typename T>
 static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t N,
                               const tfrt_scene3d* sc, double L, double dead_len, int P, int dtype,
@@ -3386,7 +3503,8 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                               int64_t cap_act, const double* g_stp, int64_t cap_stp,
                               const double* g_dead, int64_t cap_dead, double* g_fverts,
                               double* g_src, const int32_t* counts, void* workspace,
-                              size_t workspace_bytes, hipStream_t st) {
+                              size_t workspace_bytes, hipStream_t st,
+                              const ChainGoal* goal = nullptr) {
   const int M = (int)sc->n_faces;
   const Plan3 pl = make_plan(N, M);
   const Layout3 lay = make_layout(N, M, P, dtype, pl);
@@ -3426,8 +3544,9 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // (one launch sums all passes now: a block per CU is enough -- 125k rays x 11 windows, step time
   // with 1024 / 2048 / 4096 / 8192 slots per block: 0.302 / 0.278 / 0.265 / 0.268 ms)
   while (acc_chunk > 1024 && (int64_t)cdiv(N, acc_chunk) * windows < 256) acc_chunk /= 2;
-  if (wave_sums && P >= 1 && P <= CHAIN_MAXP) {
+  if ((wave_sums && P >= 1 && P <= CHAIN_MAXP) || goal != nullptr) {
     // coherent rays: the whole sweep in one launch (k_backward_chain)
+    if (!(wave_sums && P >= 1 && P <= CHAIN_MAXP)) return TFRT_E_UNSUPPORTED;
     ChainArgs<T> a;
     a.src = static_cast<const T*>(src_rays);
     a.src_stride = src_stride;
@@ -3454,9 +3573,28 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     a.g_src = g_src;
     a.N = N;
     a.g_fverts = g_fverts;
+    a.fin_rays = nullptr;
+    a.fin_cap = 0;
+    a.gf.n = 0;
+    a.goal = nullptr;
+    a.goal_stride = a.goal_ray_stride = 0;
+    a.partial = nullptr;
     ProfScope prof_bwd(TFRT_PROF_BACKWARD, st);
-    if (N > 0)
-      hipLaunchKernelGGL((k_backward_chain<T, 1>), dim3(cdiv(N, 64)), dim3(64), 0, st, a, *sc);
+    if (goal != nullptr) {
+      a.fin_rays = static_cast<const T*>(goal->fin_rays);
+      a.fin_cap = goal->fin_cap;
+      a.gf = goal->gf;
+      a.goal = goal->goal;
+      a.goal_stride = goal->goal_stride;
+      a.goal_ray_stride = goal->goal_ray_stride;
+      a.partial = goal->partial;
+      if (N > 0)
+        hipLaunchKernelGGL((k_backward_chain<T, 1, true>), dim3(cdiv(N, 64)), dim3(64), 0, st, a,
+                           *sc);
+    } else if (N > 0) {
+      hipLaunchKernelGGL((k_backward_chain<T, 1, false>), dim3(cdiv(N, 64)), dim3(64), 0, st, a,
+                         *sc);
+    }
     return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
   }
   for (int p = P - 1; p >= 0; --p) {
@@ -3577,6 +3715,75 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
   return TFRT_E_UNSUPPORTED;
 }
 
+size_t tfrt_trace3d_backward_goal_workspace_bytes(int64_t n_rays) {
+  if (n_rays < 0) return 0;
+  return align_up((size_t)cdiv(n_rays > 0 ? n_rays : 1, 64) * sizeof(double));
+}
+
+int tfrt_trace3d_backward_goal(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                               const tfrt_scene3d* scene, double new_ray_length,
+                               double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                               const tfrt_ray_out* finished, const int32_t* fields,
+                               int32_t n_fields, const double* goal, int64_t goal_stride,
+                               int64_t goal_ray_stride, double* error_out, int64_t* tests_total,
+                               void* goal_workspace, size_t goal_workspace_bytes,
+                               tfrt_goal_pending* pending, const double* grad_active,
+                               int64_t cap_active, const double* grad_stopped,
+                               int64_t cap_stopped, const double* grad_dead, int64_t cap_dead,
+                               double* grad_face_verts, double* grad_src_rays,
+                               const int32_t* counts, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (!scene_ok(scene) || n_rays < 0 || max_passes < 0 || !counts || !workspace ||
+      !grad_face_verts || !finished || !fields || n_fields < 1 || n_fields > 6 || !error_out ||
+      !pending || !goal_workspace || goal_stride < 0 || goal_ray_stride < 0 ||
+      goal_workspace_bytes < tfrt_trace3d_backward_goal_workspace_bytes(n_rays))
+    return TFRT_E_BADARG;
+  if (n_rays > 0 && (!finished->rays || finished->capacity <= 0 || !goal)) return TFRT_E_BADARG;
+  ChainGoal g;
+  g.fin_rays = finished->rays;
+  g.fin_cap = finished->capacity;
+  g.gf.n = n_fields;
+  for (int c = 0; c < 6; ++c) {
+    g.gf.row[c] = c < n_fields ? fields[c] : 0;
+    if (g.gf.row[c] < 0 || g.gf.row[c] > 5) return TFRT_E_BADARG;
+  }
+  g.goal = goal;
+  g.goal_stride = goal_stride;
+  g.goal_ray_stride = goal_ray_stride;
+  g.partial = static_cast<double*>(goal_workspace);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = TFRT_E_UNSUPPORTED;
+  if (state_dtype == TFRT_F32)
+    rc = trace3d_backward_t<float>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                   dead_ray_length, max_passes, state_dtype, nullptr, 0,
+                                   grad_active, cap_active, grad_stopped, cap_stopped, grad_dead,
+                                   cap_dead, grad_face_verts, grad_src_rays, counts, workspace,
+                                   workspace_bytes, st, &g);
+  else if (state_dtype == TFRT_F64)
+    rc = trace3d_backward_t<double>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                    dead_ray_length, max_passes, state_dtype, nullptr, 0,
+                                    grad_active, cap_active, grad_stopped, cap_stopped, grad_dead,
+                                    cap_dead, grad_face_verts, grad_src_rays, counts, workspace,
+                                    workspace_bytes, st, &g);
+  else if (state_dtype == TFRT_F16)
+    rc = trace3d_backward_t<_Float16>(src_rays, src_stride, n_rays, scene, new_ray_length,
+                                      dead_ray_length, max_passes, state_dtype, nullptr, 0,
+                                      grad_active, cap_active, grad_stopped, cap_stopped,
+                                      grad_dead, cap_dead, grad_face_verts, grad_src_rays, counts,
+                                      workspace, workspace_bytes, st, &g);
+  if (rc != 0) return rc;
+  // trailing counters of the trace: {total_active, total_finished, ..., n_tests_lo, n_tests_hi}
+  const int32_t* tail = counts + (size_t)max_passes * TFRT_COUNTS_PER_PASS;
+  pending->partial = g.partial;
+  pending->n_partial = n_rays > 0 ? cdiv(n_rays, 64) : 0;
+  pending->n_finished = tail + 1;
+  pending->n_fields = n_fields;
+  pending->error_out = error_out;
+  pending->tests_lo_hi = tail + 4;
+  pending->tests_total = tests_total;
+  return 0;
+}
+
 size_t tfrt_intersect3d_workspace_bytes(int64_t n_rays, int64_t n_faces) {
   if (n_rays < 0 || n_faces < 0) return 0;
   const Plan3 pl = make_plan(n_rays, n_faces);
@@ -3621,7 +3828,8 @@ int tfrt_intersect3d(const void* rays, int64_t stride, int64_t n_rays, int32_t s
     hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, face_verts, M, c0, nptr, (int)n_rays,
                        nptr + 8, (unsigned int*)nullptr);
     hipLaunchKernelGGL(k_spheres, dim3(cdiv(M, BLOCK)), dim3(BLOCK), 0, st, face_verts, M, c0,
-                       size_epsilion, sphere, static_cast<double*>(nullptr));
+                       size_epsilion, sphere, FaceTables(), static_cast<double*>(nullptr),
+                       (int64_t)0);
   }
 #define TFRT_SEAM(TT)                                                                          \
   launch_intersect<TT>(pl, st, static_cast<const TT*>(rays), stride, nptr, nullptr, sphere,    \

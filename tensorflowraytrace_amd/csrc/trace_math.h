@@ -142,9 +142,20 @@ TFRT_HD void snell_normal(const double P[9], double n[3]) {
   l2_normalize3(N, n);
 }
 
-// geometry.py:715-753 from the normal on (un = snell_normal() of the face).
-TFRT_HD Snell3 snell3d_unit(const double s[3], const double h[3], const double un[3],
-                            double n_in, double n_out) {
+// The two index ratios of geometry.py:727-733 (tf.math.divide_no_nan both ways): functions of
+// the face and the wavelength alone.
+TFRT_HD void snell_ratios(double n_in, double n_out, double* n1, double* n2) {
+#pragma clang fp contract(off)
+  const bool in_safe = n_in != 0.0, out_safe = n_out != 0.0;
+  const double nis = in_safe ? n_in : 1.0, nos = out_safe ? n_out : 1.0;
+  *n1 = out_safe ? nis / nos : 0.0;
+  *n2 = in_safe ? nos / nis : 0.0;
+}
+
+// geometry.py:715-753 from the normal and the ratios on (un = snell_normal() of the face,
+// (n1, n2) = snell_ratios(), mirror = (n_in == 0)).
+TFRT_HD Snell3 snell3d_core(const double s[3], const double h[3], const double un[3], double n1,
+                            double n2, bool mirror) {
 #pragma clang fp contract(off)
   Snell3 o;
   const double r[3] = {h[0] - s[0], h[1] - s[1], h[2] - s[2]};
@@ -154,15 +165,11 @@ TFRT_HD Snell3 snell3d_unit(const double s[3], const double h[3], const double u
   o.n[2] = un[2];
   o.nu = dot3(o.n, o.u);
   const bool internal = o.nu > 0.0;
-  const bool in_safe = n_in != 0.0, out_safe = n_out != 0.0;
-  const double nis = in_safe ? n_in : 1.0, nos = out_safe ? n_out : 1.0;
-  const double n1 = out_safe ? nis / nos : 0.0;
-  const double n2 = in_safe ? nos / nis : 0.0;
   o.eta = internal ? n1 : n2;
   const double nu_eta = o.eta * o.nu;
   o.k = 1.0 - o.eta * o.eta + nu_eta * nu_eta;
   const bool tir = o.k < 0.0;
-  o.reflect = tir || (n_in == 0.0);
+  o.reflect = tir || mirror;
   if (o.reflect) {
     for (int i = 0; i < 3; ++i) o.w[i] = -2.0 * o.nu * o.n[i] + o.u[i];
   } else {
@@ -171,6 +178,13 @@ TFRT_HD Snell3 snell3d_unit(const double s[3], const double h[3], const double u
     for (int i = 0; i < 3; ++i) o.w[i] = alpha * o.n[i] + o.eta * o.u[i];
   }
   return o;
+}
+
+TFRT_HD Snell3 snell3d_unit(const double s[3], const double h[3], const double un[3],
+                            double n_in, double n_out) {
+  double n1, n2;
+  snell_ratios(n_in, n_out, &n1, &n2);
+  return snell3d_core(s, h, un, n1, n2, n_in == 0.0);
 }
 
 // geometry.py:715-753.  s = ray start, h = projected ray end (the hit), norm = face normal.

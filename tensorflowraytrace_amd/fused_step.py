@@ -268,14 +268,23 @@ class FusedStep:
         stream = ops._stream(block)
         sc = scene.struct(fvc)
         o = st["outs"]
+        need_back = bool(fv.requires_grad and st["M"] > 0)
+        # coherent rays: error, gradient seed and the whole reverse sweep are ONE launch
+        # (tfrt_trace3d_backward_goal); the face-gradient block it accumulates into is cleared by
+        # the trace's set-up launch
+        folded = bool(need_back and sc.coherent_rays and not sc.deterministic and 1 <= P <= 8)
+        self.folded_backward = folded
+        if folded:
+            sc.clear_buffer, sc.clear_count = st["g_fv"].data_ptr(), st["g_fv"].numel()
         check(L.tfrt_trace3d_forward(
             ops._p(block), block.shape[1], st["N"], ctypes.byref(sc), float(eng.new_ray_length),
             float(eng.dead_ray_length or 0.0), P, dt, flags, ctypes.byref(o["finished"]),
             ctypes.byref(o["active"]), ctypes.byref(o["stopped"]), ctypes.byref(o["dead"]),
             None, None,      # (the rays still active after the last pass are not copied out)
             ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream), "tfrt_trace3d_forward")
+        if folded:      # (the struct is cached by the scene: nobody else's trace clears our block)
+            sc.clear_buffer, sc.clear_count = None, 0
         fin = st["full"]["finished"]
-        need_back = bool(fv.requires_grad and st["M"] > 0)
         # error + gradient seed; the same launch clears the face-gradient block the reverse sweep
         # accumulates into and adds the trace's test count to the running total
         # (one rank: nothing on the device waits for the error sum, so its second stage is left
@@ -290,7 +299,25 @@ class FusedStep:
             st["g_fv"].numel() if need_back else 0, ops._p(self.tests_total),
             ops._p(st["goal_ws"]), st["gws"])
         self._goal_pending = None
-        if tdist.is_distributed():
+        if folded:
+            if "chain_ws" not in st:
+                cwb = L.tfrt_trace3d_backward_goal_workspace_bytes(st["N"])
+                st["chain_ws"] = (torch.zeros(max(cwb, 1), dtype=torch.uint8, device=block.device), cwb)
+            pending = _lib.GoalPending()
+            check(L.tfrt_trace3d_backward_goal(
+                ops._p(block), block.shape[1], st["N"], ctypes.byref(sc),
+                float(eng.new_ray_length), float(eng.dead_ray_length or 0.0), P, dt,
+                ctypes.byref(o["finished"]), st["fields"], len(erf.rows), ops._p(goal),
+                1 if goal_by_ray else goal.shape[1], goal.shape[1] if goal_by_ray else 1,
+                ops._p(st["err"]), ops._p(self.tests_total), ops._p(st["chain_ws"][0]),
+                st["chain_ws"][1], ctypes.byref(pending), None, 0, None, 0, None, 0,
+                ops._p(st["g_fv"]), None, ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"],
+                stream), "tfrt_trace3d_backward_goal")
+            if tdist.is_distributed():      # (the sum goes into the collective: finished here)
+                check(L.tfrt_goal_finish(ctypes.byref(pending), stream), "tfrt_goal_finish")
+            else:
+                self._goal_pending = (pending, stream)
+        elif tdist.is_distributed():
             check(L.tfrt_goal_error3d(*goal_args, stream), "tfrt_goal_error3d")
         else:
             pending = _lib.GoalPending()
@@ -299,12 +326,13 @@ class FusedStep:
             self._goal_pending = (pending, stream)
         grads = [None] * len(opt.parameters)
         if need_back:
-            check(L.tfrt_trace3d_backward(
-                ops._p(block), block.shape[1], st["N"], ctypes.byref(sc),
-                float(eng.new_ray_length), float(eng.dead_ray_length or 0.0), P, dt,
-                ops._p(st["g_fin"]), st["capN"], None, 0, None, 0, None, 0, ops._p(st["g_fv"]),
-                None, ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream),
-                "tfrt_trace3d_backward")
+            if not folded:
+                check(L.tfrt_trace3d_backward(
+                    ops._p(block), block.shape[1], st["N"], ctypes.byref(sc),
+                    float(eng.new_ray_length), float(eng.dead_ray_length or 0.0), P, dt,
+                    ops._p(st["g_fin"]), st["capN"], None, 0, None, 0, None, 0, ops._p(st["g_fv"]),
+                    None, ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream),
+                    "tfrt_trace3d_backward")
             # Inside a graph capture: differentiate w.r.t. the aliases update() read the parameters
             # through (see boundaries.tap), never w.r.t. the leaves.  Outside a capture the leaf is
             # differentiated too -- its gradient is the total whatever route update() took -- and

@@ -48,7 +48,7 @@ def test_header_compiles_as_plain_c(tmp_path):
 
 
 def test_version_and_strerror(lib):
-    assert lib.tfrt_version() == 104
+    assert lib.tfrt_version() == 105
     assert lib.tfrt_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -99):
         assert len(lib.tfrt_strerror(code)) > 0

@@ -189,11 +189,16 @@ def test_fused_step_in_coherent_order_equals_the_generic_path():
         opt, eng, system, lens, *_rest, acc = _make(20000, mode, k=6, ray_dtype=torch.float64)
         if mode == "generic":
             eng.coherent = False              # (the reference's order all the way: the yardstick)
+        else:
+            # ("auto" would go back to natural order after three steps: a tenth of this coarse
+            # lens's wavefronts are no narrow bundles)
+            eng.coherent = True
         errs = _run(opt, None, steps)
         runs[mode] = (errs, _params(lens), opt, eng)
     g = runs["graph"][2]._fused_step
     assert g.capture_error is None and g.graph_replays >= 2
     assert getattr(runs["graph"][3], "_order_cache", None) is not None      # the sorted source
+    assert g.folded_backward        # error + seed + reverse sweep in one launch (tfrt_trace3d_backward_goal)
     assert getattr(runs["generic"][3], "_order_cache", None) is None
     np.testing.assert_allclose(runs["graph"][0], runs["generic"][0], rtol=1e-10, atol=0)
     for a, b in zip(runs["graph"][1], runs["generic"][1]):
