@@ -172,7 +172,7 @@ __device__ __forceinline__ float4 pack_sphere(const double cc[3], double reff) {
 // gathered for 72 + two dependent index loads.
 struct FaceTables {
   double* fnorm = nullptr;           // (M, 3)
-  double* feta = nullptr;            // (M, 3): n1, n2, n_in -- or nullptr: indices per ray
+  double* feta = nullptr;            // (M, 4): n1, n2, n_in, n_out -- or nullptr: indices per ray
   const int32_t* mat_in = nullptr;
   const int32_t* mat_out = nullptr;
   const double* n_table = nullptr;   // (column 0: n_table_uniform)
@@ -199,9 +199,10 @@ __device__ __forceinline__ void face_tables(const FaceTables& ft, const double* 
       no = ft.n_out[f];
     }
     snell_ratios(ni, no, &n1, &n2);
-    ft.feta[3 * (int64_t)f] = n1;
-    ft.feta[3 * (int64_t)f + 1] = n2;
-    ft.feta[3 * (int64_t)f + 2] = ni;
+    ft.feta[4 * (int64_t)f] = n1;
+    ft.feta[4 * (int64_t)f + 1] = n2;
+    ft.feta[4 * (int64_t)f + 2] = ni;
+    ft.feta[4 * (int64_t)f + 3] = no;
   }
 }
 
@@ -2428,7 +2429,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_
 #pragma unroll
       for (int q = 0; q < 3; ++q) un[q] = fp[q];
       if (feta != nullptr) {
-        const double* fe = feta + 3 * (int64_t)tri;
+        const double* fe = feta + 4 * (int64_t)tri;
         n1 = fe[0];
         n2 = fe[1];
         n_in = fe[2];
@@ -2806,12 +2807,34 @@ __device__ __forceinline__ int backward_core(
     const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
     int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
     const double* __restrict__ g_dead, int64_t cap_dead, double gs[3], double ge[3],
-    double gP[9]) {
+    double gP[9], int tri_known = -2, const double* __restrict__ feta = nullptr) {
+  // tri_known >= 0: the caller already holds the slot's face (k_backward_chain reads it on its
+  // way forward); the face, the hit parameter and the indices are then asked for together with
+  // the ray, before anything decides whether the slot carries a gradient at all -- one round
+  // trip to memory per pass instead of three dependent ones.
   int face_out = -1;
   const int cls = tape & 3;
   double s[3], e[3];
   load_ray3(rays_in, stride_in, i, s, e);
   for (int k = 0; k < 3; ++k) gs[k] = ge[k] = 0.0;
+  double P[9], t_rec = 0.0, n_in = 1.0, n_out = 1.0;
+  int tri = tri_known;
+  auto load_face = [&](bool with_indices) {
+    const double* fp = sc.face_verts + 9 * (int64_t)tri;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) P[q] = fp[q];
+    t_rec = rec_t[i];
+    if (with_indices) {
+      if (feta != nullptr) {
+        n_in = feta[4 * (int64_t)tri + 2];
+        n_out = feta[4 * (int64_t)tri + 3];
+      } else {
+        face_indices(sc, tri, ray_id_in ? ray_id_in[i] : i, &n_in, &n_out);
+      }
+    }
+  };
+  const bool early = tri_known >= 0 && cls != CLS_DEAD;
+  if (early) load_face(child_pass && cls == CLS_ACTIVE);
 
   if (cls == CLS_DEAD) {
     if (g_dead != nullptr) {
@@ -2850,16 +2873,13 @@ __device__ __forceinline__ int backward_core(
     bool nz = has_child;
     for (int k = 0; k < 3; ++k) nz = nz || g_s[k] != 0.0 || g_h[k] != 0.0;
     if (nz) {
-      const int tri = rec_tri[i];
-      const int rid = ray_id_in ? ray_id_in[i] : i;
-      double P[9], n_in = 1.0, n_out = 1.0;
-      const double* fp = sc.face_verts + 9 * (int64_t)tri;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) P[q] = fp[q];
-      if (has_child) face_indices(sc, tri, rid, &n_in, &n_out);
+      if (!early) {
+        tri = rec_tri[i];
+        load_face(has_child);
+      }
       double gn[2];
       const bool want_n = has_child && sc.grad_n_in != nullptr && sc.n_table == nullptr;
-      adjoint3d(s, e, P, rec_t[i], has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP, gn,
+      adjoint3d(s, e, P, t_rec, has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP, gn,
                 ((tape & TAPE_INTERNAL) ? 1 : 0) | ((tape & TAPE_REFLECT) ? 2 : 0), want_n);
       if (want_n) {  // "value" mode: d error / d (per-face refractive indices)
         if (gn[0] != 0.0) unsafeAtomicAdd(sc.grad_n_in + tri, gn[0]);
@@ -2950,6 +2970,7 @@ struct ChainArgs {
   const double* goal;
   int64_t goal_stride, goal_ray_stride;
   double* partial;         // one partial error sum per wavefront of the launch
+  const double* feta;      // per-face indices (FaceTables) or null
 };
 
 template <typename T, int BW, bool GOAL>
@@ -2965,19 +2986,22 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
   __shared__ double wacc[BW][WSUM_CELLS];
   __shared__ int32_t wface[BW][WSUM_SLOTS];
-  __shared__ int32_t chain[BW][CHAIN_MAXP][64];
+  extern __shared__ int4 chain_lds[];   // [wave][pass][lane]: slot, tape byte, output slot, face
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int P = a.P;
-  // forward: the slots of this ray's chain and the pass it ends in
+  int4* chain = chain_lds + (size_t)wave * P * 64;
+  // forward: the slots of this ray's chain and the pass it ends in; what the walk back needs of
+  // every slot's record is read here, three independent loads per pass
   int last = -1;
   if (i0 < n0) {
     int j = i0;
     for (int p = 0; p < P; ++p) {
-      chain[wave][p][lane] = j;
-      last = p;
       const size_t at = (size_t)p * a.n + j;
-      if ((a.rec_cls[at] & 3) != CLS_ACTIVE || p == P - 1) break;
-      j = a.rec_slot[at];
+      const int tape = a.rec_cls[at], slot = a.rec_slot[at], tri = a.rec_tri[at];
+      chain[p * 64 + lane] = make_int4(j, tape, slot, tri);
+      last = p;
+      if ((tape & 3) != CLS_ACTIVE || p == P - 1) break;
+      j = slot;
     }
   }
   // (wave-uniform bound of the walk back)
@@ -2990,12 +3014,12 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     double gP[9];
     int tri = -1;
     if (p <= last) {
-      const int j = chain[wave][p][lane];
+      const int4 rec = chain[p * 64 + lane];
+      const int j = rec.x, tape = rec.y, slot = rec.z;
       const size_t off = (size_t)p * a.n;
       const T* rin = p == 0 ? a.src : a.rays_ws + (size_t)(p - 1) * 6 * a.n;
       const int64_t sin = p == 0 ? a.src_stride : a.n;
       const int32_t* idin = p == 0 ? nullptr : a.rayid + (size_t)(p - 1) * a.n;
-      const int tape = a.rec_cls[off + j], slot = a.rec_slot[off + j];
       double seed[6] = {0, 0, 0, 0, 0, 0};
       if (GOAL && p == last && (tape & 3) == CLS_FINISHED) {
         // tfrt_goal_error3d's terms for this ray: the output AS STORED in the finished block
@@ -3015,7 +3039,8 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
       tri = backward_core<T>(j, tape, slot, rin, sin, idin, a.rec_tri + off, a.rec_t + off,
                              a.counts + (size_t)p * TFRT_COUNTS_PER_PASS, sc, a.L, a.dead_len,
                              p < P - 1, child, GOAL ? seed : nullptr, a.g_fin, a.cap_fin, a.g_act,
-                             a.cap_act, a.g_stp, a.cap_stp, a.g_dead, a.cap_dead, gs, ge, gP);
+                             a.cap_act, a.g_stp, a.cap_stp, a.g_dead, a.cap_dead, gs, ge, gP,
+                             rec.w, a.feta);
       for (int k = 0; k < 3; ++k) {
         child[k] = gs[k];
         child[3 + k] = ge[k];
@@ -3182,7 +3207,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.susphere = take((ncl + SUPER - 1) / SUPER * sizeof(float4));
   L.crec = take(ncl * CLUSTER * 3 * sizeof(float4));
   L.fnorm = take(m * 3 * sizeof(double));   // the reaction's unit normal per face (snell_normal)
-  L.feta = take(m * 3 * sizeof(double));    // ... and its index ratios (FaceTables)
+  L.feta = take(m * 4 * sizeof(double));    // ... and its indices and their ratios (FaceTables)
   // coherent-ray traces (tfrt_scene3d.coherent_rays): two class histograms (one being read, one
   // being built with atomics by both intersect kernels), the wavefronts left to the grouped kernel
   L.hist_a = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   // (+ the count of wavefronts
@@ -3579,6 +3604,13 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     a.goal = nullptr;
     a.goal_stride = a.goal_ray_stride = 0;
     a.partial = nullptr;
+    {  // (the per-face indices the forward's set-up launch left, under the same condition)
+      const bool index_mode = sc->n_table != nullptr && sc->mat_in != nullptr;
+      const bool per_face = index_mode ? sc->n_table_uniform != 0
+                                       : (sc->n_in != nullptr && sc->n_out != nullptr);
+      a.feta = per_face ? reinterpret_cast<const double*>(ws + lay.feta) : nullptr;
+    }
+    const size_t chain_lds = (size_t)P * 64 * sizeof(int4);
     ProfScope prof_bwd(TFRT_PROF_BACKWARD, st);
     if (goal != nullptr) {
       a.fin_rays = static_cast<const T*>(goal->fin_rays);
@@ -3589,11 +3621,11 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
       a.goal_ray_stride = goal->goal_ray_stride;
       a.partial = goal->partial;
       if (N > 0)
-        hipLaunchKernelGGL((k_backward_chain<T, 1, true>), dim3(cdiv(N, 64)), dim3(64), 0, st, a,
-                           *sc);
+        hipLaunchKernelGGL((k_backward_chain<T, 1, true>), dim3(cdiv(N, 64)), dim3(64), chain_lds,
+                           st, a, *sc);
     } else if (N > 0) {
-      hipLaunchKernelGGL((k_backward_chain<T, 1, false>), dim3(cdiv(N, 64)), dim3(64), 0, st, a,
-                         *sc);
+      hipLaunchKernelGGL((k_backward_chain<T, 1, false>), dim3(cdiv(N, 64)), dim3(64), chain_lds,
+                         st, a, *sc);
     }
     return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
   }
