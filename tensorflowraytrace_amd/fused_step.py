@@ -146,6 +146,11 @@ class FusedStep:
     """Runs ``SGD_Optimizer.single_step`` for a ``GoalError`` as a fixed launch sequence; see the
     module docstring.  One instance per optimizer."""
 
+    # coherent rays: error, gradient seed and reverse sweep as ONE launch (tfrt_trace3d_backward_goal);
+    # False: tfrt_goal_error3d + tfrt_trace3d_backward (what a trace in natural order always runs)
+    fold_backward = True
+    folded_backward = False           # what the last enqueued step did
+
     def __init__(self, optimizer, graph="auto", graph_warmup=3):
         self.opt = optimizer
         self.graph_mode = graph           # "auto" / True: capture after the warm-up; False: never
@@ -272,7 +277,8 @@ class FusedStep:
         # coherent rays: error, gradient seed and the whole reverse sweep are ONE launch
         # (tfrt_trace3d_backward_goal); the face-gradient block it accumulates into is cleared by
         # the trace's set-up launch
-        folded = bool(need_back and sc.coherent_rays and not sc.deterministic and 1 <= P <= 8)
+        folded = bool(self.fold_backward and need_back and sc.coherent_rays
+                      and not sc.deterministic and 1 <= P <= 8)
         self.folded_backward = folded
         if folded:
             sc.clear_buffer, sc.clear_count = st["g_fv"].data_ptr(), st["g_fv"].numel()

@@ -178,6 +178,33 @@ def test_goal_error_kernel_sum_is_reproducible_and_matches_torch():
     assert not bool(g_fin[:4].any()) and not bool(g_fin[4:6, n:].any())
 
 
+def test_folded_reverse_sweep_equals_goal_error_plus_backward():
+    """tfrt_trace3d_backward_goal (error, seed and the whole reverse sweep in one launch) against
+    tfrt_goal_error3d + tfrt_trace3d_backward on the same coherent trace: the same error to the
+    last bits of a differently ordered sum, the same parameters after eight steps; float32 ray
+    state too (the residuals are formed from the finished rows AS STORED in both)."""
+    import tensorflowraytrace_amd.fused_step as fs
+    # (the face sums are float64 atomics: their last bits differ from run to run, and eight steps
+    # of this lively optimisation amplify that to ~1e-12)
+    for ray_dtype, tol in ((torch.float64, 1e-10), (torch.float32, 1e-8)):
+        runs = {}
+        for fold in (True, False):
+            opt, eng, system, lens, *_rest, acc = _make(20000, "graph", k=6, ray_dtype=ray_dtype)
+            eng.coherent = True
+            old = fs.FusedStep.fold_backward
+            fs.FusedStep.fold_backward = fold
+            try:
+                errs = _run(opt, None, 8)
+            finally:
+                fs.FusedStep.fold_backward = old
+            g = opt._fused_step
+            assert g.capture_error is None and g.graph_replays >= 2 and g.folded_backward == fold
+            runs[fold] = (errs, _params(lens))
+        np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=tol, atol=0)
+        for a, b in zip(runs[True][1], runs[False][1]):
+            assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+
+
 def test_fused_step_in_coherent_order_equals_the_generic_path():
     """From 4096 rays on the engine sorts the source along a Hilbert curve (``coherent='auto'``:
     tfrt_ray_order, k_intersect_beam, per-wavefront face sums).  The
