@@ -11,6 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFRT_LIB_PATH") or os.path.join(HERE, "libtfrt_hip.so")
 
+ABI_VERSION = 105          # TFRT_VERSION of include/tfrt_hip.h this module's signatures are written for
 F32, F64, F16 = 0, 1, 2
 OPTICAL, STOP, TARGET = 0, 1, 2
 CLS_ACTIVE, CLS_FINISHED, CLS_STOPPED, CLS_DEAD = 0, 1, 2, 3
