@@ -681,6 +681,42 @@ def test_coherent_order_changes_no_output(dtype, n_rays, k_front):
             assert float((a - b).abs().max() / b.abs().max()) < tol, name
 
 
+@pytest.mark.parametrize("max_passes", [1, 8, 10])
+def test_coherent_reverse_sweep_at_every_trace_depth(max_passes):
+    """The one-launch reverse sweep (k_backward_chain) holds a ray's chain of slots for up to eight
+    passes; deeper traces take the per-pass sweep.  Either way, and for a one-pass trace (the
+    chain is the source slot alone), the gradients are those of the natural-order trace."""
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(20000, k_front=12, k_back=6)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, torch.float64, cluster="group")
+
+    def loss(o):      # every class and both ends of every row carry a gradient
+        tot = 0.0
+        for k, cls in enumerate(("finished", "active", "stopped", "dead")):
+            r = o[cls].double()
+            w = torch.arange(1, 7, dtype=torch.float64, device=r.device)[:, None] * (0.3 + k)
+            tot = tot + (w * r * r).sum() + (r[3:] * r[:3]).sum()
+        return tot
+    ref = ops.trace3d(src, fv, sc, max_passes=max_passes, flags=flags)
+    g_ref = torch.autograd.grad(loss(ref), [p_f, p_b], retain_graph=True)
+    order = ops.ray_order(src)
+    p64 = order.long()
+    sc2 = ops.Scene3DArgs(fv, sc.catagory, mat_in=sc.mat_in, mat_out=sc.mat_out,
+                          n_table=sc.n_table[:, p64].contiguous(), face_grad_mask=sc.face_grad_mask,
+                          cluster_order=sc.cluster_order, coherent_rays=True)
+    raw = ops.trace3d(src[:, p64].contiguous(), fv, sc2, max_passes=max_passes, flags=flags)
+    out = ops.restore_order(raw, order)
+    assert np.array_equal(out["counts"], ref["counts"])
+    g = torch.autograd.grad(loss(out), [p_f, p_b], retain_graph=True)
+    assert float(g_ref[0].abs().max()) > 0.0
+    for a, b in zip(g, g_ref):
+        if float(b.abs().max()) == 0.0:      # (one pass: the back surface is never reached)
+            assert float(a.abs().max()) == 0.0
+        else:
+            assert float((a - b).abs().max() / b.abs().max()) < 1e-11
+
+
 def test_coherent_flag_on_adversarial_soups():
     """Random triangle soups, random rays (no coherence at all, grazing rays, ties, stops): with
     the flag set and any order of the rays the all-pairs result comes back bit for bit."""
