@@ -41,3 +41,5 @@ for P in (1, 2, 3):
         idx = r.view(torch.int32)[:, 6]
         for k in range(r.shape[0]):
             print(q0 - 8 + k, int(idx[k]), [round(float(v), 5) for v in r[k, :6]])
+    if not ticks_only and cur[4] > 0:
+        print(f"   decisions: pairs decided {cur[4]/w:.1f} per wavefront, of them valid hits {cur[5]/w:.1f}", flush=True)
