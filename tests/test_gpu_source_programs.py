@@ -204,6 +204,43 @@ def test_point_and_angular_sources_assemble_like_the_torch_path():
     assert torch.allclose(torch.stack([an["x_end"], an["y_end"], an["z_end"]], 1), e0, atol=1e-13)
 
 
+def test_order_of_point_and_angular_programs_and_of_tiny_sources():
+    """tfrt_source3d_order on the other source kinds: a point source (directions without a common
+    axis: the octahedral map), an angular source (a frame from the mean direction), and sources of
+    fewer rays than the 256 samples the frame is made from -- always a permutation; where there
+    are wavefronts, their end points lie closer together than those of a random order."""
+    import tfrt.sources as sources
+    d = _dist()
+    d.seed(13)
+
+    def check(src, n):
+        src.update()
+        rs = src._fields
+        perm = rs.order()
+        assert perm.dtype == torch.int32 and perm.shape == (n,)
+        assert torch.equal(torch.sort(perm.long())[0], torch.arange(n, device=perm.device))
+        if n < 64 * 32:
+            return
+        block = rs.ray_block(torch.float32)
+
+        def spread(p):
+            e = block[3:6, p.long()][:, :n // 64 * 64].reshape(3, -1, 64)
+            return float((e.max(dim=2)[0] - e.min(dim=2)[0]).pow(2).sum(dim=0).sqrt().mean())
+        g = torch.Generator().manual_seed(0)
+        assert spread(perm) < 0.35 * spread(torch.randperm(n, generator=g).to(perm.device))
+
+    n = 40000
+    ang = d.RandomUniformSphere(PI, n)                       # every direction: no common axis
+    check(sources.PointSource(3, (1.0, -2.0, 0.5), (1.0, 0.0, 0.0), ang, [500.0], dense=False,
+                              ray_length=2.5), n)
+    base = d.RandomUniformSquare(0.3, 200, 0.1, 200)         # (200 x 200 = n points)
+    ang2 = d.RandomUniformSphere(0.2, n)
+    check(sources.AngularSource(3, (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), ang2, base, [500.0], dense=False), n)
+    for m in (1, 63, 100, 257):
+        src, a, b = _aperture(m)
+        check(src, m)
+
+
 def test_trace_of_a_device_made_source_equals_the_trace_of_its_rays_as_plain_tensors():
     """ray_trace() over a re-drawn source runs ordered (tfrt_ray_order every trace) and restored;
     the same rays handed over as a ManualSource and traced in natural order give every ray set
