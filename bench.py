@@ -233,6 +233,10 @@ def main(argv=None):
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the separately reported legs (all-pairs mode, float64 state, ...)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--collective-in-graph", action="store_true",
+                    help="several ranks: capture the RCCL all-reduce inside the step's graph "
+                         "(FusedStep.capture_collective; default: called between two graphs -- the "
+                         "captured form has only been replayed with a one-rank group so far)")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -252,6 +256,9 @@ def main(argv=None):
     from tensorflowraytrace_amd import _lib, distributed as tdist
     import tfrt.optimizer as optimizer
 
+    if args.collective_in_graph:
+        from tensorflowraytrace_amd import fused_step
+        fused_step.FusedStep.capture_collective = True
     rank, world, local = tdist.init_from_env()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         world = torch.distributed.get_world_size()
@@ -335,6 +342,7 @@ def main(argv=None):
                    mode=eng._trace_mode(system),
                    visiting=getattr(eng, "_order_cache", None) is not None,
                    graph_replays=fs.graph_replays if fs is not None else 0,
+                   collective_in_graph=bool(fs.collective_in_graph) if fs is not None else None,
                    capture_error=repr(fs.capture_error) if fs is not None and fs.capture_error
                    else None)
         del eng, system, params, opt
@@ -533,6 +541,7 @@ def main(argv=None):
                               args.step_mode],
             "graph_replays": main_leg["graph_replays"],
             "ranks": world, "backend": backend,
+            "collective_in_graph": main_leg.get("collective_in_graph"),
             "parallelism": (f"rays sharded over {world} ranks (one per GPU), 1 {backend} "
                             f"all-reduce of the parameter gradients per step")
             if tdist.is_distributed() else "single GPU, no collective",

@@ -150,6 +150,14 @@ class FusedStep:
     # False: tfrt_goal_error3d + tfrt_trace3d_backward (what a trace in natural order always runs)
     fold_backward = True
     folded_backward = False           # what the last enqueued step did
+    # Several ranks: capture the RCCL all-reduce inside the step's graph (one graph per step) instead
+    # of calling it eagerly between two graphs.  "auto": only with a one-rank group -- the form has
+    # been replayed with a one-rank RCCL group (tests/test_gpu_zz_rccl.py), never yet with several
+    # RCCL ranks (no multi-GPU box in this round's pool), and a capture that goes wrong ACROSS ranks
+    # does not raise, it hangs; the split form is plain eager torch.distributed and costs ~10 us
+    # per step.  True: always try (bench.py --collective-in-graph).
+    capture_collective = "auto"
+    collective_in_graph = False
 
     def __init__(self, optimizer, graph="auto", graph_warmup=3):
         self.opt = optimizer
@@ -629,7 +637,10 @@ class FusedStep:
             sig = self._signature(accumulators)
             pool = torch.cuda.graph_pool_handle()
             ga, gb, grads = None, None, None
-            if world > 1 and torch.distributed.get_backend() == "nccl":
+            want = self.capture_collective
+            if want == "auto":
+                want = torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1
+            if world > 1 and want and torch.distributed.get_backend() == "nccl":
                 # RCCL collectives can be captured: update ... gradients | all-reduce | apply as ONE
                 # graph, one launch per step (two graphs with an eager collective between them
                 # otherwise: gloo, or a runtime that refuses the capture)
