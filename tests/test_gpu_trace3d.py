@@ -717,6 +717,30 @@ def test_coherent_reverse_sweep_at_every_trace_depth(max_passes):
             assert float((a - b).abs().max() / b.abs().max()) < 1e-11
 
 
+def test_coherent_reverse_sweep_gives_the_source_ray_gradient():
+    """grad_src_rays out of the one-launch reverse sweep (a lane ends its walk back at its source
+    ray): equal to the per-pass sweep's, for rays handed over in a coherent order."""
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(20000, k_front=12, k_back=6)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, torch.float64, cluster="group")
+    order = ops.ray_order(src).long()
+    grads = {}
+    for coherent in (False, True):
+        rays = src[:, order].contiguous().requires_grad_(True)
+        sc2 = ops.Scene3DArgs(fv, sc.catagory, mat_in=sc.mat_in, mat_out=sc.mat_out,
+                              n_table=sc.n_table[:, order].contiguous(),
+                              face_grad_mask=sc.face_grad_mask, cluster_order=sc.cluster_order,
+                              coherent_rays=coherent)
+        out = ops.trace3d(rays, fv, sc2, max_passes=4, flags=flags)
+        loss = sum((o.double() ** 2).sum() * (k + 1) for k, o in
+                   enumerate(out[c] for c in ("finished", "active", "stopped", "dead")))
+        grads[coherent] = torch.autograd.grad(loss, [rays, p_f, p_b], retain_graph=True)
+    for a, b in zip(grads[True], grads[False]):
+        assert float(b.abs().max()) > 0.0
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-11
+
+
 def test_coherent_flag_on_adversarial_soups():
     """Random triangle soups, random rays (no coherence at all, grazing rays, ties, stops): with
     the flag set and any order of the rays the all-pairs result comes back bit for bit."""
