@@ -81,6 +81,29 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert lib.tfrt_snell3d(-5, *([None] * 9), 1.0, None, None) == -1
     assert lib.tfrt_segment_intersection(None, 0, -1, 0, None, 0, 0.0, 0.0, 0.0, None, None, None,
                                          None, None, None, None) == -1
+    # round 4 entry points: the folded reverse sweep, the orders, the source programs
+    ok = _lib.Scene3D()
+    ok.n_faces = 0
+    fin, pend = _lib.RayOut(), _lib.GoalPending()
+    fields = (ctypes.c_int32 * 6)(4, 5, 0, 0, 0, 0)
+    dummy = ctypes.create_string_buffer(1 << 16)
+    ptr = ctypes.cast(dummy, ctypes.c_void_p)
+
+    def backward_goal(n_fields=2, goal_ws_bytes=1 << 16, pending=ctypes.byref(pend), stride=10):
+        return lib.tfrt_trace3d_backward_goal(
+            None, 0, 10, ctypes.byref(ok), 1.0, 0.0, 3, 0, ctypes.byref(fin), fields, n_fields, ptr,
+            stride, 1, ptr, None, ptr, goal_ws_bytes, pending, None, 0, None, 0, None, 0, ptr, None,
+            ptr, ptr, 1 << 16, None)
+    assert backward_goal(n_fields=0) == -1 and backward_goal(n_fields=7) == -1
+    assert backward_goal(goal_ws_bytes=0) == -1 and backward_goal(pending=None) == -1
+    assert backward_goal(stride=-1) == -1
+    assert backward_goal() == -1                     # (no finished-ray block: rays is NULL)
+    assert lib.tfrt_trace3d_backward_goal_workspace_bytes(1_000_000) >= 15_625 * 8
+    assert lib.tfrt_trace3d_backward_goal_workspace_bytes(-1) == 0
+    assert lib.tfrt_ray_order(None, 0, -1, 0, None, 0, None, None, None, None, 0, None) == -1
+    assert lib.tfrt_ray_order_workspace_bytes(1_000_000) > 0
+    assert lib.tfrt_source3d_order(None, 0, 10, None, 0, None, None, None, None, 0, None) == -1
+    assert lib.tfrt_epoch_advance(None, 9, None) == -1
 
 
 def test_ops_refuse_cpu_tensors():
