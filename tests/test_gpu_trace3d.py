@@ -741,6 +741,44 @@ def test_coherent_reverse_sweep_gives_the_source_ray_gradient():
         assert float((a - b).abs().max() / b.abs().max()) < 1e-11
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("coherent", [False, True])
+def test_one_wavelength_table_and_per_face_tables_change_no_bit(dtype, coherent):
+    """tfrt_scene3d.n_table_uniform (one table column read by every ray) lets the trace's set-up
+    launch form the face's unit normal AND its index ratios once per face (FaceTables) and the
+    reverse sweep read the indices per face: against the same trace with one table column per
+    ray -- the reaction's per-ray path -- every output bit is the same, in natural and in
+    coherent order, and the gradients agree to the last bits of a differently ordered sum."""
+    from tensorflowraytrace_amd import ops, _lib
+    scene = scene_util.lens_scene(30000, k_front=12, k_back=6)
+    scene["wavelength"] = np.full_like(np.asarray(scene["wavelength"], dtype=np.float64), 587.6)
+    flags = _lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED | _lib.COMPILE_DEAD | _lib.COMPILE_STOPPED
+    src, fv, sc, (p_f, p_b) = _gpu_scene(scene, dtype, cluster="group")
+    if coherent:
+        order = ops.ray_order(src).long()
+        src = src[:, order].contiguous()
+
+    def run(uniform):
+        table = sc.n_table[:, :1].contiguous() if uniform else sc.n_table
+        sc2 = ops.Scene3DArgs(fv, sc.catagory, mat_in=sc.mat_in, mat_out=sc.mat_out, n_table=table,
+                              face_grad_mask=sc.face_grad_mask, cluster_order=sc.cluster_order,
+                              coherent_rays=coherent)
+        sc2.n_table_uniform = uniform
+        out = ops.trace3d(src, fv, sc2, max_passes=4, flags=flags)
+        loss = sum((out[c].double() ** 2).sum() * (k + 1)
+                   for k, c in enumerate(("finished", "active", "stopped", "dead")))
+        return out, torch.autograd.grad(loss, [p_f, p_b], retain_graph=True)
+    ref, g_ref = run(False)
+    out, g = run(True)
+    assert np.array_equal(out["counts"], ref["counts"])
+    for cls in ("finished", "active", "dead", "stopped", "unfinished"):
+        assert torch.equal(out[cls + "_id"], ref[cls + "_id"]), cls
+        assert torch.equal(out[cls], ref[cls]), cls            # every bit
+    assert ref["finished"].shape[1] > 1000
+    for a, b in zip(g, g_ref):
+        assert float((a - b).abs().max() / b.abs().max()) < 1e-11
+
+
 def test_coherent_flag_on_adversarial_soups():
     """Random triangle soups, random rays (no coherence at all, grazing rays, ties, stops): with
     the flag set and any order of the rays the all-pairs result comes back bit for bit."""
