@@ -226,6 +226,35 @@ TFRT_HD double snell2d_angle(double xs, double ys, double xe, double ye, double 
   return norm + theta1 + PI;
 }
 
+// Reciprocal and reciprocal square root for the REVERSE sweep only (the forward's quotients decide
+// hits and must round like the reference's): on the device the hardware estimate refined by
+// Newton steps to the last bit or two -- 6-8 instructions instead of the ~15 of an IEEE float64
+// division or square root; the reverse sweep is bound by float64 issue and its tolerance is
+// 1e-8, not the last bit.  On the host (tests/host_math) the plain operations.
+TFRT_HD double adj_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+TFRT_HD double adj_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  // y <- y + y (1 - x y^2) / 2, twice (the estimate carries ~26 bits)
+  double e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  e = __builtin_fma(-x * y, y, 1.0);
+  y = __builtin_fma(0.5 * y, e, y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // Reverse-mode of one ray through one pass.
 //
@@ -272,12 +301,12 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
     // the forward's second normalisation of an already-unit vector, and only the index ratio
     // that is used is formed: 5 float64 divisions and 3 square roots instead of 14 and 5
     // (a float64 division is ~30 instructions; the kernel is bound by float64 VALU issue).
-    const double inv_c = 1.0 / sqrt(dot3(C, C));
+    const double inv_c = adj_rsqrt(dot3(C, C));
     const double n[3] = {C[0] * inv_c, C[1] * inv_c, C[2] * inv_c};
     const double r[3] = {h[0] - s[0], h[1] - s[1], h[2] - s[2]};
     const double rsq = dot3(r, r);
     const bool clamped = rsq < 1e-12;               // l2_normalize's max(sum x^2, 1e-12)
-    const double inv_r = clamped ? 1e6 : 1.0 / sqrt(rsq);
+    const double inv_r = clamped ? 1e6 : adj_rsqrt(rsq);
     const double u[3] = {r[0] * inv_r, r[1] * inv_r, r[2] * inv_r};
     const double nu = dot3(n, u);
     const bool in_safe = n_in != 0.0, out_safe = n_out != 0.0;
@@ -305,13 +334,15 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
     } else {
       const double sg = branch >= 0 ? (internal ? 1.0 : (nu < 0.0 ? -1.0 : 0.0))
                                     : ((nu > 0.0) ? 1.0 : ((nu < 0.0) ? -1.0 : 0.0));
-      const double rk = sqrt(k);
+      // (k = 0 at the critical angle: 1 / sqrt(k) is infinite there, like the reference's gradient)
+      const double irk = k > 0.0 ? adj_rsqrt(k) : INFINITY;
+      const double rk = k > 0.0 ? k * irk : 0.0;
       const double alpha = sg * rk - nu_eta;
       const double ab = dot3(wb, n);
-      nub = ab * (sg * eta * nu_eta / rk - eta);
+      nub = ab * (sg * eta * nu_eta * irk - eta);
       if (gn != nullptr && gn_wanted) {
         // w = alpha n + eta u, alpha = sg sqrt(1 - eta^2 + eta^2 nu^2) - eta nu
-        const double etab = dot3(wb, u) + ab * (sg * eta * (nu * nu - 1.0) / rk - nu);
+        const double etab = dot3(wb, u) + ab * (sg * eta * (nu * nu - 1.0) * irk - nu);
         if (internal) {            // eta = n_in / n_out
           if (out_safe) {
             gn[0] = in_safe ? etab / nos : 0.0;
@@ -370,7 +401,7 @@ TFRT_HD void adjoint3d(const double s[3], const double e[3], const double P[9], 
   }
   // t = num / den, num = (P0 - s).C, den = d.C
   const double den = dot3(d, C);
-  const double numb = tb / den;
+  const double numb = tb * adj_rcp(den);
   const double denb = -numb * t;
   double Cb[3];
   for (int i = 0; i < 3; ++i) {
