@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFRT_VERSION 105 /* 0.1.0 */
+#define TFRT_VERSION 106 /* 0.1.0 */
 
 #define TFRT_F32 0
 #define TFRT_F64 1
@@ -266,6 +266,21 @@ typedef struct tfrt_scene3d {
    * tfrt_trace3d_backward_goal), cleared without a launch of its own.  NULL / 0: nothing. */
   double* clear_buffer;
   int64_t clear_count;
+  /* With coherent_rays and cluster_order, max_passes >= 1.  1: ALL passes of the trace run in ONE
+   * launch with every ray kept in its slot (k_trace_inplace): a lane intersects, classifies and
+   * refracts its ray pass after pass, the tape holds one record per pass at slot = ray index, and
+   * nothing is compacted between passes -- StandardReaction emits exactly one child per active ray
+   * (tfrt/operation.py:255-307), so the reference's per-pass boolean_mask (tfrt/engine.py:2069-2111)
+   * is not needed to go on tracing.  The reference's output order is made afterwards: a scan of
+   * per-wavefront class counts always (it fills `counts`), and a gather of the class rows only when
+   * tfrt_trace3d_forward is given somewhere to put them (any tfrt_ray_out with rays, or
+   * `unfinished`) -- or later by tfrt_trace3d_compact.  Outputs, counts and gradients are those of
+   * the per-pass path bit for bit (reverse-sweep sums: to the last bits of a differently ordered
+   * sum).  Every wavefront is finished by the one kernel, however wide its bundle (like
+   * coherent_only, which it implies): meant for sources whose earlier traces left no wavefront
+   * over.  The SAME value must be passed to the reverse sweep.  Ignored (per-pass path) when the
+   * conditions above do not hold. */
+  int32_t in_place;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in
@@ -307,6 +322,23 @@ int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
                          uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
                          tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
                          int32_t* unfinished_id, int32_t* counts, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* The class outputs of an in-place trace (tfrt_scene3d.in_place) that tfrt_trace3d_forward was
+ * given no room for: every class compacted stably into `finished` / `active` / `stopped` / `dead`
+ * (+ `unfinished`), rows recomputed from the tape in `workspace`, exactly as a forward call with
+ * these outputs would have left them; `counts` is the array that forward call filled (read here;
+ * its error flag is set when a capacity is exceeded).  Also records every tape entry's output row,
+ * which tfrt_trace3d_backward / _backward_goal need to read class gradients (grad_finished, ...):
+ * call it (or give forward its outputs) before a reverse sweep that is handed any.  Same
+ * src_rays / n_rays / max_passes / state_dtype / flags / dead_ray_length as the forward call.
+ * Replaces the ray-set properties of tfrt/engine.py:1379-1403 for a trace whose sets are cut
+ * lazily. */
+int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                         double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                         uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
+                         tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
+                         int32_t* unfinished_id, int32_t* counts, int64_t n_faces, void* workspace,
                          size_t workspace_bytes, void* stream);
 
 /* Reverse sweep over the tape left in `workspace` by tfrt_trace3d_forward with the same

@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFRT_LIB_PATH") or os.path.join(HERE, "libtfrt_hip.so")
 
-ABI_VERSION = 105          # TFRT_VERSION of include/tfrt_hip.h this module's signatures are written for
+ABI_VERSION = 106          # TFRT_VERSION of include/tfrt_hip.h this module's signatures are written for
 F32, F64, F16 = 0, 1, 2
 OPTICAL, STOP, TARGET = 0, 1, 2
 CLS_ACTIVE, CLS_FINISHED, CLS_STOPPED, CLS_DEAD = 0, 1, 2, 3
@@ -32,6 +32,7 @@ class Scene3D(ctypes.Structure):
         ("face_grad_mask", c_vp), ("cluster_order", c_vp), ("n_table_uniform", c_i32),
         ("deterministic", c_i32), ("coherent_rays", c_i32), ("coherent_only", c_i32),
         ("grad_n_in", c_vp), ("grad_n_out", c_vp), ("clear_buffer", c_vp), ("clear_count", c_i64),
+        ("in_place", c_i32),
     ]
 
 
@@ -132,6 +133,9 @@ SIGNATURES = {
     "tfrt_trace3d_forward": (c_i32, [
         c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32, c_u32,
         _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "tfrt_trace3d_compact": (c_i32, [
+        c_vp, c_i64, c_i64, c_f64, c_i32, c_i32, c_u32,
+        _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "tfrt_trace3d_backward": (c_i32, [
         c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32,
         c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -1629,59 +1629,59 @@ __device__ __forceinline__ void beam_decide(const int nb, const int lane, LdsPtr
   wave_fence();
 }
 
-// BW wavefronts per workgroup.  The wavefronts of a workgroup share nothing and never meet at a
-// barrier, so one per workgroup (BW = 1) lets the dispatcher hand out work wavefront by wavefront:
-// a four-wavefront workgroup holds its LDS and its wave slots until the slowest of the four is done.
-template <typename T, int BW>
-__global__ __launch_bounds__(64 * BW) void k_intersect_beam(
-    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
-    const int32_t* __restrict__ last_tri, const float4* __restrict__ susphere,
-    const float4* __restrict__ clsphere, const float4* __restrict__ csphere,
-    const float4* __restrict__ crec, const double* __restrict__ fverts,
-    const double* __restrict__ c0, int n_clusters, int n_super, double eps_int, double eps_size,
-    double eps_start, const int32_t* __restrict__ catagory, int32_t* __restrict__ rec_tri,
-    double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls, int32_t* __restrict__ hist,
-    int32_t* __restrict__ left_list, int32_t* __restrict__ left_count,
-    int32_t* __restrict__ left_total, int coherent_only, int bundle) {
-  // bundle = rays per wavefront: 64, or 32 (lanes 32..63 carry no ray; they still test nodes) for
-  // launches that leave the chip half empty -- twice the wavefronts, each with fewer candidate
-  // faces and half the decisions: the launch is as long as ONE wavefront's chain of dependent
-  // steps then, not as the work.  (32 only with coherent_only: the grouped kernel takes whole
-  // 64-ray wavefronts.)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int qwave = blockIdx.x * BW + wave;
-  const int q = qwave * bundle + lane;
-  const int n = *n_ptr;
-  if (qwave * bundle >= n) return;  // (whole wave; no block-level synchronisation in this kernel)
+// LDS of one wavefront of the beam walk (k_intersect_beam, k_trace_inplace)
+template <typename RT>
+struct BeamLds {
+  uint16_t slist[BEAM_SLIST];
+  uint16_t clist[BEAM_CLIST];
+  uint32_t flist[BEAM_FLIST];
+  uint32_t x_pair[192];  // face << 6 | lane of the ray (faces < 2^24)
+  float4 ftab[64][4];    // records of a chunk's faces, nearest first (face_frame)
+  RT rtab[6][64];        // the wave's rays as stored (the exact test reads them by slot)
+  unsigned long long best_k[64];
+  int32_t best_i[64];
+};
+
+// the scene as the beam walk reads it (device pointers of one trace)
+struct BeamScene {
+  const float4* susphere;
+  const float4* clsphere;
+  const float4* csphere;
+  const float4* crec;
+  const double* fverts;
+  const double* c0;
+  int n_clusters, n_super;
+  double eps_int, eps_size, eps_start;
+};
+
+#ifdef TFRT_TICKS
+#define TFRT_WI_ARG _wi
+#else
+#define TFRT_WI_ARG nullptr
+#endif
+
+// ONE pass of one wavefront: the rays wait in W.rtab (as stored), `live` lanes carry a ray of this
+// pass, `skip` is the face a ray starts on (-1: none).  Leaves every live ray's nearest valid hit in
+// W.best_k (order-preserving key of ray_u) / W.best_i (face, -1: none).  Returns false when the
+// wavefront is no (few) narrow bundle(s) and the caller should leave it to the grouped kernel
+// (never with coherent_only).
+template <typename T, typename RT>
+__device__ __forceinline__ bool beam_pass(BeamLds<RT>& W, const BeamScene& g, const int lane,
+                                          const int bundle, const bool live, const int skip,
+                                          const bool first_pass, const int coherent_only,
+                                          unsigned* _wi) {
   TFRT_TICK_INIT;
-  TFRT_WAVE_BEGIN;
-  const bool first_pass = last_tri == nullptr;
-
-  // this lane's ray: coalesced reads of the ray block
-  using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
-  const int i = (lane < bundle && q < n) ? q : -1;
-  const bool live = i >= 0;
-  const int64_t ii = live ? i : 0;
-  RT own0[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) own0[k] = static_cast<RT>(rays[k * stride + ii]);
-  const int skip = (live && last_tri != nullptr) ? last_tri[ii] : -1;
+  const float4* __restrict__ susphere = g.susphere;
+  const float4* __restrict__ clsphere = g.clsphere;
+  const float4* __restrict__ csphere = g.csphere;
+  const float4* __restrict__ crec = g.crec;
+  const double* __restrict__ fverts = g.fverts;
+  const double* __restrict__ c0 = g.c0;
+  const int n_clusters = g.n_clusters, n_super = g.n_super;
+  const double eps_int = g.eps_int, eps_size = g.eps_size, eps_start = g.eps_start;
   const float4 never = make_float4(0.f, 0.f, 0.f, -1.f);
-
-  __shared__ uint16_t slist[BW][BEAM_SLIST];
-  __shared__ uint16_t clist[BW][BEAM_CLIST];
-  __shared__ uint32_t flist[BW][BEAM_FLIST];
-  __shared__ uint32_t x_pair[BW][192];  // face << 6 | lane of the ray (faces < 2^24)
-  // records of a chunk's faces, nearest first (face_frame)
-  __shared__ float4 ftab[BW][64][4];
-  __shared__ RT rtab[BW][6][64];  // the wave's rays as stored (the exact test reads them by slot)
-  __shared__ unsigned long long best_k[BW][64];
-  __shared__ int32_t best_i[BW][64];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) rtab[wave][k][lane] = own0[k];
-  best_k[wave][lane] = dkey(INFINITY);
-  best_i[wave][lane] = -1;
-
+  W.best_k[lane] = dkey(INFINITY);
+  W.best_i[lane] = -1;
   const double cx = c0[0], cy = c0[1], cz = c0[2];
   // (exact: c0 is rounded to float32)
   const float cxf = uniform_f((float)cx), cyf = uniform_f((float)cy), czf = uniform_f((float)cz);
@@ -1697,9 +1697,9 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
     TFRT_STAT(28, 1);
     TFRT_WAVE_NOTE(1, 1);
     wave_fence();
-    beam_decide<RT>(nb, lane, (LdsPtr<const uint32_t>)&x_pair[wave][0],
-                    (LdsPtr<const RT>)&rtab[wave][0][0], (LdsPtr<unsigned long long>)&best_k[wave][0],
-                    (LdsPtr<int32_t>)&best_i[wave][0], fverts, eps_int, eps_size, eps_start);
+    beam_decide<RT>(nb, lane, (LdsPtr<const uint32_t>)&W.x_pair[0],
+                    (LdsPtr<const RT>)&W.rtab[0][0], (LdsPtr<unsigned long long>)&W.best_k[0],
+                    (LdsPtr<int32_t>)&W.best_i[0], fverts, eps_int, eps_size, eps_start);
   };
 
   // The wavefront's lanes are taken as ONE bundle; if that bundle is not narrow (the ray order
@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
     wave_fence();
     RT own[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) own[k] = rtab[wave][k][lane];
+    for (int k = 0; k < 6; ++k) own[k] = W.rtab[k][lane];
     const float sx = rel(own[0], cx, cxf), sy = rel(own[1], cy, cyf), sz = rel(own[2], cz, czf);
     const float dx = (float)(own[3] - own[0]), dy = (float)(own[4] - own[1]),
                 dz = (float)(own[5] - own[2]);
@@ -1851,7 +1851,7 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
           const unsigned long long m = __ballot(hit);
           if (hit) {
             const int pos = ns + rank_below(m);
-            if (pos < BEAM_SLIST) slist[wave][pos] = (uint16_t)node;
+            if (pos < BEAM_SLIST) W.slist[pos] = (uint16_t)node;
           }
           ns += __popcll(m);
         }
@@ -1865,13 +1865,13 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
           bool hit = false;
           int cl = 0;
           if (k < ns * SUPER) {
-            cl = (int)slist[wave][k >> 3] * SUPER + (k & 7);
+            cl = (int)W.slist[k >> 3] * SUPER + (k & 7);
             if (cl < n_clusters) hit = beam_touch(bm, clsphere[cl]);
           }
           const unsigned long long m = __ballot(hit);
           if (hit) {
             const int pos = nc + rank_below(m);
-            if (pos < BEAM_CLIST) clist[wave][pos] = (uint16_t)cl;
+            if (pos < BEAM_CLIST) W.clist[pos] = (uint16_t)cl;
           }
           nc += __popcll(m);
         }
@@ -1885,13 +1885,13 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
           bool hit = false;
           unsigned slot = 0;
           if (k < nc * CLUSTER) {
-            slot = (unsigned)clist[wave][k >> 4] * CLUSTER + (unsigned)(k & 15);
+            slot = (unsigned)W.clist[k >> 4] * CLUSTER + (unsigned)(k & 15);
             hit = beam_touch(bm, csphere[slot]);
           }
           const unsigned long long m = __ballot(hit);
           if (hit) {
             const int pos = nf + rank_below(m);
-            if (pos < BEAM_FLIST) flist[wave][pos] = slot;
+            if (pos < BEAM_FLIST) W.flist[pos] = slot;
           }
           nf += __popcll(m);
         }
@@ -1943,12 +1943,8 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
       } else {
         // not a wavefront of (a few) narrow bundles: the grouped kernel does it
         TFRT_STAT(ns > BEAM_SLIST ? 10 : (nc > BEAM_CLIST ? 11 : (nf > BEAM_FLIST ? 12 : 9)), 1);
-        TFRT_STAT(15, qwave * bundle + lo);
-        if (lane == 0) {
-          left_list[atomicAdd(left_count, 1)] = qwave;
-          atomicAdd(left_total, 1);
-        }
-        return;
+        TFRT_STAT(15, lo);
+        return false;
       }
     }
 
@@ -1967,7 +1963,7 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
     TFRT_TICK(5);
     // upper bound of the axial coordinate of this ray's nearest hit so far (inf: none)
     auto reach_now = [&]() {
-      const double best = dkey_inv(best_k[wave][lane]);
+      const double best = dkey_inv(W.best_k[lane]);
       const float bu = nextafterf((float)best, INFINITY) * ray_dt;  // (d . w > 0: cos > 0.7)
       return ray_t + bu + 1e-5f * fabsf(bu) + ray_terr;
     };
@@ -1996,7 +1992,7 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
         cand = v2 - vu * vu <= rr * rr + 4e-6f * v2;  // (padding: w < 0, NaN, never)
       }
       if (cand) {
-        const int64_t memb = brute ? (int64_t)(f0 + lane) : (int64_t)flist[wave][f0 + lane];
+        const int64_t memb = brute ? (int64_t)(f0 + lane) : (int64_t)W.flist[f0 + lane];
         const float4 r0 = crec[3 * memb], r1 = crec[3 * memb + 1], r2 = crec[3 * memb + 2];
         touch = face_frame(bm, r0, r1, r2, es_f, rec) && __float_as_int(r0.w) >= 0;
         tnear = rec[0].w;
@@ -2016,10 +2012,10 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
       }
       wave_fence();  // (the previous chunk's records have been read)
       if (touch) {
-        ftab[wave][place][0] = rec[0];
-        ftab[wave][place][1] = rec[1];
-        ftab[wave][place][2] = rec[2];
-        ftab[wave][place][3] = rec[3];
+        W.ftab[place][0] = rec[0];
+        W.ftab[place][1] = rec[1];
+        W.ftab[place][2] = rec[2];
+        W.ftab[place][3] = rec[3];
       }
       wave_fence();
       TFRT_STAT(27, nt);
@@ -2047,7 +2043,7 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
         const bool end = c >= nt;  // (behind the chunk's last face: only decisions, if any)
         const bool two = c + 1 < nt;
         const float word =
-            reinterpret_cast<const float*>(&ftab[wave][end ? 0 : c][0])[lane & (two ? 31 : 15)];
+            reinterpret_cast<const float*>(&W.ftab[end ? 0 : c][0])[lane & (two ? 31 : 15)];
         const float tn = end ? INFINITY : bcast_f(word, 3);
         // decide what is queued: full batches; or at a gap in depth when every ray has a hit or
         // a candidate (the walk may end here); or at the very end
@@ -2060,11 +2056,11 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
           decide(nd);
           // (what is left, fewer than 128 pairs, moves to the front)
           uint32_t tp = 0u, tq = 0u;
-          if (lane < xn - nd) tp = x_pair[wave][nd + lane];
-          if (lane + 64 < xn - nd) tq = x_pair[wave][nd + 64 + lane];
+          if (lane < xn - nd) tp = W.x_pair[nd + lane];
+          if (lane + 64 < xn - nd) tq = W.x_pair[nd + 64 + lane];
           wave_fence();
-          if (lane < xn - nd) x_pair[wave][lane] = tp;
-          if (lane + 64 < xn - nd) x_pair[wave][64 + lane] = tq;
+          if (lane < xn - nd) W.x_pair[lane] = tp;
+          if (lane + 64 < xn - nd) W.x_pair[64 + lane] = tq;
           xn -= nd;
           wave_fence();
           // (rays with a pair among those moved stay "queued")
@@ -2087,8 +2083,8 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
         span = fmaxf(span, fmaxf(thia, thib));
         const unsigned long long kma = __ballot(keepa), kmb = __ballot(keepb);
         const int na = __popcll(kma);
-        if (keepa) x_pair[wave][xn + rank_below(kma)] = ((uint32_t)ja << 6) | (uint32_t)lane;
-        if (keepb) x_pair[wave][xn + na + rank_below(kmb)] = ((uint32_t)jb << 6) | (uint32_t)lane;
+        if (keepa) W.x_pair[xn + rank_below(kma)] = ((uint32_t)ja << 6) | (uint32_t)lane;
+        if (keepb) W.x_pair[xn + na + rank_below(kmb)] = ((uint32_t)jb << 6) | (uint32_t)lane;
         queued = queued || keepa || keepb;
         xn += na + __popcll(kmb);
         TFRT_STAT(14, na + __popcll(kmb));
@@ -2098,14 +2094,59 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
     lo = hi;  // this bundle is done: the next one starts behind it
   }
   wave_fence();
+  return true;
+}
+
+// BW wavefronts per workgroup.  The wavefronts of a workgroup share nothing and never meet at a
+// barrier, so one per workgroup (BW = 1) lets the dispatcher hand out work wavefront by wavefront:
+// a four-wavefront workgroup holds its LDS and its wave slots until the slowest of the four is done.
+template <typename T, int BW>
+__global__ __launch_bounds__(64 * BW) void k_intersect_beam(
+    const T* __restrict__ rays, int64_t stride, const int32_t* __restrict__ n_ptr,
+    const int32_t* __restrict__ last_tri, BeamScene g, const int32_t* __restrict__ catagory,
+    int32_t* __restrict__ rec_tri, double* __restrict__ rec_t, uint8_t* __restrict__ rec_cls,
+    int32_t* __restrict__ hist, int32_t* __restrict__ left_list, int32_t* __restrict__ left_count,
+    int32_t* __restrict__ left_total, int coherent_only, int bundle) {
+  // bundle = rays per wavefront: 64, or 32 (lanes 32..63 carry no ray; they still test nodes) for
+  // launches that leave the chip half empty -- twice the wavefronts, each with fewer candidate
+  // faces and half the decisions: the launch is as long as ONE wavefront's chain of dependent
+  // steps then, not as the work.  (32 only with coherent_only: the grouped kernel takes whole
+  // 64-ray wavefronts.)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qwave = blockIdx.x * BW + wave;
+  const int q = qwave * bundle + lane;
+  const int n = *n_ptr;
+  if (qwave * bundle >= n) return;  // (whole wave; no block-level synchronisation in this kernel)
+  TFRT_WAVE_BEGIN;
+
+  // this lane's ray: coalesced reads of the ray block
+  using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
+  const int i = (lane < bundle && q < n) ? q : -1;
+  const bool live = i >= 0;
+  const int64_t ii = live ? i : 0;
+  __shared__ BeamLds<RT> lds[BW];
+  BeamLds<RT>& W = lds[wave];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W.rtab[k][lane] = static_cast<RT>(rays[k * stride + ii]);
+  const int skip = (live && last_tri != nullptr) ? last_tri[ii] : -1;
+  if (!beam_pass<T, RT>(W, g, lane, bundle, live, skip, last_tri == nullptr, coherent_only,
+                        TFRT_WI_ARG)) {
+    // not a wavefront of (a few) narrow bundles: the grouped kernel does it
+    if (lane == 0) {
+      left_list[atomicAdd(left_count, 1)] = qwave;
+      atomicAdd(left_total, 1);
+    }
+    return;
+  }
+  wave_fence();
 
   // ---- hit record, class and this wavefront's share of its 256-ray block's class histogram
   int cls = -1;
   if (live) {
-    const int bi = best_i[wave][lane];
+    const int bi = W.best_i[lane];
     cls = (bi < 0) ? CLS_DEAD : cat_to_cls(catagory[bi]);
     rec_tri[i] = bi;
-    rec_t[i] = dkey_inv(best_k[wave][lane]);
+    rec_t[i] = dkey_inv(W.best_k[lane]);
     rec_cls[i] = (uint8_t)cls;
   }
 #pragma unroll
@@ -2113,7 +2154,6 @@ __global__ __launch_bounds__(64 * BW) void k_intersect_beam(
     const int cnt_c = __popcll(__ballot(cls == c));
     if (lane == c && cnt_c > 0) atomicAdd(&hist[((qwave * bundle) >> 8) * 4 + c], cnt_c);
   }
-  TFRT_TICK(9);
   TFRT_WAVE_END(qwave);
 }
 
@@ -2467,6 +2507,305 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_
   if (!ok) atomicOr(err, ERR_CAPACITY);
 }
 
+// ------------------------------------------------------------------ in-place trace
+//
+// tfrt_scene3d.in_place: ALL passes of a trace over coherent rays in ONE launch.  The per-pass
+// sequence above (intersect -> [scan] -> react) exists because the reference compacts the children
+// between passes (engine.py:2069-2111) -- but StandardReaction emits exactly one child per active
+// ray (operation.py:255-307), so a lane can keep its ray: intersect (beam_pass), classify, Snell,
+// next pass, with the ray in LDS / registers and one tape record per pass at slot = ray index.
+// Nothing is compacted while tracing: no scan, no block of children written and read back per
+// pass, one launch ramp instead of 2 P.  A wavefront whose rays have all ended leaves the loop;
+// wavefronts never meet (no grid barrier).  The reference's output order -- every class lists its
+// rays pass after pass in source order, engine.py:2095, 1379-1403 -- is made afterwards from the
+// per-wavefront class counts the trace leaves: one scan (k_inplace_scan: the per-pass counts the
+// host reads, and every wavefront's bases) and, only when a ray set is asked for, one gather
+// (k_inplace_gather: rows recomputed from the tape, which holds everything they are made of).
+// Results are those of the per-pass path bit for bit: a ray's nearest hit does not depend on which
+// rays share its wavefront (every stage of the walk only removes pairs that cannot win), and the
+// child is rounded to the state type exactly where the per-pass path stores it.
+inline int inplace_bundle(int64_t N) { return N <= 160 * 1024 ? 32 : 64; }
+
+template <typename T>
+struct InplaceArgs {
+  const T* src;          // source rays (inputs of pass 1)
+  int64_t src_stride;
+  int32_t N, P, bundle, nwaves;
+  T* rays_ws;            // child of pass p (input of pass p + 1) at (p * 6 + k) * n + ray
+  int32_t* rec_tri;      // [p * n + ray]
+  double* rec_t;
+  uint8_t* rec_cls;
+  int64_t n;
+  uint32_t* wcount;      // [p * nwaves + wavefront]: four class counts, one byte each
+  const int32_t* catagory;
+  const double* fnorm;   // FaceTables
+  const double* feta;    // ... or null: the indices depend on the ray (n_table, one column per ray)
+  const double* n_table;
+  const int32_t* mat_in;
+  const int32_t* mat_out;
+  int64_t n_table_stride;
+  double L;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_trace_inplace(InplaceArgs<T> a, BeamScene g) {
+  using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
+  const int lane = threadIdx.x, qwave = blockIdx.x;
+  const int q = qwave * a.bundle + lane;
+  const bool has = lane < a.bundle && q < a.N;
+  const int64_t i = has ? q : 0;
+  __shared__ BeamLds<RT> lds;
+  BeamLds<RT>& W = lds;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) W.rtab[k][lane] = static_cast<RT>(a.src[k * a.src_stride + i]);
+  bool active = has;
+  int skip = -1;
+  int p = 0;
+  for (; p < a.P; ++p) {
+    if (__ballot(active) == 0ull) break;  // (wave-uniform: every ray of the wavefront has ended)
+    beam_pass<T, RT>(W, g, lane, a.bundle, active, skip, p == 0, /*coherent_only=*/1, nullptr);
+    wave_fence();
+    int cls = -1;
+    if (active) {
+      const int bi = W.best_i[lane];
+      const double t = dkey_inv(W.best_k[lane]);
+      cls = (bi < 0) ? CLS_DEAD : cat_to_cls(a.catagory[bi]);
+      const size_t at = (size_t)p * a.n + i;
+      a.rec_tri[at] = bi;
+      a.rec_t[at] = t;
+      int tape = cls;
+      if (cls == CLS_ACTIVE) {
+        // k_react3d's reaction: project the end onto the hit, refract / reflect (float64 Snell)
+        double s[3], e[3], h[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          s[k] = static_cast<double>(W.rtab[k][lane]);
+          e[k] = static_cast<double>(W.rtab[3 + k][lane]);
+        }
+        hit_point(s, e, t, h);
+        double un[3], n1, n2, n_in;
+        const double* fp = a.fnorm + 3 * (int64_t)bi;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) un[k] = fp[k];
+        if (a.feta != nullptr) {
+          const double* fe = a.feta + 4 * (int64_t)bi;
+          n1 = fe[0];
+          n2 = fe[1];
+          n_in = fe[2];
+        } else {
+          // (feta is only absent in "index" mode with one table column per source ray)
+          n_in = a.n_table[(int64_t)a.mat_in[bi] * a.n_table_stride + i];
+          const double n_out = a.n_table[(int64_t)a.mat_out[bi] * a.n_table_stride + i];
+          snell_ratios(n_in, n_out, &n1, &n2);
+        }
+        const Snell3 f = snell3d_core(s, h, un, n1, n2, n_in == 0.0);
+        tape |= (f.nu > 0.0 ? TAPE_INTERNAL : 0) | (f.reflect ? TAPE_REFLECT : 0);
+        // the child, rounded to the state type where the per-pass path stores it; it stays here
+        T* out = a.rays_ws + (size_t)p * 6 * a.n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const T hs = static_cast<T>(h[k]);
+          const T es = static_cast<T>(advance(h[k], a.L, f.w[k]));
+          out[k * a.n + i] = hs;
+          out[(3 + k) * a.n + i] = es;
+          W.rtab[k][lane] = static_cast<RT>(hs);
+          W.rtab[3 + k][lane] = static_cast<RT>(es);
+        }
+        skip = bi;
+      } else {
+        active = false;
+      }
+      a.rec_cls[at] = (uint8_t)tape;
+    }
+    uint32_t word = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) word |= (uint32_t)__popcll(__ballot(cls == c)) << (8 * c);
+    if (lane == 0) a.wcount[(size_t)p * a.nwaves + qwave] = word;
+  }
+  // (passes this wavefront never reached: no rays)
+  for (int pp = p + lane; pp < a.P; pp += 64) a.wcount[(size_t)pp * a.nwaves + qwave] = 0u;
+}
+
+// The counts of an in-place trace: workgroup p sums the class counts of the passes before its own
+// (the rays every class has listed so far: base_*), scans its own pass's per-wavefront counts
+// (wbase: where a wavefront's rays of each class begin within the pass) and writes its row of
+// `counts`; the last one also writes the trailing totals and the test count.  No workgroup waits
+// for another (each reads (p + 1) x nwaves words: a few hundred KB from the L2).
+__global__ __launch_bounds__(1024) void k_inplace_scan(const uint32_t* __restrict__ wcount,
+                                                       int nwaves, int P, int N, int M,
+                                                       int4* __restrict__ wbase,
+                                                       int32_t* __restrict__ counts) {
+  const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int wsum[16][4];
+  __shared__ int red[4];
+  auto unpack = [](uint32_t w, int v[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += (int)((w >> (8 * c)) & 0xFFu);
+  };
+  // rays of each class listed by earlier passes
+  int before[4] = {0, 0, 0, 0};
+  {
+    int acc[4] = {0, 0, 0, 0};
+    const int64_t total = (int64_t)p * nwaves;
+    for (int64_t k = tid; k < total; k += 1024) unpack(wcount[k], acc);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) acc[c] += __shfl_xor(acc[c], d, 64);
+      if (lane == 0) wsum[wave][c] = acc[c];
+    }
+    __syncthreads();
+    if (tid < 4) {
+      int r = 0;
+      for (int w = 0; w < 16; ++w) r += wsum[w][tid];
+      red[tid] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) before[c] = red[c];
+    __syncthreads();
+  }
+  // this pass: every thread takes a run of consecutive wavefronts
+  const uint32_t* row = wcount + (size_t)p * nwaves;
+  const int seg = (nwaves + 1023) / 1024;
+  const int w0 = min(tid * seg, nwaves), w1 = min(w0 + seg, nwaves);
+  int mine[4] = {0, 0, 0, 0};
+  for (int w = w0; w < w1; ++w) unpack(row[w], mine);
+  int pre[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int x = mine[c];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(x, d, 64);
+      if (lane >= d) x += o;
+    }
+    pre[c] = x - mine[c];
+    if (lane == 63) wsum[wave][c] = x;
+  }
+  __syncthreads();
+  int tot[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    int r = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w == wave) pre[c] += r;
+      r += wsum[w][c];
+    }
+    tot[c] = r;
+  }
+  int4* out = wbase + (size_t)p * nwaves;
+  for (int w = w0; w < w1; ++w) {
+    out[w] = make_int4(pre[0], pre[1], pre[2], pre[3]);
+    unpack(row[w], pre);
+  }
+  if (tid < 4) {
+    counts[(size_t)p * TFRT_COUNTS_PER_PASS + tid] = tot[tid];
+    counts[(size_t)p * TFRT_COUNTS_PER_PASS + 4 + tid] = before[tid];
+  }
+  if (p == P - 1) {
+    int32_t* tail = counts + (size_t)P * TFRT_COUNTS_PER_PASS;
+    if (tid < 4) tail[tid] = before[tid] + tot[tid];
+    if (tid == 4) {
+      // rays entering pass 1..P: the source, then the rays still active after each pass
+      const unsigned long long tests =
+          ((unsigned long long)N + (unsigned long long)before[CLS_ACTIVE]) * (unsigned long long)M;
+      tail[4] = (int32_t)(uint32_t)(tests & 0xFFFFFFFFull);
+      tail[5] = (int32_t)(uint32_t)(tests >> 32);
+    }
+  }
+}
+
+// The ray sets of an in-place trace in the reference's order: a wavefront's lanes walk their
+// rays' records, rank themselves inside their class (ballots) behind their wavefront's base, and
+// write the rows k_react3d would have written at the same slots -- recomputed from the tape, which
+// holds everything a row is made of (the pass's input ray and the hit parameter).  rec_slot
+// receives every record's output slot within its class (the reverse sweep reads class gradients
+// through it).
+template <typename T>
+struct GatherArgs {
+  const T* src;
+  int64_t src_stride;
+  int32_t N, P, bundle, nwaves;
+  const T* rays_ws;
+  const int32_t* rec_tri;
+  const double* rec_t;
+  const uint8_t* rec_cls;
+  int32_t* rec_slot;
+  int64_t n;
+  const int4* wbase;
+  const int32_t* counts;
+  uint32_t flags;
+  double dead_len;
+  tfrt_ray_out fin, act, stp, dead;
+  T* unfinished;
+  int32_t* unfinished_id;
+  int32_t* err;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_inplace_gather(GatherArgs<T> a) {
+  const int lane = threadIdx.x, qwave = blockIdx.x;
+  const int q = qwave * a.bundle + lane;
+  const bool has = lane < a.bundle && q < a.N;
+  const int64_t i = has ? q : 0;
+  bool alive = has, ok = true;
+  int p = 0;
+  for (; p < a.P; ++p) {
+    if (__ballot(alive) == 0ull) break;
+    const size_t at = (size_t)p * a.n + i;
+    const int cls = alive ? ((int)a.rec_cls[at] & 3) : -1;
+    int rank = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const unsigned long long m = __ballot(cls == c);
+      if (cls == c) rank = rank_below(m);
+    }
+    if (alive) {
+      const int4 wb = a.wbase[(size_t)p * a.nwaves + qwave];
+      const int in_pass = (cls == 0 ? wb.x : (cls == 1 ? wb.y : (cls == 2 ? wb.z : wb.w))) + rank;
+      const int64_t gslot = (int64_t)a.counts[(size_t)p * TFRT_COUNTS_PER_PASS + 4 + cls] + in_pass;
+      a.rec_slot[at] = (int32_t)gslot;
+      const T* rin = p == 0 ? a.src : a.rays_ws + (size_t)(p - 1) * 6 * a.n;
+      const int64_t sin = p == 0 ? a.src_stride : a.n;
+      double s[3], e[3];
+      load_ray3(rin, sin, i, s, e);
+      const int tri = a.rec_tri[at];
+      if (cls == CLS_DEAD) {
+        if (a.flags & TFRT_COMPILE_DEAD) {
+          double e2[3] = {e[0], e[1], e[2]};
+          if (a.dead_len != 0.0)
+            for (int k = 0; k < 3; ++k) e2[k] = advance_between(s[k], a.dead_len, e[k]);
+          ok = emit<T>(a.dead, gslot, s, e2, (int)i, -1) && ok;
+        }
+      } else {
+        double h[3];
+        hit_point(s, e, a.rec_t[at], h);
+        if (cls == CLS_FINISHED) {
+          if (a.flags & TFRT_COMPILE_FINISHED) ok = emit<T>(a.fin, gslot, s, h, (int)i, tri) && ok;
+        } else if (cls == CLS_STOPPED) {
+          if (a.flags & TFRT_COMPILE_STOPPED) ok = emit<T>(a.stp, gslot, s, h, (int)i, tri) && ok;
+        } else if (a.flags & TFRT_COMPILE_ACTIVE) {
+          ok = emit<T>(a.act, gslot, s, h, (int)i, tri) && ok;
+        }
+      }
+      if (cls != CLS_ACTIVE) alive = false;
+    }
+  }
+  if (!ok) atomicOr(a.err, ERR_CAPACITY);
+  // the rays still active after the last pass (what single_pass returns, engine.py:2302)
+  if (p == a.P && a.P > 0 && a.unfinished != nullptr) {
+    const unsigned long long m = __ballot(alive);
+    if (alive) {
+      const int slot = a.wbase[(size_t)(a.P - 1) * a.nwaves + qwave].x + rank_below(m);
+      const T* rin = a.rays_ws + (size_t)(a.P - 1) * 6 * a.n;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a.unfinished[(int64_t)k * a.N + slot] = rin[k * a.n + i];
+      if (a.unfinished_id != nullptr) a.unfinished_id[slot] = (int32_t)i;
+    }
+  }
+}
+
 // -------------------------------------------------------------------------- backward
 
 template <typename G>
@@ -2807,7 +3146,10 @@ __device__ __forceinline__ int backward_core(
     const double* __restrict__ g_fin, int64_t cap_fin, const double* __restrict__ g_act,
     int64_t cap_act, const double* __restrict__ g_stp, int64_t cap_stp,
     const double* __restrict__ g_dead, int64_t cap_dead, double gs[3], double ge[3],
-    double gP[9], int tri_known = -2, const double* __restrict__ feta = nullptr) {
+    double gP[9], int tri_known = -2, const double* __restrict__ feta = nullptr,
+    bool slot_global = false) {
+  // slot_global: `slot` is the row of the slot's output class in the whole trace (in-place traces:
+  // rec_slot as k_inplace_gather left it), not the row within its pass
   // tri_known >= 0: the caller already holds the slot's face (k_backward_chain reads it on its
   // way forward); the face, the hit parameter and the indices are then asked for together with
   // the ray, before anything decides whether the slot carries a gradient at all -- one round
@@ -2861,7 +3203,8 @@ __device__ __forceinline__ int backward_core(
     } else if (cls == CLS_STOPPED) {
       add6(g_stp, cap_stp, slot, g_s, g_h);
     } else {
-      add6(g_act, cap_act, (int64_t)pass_counts[4 + CLS_ACTIVE] + slot, g_s, g_h);
+      if (g_act != nullptr)
+        add6(g_act, cap_act, (slot_global ? 0 : (int64_t)pass_counts[4 + CLS_ACTIVE]) + slot, g_s, g_h);
       if (child_pass) {
         has_child = true;
         for (int k = 0; k < 3; ++k) {
@@ -2971,6 +3314,12 @@ struct ChainArgs {
   int64_t goal_stride, goal_ray_stride;
   double* partial;         // one partial error sum per wavefront of the launch
   const double* feta;      // per-face indices (FaceTables) or null
+  // tape of an in-place trace (tfrt_scene3d.in_place): a ray keeps its slot through all passes.
+  // 1: rec_slot holds every record's row in its output class (k_inplace_gather ran: the class
+  // gradients are read through it); 2: no class gradient but the built-in goal's -- rec_slot is
+  // never read, the finished row is recomputed from the tape
+  int32_t inplace;
+  int32_t chain_in_lds;    // the chain's records wait in LDS (P <= CHAIN_MAXP), else re-read (in place only)
 };
 
 template <typename T, int BW, bool GOAL>
@@ -2997,11 +3346,12 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     int j = i0;
     for (int p = 0; p < P; ++p) {
       const size_t at = (size_t)p * a.n + j;
-      const int tape = a.rec_cls[at], slot = a.rec_slot[at], tri = a.rec_tri[at];
-      chain[p * 64 + lane] = make_int4(j, tape, slot, tri);
+      const int tape = a.rec_cls[at], tri = a.rec_tri[at];
+      const int slot = a.inplace == 2 ? j : a.rec_slot[at];
+      if (a.chain_in_lds) chain[p * 64 + lane] = make_int4(j, tape, slot, tri);
       last = p;
       if ((tape & 3) != CLS_ACTIVE || p == P - 1) break;
-      j = slot;
+      if (!a.inplace) j = slot;
     }
   }
   // (wave-uniform bound of the walk back)
@@ -3014,19 +3364,48 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     double gP[9];
     int tri = -1;
     if (p <= last) {
-      const int4 rec = chain[p * 64 + lane];
+      int4 rec;
+      if (a.chain_in_lds) {
+        rec = chain[p * 64 + lane];
+      } else {  // (an in-place tape of more passes than the LDS columns hold: the ray stays at i0)
+        const size_t at = (size_t)p * a.n + i0;
+        rec = make_int4(i0, a.rec_cls[at], a.inplace == 2 ? i0 : a.rec_slot[at], a.rec_tri[at]);
+      }
       const int j = rec.x, tape = rec.y, slot = rec.z;
       const size_t off = (size_t)p * a.n;
       const T* rin = p == 0 ? a.src : a.rays_ws + (size_t)(p - 1) * 6 * a.n;
       const int64_t sin = p == 0 ? a.src_stride : a.n;
-      const int32_t* idin = p == 0 ? nullptr : a.rayid + (size_t)(p - 1) * a.n;
+      // (in place a slot's source ray is the slot itself)
+      const int32_t* idin = (p == 0 || a.inplace) ? nullptr : a.rayid + (size_t)(p - 1) * a.n;
       double seed[6] = {0, 0, 0, 0, 0, 0};
       if (GOAL && p == last && (tape & 3) == CLS_FINISHED) {
         // tfrt_goal_error3d's terms for this ray: the output AS STORED in the finished block
         // minus the goal row of the source ray; d (sum of squares) = 2 (output - goal)
+        // (in-place traces write no finished block: the row k_inplace_gather would store is
+        // recomputed from the tape -- the pass's input ray and the hit parameter -- and rounded
+        // to the state type like the stored one)
+        double fin_row[6] = {0, 0, 0, 0, 0, 0};
+        if (a.inplace) {
+          double s0[3], e0[3], h0[3];
+          load_ray3(rin, sin, j, s0, e0);
+          hit_point(s0, e0, a.rec_t[off + j], h0);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            fin_row[k] = s0[k];
+            fin_row[3 + k] = static_cast<double>(static_cast<T>(h0[k]));
+          }
+        }
         for (int c = 0; c < a.gf.n; ++c) {
           const int row = a.gf.row[c];
-          const double r = ldd(a.fin_rays, (int64_t)row * a.fin_cap + slot) -
+          double out_c = 0.0;
+          if (a.inplace) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k)   // (no dynamic register index)
+              if (k == row) out_c = fin_row[k];
+          } else {
+            out_c = ldd(a.fin_rays, (int64_t)row * a.fin_cap + slot);
+          }
+          const double r = out_c -
                            a.goal[(int64_t)c * a.goal_stride + (int64_t)i0 * a.goal_ray_stride];
           const double g = 2.0 * r;
 #pragma unroll
@@ -3040,7 +3419,7 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
                              a.counts + (size_t)p * TFRT_COUNTS_PER_PASS, sc, a.L, a.dead_len,
                              p < P - 1, child, GOAL ? seed : nullptr, a.g_fin, a.cap_fin, a.g_act,
                              a.cap_act, a.g_stp, a.cap_stp, a.g_dead, a.cap_dead, gs, ge, gP,
-                             rec.w, a.feta);
+                             rec.w, a.feta, a.inplace != 0);
       for (int k = 0; k < 3; ++k) {
         child[k] = gs[k];
         child[3 + k] = ge[k];
@@ -3174,7 +3553,8 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
-  size_t csphere, cface, clsphere, susphere, crec, fnorm, feta, hist_a, hist_b, left_list;
+  size_t csphere, cface, clsphere, susphere, crec, fnorm, feta, hist_a, hist_b, left_list, wcount,
+      wbase;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -3213,6 +3593,10 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.hist_a = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   // (+ the count of wavefronts
   L.hist_b = take(((size_t)pl.nblk * 4 + 1) * sizeof(int32_t));   //  left to the grouped kernel)
   L.left_list = take((n + 63) / 64 * sizeof(int32_t));
+  // in-place traces (tfrt_scene3d.in_place): per pass and wavefront (of 32 rays at least) the packed
+  // class counts and the bases k_inplace_scan makes of them
+  L.wcount = take((size_t)(P > 0 ? P : 1) * ((n + 31) / 32) * sizeof(uint32_t));
+  L.wbase = take((size_t)(P > 0 ? P : 1) * ((n + 31) / 32) * sizeof(int4));
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -3304,9 +3688,10 @@ static int launch_intersect(const Plan3& pl, hipStream_t st, const T* rays, int6
     int bundle = 64;
     if (od->coherent_only && od->nq <= 160 * 1024) bundle = 32;  // (125k rays: 0.191 against 0.200 ms per step; 250k: 0.223 against 0.211)
     constexpr int BEAM_BW = 1;
+    const BeamScene bs = {ac->susphere, ac->clsphere, ac->csphere, ac->crec, fverts, c0,
+                          ac->n_clusters, od->n_super, ei, es, er};
     hipLaunchKernelGGL((k_intersect_beam<T, BEAM_BW>), dim3(cdiv(od->nq, BEAM_BW * bundle)),
-                       dim3(64 * BEAM_BW), 0, st, rays, stride, n_ptr, last_tri, ac->susphere, ac->clsphere, ac->csphere,
-                       ac->crec, fverts, c0, ac->n_clusters, od->n_super, ei, es, er, fz.catagory,
+                       dim3(64 * BEAM_BW), 0, st, rays, stride, n_ptr, last_tri, bs, fz.catagory,
                        fz.rec_tri, fz.rec_t, fz.rec_cls, od->hist, od->left_list,
                        od->left_count, od->left_total, od->coherent_only, bundle);
     // (enough workgroups to fill the chip when every wavefront is left over; they loop)
@@ -3345,6 +3730,50 @@ static bool scene_ok(const tfrt_scene3d* sc) {
   const bool index_mode = sc->mat_in && sc->mat_out && sc->n_table;
   const bool value_mode = sc->n_in && sc->n_out;
   return sc->n_faces == 0 || index_mode || value_mode;
+}
+
+// does this trace take the in-place route (tfrt_scene3d.in_place)?  The same test in the forward,
+// the reverse sweep and tfrt_trace3d_compact.
+static bool inplace_trace(const tfrt_scene3d* sc, int64_t N, int64_t M, int P) {
+  const bool hierarchy = M >= 4 * CLUSTER && M < (1 << 24) - CLUSTER && sc->cluster_order != nullptr;
+  return sc->in_place != 0 && sc->coherent_rays != 0 && sc->deterministic == 0 && hierarchy &&
+         N >= 64 && P >= 1;
+}
+
+template <typename T>
+static int inplace_gather_t(const void* src_rays, int64_t src_stride, int64_t N, double dead_len,
+                            int P, uint32_t flags, const tfrt_ray_out* fin, const tfrt_ray_out* act,
+                            const tfrt_ray_out* stp, const tfrt_ray_out* dead, void* unfinished,
+                            int32_t* unfinished_id, int32_t* counts, char* ws, const Layout3& lay,
+                            hipStream_t st) {
+  const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};
+  const size_t n = N > 0 ? N : 1;
+  GatherArgs<T> a;
+  a.src = static_cast<const T*>(src_rays);
+  a.src_stride = src_stride;
+  a.N = (int32_t)N;
+  a.P = P;
+  a.bundle = inplace_bundle(N);
+  a.nwaves = cdiv(N, a.bundle);
+  a.rays_ws = reinterpret_cast<const T*>(ws + lay.rays);
+  a.rec_tri = reinterpret_cast<const int32_t*>(ws + lay.rec_tri);
+  a.rec_t = reinterpret_cast<const double*>(ws + lay.rec_t);
+  a.rec_cls = reinterpret_cast<const uint8_t*>(ws + lay.rec_cls);
+  a.rec_slot = reinterpret_cast<int32_t*>(ws + lay.rec_slot);
+  a.n = (int64_t)n;
+  a.wbase = reinterpret_cast<const int4*>(ws + lay.wbase);
+  a.counts = counts;
+  a.flags = flags;
+  a.dead_len = dead_len;
+  a.fin = fin ? *fin : none;
+  a.act = act ? *act : none;
+  a.stp = stp ? *stp : none;
+  a.dead = dead ? *dead : none;
+  a.unfinished = static_cast<T*>(unfinished);
+  a.unfinished_id = unfinished_id;
+  a.err = counts + (size_t)P * TFRT_COUNTS_PER_PASS + 6;
+  hipLaunchKernelGGL((k_inplace_gather<T>), dim3(a.nwaves), dim3(64), 0, st, a);
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 
 template <typename T>
@@ -3414,6 +3843,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     pl.g_chunks = 1;
     pl.g_chunk_clusters = (ac.n_clusters + 7) / 8 * 8;
   }
+  const bool inplace = inplace_trace(sc, N, M, P);
   if (M > 0) {
     if (ac.order != nullptr) {  // (the hierarchy kernel also does k_center's work)
       const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
@@ -3421,7 +3851,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL(k_hierarchy_spheres, dim3(n_super + cl_blocks), dim3(BLOCK), 0, st,
                          sc->face_verts, M, ac.order, c0, sc->size_epsilion, ac.n_clusters,
                          n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
-                         (int)N, tail, ticket, hist_ab[0], coherent ? pl.nblk * 4 + 1 : 0, ft,
+                         (int)N, tail, ticket, hist_ab[0],
+                         (coherent && !inplace) ? pl.nblk * 4 + 1 : 0, ft,
                          sc->clear_buffer, sc->clear_buffer ? sc->clear_count : 0);
     } else {
       hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
@@ -3431,8 +3862,47 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                          sc->clear_buffer ? sc->clear_count : 0);
     }
   }
-  const int chunks_used = ac.order == nullptr ? pl.chunks : pl.g_chunks;
   const tfrt_ray_out none = {nullptr, nullptr, nullptr, 0};
+  if (inplace) {
+    // every pass in one launch, rays in place; then the counts, then (only if asked) the ray sets
+    InplaceArgs<T> a;
+    a.src = static_cast<const T*>(src_rays);
+    a.src_stride = src_stride;
+    a.N = (int32_t)N;
+    a.P = P;
+    a.bundle = inplace_bundle(N);
+    a.nwaves = cdiv(N, a.bundle);
+    a.rays_ws = rays_ws;
+    a.rec_tri = rec_tri;
+    a.rec_t = rec_t;
+    a.rec_cls = rec_cls;
+    a.n = (int64_t)n;
+    a.wcount = reinterpret_cast<uint32_t*>(ws + lay.wcount);
+    a.catagory = sc->catagory;
+    a.fnorm = ft.fnorm;
+    a.feta = ft.feta;
+    a.n_table = sc->n_table;
+    a.mat_in = sc->mat_in;
+    a.mat_out = sc->mat_out;
+    a.n_table_stride = sc->n_table_stride;
+    a.L = L;
+    const BeamScene bs = {ac.susphere, ac.clsphere, ac.csphere, ac.crec, sc->face_verts, c0,
+                          ac.n_clusters, cdiv(ac.n_clusters, SUPER), sc->intersect_epsilion,
+                          sc->size_epsilion, sc->ray_start_epsilion};
+    {
+      ProfScope prof(TFRT_PROF_INTERSECT, st);
+      hipLaunchKernelGGL((k_trace_inplace<T>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
+    }
+    hipLaunchKernelGGL(k_inplace_scan, dim3(P), dim3(1024), 0, st, a.wcount, a.nwaves, P, (int)N, M,
+                       reinterpret_cast<int4*>(ws + lay.wbase), counts);
+    const bool want_rows = (fin && fin->rays) || (act && act->rays) || (stp && stp->rays) ||
+                           (dead && dead->rays) || unfinished != nullptr;
+    if (want_rows)
+      return inplace_gather_t<T>(src_rays, src_stride, N, dead_len, P, flags, fin, act, stp, dead,
+                                 unfinished, unfinished_id, counts, ws, lay, st);
+    return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+  }
+  const int chunks_used = ac.order == nullptr ? pl.chunks : pl.g_chunks;
   for (int p = 0; p < P; ++p) {
     const T* rin = p == 0 ? static_cast<const T*>(src_rays) : rays_ws + (size_t)(p - 1) * 6 * n;
     const int64_t sin = p == 0 ? src_stride : (int64_t)n;
@@ -3569,9 +4039,11 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
   // (one launch sums all passes now: a block per CU is enough -- 125k rays x 11 windows, step time
   // with 1024 / 2048 / 4096 / 8192 slots per block: 0.302 / 0.278 / 0.265 / 0.268 ms)
   while (acc_chunk > 1024 && (int64_t)cdiv(N, acc_chunk) * windows < 256) acc_chunk /= 2;
-  if ((wave_sums && P >= 1 && P <= CHAIN_MAXP) || goal != nullptr) {
+  const bool inplace = inplace_trace(sc, N, M, P);
+  if (inplace && !wave_sums) return TFRT_E_UNSUPPORTED;   // (deterministic: not with in_place)
+  if ((wave_sums && P >= 1 && (P <= CHAIN_MAXP || inplace)) || goal != nullptr) {
     // coherent rays: the whole sweep in one launch (k_backward_chain)
-    if (!(wave_sums && P >= 1 && P <= CHAIN_MAXP)) return TFRT_E_UNSUPPORTED;
+    if (!(wave_sums && P >= 1 && (P <= CHAIN_MAXP || inplace))) return TFRT_E_UNSUPPORTED;
     ChainArgs<T> a;
     a.src = static_cast<const T*>(src_rays);
     a.src_stride = src_stride;
@@ -3598,6 +4070,10 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     a.g_src = g_src;
     a.N = N;
     a.g_fverts = g_fverts;
+    // (in-place tape: class gradients are read through rec_slot, which k_inplace_gather fills;
+    // a sweep that is handed none but the built-in goal's never reads it)
+    a.inplace = !inplace ? 0 : ((g_fin || g_act || g_stp || g_dead || goal == nullptr) ? 1 : 2);
+    a.chain_in_lds = P <= CHAIN_MAXP ? 1 : 0;
     a.fin_rays = nullptr;
     a.fin_cap = 0;
     a.gf.n = 0;
@@ -3610,7 +4086,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
                                        : (sc->n_in != nullptr && sc->n_out != nullptr);
       a.feta = per_face ? reinterpret_cast<const double*>(ws + lay.feta) : nullptr;
     }
-    const size_t chain_lds = (size_t)P * 64 * sizeof(int4);
+    const size_t chain_lds = a.chain_in_lds ? (size_t)P * 64 * sizeof(int4) : 0;
     ProfScope prof_bwd(TFRT_PROF_BACKWARD, st);
     if (goal != nullptr) {
       a.fin_rays = static_cast<const T*>(goal->fin_rays);
@@ -3713,6 +4189,35 @@ int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
   return TFRT_E_UNSUPPORTED;
 }
 
+int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_rays,
+                         double dead_ray_length, int32_t max_passes, int32_t state_dtype,
+                         uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
+                         tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
+                         int32_t* unfinished_id, int32_t* counts, int64_t n_faces, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  if (n_rays < 64 || n_rays >= (1ll << 31) - 4096 || max_passes < 1 || !counts || !workspace ||
+      !src_rays || src_stride < n_rays || n_faces < 0)
+    return TFRT_E_BADARG;
+  const Plan3 pl = make_plan(n_rays, n_faces);
+  const Layout3 lay = make_layout(n_rays, n_faces, max_passes, state_dtype, pl);
+  if (workspace_bytes < lay.total) return TFRT_E_WORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* ws = static_cast<char*>(workspace);
+  if (state_dtype == TFRT_F32)
+    return inplace_gather_t<float>(src_rays, src_stride, n_rays, dead_ray_length, max_passes, flags,
+                                   finished, active, stopped, dead, unfinished, unfinished_id,
+                                   counts, ws, lay, st);
+  if (state_dtype == TFRT_F64)
+    return inplace_gather_t<double>(src_rays, src_stride, n_rays, dead_ray_length, max_passes,
+                                    flags, finished, active, stopped, dead, unfinished,
+                                    unfinished_id, counts, ws, lay, st);
+  if (state_dtype == TFRT_F16)
+    return inplace_gather_t<_Float16>(src_rays, src_stride, n_rays, dead_ray_length, max_passes,
+                                      flags, finished, active, stopped, dead, unfinished,
+                                      unfinished_id, counts, ws, lay, st);
+  return TFRT_E_UNSUPPORTED;
+}
+
 int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_rays,
                           const tfrt_scene3d* scene, double new_ray_length,
                           double dead_ray_length, int32_t max_passes, int32_t state_dtype,
@@ -3770,7 +4275,10 @@ int tfrt_trace3d_backward_goal(const void* src_rays, int64_t src_stride, int64_t
       !pending || !goal_workspace || goal_stride < 0 || goal_ray_stride < 0 ||
       goal_workspace_bytes < tfrt_trace3d_backward_goal_workspace_bytes(n_rays))
     return TFRT_E_BADARG;
-  if (n_rays > 0 && (!finished->rays || finished->capacity <= 0 || !goal)) return TFRT_E_BADARG;
+  // (an in-place trace leaves no finished block: the rows are recomputed from its tape)
+  const bool tape_rows = inplace_trace(scene, n_rays, scene->n_faces, max_passes);
+  if (n_rays > 0 && (!goal || (!tape_rows && (!finished->rays || finished->capacity <= 0))))
+    return TFRT_E_BADARG;
   ChainGoal g;
   g.fin_rays = finished->rays;
   g.fin_cap = finished->capacity;

@@ -596,7 +596,7 @@ class OpticalEngine:
                  dead_ray_length=None, compile_geometry_specific_result=False,
                  new_ray_length=1.0, simple_ray_inheritance={"wavelength"}, ray_dtype=None,
                  ray_shard="auto", accelerate="auto", deterministic=False,
-                 finite_tir_gradient=False, coherent="auto"):
+                 finite_tir_gradient=False, coherent="auto", in_place="auto"):
         if dimension not in (2, 3):
             raise ValueError(f"RayEngine: dimension must be 2 or 3, but was given {dimension}.")
         self._dimension = dimension
@@ -643,6 +643,15 @@ class OpticalEngine:
         if coherent not in ("auto", True, False):
             raise ValueError(f"OpticalEngine: coherent must be 'auto', True or False, got {coherent!r}")
         self.coherent = coherent
+        # Coherent traces only.  "auto" / True (default): once a source has shown that its
+        # wavefronts are narrow bundles (a trace of it left none to the grouped kernel), all passes
+        # of its later traces run in ONE launch with every ray kept in its slot
+        # (tfrt_scene3d.in_place: no per-pass compaction, scan or reaction launch); the ray sets
+        # are compacted into the reference's order afterwards, when they are asked for.  Results
+        # do not depend on it.  False: always the per-pass launch sequence.
+        if in_place not in ("auto", True, False):
+            raise ValueError(f"OpticalEngine: in_place must be 'auto', True or False, got {in_place!r}")
+        self.in_place = in_place
         # 2-D only.  False (default, the reference): a totally reflected ray has a NaN gradient
         # (tf.asin in the unselected tf.where branch, geometry.py:640-646) which poisons every
         # boundary entry it touched; SGD_Optimizer zeroes those (optimizer.py:226-229).  True:
@@ -926,6 +935,8 @@ class OpticalEngine:
             ident = self._source_identity(rays, key)
             scene.coherent_only = (perm is not None
                                    and getattr(self, "_visit_all_key", None) == ident)
+            scene.in_place = bool(scene.coherent_only and self.in_place is not False
+                                  and not self.deterministic)
             self._visit_key = ident if perm is not None else None
             self._trace_perm = perm
         else:

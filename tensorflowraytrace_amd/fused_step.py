@@ -150,6 +150,7 @@ class FusedStep:
     # False: tfrt_goal_error3d + tfrt_trace3d_backward (what a trace in natural order always runs)
     fold_backward = True
     folded_backward = False           # what the last enqueued step did
+    in_place = False                  # ... its trace ran all passes in one launch, rays in place
     # Several ranks: capture the RCCL all-reduce inside the step's graph (one graph per step) instead
     # of calling it eagerly between two graphs.  "auto": only with a one-rank group -- the form has
     # been replayed with a one-rank RCCL group (tests/test_gpu_zz_rccl.py), never yet with several
@@ -229,6 +230,7 @@ class FusedStep:
             err=torch.zeros(3, dtype=torch.float64, device=dev),
             goal_ws=torch.zeros(max(gws, 1), dtype=torch.uint8, device=dev), gws=gws,
             fields=(ctypes.c_int32 * 6)(*(self.opt.error_function.rows + [0] * 6)[:6]),
+            no_outs={name: ops._ray_out(None, None, None) for name, _ in _CLASS_FLAGS},
         )
         self._state = st
         self._graphs = None
@@ -288,15 +290,24 @@ class FusedStep:
         folded = bool(self.fold_backward and need_back and sc.coherent_rays
                       and not sc.deterministic and 1 <= P <= 8)
         self.folded_backward = folded
+        # all passes in one launch, rays in place (tfrt_scene3d.in_place): the folded reverse sweep
+        # needs no ray set, so none is compacted here -- _publish_lazily does it if somebody asks
+        inplace = bool(folded and sc.in_place and st["N"] >= 64 and P >= 1)
+        self.in_place = inplace
+        if not inplace:
+            sc.in_place = 0
         if folded:
             sc.clear_buffer, sc.clear_count = st["g_fv"].data_ptr(), st["g_fv"].numel()
-        check(L.tfrt_trace3d_forward(
-            ops._p(block), block.shape[1], st["N"], ctypes.byref(sc), float(eng.new_ray_length),
-            float(eng.dead_ray_length or 0.0), P, dt, flags, ctypes.byref(o["finished"]),
-            ctypes.byref(o["active"]), ctypes.byref(o["stopped"]), ctypes.byref(o["dead"]),
-            None, None,      # (the rays still active after the last pass are not copied out)
-            ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream), "tfrt_trace3d_forward")
-        if folded:      # (the struct is cached by the scene: nobody else's trace clears our block)
+        fo = st["no_outs"] if inplace else o
+        try:
+            check(L.tfrt_trace3d_forward(
+                ops._p(block), block.shape[1], st["N"], ctypes.byref(sc), float(eng.new_ray_length),
+                float(eng.dead_ray_length or 0.0), P, dt, flags, ctypes.byref(fo["finished"]),
+                ctypes.byref(fo["active"]), ctypes.byref(fo["stopped"]), ctypes.byref(fo["dead"]),
+                None, None,      # (the rays still active after the last pass are not copied out)
+                ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream), "tfrt_trace3d_forward")
+        finally:
+            # (the struct is cached by the scene: nobody else's trace clears our block)
             sc.clear_buffer, sc.clear_count = None, 0
         fin = st["full"]["finished"]
         # error + gradient seed; the same launch clears the face-gradient block the reverse sweep
@@ -394,17 +405,29 @@ class FusedStep:
                 grads[i] = g
             if not capturing:
                 self._tap_checks += 1
-        self._publish_lazily(st, src, P, flags, perm)
+        self._publish_lazily(st, src, P, flags, perm, (block, float(eng.dead_ray_length or 0.0))
+                             if inplace else None)
         return grads, st["err"]
 
-    def _publish_lazily(self, st, src, P, flags, perm=None):
+    def _publish_lazily(self, st, src, P, flags, perm=None, inplace=None):
         eng = self.opt.engine
         eng._trace_src = src
         eng._trace_sig = (src.n_rays if hasattr(src, "n_rays") else src["x_start"].shape[0], P, flags)
         full, aux = st["full"], st["aux"]
-        self._last_perm = perm
+        self._last_perm, self._last_inplace = perm, inplace
 
         def publish():
+            if inplace is not None:
+                # the trace ran in place and compacted nothing: the ray sets are gathered from its
+                # tape now, into the reference's (per-pass, stable) order of the traced rays
+                block, dead_len = inplace
+                o = st["outs"]
+                check(_lib.lib().tfrt_trace3d_compact(
+                    ops._p(block), block.shape[1], st["N"], dead_len, P, st["dt"], flags,
+                    ctypes.byref(o["finished"]), ctypes.byref(o["active"]),
+                    ctypes.byref(o["stopped"]), ctypes.byref(o["dead"]), None, None,
+                    ops._p(st["counts"]), st["M"], ops._p(st["ws"]), st["wsb"],
+                    ops._stream(block)), "tfrt_trace3d_compact")
             out = ops._finish_trace(dict(full), dict(aux), P, None)
             return out if perm is None else ops.restore_order(out, perm)
         eng._pending_trace = publish
@@ -543,7 +566,7 @@ class FusedStep:
                 id(opt.error_function), id(opt.error_function.goal), opt.error_function.fields,
                 tdist.world_size(), eng.optical_system.scene_signature(), bool(eng.deterministic),
                 id((getattr(eng, "_order_cache", None) or (None, None, None))[2]),
-                getattr(eng, "_visit_all_key", None) is not None)
+                getattr(eng, "_visit_all_key", None) is not None, eng.in_place)
 
     def step(self, accumulators, lr_scale):
         """One optimiser step.  Returns the error tensor {sum, n_terms, mean} (device)."""
@@ -606,7 +629,7 @@ class FusedStep:
         eng = self.opt.engine
         eng.clear_ray_history()
         self._publish_lazily(st, eng._trace_src, st["P"], st["flags"],
-                             getattr(self, "_last_perm", None))
+                             getattr(self, "_last_perm", None), getattr(self, "_last_inplace", None))
 
     def _capture(self, sig, accumulators, world):
         """Run THIS step eagerly on the capture stream, then capture the sequence there (capturing

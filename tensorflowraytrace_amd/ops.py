@@ -552,6 +552,8 @@ class Scene3DArgs:
         # with coherent_rays: True = launch no grouped kernel behind k_intersect_beam (a source
         # whose earlier traces left no wavefront over: out["left_over"] == 0)
         self.coherent_only = False
+        # with coherent_rays: all passes in ONE launch, rays kept in place (tfrt_scene3d.in_place)
+        self.in_place = False
         self.eps = (float(intersect_epsilion), float(size_epsilion), float(ray_start_epsilion))
 
     def struct(self, face_verts):
@@ -564,6 +566,7 @@ class Scene3DArgs:
             sc.coherent_rays = 1 if self.coherent_rays else 0
             sc.coherent_only = 1 if (self.coherent_only and self.coherent_rays) else 0
             sc.n_table_uniform = 1 if self.n_table_uniform else 0
+            sc.in_place = 1 if (self.in_place and self.coherent_rays) else 0
             return sc
         sc = Scene3D()
         sc.face_verts = face_verts.data_ptr() if M else None
@@ -589,6 +592,7 @@ class Scene3DArgs:
         sc.deterministic = 1 if self.deterministic else 0
         sc.coherent_rays = 1 if self.coherent_rays else 0
         sc.coherent_only = 1 if (self.coherent_only and self.coherent_rays) else 0
+        sc.in_place = 1 if (self.in_place and self.coherent_rays) else 0
         self._struct_cache = (M, sc)
         return sc
 
