@@ -179,6 +179,14 @@ typedef struct tfrt_goal_pending {
   double* error_out;           /* {sum, n_terms, mean} */
   const int32_t* tests_lo_hi;  /* the trace's test count (two int32) or NULL */
   int64_t* tests_total;        /* running total it is added to, or NULL */
+  /* A reverse sweep over an in-place tape (tfrt_scene3d.in_place) whose trace was not asked for
+   * ray sets counts for itself: per partial sum two int32 {finished rays, passes the wavefront's
+   * rays entered}.  When given, the number of error terms and the trace's test count (passes x
+   * n_faces) are summed from them instead of being read through n_finished / tests_lo_hi, and
+   * left in counts_tail ([1] finished total, [4] / [5] test count) if that is given too. */
+  const int32_t* partial_counts;
+  int64_t n_faces;
+  int32_t* counts_tail;
 } tfrt_goal_pending;
 
 int tfrt_sgd_process_multi(int32_t n_tensors, const void* const* grad, void* const* processed,
@@ -279,7 +287,10 @@ typedef struct tfrt_scene3d {
    * sum).  Every wavefront is finished by the one kernel, however wide its bundle (like
    * coherent_only, which it implies): meant for sources whose earlier traces left no wavefront
    * over.  The SAME value must be passed to the reverse sweep.  Ignored (per-pass path) when the
-   * conditions above do not hold. */
+   * conditions above do not hold.
+   * `counts`: a forward call that is given no room for ray sets does not run the scan either -- a
+   * folded reverse sweep (tfrt_trace3d_backward_goal) needs neither and counts the finished rays
+   * and the tests itself; tfrt_trace3d_compact then fills `counts` together with the sets. */
   int32_t in_place;
 } tfrt_scene3d;
 
@@ -327,8 +338,8 @@ int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
 /* The class outputs of an in-place trace (tfrt_scene3d.in_place) that tfrt_trace3d_forward was
  * given no room for: every class compacted stably into `finished` / `active` / `stopped` / `dead`
  * (+ `unfinished`), rows recomputed from the tape in `workspace`, exactly as a forward call with
- * these outputs would have left them; `counts` is the array that forward call filled (read here;
- * its error flag is set when a capacity is exceeded).  Also records every tape entry's output row,
+ * these outputs would have left them, and `counts` filled like that call would have filled it (its
+ * error flag is set when a capacity is exceeded).  Also records every tape entry's output row,
  * which tfrt_trace3d_backward / _backward_goal need to read class gradients (grad_finished, ...):
  * call it (or give forward its outputs) before a reverse sweep that is handed any.  Same
  * src_rays / n_rays / max_passes / state_dtype / flags / dead_ray_length as the forward call.

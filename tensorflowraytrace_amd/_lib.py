@@ -75,7 +75,8 @@ class GoalPending(ctypes.Structure):
     _fields_ = [("partial", ctypes.c_void_p), ("n_partial", ctypes.c_int32),
                 ("n_finished", ctypes.c_void_p), ("n_fields", ctypes.c_int32),
                 ("error_out", ctypes.c_void_p), ("tests_lo_hi", ctypes.c_void_p),
-                ("tests_total", ctypes.c_void_p)]
+                ("tests_total", ctypes.c_void_p), ("partial_counts", ctypes.c_void_p),
+                ("n_faces", ctypes.c_int64), ("counts_tail", ctypes.c_void_p)]
 
 
 class RayOut(ctypes.Structure):

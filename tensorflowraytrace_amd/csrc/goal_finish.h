@@ -32,18 +32,71 @@ __device__ __forceinline__ void goal_finish_block(const tfrt_goal_pending& g) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
   if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
+  // (an in-place trace that compacted nothing: the sweep counted finished rays and passes itself)
+  __shared__ long long wcnt[WAVES][2];
+  if (g.partial_counts != nullptr) {
+    long long c0 = 0, c1 = 0;
+    const int2* pc = reinterpret_cast<const int2*>(g.partial_counts);
+    int k = threadIdx.x;
+    for (; k + 7 * BLOCK < g.n_partial; k += 8 * BLOCK) {
+      int2 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = pc[k + j * BLOCK];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        c0 += v[j].x;
+        c1 += v[j].y;
+      }
+    }
+    for (; k < g.n_partial; k += BLOCK) {
+      const int2 v = pc[k];
+      c0 += v.x;
+      c1 += v.y;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      c0 += __shfl_xor(c0, d, 64);
+      c1 += __shfl_xor(c1, d, 64);
+    }
+    if (lane_id() == 0) {
+      wcnt[threadIdx.x >> 6][0] = c0;
+      wcnt[threadIdx.x >> 6][1] = c1;
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int w = 0; w < WAVES; ++w) tot += wsum[w];
-    const double terms = (double)(*g.n_finished) * (double)g.n_fields;
+    long long n_fin, tests = 0;
+    bool have_tests = false;
+    if (g.partial_counts != nullptr) {
+      long long passes = 0;
+      n_fin = 0;
+      for (int w = 0; w < WAVES; ++w) {
+        n_fin += wcnt[w][0];
+        passes += wcnt[w][1];
+      }
+      tests = passes * (long long)g.n_faces;
+      have_tests = true;
+      if (g.counts_tail != nullptr) {
+        g.counts_tail[1] = (int32_t)n_fin;
+        g.counts_tail[4] = (int32_t)(uint32_t)((unsigned long long)tests & 0xFFFFFFFFull);
+        g.counts_tail[5] = (int32_t)(uint32_t)((unsigned long long)tests >> 32);
+      }
+    } else {
+      n_fin = *g.n_finished;
+      if (g.tests_lo_hi != nullptr) {
+        tests = (long long)((unsigned long long)(uint32_t)g.tests_lo_hi[0] |
+                            ((unsigned long long)(uint32_t)g.tests_lo_hi[1] << 32));
+        have_tests = true;
+      }
+    }
+    const double terms = (double)n_fin * (double)g.n_fields;
     g.error_out[0] = tot;
     g.error_out[1] = terms;
     // reduce_mean of optimizer.py:257 (no finished ray: the mean of nothing is NaN there too)
     g.error_out[2] = terms > 0.0 ? tot / terms : __builtin_nan("");
-    if (g.tests_total != nullptr && g.tests_lo_hi != nullptr)
-      *g.tests_total += (long long)((unsigned long long)(uint32_t)g.tests_lo_hi[0] |
-                                    ((unsigned long long)(uint32_t)g.tests_lo_hi[1] << 32));
+    if (g.tests_total != nullptr && have_tests) *g.tests_total += tests;
   }
 }
 

@@ -119,7 +119,7 @@ static int goal_error_launch(const void* finished_rays, int64_t capacity,
     return TFRT_E_BADARG;
   }
 #undef TFRT_GOAL
-  tfrt_goal_pending g;
+  tfrt_goal_pending g = {};
   g.partial = partial;
   g.n_partial = nblk;
   g.n_finished = n_finished;
@@ -166,7 +166,8 @@ int tfrt_goal_error3d_deferred(const void* finished_rays, int64_t capacity,
 }
 
 int tfrt_goal_finish(const tfrt_goal_pending* pending, void* stream) {
-  if (!pending || !pending->partial || !pending->n_finished || !pending->error_out ||
+  if (!pending || !pending->partial || (!pending->n_finished && !pending->partial_counts) ||
+      !pending->error_out ||
       pending->n_partial < 0)
     return TFRT_E_BADARG;
   hipLaunchKernelGGL(k_goal_finish, dim3(1), dim3(BLOCK), 0, static_cast<hipStream_t>(stream),

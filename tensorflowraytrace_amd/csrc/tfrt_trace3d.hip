@@ -775,7 +775,10 @@ __global__ __launch_bounds__(BLOCK) void k_intersect3d(
 // All filters are conservative, so the float64 stage sees every pair that can win and the
 // results equal those of k_intersect3d.
 __device__ __forceinline__ unsigned long long dkey(double x) {  // monotone double -> u64
-  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  // (-0.0 and +0.0 get ONE key: they compare equal in the reference's argmin, engine.py:1148, so
+  // the lower face index must win between them -- two coplanar faces through a ray's start give
+  // ray_u = -0.0 and +0.0, valid hits once ray_start_epsilion <= 0)
+  const unsigned long long b = x == 0.0 ? 0ull : (unsigned long long)__double_as_longlong(x);
   return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 __device__ __forceinline__ double dkey_inv(unsigned long long k) {
@@ -2525,6 +2528,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_sgpr(80))) void k_
 // rays share its wavefront (every stage of the walk only removes pairs that cannot win), and the
 // child is rounded to the state type exactly where the per-pass path stores it.
 inline int inplace_bundle(int64_t N) { return N <= 160 * 1024 ? 32 : 64; }
+// words per pass of the per-wavefront count rows (wavefronts of 32 rays at least; rows start on
+// 256-byte boundaries)
+inline size_t inplace_wstride(int64_t N) { return ((size_t)((N > 0 ? N : 1) + 31) / 32 + 63) / 64 * 64; }
 
 template <typename T>
 struct InplaceArgs {
@@ -2536,7 +2542,8 @@ struct InplaceArgs {
   double* rec_t;
   uint8_t* rec_cls;
   int64_t n;
-  uint32_t* wcount;      // [p * nwaves + wavefront]: four class counts, one byte each
+  uint32_t* wcount;      // [p * wstride + wavefront]: four class counts, one byte each
+  int32_t wstride;
   const int32_t* catagory;
   const double* fnorm;   // FaceTables
   const double* feta;    // ... or null: the indices depend on the ray (n_table, one column per ray)
@@ -2547,8 +2554,13 @@ struct InplaceArgs {
   double L;
 };
 
+#ifdef TFRT_INPLACE_WAVES   // (tuning builds: scratch/build_variants.py)
+#define TFRT_INPLACE_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_INPLACE_WAVES, TFRT_INPLACE_WAVES)))
+#else
+#define TFRT_INPLACE_ATTR
+#endif
 template <typename T>
-__global__ __launch_bounds__(64) void k_trace_inplace(InplaceArgs<T> a, BeamScene g) {
+__global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceArgs<T> a, BeamScene g) {
   using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
   const int lane = threadIdx.x, qwave = blockIdx.x;
   const int q = qwave * a.bundle + lane;
@@ -2620,19 +2632,21 @@ __global__ __launch_bounds__(64) void k_trace_inplace(InplaceArgs<T> a, BeamScen
     uint32_t word = 0u;
 #pragma unroll
     for (int c = 0; c < 4; ++c) word |= (uint32_t)__popcll(__ballot(cls == c)) << (8 * c);
-    if (lane == 0) a.wcount[(size_t)p * a.nwaves + qwave] = word;
+    if (lane == 0) a.wcount[(size_t)p * a.wstride + qwave] = word;
   }
   // (passes this wavefront never reached: no rays)
-  for (int pp = p + lane; pp < a.P; pp += 64) a.wcount[(size_t)pp * a.nwaves + qwave] = 0u;
+  for (int pp = p + lane; pp < a.P; pp += 64) a.wcount[(size_t)pp * a.wstride + qwave] = 0u;
 }
 
 // The counts of an in-place trace: workgroup p sums the class counts of the passes before its own
 // (the rays every class has listed so far: base_*), scans its own pass's per-wavefront counts
 // (wbase: where a wavefront's rays of each class begin within the pass) and writes its row of
 // `counts`; the last one also writes the trailing totals and the test count.  No workgroup waits
-// for another (each reads (p + 1) x nwaves words: a few hundred KB from the L2).
+// for another (each reads (p + 1) x nwaves words: a few hundred KB from the L2).  Every loop keeps
+// several independent loads in flight per thread: a first version that read word after word took
+// 35 us for 3 x 15,625 words -- sixteen dependent round trips per thread.
 __global__ __launch_bounds__(1024) void k_inplace_scan(const uint32_t* __restrict__ wcount,
-                                                       int nwaves, int P, int N, int M,
+                                                       int nwaves, int wstride, int P, int N, int M,
                                                        int4* __restrict__ wbase,
                                                        int32_t* __restrict__ counts) {
   const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2642,12 +2656,21 @@ __global__ __launch_bounds__(1024) void k_inplace_scan(const uint32_t* __restric
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] += (int)((w >> (8 * c)) & 0xFFu);
   };
-  // rays of each class listed by earlier passes
+  // rays of each class listed by earlier passes (rows are padded to wstride words; the padding
+  // is never written: masked)
   int before[4] = {0, 0, 0, 0};
-  {
+  if (p > 0) {
     int acc[4] = {0, 0, 0, 0};
-    const int64_t total = (int64_t)p * nwaves;
-    for (int64_t k = tid; k < total; k += 1024) unpack(wcount[k], acc);
+    for (int q = 0; q < p; ++q) {
+      const uint32_t* rq = wcount + (size_t)q * wstride;
+      for (int k0 = tid; k0 < nwaves; k0 += 8 * 1024) {
+        uint32_t w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = (k0 + j * 1024 < nwaves) ? rq[k0 + j * 1024] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) unpack(w[j], acc);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -2665,39 +2688,56 @@ __global__ __launch_bounds__(1024) void k_inplace_scan(const uint32_t* __restric
     for (int c = 0; c < 4; ++c) before[c] = red[c];
     __syncthreads();
   }
-  // this pass: every thread takes a run of consecutive wavefronts
-  const uint32_t* row = wcount + (size_t)p * nwaves;
-  const int seg = (nwaves + 1023) / 1024;
-  const int w0 = min(tid * seg, nwaves), w1 = min(w0 + seg, nwaves);
-  int mine[4] = {0, 0, 0, 0};
-  for (int w = w0; w < w1; ++w) unpack(row[w], mine);
-  int pre[4];
+  // this pass: every thread takes sixteen consecutive wavefronts (four 16-byte loads), the
+  // workgroup 16,384 at a time
+  const uint4* row4 = reinterpret_cast<const uint4*>(wcount + (size_t)p * wstride);
+  int4* out = wbase + (size_t)p * wstride;
+  int tot[4] = {0, 0, 0, 0};   // of the wavefronts before this round's
+  for (int base = 0; base < nwaves; base += 16 * 1024) {
+    const int w0 = base + tid * 16;
+    uint32_t w[16];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    int x = mine[c];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(x, d, 64);
-      if (lane >= d) x += o;
+    for (int j = 0; j < 4; ++j) {
+      const uint4 v = (w0 + 4 * j < nwaves) ? row4[(w0 >> 2) + j] : make_uint4(0u, 0u, 0u, 0u);
+      w[4 * j] = v.x;
+      w[4 * j + 1] = v.y;
+      w[4 * j + 2] = v.z;
+      w[4 * j + 3] = v.w;
     }
-    pre[c] = x - mine[c];
-    if (lane == 63) wsum[wave][c] = x;
-  }
-  __syncthreads();
-  int tot[4];
+    int mine[4] = {0, 0, 0, 0};
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    int r = 0;
-    for (int w = 0; w < 16; ++w) {
-      if (w == wave) pre[c] += r;
-      r += wsum[w][c];
+    for (int j = 0; j < 16; ++j) {
+      if (w0 + j >= nwaves) w[j] = 0u;
+      unpack(w[j], mine);
     }
-    tot[c] = r;
-  }
-  int4* out = wbase + (size_t)p * nwaves;
-  for (int w = w0; w < w1; ++w) {
-    out[w] = make_int4(pre[0], pre[1], pre[2], pre[3]);
-    unpack(row[w], pre);
+    int pre[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int x = mine[c];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(x, d, 64);
+        if (lane >= d) x += o;
+      }
+      pre[c] = x - mine[c] + tot[c];
+      if (lane == 63) wsum[wave][c] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int r = 0;
+      for (int ww = 0; ww < 16; ++ww) {
+        if (ww == wave) pre[c] += r;
+        r += wsum[ww][c];
+      }
+      tot[c] += r;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (w0 + j < nwaves) out[w0 + j] = make_int4(pre[0], pre[1], pre[2], pre[3]);
+      unpack(w[j], pre);
+    }
+    __syncthreads();   // (wsum is written again by the next round)
   }
   if (tid < 4) {
     counts[(size_t)p * TFRT_COUNTS_PER_PASS + tid] = tot[tid];
@@ -2733,7 +2773,8 @@ struct GatherArgs {
   const uint8_t* rec_cls;
   int32_t* rec_slot;
   int64_t n;
-  const int4* wbase;
+  const int4* wbase;     // [p * wstride + wavefront]
+  int32_t wstride;
   const int32_t* counts;
   uint32_t flags;
   double dead_len;
@@ -2762,7 +2803,7 @@ __global__ __launch_bounds__(64) void k_inplace_gather(GatherArgs<T> a) {
       if (cls == c) rank = rank_below(m);
     }
     if (alive) {
-      const int4 wb = a.wbase[(size_t)p * a.nwaves + qwave];
+      const int4 wb = a.wbase[(size_t)p * a.wstride + qwave];
       const int in_pass = (cls == 0 ? wb.x : (cls == 1 ? wb.y : (cls == 2 ? wb.z : wb.w))) + rank;
       const int64_t gslot = (int64_t)a.counts[(size_t)p * TFRT_COUNTS_PER_PASS + 4 + cls] + in_pass;
       a.rec_slot[at] = (int32_t)gslot;
@@ -2797,7 +2838,7 @@ __global__ __launch_bounds__(64) void k_inplace_gather(GatherArgs<T> a) {
   if (p == a.P && a.P > 0 && a.unfinished != nullptr) {
     const unsigned long long m = __ballot(alive);
     if (alive) {
-      const int slot = a.wbase[(size_t)(a.P - 1) * a.nwaves + qwave].x + rank_below(m);
+      const int slot = a.wbase[(size_t)(a.P - 1) * a.wstride + qwave].x + rank_below(m);
       const T* rin = a.rays_ws + (size_t)(a.P - 1) * 6 * a.n;
 #pragma unroll
       for (int k = 0; k < 6; ++k) a.unfinished[(int64_t)k * a.N + slot] = rin[k * a.n + i];
@@ -3313,6 +3354,7 @@ struct ChainArgs {
   const double* goal;
   int64_t goal_stride, goal_ray_stride;
   double* partial;         // one partial error sum per wavefront of the launch
+  int32_t* partial_cnt;    // ... and {finished rays, passes entered} per wavefront, or null
   const double* feta;      // per-face indices (FaceTables) or null
   // tape of an in-place trace (tfrt_scene3d.in_place): a ray keeps its slot through all passes.
   // 1: rec_slot holds every record's row in its output class (k_inplace_gather ran: the class
@@ -3330,7 +3372,10 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const int n0 = a.nrays[0];
   const int i0 = blockIdx.x * (64 * BW) + threadIdx.x;
   if ((i0 & ~63) >= n0) {  // (whole wave)
-    if (GOAL && (threadIdx.x & 63) == 0) a.partial[i0 >> 6] = 0.0;
+    if (GOAL && (threadIdx.x & 63) == 0) {
+      a.partial[i0 >> 6] = 0.0;
+      if (a.partial_cnt != nullptr) a.partial_cnt[2 * (i0 >> 6)] = a.partial_cnt[2 * (i0 >> 6) + 1] = 0;
+    }
     return;
   }
   __shared__ double wacc[BW][WSUM_CELLS];
@@ -3360,9 +3405,11 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   for (int d = 32; d > 0; d >>= 1) top = max(top, __shfl_xor(top, d, 64));
   double child[6] = {0, 0, 0, 0, 0, 0};
   double err = 0.0;
+  int n_fin = 0, n_entered = 0;   // (wave-uniform) finished rays, passes the wavefront's rays entered
   for (int p = top; p >= 0; --p) {
     double gP[9];
     int tri = -1;
+    bool fin_here = false;
     if (p <= last) {
       int4 rec;
       if (a.chain_in_lds) {
@@ -3379,6 +3426,7 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
       const int32_t* idin = (p == 0 || a.inplace) ? nullptr : a.rayid + (size_t)(p - 1) * a.n;
       double seed[6] = {0, 0, 0, 0, 0, 0};
       if (GOAL && p == last && (tape & 3) == CLS_FINISHED) {
+        fin_here = true;
         // tfrt_goal_error3d's terms for this ray: the output AS STORED in the finished block
         // minus the goal row of the source ray; d (sum of squares) = 2 (output - goal)
         // (in-place traces write no finished block: the row k_inplace_gather would store is
@@ -3425,6 +3473,10 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         child[3 + k] = ge[k];
       }
     }
+    if (GOAL) {
+      n_fin += __popcll(__ballot(fin_here));
+      n_entered += __popcll(__ballot(p <= last));
+    }
     wave_face_sums(tri, gP, wacc[wave], wface[wave], a.g_fverts);
   }
   if (a.g_src != nullptr && i0 < n0) {
@@ -3435,7 +3487,13 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // fixed-shape reduction: xor butterflies inside the wave (k_goal_finish sums the partials)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) err += __shfl_xor(err, d, 64);
-    if (lane == 0) a.partial[i0 >> 6] = err;
+    if (lane == 0) {
+      a.partial[i0 >> 6] = err;
+      if (a.partial_cnt != nullptr) {
+        a.partial_cnt[2 * (i0 >> 6)] = n_fin;
+        a.partial_cnt[2 * (i0 >> 6) + 1] = n_entered;
+      }
+    }
   }
 }
 
@@ -3595,8 +3653,8 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.left_list = take((n + 63) / 64 * sizeof(int32_t));
   // in-place traces (tfrt_scene3d.in_place): per pass and wavefront (of 32 rays at least) the packed
   // class counts and the bases k_inplace_scan makes of them
-  L.wcount = take((size_t)(P > 0 ? P : 1) * ((n + 31) / 32) * sizeof(uint32_t));
-  L.wbase = take((size_t)(P > 0 ? P : 1) * ((n + 31) / 32) * sizeof(int4));
+  L.wcount = take((size_t)(P > 0 ? P : 1) * inplace_wstride(n) * sizeof(uint32_t));
+  L.wbase = take((size_t)(P > 0 ? P : 1) * inplace_wstride(n) * sizeof(int4));
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -3741,8 +3799,8 @@ static bool inplace_trace(const tfrt_scene3d* sc, int64_t N, int64_t M, int P) {
 }
 
 template <typename T>
-static int inplace_gather_t(const void* src_rays, int64_t src_stride, int64_t N, double dead_len,
-                            int P, uint32_t flags, const tfrt_ray_out* fin, const tfrt_ray_out* act,
+static int inplace_gather_t(const void* src_rays, int64_t src_stride, int64_t N, int64_t M,
+                            double dead_len, int P, uint32_t flags, const tfrt_ray_out* fin, const tfrt_ray_out* act,
                             const tfrt_ray_out* stp, const tfrt_ray_out* dead, void* unfinished,
                             int32_t* unfinished_id, int32_t* counts, char* ws, const Layout3& lay,
                             hipStream_t st) {
@@ -3762,6 +3820,7 @@ static int inplace_gather_t(const void* src_rays, int64_t src_stride, int64_t N,
   a.rec_slot = reinterpret_cast<int32_t*>(ws + lay.rec_slot);
   a.n = (int64_t)n;
   a.wbase = reinterpret_cast<const int4*>(ws + lay.wbase);
+  a.wstride = (int32_t)inplace_wstride(N);
   a.counts = counts;
   a.flags = flags;
   a.dead_len = dead_len;
@@ -3772,6 +3831,10 @@ static int inplace_gather_t(const void* src_rays, int64_t src_stride, int64_t N,
   a.unfinished = static_cast<T*>(unfinished);
   a.unfinished_id = unfinished_id;
   a.err = counts + (size_t)P * TFRT_COUNTS_PER_PASS + 6;
+  // the counts (per pass and class, bases, totals, tests) and every wavefront's bases, then the rows
+  hipLaunchKernelGGL(k_inplace_scan, dim3(P), dim3(1024), 0, st,
+                     reinterpret_cast<const uint32_t*>(ws + lay.wcount), a.nwaves, a.wstride, P,
+                     (int)N, (int)M, reinterpret_cast<int4*>(ws + lay.wbase), counts);
   hipLaunchKernelGGL((k_inplace_gather<T>), dim3(a.nwaves), dim3(64), 0, st, a);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
@@ -3878,6 +3941,7 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     a.rec_cls = rec_cls;
     a.n = (int64_t)n;
     a.wcount = reinterpret_cast<uint32_t*>(ws + lay.wcount);
+    a.wstride = (int32_t)inplace_wstride(N);
     a.catagory = sc->catagory;
     a.fnorm = ft.fnorm;
     a.feta = ft.feta;
@@ -3893,12 +3957,11 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       ProfScope prof(TFRT_PROF_INTERSECT, st);
       hipLaunchKernelGGL((k_trace_inplace<T>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
     }
-    hipLaunchKernelGGL(k_inplace_scan, dim3(P), dim3(1024), 0, st, a.wcount, a.nwaves, P, (int)N, M,
-                       reinterpret_cast<int4*>(ws + lay.wbase), counts);
+    // (no room for ray sets: no scan either -- tfrt_trace3d_compact makes counts and sets later)
     const bool want_rows = (fin && fin->rays) || (act && act->rays) || (stp && stp->rays) ||
                            (dead && dead->rays) || unfinished != nullptr;
     if (want_rows)
-      return inplace_gather_t<T>(src_rays, src_stride, N, dead_len, P, flags, fin, act, stp, dead,
+      return inplace_gather_t<T>(src_rays, src_stride, N, M, dead_len, P, flags, fin, act, stp, dead,
                                  unfinished, unfinished_id, counts, ws, lay, st);
     return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
   }
@@ -3989,6 +4052,7 @@ struct ChainGoal {
   const double* goal;
   int64_t goal_stride, goal_ray_stride;
   double* partial;
+  int32_t* partial_cnt;
 };
 
 template <typename T>
@@ -4080,6 +4144,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     a.goal = nullptr;
     a.goal_stride = a.goal_ray_stride = 0;
     a.partial = nullptr;
+    a.partial_cnt = nullptr;
     {  // (the per-face indices the forward's set-up launch left, under the same condition)
       const bool index_mode = sc->n_table != nullptr && sc->mat_in != nullptr;
       const bool per_face = index_mode ? sc->n_table_uniform != 0
@@ -4096,6 +4161,7 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
       a.goal_stride = goal->goal_stride;
       a.goal_ray_stride = goal->goal_ray_stride;
       a.partial = goal->partial;
+      a.partial_cnt = goal->partial_cnt;
       if (N > 0)
         hipLaunchKernelGGL((k_backward_chain<T, 1, true>), dim3(cdiv(N, 64)), dim3(64), chain_lds,
                            st, a, *sc);
@@ -4204,15 +4270,15 @@ int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_ray
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* ws = static_cast<char*>(workspace);
   if (state_dtype == TFRT_F32)
-    return inplace_gather_t<float>(src_rays, src_stride, n_rays, dead_ray_length, max_passes, flags,
+    return inplace_gather_t<float>(src_rays, src_stride, n_rays, n_faces, dead_ray_length, max_passes, flags,
                                    finished, active, stopped, dead, unfinished, unfinished_id,
                                    counts, ws, lay, st);
   if (state_dtype == TFRT_F64)
-    return inplace_gather_t<double>(src_rays, src_stride, n_rays, dead_ray_length, max_passes,
+    return inplace_gather_t<double>(src_rays, src_stride, n_rays, n_faces, dead_ray_length, max_passes,
                                     flags, finished, active, stopped, dead, unfinished,
                                     unfinished_id, counts, ws, lay, st);
   if (state_dtype == TFRT_F16)
-    return inplace_gather_t<_Float16>(src_rays, src_stride, n_rays, dead_ray_length, max_passes,
+    return inplace_gather_t<_Float16>(src_rays, src_stride, n_rays, n_faces, dead_ray_length, max_passes,
                                       flags, finished, active, stopped, dead, unfinished,
                                       unfinished_id, counts, ws, lay, st);
   return TFRT_E_UNSUPPORTED;
@@ -4254,7 +4320,8 @@ int tfrt_trace3d_backward(const void* src_rays, int64_t src_stride, int64_t n_ra
 
 size_t tfrt_trace3d_backward_goal_workspace_bytes(int64_t n_rays) {
   if (n_rays < 0) return 0;
-  return align_up((size_t)cdiv(n_rays > 0 ? n_rays : 1, 64) * sizeof(double));
+  // per 64 rays: one partial error sum + two int32 counts (in-place tapes)
+  return 2 * align_up((size_t)cdiv(n_rays > 0 ? n_rays : 1, 64) * sizeof(double));
 }
 
 int tfrt_trace3d_backward_goal(const void* src_rays, int64_t src_stride, int64_t n_rays,
@@ -4291,6 +4358,14 @@ int tfrt_trace3d_backward_goal(const void* src_rays, int64_t src_stride, int64_t
   g.goal_stride = goal_stride;
   g.goal_ray_stride = goal_ray_stride;
   g.partial = static_cast<double*>(goal_workspace);
+  // (an in-place trace that was given no room for ray sets ran no scan: `counts` holds nothing yet,
+  // the sweep counts the finished rays and the tests itself)
+  const bool own_counts = tape_rows && !grad_active && !grad_stopped && !grad_dead;
+  g.partial_cnt = own_counts
+                      ? reinterpret_cast<int32_t*>(static_cast<char*>(goal_workspace) +
+                                                   align_up((size_t)cdiv(n_rays > 0 ? n_rays : 1, 64) *
+                                                            sizeof(double)))
+                      : nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc = TFRT_E_UNSUPPORTED;
   if (state_dtype == TFRT_F32)
@@ -4321,6 +4396,9 @@ int tfrt_trace3d_backward_goal(const void* src_rays, int64_t src_stride, int64_t
   pending->error_out = error_out;
   pending->tests_lo_hi = tail + 4;
   pending->tests_total = tests_total;
+  pending->partial_counts = g.partial_cnt;
+  pending->n_faces = scene->n_faces;
+  pending->counts_tail = g.partial_cnt != nullptr ? const_cast<int32_t*>(tail) : nullptr;
   return 0;
 }
 

@@ -133,7 +133,8 @@ static int sgd_multi_launch(int32_t n_tensors, const void* const* grad, void* co
                             const tfrt_goal_pending* pending, void* stream) {
   if (n_tensors < 0 || n_tensors > SGD_BATCH || (n_tensors > 0 && (!grad || !n || !hyper)))
     return TFRT_E_BADARG;
-  if (pending != nullptr && (!pending->partial || !pending->n_finished || !pending->error_out ||
+  if (pending != nullptr && (!pending->partial || (!pending->n_finished && !pending->partial_counts) ||
+      !pending->error_out ||
                              pending->n_partial < 0))
     return TFRT_E_BADARG;
   SgdBatch b;

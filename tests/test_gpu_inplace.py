@@ -155,8 +155,6 @@ def test_compact_entry_fills_the_sets_a_forward_call_without_outputs_left_out():
     _lib.check(L.tfrt_trace3d_forward(ops._p(rays), N, N, ctypes.byref(st_), 1.0, 0.0, P, _lib.F32,
                                       _flags(), *[ctypes.byref(o) for o in none], None, None,
                                       ops._p(counts), ops._p(ws), wsb, stream), "forward")
-    host = counts.cpu().numpy()
-    assert np.array_equal(host[:P * 8].reshape(P, 8), ref["counts"])      # the scan alone made them
     caps = {"finished": N, "active": N * P, "stopped": N, "dead": N}
     bufs = {k: (torch.empty((6, c), dtype=torch.float32, device=DEV),
                 torch.empty(c, dtype=torch.int32, device=DEV),
@@ -166,6 +164,10 @@ def test_compact_entry_fills_the_sets_a_forward_call_without_outputs_left_out():
     _lib.check(L.tfrt_trace3d_compact(ops._p(rays), N, N, 0.0, P, _lib.F32, _flags(),
                                       *[ctypes.byref(o) for o in outs], ops._p(unf), ops._p(unf_id),
                                       ops._p(counts), M, ops._p(ws), wsb, stream), "compact")
+    host = counts.cpu().numpy()
+    assert np.array_equal(host[:P * 8].reshape(P, 8), ref["counts"])
+    assert host[P * 8 + 6] == 0                                           # no capacity error
+    assert (int(np.uint32(host[P * 8 + 4])) | (int(np.uint32(host[P * 8 + 5])) << 32)) == ref["n_tests"]
     for k in ("finished", "active", "stopped", "dead"):
         n = ref[k].shape[1]
         assert torch.equal(bufs[k][0][:, :n], ref[k]), k
@@ -192,7 +194,8 @@ def test_fused_step_in_place_equals_the_per_pass_fused_step():
         assert fs.graph_replays >= 3
         assert fs.in_place == in_place, (fs.in_place, in_place)
         fin = {f: eng.finished_rays[f].detach().clone() for f in ("x_start", "y_end", "z_end", "object_coords")}
-        runs[in_place] = (errs, _params(lens), fin, eng.last_trace["counts"].copy())
+        runs[in_place] = (errs, _params(lens), fin, eng.last_trace["counts"].copy(),
+                          int(float(opt.last_error_terms)), int(fs.tests_total))
     a, b = runs[True], runs[False]
     # (the two runs take the same parameters only up to the last bits of the atomically summed
     # gradients: after the first steps the errors agree to rounding, not bit for bit)
@@ -201,5 +204,6 @@ def test_fused_step_in_place_equals_the_per_pass_fused_step():
     for p, q in zip(a[1], b[1]):
         assert float((p - q).abs().max()) <= 1e-10
     assert np.array_equal(a[3], b[3])
+    assert a[4] == b[4] > 0 and a[5] == b[5] > 0     # error terms, ray-face tests of all steps
     for f in a[2]:
         np.testing.assert_allclose(a[2][f].cpu().numpy(), b[2][f].cpu().numpy(), rtol=0, atol=1e-6, err_msg=f)
