@@ -276,11 +276,14 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     def timed_leg(global_rays, trace_mode, step_mode, dtype, profile=False, random_rays=False,
-                  coherent="auto"):
+                  coherent="auto", exact_steps=False):
         """Build the scene with `global_rays` source rays (each rank traces its contiguous
-        shard), run warmup + exactly `steps` optimiser steps between barriers.  Returns a dict:
-        seconds (max over ranks), tests (sum over ranks), per-launch ms of the dominant kernel
-        (only with `profile`, which needs eagerly launched kernels), pass counts, faces, mode."""
+        shard), run warmup steps, then time optimiser steps between barriers: EXACTLY --steps of
+        them with `exact_steps` (the headline leg: the contract's K), else at least
+        MIN_TIMED_SECONDS worth (side legs).  The headline leg then runs a second, longer loop
+        (`steady`: >= MIN_TIMED_SECONDS, reported beside the line, never `value`).  Returns a dict:
+        seconds (max over ranks), tests (sum over ranks), per-launch ms of the hot kernels (only
+        with `profile`, which needs eagerly launched kernels), pass counts, faces, mode."""
         ray_dtype = torch.float32 if dtype == "f32" else torch.float64
         eng, system, params = build_scene(global_rays, args.k_front, args.k_back, ray_dtype,
                                           accelerate=trace_mode, random_rays=random_rays,
@@ -295,31 +298,45 @@ def main(argv=None):
             opt.single_step(None)
         fs = opt._fused_step
         barrier()
-        # at least MIN_TIMED_SECONDS inside the timed region: the requested step count is raised
-        # when K steps would be shorter (every rank takes the same count: max over ranks)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            opt.single_step(None)
-        torch.cuda.synchronize()
-        est = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device="cuda")
-        if world > 1:
-            torch.distributed.all_reduce(est, op=torch.distributed.ReduceOp.MIN)
-        steps = max(args.steps, int(np.ceil(MIN_TIMED_SECONDS / max(float(est.item()), 1e-6))))
-        barrier()
+
+        def run(n_steps):
+            tests0 = int(fs.tests_total.item()) if fs is not None else 0
+            tests_local = 0
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                opt.single_step(None)
+                if fs is None:
+                    tests_local += eng.last_trace["n_tests"]
+            barrier()
+            dt = time.perf_counter() - t0
+            if fs is not None:
+                tests_local = int(fs.tests_total.item()) - tests0
+            tests_total = float(tests_local)
+            if world > 1:
+                stats = torch.tensor([dt, float(tests_local)], dtype=torch.float64, device="cuda")
+                tmax = stats[:1].clone()
+                torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+                tsum = stats[1:].clone()
+                torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
+                dt, tests_total = float(tmax.item()), float(tsum.item())
+            return dt, tests_total
+
+        def enough_steps():
+            # (every rank takes the same count: the slowest rank's estimate)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                opt.single_step(None)
+            torch.cuda.synchronize()
+            est = torch.tensor([(time.perf_counter() - t0) / 3], dtype=torch.float64, device="cuda")
+            if world > 1:
+                torch.distributed.all_reduce(est, op=torch.distributed.ReduceOp.MIN)
+            return max(args.steps, int(np.ceil(MIN_TIMED_SECONDS / max(float(est.item()), 1e-6))))
+
+        steps = args.steps if exact_steps else enough_steps()
         if profile:
             lib.tfrt_profile_enable(1)
-        tests0 = int(fs.tests_total.item()) if fs is not None else 0
-        tests_local = 0
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            opt.single_step(None)
-            if fs is None:
-                tests_local += eng.last_trace["n_tests"]
-        barrier()
-        dt = time.perf_counter() - t0
-        if fs is not None:
-            tests_local = int(fs.tests_total.item()) - tests0
+        dt, tests_total = run(steps)
         kernel_ms = []
         if profile:
             import ctypes
@@ -329,18 +346,29 @@ def main(argv=None):
                 nrec = lib.tfrt_profile_read_kind(kind, buf, 8192)
                 kernel_ms[name] = [buf[i] for i in range(max(nrec, 0))]
             lib.tfrt_profile_enable(0)
-        tests_total = float(tests_local)
-        if world > 1:
-            stats = torch.tensor([dt, float(tests_local)], dtype=torch.float64, device="cuda")
-            tmax = stats[:1].clone()
-            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-            tsum = stats[1:].clone()
-            torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
-            dt, tests_total = float(tmax.item()), float(tsum.item())
-        out = dict(dt=dt, steps=steps, tests=tests_total, kernel_ms=kernel_ms,
+        steady = None
+        if exact_steps:
+            n2 = enough_steps()
+            dt2, tests2 = run(n2)
+            steady = {"steps": n2, "seconds": dt2, "ms_per_step": dt2 / n2 * 1e3,
+                      "tests_per_s": tests2 / dt2}
+        # work the in-place trace executed in its last step (rank 0's shard)
+        executed = None
+        st = fs._state if fs is not None else None
+        if fs is not None and fs.in_place and st is not None:
+            ex = torch.zeros(2, dtype=torch.int64, device="cuda")
+            from tensorflowraytrace_amd import ops as _ops
+            rc = lib.tfrt_trace3d_executed(st["N"], st["M"], st["P"], st["dt"],
+                                           st["ws"].data_ptr(), st["wsb"], ex.data_ptr(),
+                                           _ops._stream(ex))
+            torch.cuda.synchronize()
+            if rc == 0:
+                executed = [int(v) for v in ex.tolist()]
+        out = dict(dt=dt, steps=steps, tests=tests_total, kernel_ms=kernel_ms, steady=steady,
                    counts=eng.last_trace["counts"], M=int(system._merged_face_verts.shape[0]),
                    mode=eng._trace_mode(system),
                    visiting=getattr(eng, "_order_cache", None) is not None,
+                   in_place=bool(fs.in_place) if fs is not None else False, executed=executed,
                    graph_replays=fs.graph_replays if fs is not None else 0,
                    collective_in_graph=bool(fs.collective_in_graph) if fs is not None else None,
                    capture_error=repr(fs.capture_error) if fs is not None and fs.capture_error
@@ -351,7 +379,7 @@ def main(argv=None):
 
     per_rank = args.scaling == "weak"
     global_rays = args.rays * world if per_rank else args.rays
-    main_leg = timed_leg(global_rays, args.trace_mode, args.step_mode, args.dtype)
+    main_leg = timed_leg(global_rays, args.trace_mode, args.step_mode, args.dtype, exact_steps=True)
     side = {}
     if world > 1 and not args.no_extra_legs:
         # the other scaling convention, separately reported (never `value`)
@@ -376,18 +404,17 @@ def main(argv=None):
     n_active = [int(c[:4].sum()) for c in counts]          # rays entering each pass (rank 0)
     P = len(n_active)
     visiting = bool(main_leg["visiting"]) and mode == "group"
-    kernel_name = ("tfrt::k_intersect_beam" if visiting else
+    in_place = bool(main_leg["in_place"]) and visiting
+    kernel_name = ("tfrt::k_trace_inplace" if in_place else "tfrt::k_intersect_beam" if visiting else
                    {"all-pairs": "tfrt::k_intersect3d", "group": "tfrt::k_intersect_group"}[mode])
-    roofline = {"kernel": kernel_name, "bound": "valu"}
     same_workload = (args.rays == 1_000_000 and world == 1 and args.k_front == 41
                      and args.k_back == 9 and args.dtype == "f32")
     src_hash = _source_hash()
 
     def pmc_of(tag):
         """Counters of one kernel from profiles/ (separate rocprofv3 --pmc runs of the same step,
-        scratch/collect_profiles.sh) -- only for the kernel sources and workload they were
-        collected on."""
-        path = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % tag)
+        scratch/r05_pmc.sh) -- only for the kernel sources and workload they were collected on."""
+        path = os.path.join(ROOT, "profiles", "r05_pmc_%s.json" % tag)
         if not (same_workload and os.path.exists(path)):
             return None, path
         doc = json.load(open(path))
@@ -398,78 +425,84 @@ def main(argv=None):
         write = float(np.mean([p["WRITE_SIZE_KB"] for p in doc["passes"]])) * 1024.0
         return 2.0 * fetch + write      # guide: FETCH_SIZE counts half of wide reads on gfx950
 
+    # ROOFLINE of the dominant kernel, SURVEY.md 8d's quantity: algorithmic bytes per launch
+    # (64 B per ray entering a pass + 48 B per face and pass, for the passes ONE launch covers)
+    # / that kernel's average launch duration (HIP events on the launch stream, measured live)
+    # / 8 TB/s.  With the spatial index the path is bandwidth / latency bound, so the
+    # bound is "hbm"; how busy the vector units are is kept beside it as valu_issue_frac.
+    roofline = {"kernel": kernel_name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBPS,
+                "unit": "GB/s", "frac": None, "traffic": None}
     kms = prof_leg["kernel_ms"] if prof_leg is not None else {}
     if kms.get("intersect"):
         ms = np.asarray(kms["intersect"], dtype=np.float64)
-        ms = ms[:len(ms) // P * P].reshape(-1, P)
-        per_pass_ms = ms.mean(axis=0)
-        avg_ms = float(ms.mean())
-        tests_per_launch = float(np.mean([n * M for n in n_active]))
-        alg_bytes = float(np.mean(n_active)) * BYTES_PER_RAY_FWD + M * BYTES_PER_FACE
+        per_launch_passes = P if in_place else 1
+        if in_place:
+            avg_ms = float(ms.mean())
+            per_pass_ms = None
+            alg_bytes = float(sum(n_active)) * BYTES_PER_RAY_FWD + P * M * BYTES_PER_FACE
+            tests_per_launch = float(sum(n * M for n in n_active))
+        else:
+            ms = ms[:len(ms) // P * P].reshape(-1, P)
+            per_pass_ms = [float(x) for x in ms.mean(axis=0)]
+            avg_ms = float(ms.mean())
+            alg_bytes = float(np.mean(n_active)) * BYTES_PER_RAY_FWD + M * BYTES_PER_FACE
+            tests_per_launch = float(np.mean([n * M for n in n_active]))
+        tag = "inplace" if in_place else ("beam" if visiting else mode.replace("-", "_"))
+        pmc, pmc_path = pmc_of(tag)
         roofline.update({
-            "avg_launch_ms": avg_ms, "per_pass_launch_ms": [float(x) for x in per_pass_ms],
+            "achieved": alg_bytes / (avg_ms * 1e-3) / 1e9,
+            "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_note": "SURVEY 8d: 64 B x rays entering a pass + 48 B x faces per "
+                                      "pass, summed over the %d pass(es) one launch covers"
+                                      % per_launch_passes,
+            "avg_launch_ms": avg_ms, "launches_per_step": 1 if in_place else P,
             "launches_timed": int(ms.size),
             "timed_by": "HIP events on the launch stream (tfrt_profile_*), eager fused sequence "
-                        "run after the timed region with the same steps"
-                        + ("; one record = the pass's k_intersect_beam launch + the "
-                           "k_intersect_group launch for left-over wavefronts (none on this "
-                           "workload: it reads one counter and retires)" if visiting else ""),
-            "tests_per_launch": tests_per_launch,
-            # SURVEY.md 8d cost model, kept as a separately named field: pairs DECIDED x 45 flop.
-            # The kernel decides pairs through conservative sphere tests, so this is not a
-            # utilisation of anything (it exceeds the VALU peak)
-            "algorithmic_tflops": tests_per_launch * FLOPS_PER_TEST / (avg_ms * 1e-3) / 1e12,
-            "hbm": {
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "achieved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9,
-                "peak_GBps": PEAK_HBM_GBPS,
-                "frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-            },
+                        "run after the timed region with the same steps",
+            "tests_decided_per_launch": tests_per_launch,
         })
-        # executed work: VALU wave-instructions per launch from the PMC passes, combined with the
-        # launch time measured live above
-        tag = "beam" if visiting else mode.replace("-", "_")
-        pmc, pmc_path = pmc_of(tag)
+        if per_pass_ms is not None:
+            roofline["per_pass_launch_ms"] = per_pass_ms
         if pmc is not None:
             valu = float(np.mean([p["SQ_INSTS_VALU"] for p in pmc["passes"]]))
-            issue_rate = valu / (avg_ms * 1e-3)                     # wave-instructions / s
-            peak = VALU_SIMDS * CLOCK_HZ / CYCLES_PER_WAVE_OP
             traffic = traffic_of(pmc)
             roofline.update({
-                "achieved": issue_rate, "peak": peak, "unit": "VALU wave-instructions/s",
-                "frac": issue_rate / peak,
-                "peak_model": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 op "
-                              "(MI355X_MICROARCH.md, v_fma_f32 row)",
+                "traffic": traffic,
+                "traffic_unit": "HBM-side bytes per launch from the PMC counters: 2 x FETCH_SIZE + "
+                                "WRITE_SIZE (the guide's gfx950 correction for wide reads), separate "
+                                "--pmc passes",
+                "traffic_over_algorithmic": traffic / alg_bytes,
+                # how busy the vector units are (NOT the roofline fraction): executed VALU
+                # wave-instructions / launch time / (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 op)
+                "valu_issue_frac": valu / (avg_ms * 1e-3) / (VALU_SIMDS * CLOCK_HZ / CYCLES_PER_WAVE_OP),
                 "valu_wave_instructions_per_launch": valu,
                 "salu_per_valu": float(np.mean([p["SQ_INSTS_SALU"] / p["SQ_INSTS_VALU"]
                                                 for p in pmc["passes"]])),
                 "lds_bank_conflict_ratio": float(np.mean(
                     [p["SQ_LDS_BANK_CONFLICT"] / max(p["SQ_LDS_IDX_ACTIVE"], 1.0)
                      for p in pmc["passes"]])),
-                "executed_valu_lane_ops_per_test": valu * 64.0 / tests_per_launch,
                 "wait_fraction_of_wave_cycles": float(np.mean(
                     [p["SQ_WAIT_ANY"] / p["SQ_WAVE_CYCLES"] for p in pmc["passes"]])),
-                "traffic": traffic,
-                "traffic_unit": "HBM-side bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE "
-                                "(gfx950 correction of the guide for wide reads)",
                 "pmc_source": os.path.relpath(pmc_path, ROOT),
             })
-            roofline["hbm"]["traffic_frac"] = traffic / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS
         else:
-            roofline.update({
-                "achieved": None, "peak": None, "unit": "VALU wave-instructions/s", "frac": None,
-                "traffic": None,
-                "pmc_note": "no PMC profile of this kernel source / workload under profiles/ "
-                            "(regenerate with scratch/collect_profiles.sh); counter-derived "
-                            "fields withheld"})
-        # every hot kernel of the step: live launch time, the roof that bounds it, SURVEY 8d's
-        # algorithmic bytes beside the counter traffic
+            roofline["pmc_note"] = ("no PMC profile of this kernel source / workload under profiles/ "
+                                    "(regenerate with scratch/r05_pmc.sh); counter-derived fields "
+                                    "withheld")
+        # every hot kernel of the step: live launch time, SURVEY 8d's algorithmic bytes beside the
+        # counter traffic
         n_fwd = float(np.mean(n_active))
-        # coherent rays: the reverse sweep is ONE launch per step (as many records as react has / P)
-        bwd_one = len(kms.get("backward") or []) * P <= len(kms.get("react") or []) + P - 1
-        rows = [dict(name=kernel_name, kind="intersect", launches_per_step=P, bound="valu",
-                     avg_ms=avg_ms, frac=roofline.get("frac"),
-                     algorithmic_bytes=alg_bytes, traffic=roofline.get("traffic"))]
+        # coherent rays: the reverse sweep is ONE launch per step
+        n_bwd = len(kms.get("backward") or [])
+        n_int = len(kms.get("intersect") or [])
+        bwd_one = in_place or n_bwd * P <= n_int + P - 1
+        rows = [dict(name=kernel_name, kind="trace" if in_place else "intersect",
+                     launches_per_step=1 if in_place else P, bound="hbm", avg_ms=avg_ms,
+                     algorithmic_bytes=alg_bytes, achieved_GBps=roofline["achieved"],
+                     frac=roofline["frac"], traffic=roofline.get("traffic"),
+                     note="all passes in one launch: beam walk, classification, Snell, tape"
+                     if in_place else None)]
         for kind, kname, per_step, alg, note in (
                 ("react", "tfrt::k_react3d", P, n_fwd * BYTES_PER_RAY_FWD,
                  "SURVEY 8d forward bytes: 64 B per ray entering the pass"),
@@ -477,14 +510,13 @@ def main(argv=None):
                  1 if bwd_one else P,
                  (float(sum(n_active)) if bwd_one else n_fwd) * BYTES_PER_RAY_BWD,
                  "SURVEY 8d backward bytes: 116 B per ray entering a pass" +
-                 (", all passes in the one launch (coherent rays: a lane walks its ray's chain of "
-                  "slots back with the child gradient in registers; the face-gradient terms are summed "
-                  "per wavefront in LDS and leave as one atomic per face and term)" if bwd_one else
-                  " (one launch per pass)")),
+                 (", all passes in the one launch (a lane walks its ray's records back with the child "
+                  "gradient in registers; face-gradient terms summed per wavefront in LDS)"
+                  if bwd_one else " (one launch per pass)")),
                 ("accumulate", "tfrt::k_face_accumulate", 1, float(sum(n_active)) * 40.0,
                  "the stash read once: 36 B of terms + 4 B face index per ray and pass")):
             v = np.asarray(kms.get(kind) or [], dtype=np.float64)
-            if not v.size:      # (coherent rays: no stash, no accumulate launch)
+            if not v.size:      # (in-place traces: no reaction launch; coherent rays: no stash)
                 continue
             k_ms = float(v.mean())
             doc, path = pmc_of(kind)
@@ -499,13 +531,11 @@ def main(argv=None):
                 if traffic is not None else None,
                 pmc_source=os.path.relpath(path, ROOT) if doc is not None else None))
         roofline["kernels"] = rows
-        roofline["kernels_note"] = ("avg_ms: HIP events per launch (eager fused sequence); "
-                                    "frac: VALU issue fraction (intersect) or algorithmic bytes / "
-                                    "time / 8 TB/s (HBM-bound kernels); traffic: 2 x FETCH_SIZE + "
-                                    "WRITE_SIZE per launch from profiles/ when collected on these "
-                                    "kernel sources, else null")
-        step_ms = sum(r["avg_ms"] * r["launches_per_step"] for r in rows)
-        roofline["hot_kernels_ms_per_step"] = step_ms
+        roofline["kernels_note"] = ("avg_ms: HIP events per launch (eager fused sequence); frac: "
+                                    "SURVEY 8d algorithmic bytes / time / 8 TB/s; traffic: 2 x "
+                                    "FETCH_SIZE + WRITE_SIZE per launch from profiles/ when collected "
+                                    "on these kernel sources, else null")
+        roofline["hot_kernels_ms_per_step"] = sum(r["avg_ms"] * r["launches_per_step"] for r in rows)
     dt, tests_total = main_leg["dt"], main_leg["tests"]
     line = {
         "metric": "ray-surface intersection tests/sec (fwd+bwd)",
@@ -513,9 +543,9 @@ def main(argv=None):
         "unit": "tests/s",
         "n_gpus": world,
         "steps": main_leg["steps"],
-        "steps_requested": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / main_leg["steps"] * 1e3,
+        "timed_region_s": dt,
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
@@ -533,8 +563,9 @@ def main(argv=None):
             "trace_depth": 3,
             "trace_mode": {"all-pairs": "all-pairs float32 sphere filter",
                            "group": "sphere hierarchy over k-d face clusters (default)"}[mode]
-            + (", rays visited in a coherent (Hilbert) order: wavefronts share one walk "
-               "(k_intersect_beam)" if visiting else ""),
+            + (", rays visited in a coherent (Hilbert) order: wavefronts share one walk"
+               + (", all passes in ONE launch with the rays kept in place (k_trace_inplace)"
+                  if in_place else " (k_intersect_beam)") if visiting else ""),
             "step_mode": {"graph": "fused launch sequence (GoalError), HIP-graph replay",
                           "fused": "fused launch sequence (GoalError), eager launches",
                           "generic": "error function as torch code through autograd"}[
@@ -548,10 +579,27 @@ def main(argv=None):
         },
         "value_note": "tests = ray-face pairs DECIDED (sum over passes of N_active x M, counted "
                       "by the kernels); the hierarchy decides most pairs without executing a "
-                      "per-pair test -- ms_per_step is the comparable number, and "
-                      "other_legs.all_pairs is the same step with every pair executed",
+                      "per-pair test -- ms_per_step is the comparable number, value_executed "
+                      "counts the pair tests that ran, and other_legs.all_pairs is the same step "
+                      "with every pair through the float32 filter",
         "roofline": roofline,
     }
+    if dt < MIN_TIMED_SECONDS:
+        line["timed_region_note"] = ("exactly --steps steps were timed: %.1f ms, shorter than %.1f s; "
+                                     "`steady` is the same step over a longer loop"
+                                     % (dt * 1e3, MIN_TIMED_SECONDS))
+    if main_leg.get("steady"):
+        line["steady"] = main_leg["steady"]
+    if main_leg.get("executed"):
+        ex = main_leg["executed"]
+        per_s = main_leg["steps"] / dt * world     # (rank 0's shard x ranks)
+        line["value_executed"] = {
+            "exact_pair_tests_per_s": ex[0] * per_s, "faces_tested_against_bundles_per_s": ex[1] * per_s,
+            "exact_pair_tests_per_step": ex[0] * world, "faces_tested_against_bundles_per_step": ex[1] * world,
+            "note": "work the forward trace of one step executed: (ray, face) pairs through the exact "
+                    "float64 test (tfrt/geometry.py:286-311) and candidate faces tested as triangles "
+                    "against a wavefront's bundle (tfrt_trace3d_executed); the reverse sweep re-derives "
+                    "one pair per ray and pass"}
     # whole step against the HBM roof: SURVEY 8d bytes (64 B forward + 116 B backward per ray
     # entering a pass, 48 B per face and pass) / ms_per_step / 8 TB/s
     step_bytes = (sum(n_active) * (BYTES_PER_RAY_FWD + BYTES_PER_RAY_BWD) * world   # (rank 0's shard x ranks)

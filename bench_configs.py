@@ -42,15 +42,10 @@ def _cores():
     return max(1, min(avail, 16))
 
 
-def _timed(step, warmup, steps, min_seconds=0.2):
+def _timed(step, warmup, steps):
+    """warm-up, then EXACTLY `steps` steps between device synchronisations"""
     for _ in range(warmup):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    step()
-    torch.cuda.synchronize()
-    est = time.perf_counter() - t0
-    steps = max(steps, int(np.ceil(min_seconds / max(est, 1e-6))))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -105,7 +100,7 @@ def _line(name, dt, steps, args, tests, n_active, M, backward, extra_config, cpu
     line = {
         "metric": "ray-surface intersection tests/sec (" + ("fwd+bwd" if backward else "fwd") + ")",
         "value": tests / dt, "unit": "tests/s", "n_gpus": 1, "steps": steps,
-        "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "warmup": args.warmup, "ms_per_step": ms, "timed_region_s": dt,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": dtype, "data": "synthetic",
         "config": dict({"workload": WORKLOADS[name], "faces": M, "passes": P,
@@ -199,7 +194,7 @@ def run(name, args):
         for tag, dt_ in (("f32", torch.float32), ("f16", torch.float16), ("f64", torch.float64)):
             eng, system, parts = sc5._build_5a(dt_, compile_all=False)
             t, steps = _timed(lambda: eng.ray_trace(sc5.PASSES_5A), min(args.warmup, 3),
-                              min(args.steps, 10), min_seconds=0.1)
+                              min(args.steps, 10))
             counts = eng.last_trace["counts"]
             M = int(system._merged_face_verts.shape[0])
             n_active = [int(c[:4].sum()) for c in counts]
@@ -214,7 +209,7 @@ def run(name, args):
                 rows = _kernel_rows(lib, n_active, M, len(n_active))
                 lib.tfrt_profile_enable(0)
                 eng_nat, *_ = sc5._build_5a(dt_, compile_all=False, coherent=False)
-                tn, sn = _timed(lambda: eng_nat.ray_trace(sc5.PASSES_5A), 2, 5, min_seconds=0.1)
+                tn, sn = _timed(lambda: eng_nat.ray_trace(sc5.PASSES_5A), 2, 5)
                 legs["f32_natural_order"] = dict(dt=tn, steps=sn)
                 if not args.no_cpu_baseline:
                     cpu = _cpu_5a(parts, eng, args.cpu_seconds)
@@ -244,7 +239,7 @@ def run(name, args):
             loss = (out["finished"][3].double() ** 2).sum()
             torch.autograd.grad(loss, geo)
             last["out"] = out
-        dt, steps = _timed(step, min(args.warmup, 3), min(args.steps, 20), min_seconds=0.1)
+        dt, steps = _timed(step, min(args.warmup, 3), min(args.steps, 20))
         counts = last["out"]["counts"]
         n_active = [int(c[:4].sum()) for c in counts]
         M = 320

@@ -352,6 +352,15 @@ int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_ray
                          int32_t* unfinished_id, int32_t* counts, int64_t n_faces, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* Work an in-place trace actually executed (measurement; no reference counterpart -- the reference
+ * executes every pair, tfrt/engine.py:1103-1166): executed[0] = (ray, face) pairs that reached the
+ * exact float64 test of tfrt/geometry.py:286-311, executed[1] = candidate faces tested as triangles
+ * against a wavefront's bundle; both summed over the passes of the trace whose tape is in
+ * `workspace`.  `counts` tells how many pairs the trace DECIDED (n_tests). */
+int tfrt_trace3d_executed(int64_t n_rays, int64_t n_faces, int32_t max_passes, int32_t state_dtype,
+                          const void* workspace, size_t workspace_bytes, int64_t* executed,
+                          void* stream);
+
 /* Reverse sweep over the tape left in `workspace` by tfrt_trace3d_forward with the same
  * arguments.  Replaces the ray-dependent part of tape.gradient in
  * SGD_Optimizer.process_gradient, tfrt/optimizer.py:216-220.

@@ -137,6 +137,7 @@ SIGNATURES = {
     "tfrt_trace3d_compact": (c_i32, [
         c_vp, c_i64, c_i64, c_f64, c_i32, c_i32, c_u32,
         _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "tfrt_trace3d_executed": (c_i32, [c_i64, c_i64, c_i32, c_i32, c_vp, c_sz, c_vp, c_vp]),
     "tfrt_trace3d_backward": (c_i32, [
         c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32,
         c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),

@@ -1672,7 +1672,9 @@ template <typename T, typename RT>
 __device__ __forceinline__ bool beam_pass(BeamLds<RT>& W, const BeamScene& g, const int lane,
                                           const int bundle, const bool live, const int skip,
                                           const bool first_pass, const int coherent_only,
-                                          unsigned* _wi) {
+                                          unsigned* _wi, unsigned* work = nullptr) {
+  // work (wave-uniform, optional): [0] += (ray, face) pairs that reach the exact float64 test,
+  // [1] += candidate faces tested as triangles against a bundle (face_frame)
   TFRT_TICK_INIT;
   const float4* __restrict__ susphere = g.susphere;
   const float4* __restrict__ clsphere = g.clsphere;
@@ -1980,6 +1982,7 @@ __device__ __forceinline__ bool beam_pass(BeamLds<RT>& W, const BeamScene& g, co
     int f0 = 0;
     do {
       const int nb = min(64, n_cand - f0);
+      if (work != nullptr) work[1] += (unsigned)nb;
       float4 rec[4] = {never, never, never, never};  // (set: nothing is carried around the loop)
       bool touch = false;
       float tnear = INFINITY;
@@ -2090,6 +2093,7 @@ __device__ __forceinline__ bool beam_pass(BeamLds<RT>& W, const BeamScene& g, co
         if (keepb) W.x_pair[xn + na + rank_below(kmb)] = ((uint32_t)jb << 6) | (uint32_t)lane;
         queued = queued || keepa || keepb;
         xn += na + __popcll(kmb);
+        if (work != nullptr) work[0] += (unsigned)(na + __popcll(kmb));
         TFRT_STAT(14, na + __popcll(kmb));
         TFRT_TICK(7);
       }
@@ -2543,7 +2547,7 @@ struct InplaceArgs {
   uint8_t* rec_cls;
   int64_t n;
   uint32_t* wcount;      // [p * wstride + wavefront]: four class counts, one byte each
-  int32_t wstride;
+  int32_t wstride;       // rows P and P + 1: the wavefront's executed work (beam_pass `work`)
   const int32_t* catagory;
   const double* fnorm;   // FaceTables
   const double* feta;    // ... or null: the indices depend on the ray (n_table, one column per ray)
@@ -2573,10 +2577,14 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
   bool active = has;
   int skip = -1;
   int p = 0;
+  TFRT_WAVE_BEGIN;
+  unsigned work[2] = {0u, 0u};
   for (; p < a.P; ++p) {
     if (__ballot(active) == 0ull) break;  // (wave-uniform: every ray of the wavefront has ended)
-    beam_pass<T, RT>(W, g, lane, a.bundle, active, skip, p == 0, /*coherent_only=*/1, nullptr);
+    beam_pass<T, RT>(W, g, lane, a.bundle, active, skip, p == 0, /*coherent_only=*/1, TFRT_WI_ARG,
+                     work);
     wave_fence();
+    TFRT_TICK_INIT;
     int cls = -1;
     if (active) {
       const int bi = W.best_i[lane];
@@ -2633,9 +2641,12 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
 #pragma unroll
     for (int c = 0; c < 4; ++c) word |= (uint32_t)__popcll(__ballot(cls == c)) << (8 * c);
     if (lane == 0) a.wcount[(size_t)p * a.wstride + qwave] = word;
+    TFRT_TICK(11);
   }
   // (passes this wavefront never reached: no rays)
   for (int pp = p + lane; pp < a.P; pp += 64) a.wcount[(size_t)pp * a.wstride + qwave] = 0u;
+  if (lane < 2) a.wcount[(size_t)(a.P + lane) * a.wstride + qwave] = work[lane];
+  TFRT_WAVE_END(qwave);
 }
 
 // The counts of an in-place trace: workgroup p sums the class counts of the passes before its own
@@ -2753,6 +2764,24 @@ __global__ __launch_bounds__(1024) void k_inplace_scan(const uint32_t* __restric
       tail[4] = (int32_t)(uint32_t)(tests & 0xFFFFFFFFull);
       tail[5] = (int32_t)(uint32_t)(tests >> 32);
     }
+  }
+}
+
+// sums of the two work rows (tfrt_trace3d_executed)
+__global__ __launch_bounds__(BLOCK) void k_inplace_work(const uint32_t* __restrict__ rows, int nwaves,
+                                                        int wstride, unsigned long long* out) {
+  __shared__ unsigned long long part[WAVES];
+  const uint32_t* r = rows + (size_t)blockIdx.x * wstride;
+  unsigned long long acc = 0ull;
+  for (int k = threadIdx.x; k < nwaves; k += BLOCK) acc += r[k];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0ull;
+    for (int w = 0; w < WAVES; ++w) t += part[w];
+    out[blockIdx.x] = t;
   }
 }
 
@@ -3653,7 +3682,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.left_list = take((n + 63) / 64 * sizeof(int32_t));
   // in-place traces (tfrt_scene3d.in_place): per pass and wavefront (of 32 rays at least) the packed
   // class counts and the bases k_inplace_scan makes of them
-  L.wcount = take((size_t)(P > 0 ? P : 1) * inplace_wstride(n) * sizeof(uint32_t));
+  L.wcount = take((size_t)((P > 0 ? P : 1) + 2) * inplace_wstride(n) * sizeof(uint32_t));
   L.wbase = take((size_t)(P > 0 ? P : 1) * inplace_wstride(n) * sizeof(int4));
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
@@ -4253,6 +4282,22 @@ int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
                                      active, stopped, dead, unfinished, unfinished_id, counts,
                                      workspace, workspace_bytes, st);
   return TFRT_E_UNSUPPORTED;
+}
+
+int tfrt_trace3d_executed(int64_t n_rays, int64_t n_faces, int32_t max_passes, int32_t state_dtype,
+                          const void* workspace, size_t workspace_bytes, int64_t* executed,
+                          void* stream) {
+  if (n_rays < 64 || n_faces < 0 || max_passes < 1 || !workspace || !executed) return TFRT_E_BADARG;
+  const Plan3 pl = make_plan(n_rays, n_faces);
+  const Layout3 lay = make_layout(n_rays, n_faces, max_passes, state_dtype, pl);
+  if (workspace_bytes < lay.total) return TFRT_E_WORKSPACE;
+  const int wstride = (int)inplace_wstride(n_rays);
+  const uint32_t* rows = reinterpret_cast<const uint32_t*>(static_cast<const char*>(workspace) +
+                                                           lay.wcount) + (size_t)max_passes * wstride;
+  hipLaunchKernelGGL(k_inplace_work, dim3(2), dim3(BLOCK), 0, static_cast<hipStream_t>(stream), rows,
+                     cdiv(n_rays, inplace_bundle(n_rays)), wstride,
+                     reinterpret_cast<unsigned long long*>(executed));
+  return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 
 int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_rays,
