@@ -17,42 +17,54 @@ __device__ __forceinline__ void goal_finish_block(const tfrt_goal_pending& g) {
 #pragma clang fp contract(off)
   __shared__ double wsum[WAVES];
   // (eight loads in flight per thread: one workgroup reads up to n_rays / 64 partial sums, and a
-  // chain of dependent load-add pairs took 16 us for 15,625 of them; the order stays fixed)
+  // chain of dependent load-add pairs took 16 us for 15,625 of them; the order stays fixed.  The
+  // counts of an in-place trace that compacted nothing -- the sweep counted finished rays and
+  // passes itself -- ride along in the same rounds: a second loop of their own cost 5 us more)
   double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long c0 = 0, c1 = 0;
+  const bool counted = g.partial_counts != nullptr;
+  const int2* pc = reinterpret_cast<const int2*>(g.partial_counts);
   int b = threadIdx.x;
-  for (; b + 7 * BLOCK < g.n_partial; b += 8 * BLOCK) {
-    double v[8];
+  if (counted) {   // (two loops, no branch between the loads of a round: a conditional load inside
+                   // the round made every load wait for the one before it, 8 -> 22 us)
+    for (; b + 7 * BLOCK < g.n_partial; b += 8 * BLOCK) {
+      double v[8];
+      int2 w[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = g.partial[b + k * BLOCK];
+      for (int k = 0; k < 8; ++k) {
+        v[k] = g.partial[b + k * BLOCK];
+        w[k] = pc[b + k * BLOCK];
+      }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a[k] += v[k];
+      for (int k = 0; k < 8; ++k) {
+        a[k] += v[k];
+        c0 += w[k].x;
+        c1 += w[k].y;
+      }
+    }
+  } else {
+    for (; b + 7 * BLOCK < g.n_partial; b += 8 * BLOCK) {
+      double v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = g.partial[b + k * BLOCK];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a[k] += v[k];
+    }
   }
-  for (int k = 0; b < g.n_partial; b += BLOCK, ++k) a[k] += g.partial[b];
+  for (int k = 0; b < g.n_partial; b += BLOCK, ++k) {
+    a[k] += g.partial[b];
+    if (counted) {
+      const int2 w = pc[b];
+      c0 += w.x;
+      c1 += w.y;
+    }
+  }
   double s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
   if (lane_id() == 0) wsum[threadIdx.x >> 6] = s;
-  // (an in-place trace that compacted nothing: the sweep counted finished rays and passes itself)
   __shared__ long long wcnt[WAVES][2];
-  if (g.partial_counts != nullptr) {
-    long long c0 = 0, c1 = 0;
-    const int2* pc = reinterpret_cast<const int2*>(g.partial_counts);
-    int k = threadIdx.x;
-    for (; k + 7 * BLOCK < g.n_partial; k += 8 * BLOCK) {
-      int2 v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = pc[k + j * BLOCK];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        c0 += v[j].x;
-        c1 += v[j].y;
-      }
-    }
-    for (; k < g.n_partial; k += BLOCK) {
-      const int2 v = pc[k];
-      c0 += v.x;
-      c1 += v.y;
-    }
+  if (counted) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
       c0 += __shfl_xor(c0, d, 64);
