@@ -555,6 +555,11 @@ int tfrt_snell2d(int64_t n, const double* x_start, const double* y_start, const 
 #define TFRT_SELFTEST_SQRT 1
 #define TFRT_SELFTEST_RSQRT 2
 #define TFRT_SELFTEST_MULADD 3
+/* the reverse sweep's own reciprocal and reciprocal square root (hardware estimate + two Newton
+ * steps, csrc/trace_math.h adj_rcp / adj_rsqrt; `b` unused): not correctly rounded by design --
+ * the test bounds their error against the host's IEEE results */
+#define TFRT_SELFTEST_ADJ_RCP 4
+#define TFRT_SELFTEST_ADJ_RSQRT 5
 int tfrt_selftest_f64(int op, int64_t n, const double* a, const double* b, double* out,
                       void* stream);
 

@@ -175,4 +175,24 @@ __device__ __forceinline__ void eval_ray(const tfrt_source3d_program& sp, int64_
   }
 }
 
+// Host-side validity of the programs: everything a kernel dereferences or indexes by
+// (tfrt_points_generate, tfrt_source3d_generate and tfrt_source3d_order refuse what fails here with
+// TFRT_E_BADARG instead of launching on it).
+inline bool points_program_ok(const tfrt_points_program* pg) {
+  if (!pg || pg->count < 0) return false;
+  if (pg->kind == TFRT_PTS_TABLE) return pg->count == 0 || pg->table != nullptr;
+  if (pg->kind < TFRT_PTS_TABLE || pg->kind > TFRT_PTS_SPHERE_LAMBERT) return false;
+  return pg->epoch != nullptr;
+}
+
+inline bool source_program_ok(const tfrt_source3d_program* sp) {
+  if (!sp || sp->n_rays < 0) return false;
+  if (sp->kind < TFRT_SRC_APERTURE || sp->kind > TFRT_SRC_ANGULAR) return false;
+  if (!points_program_ok(&sp->b)) return false;
+  if (sp->kind != TFRT_SRC_POINT && !points_program_ok(&sp->a)) return false;
+  // (undense: every input has one sample or one per ray)
+  const int64_t ca = sp->kind == TFRT_SRC_POINT ? 1 : sp->a.count, cb = sp->b.count;
+  return (ca == 1 || ca == sp->n_rays) && (cb == 1 || cb == sp->n_rays);
+}
+
 }  // namespace tfrt

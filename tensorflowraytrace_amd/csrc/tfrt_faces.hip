@@ -343,6 +343,8 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_f64(int op, int64_t n, const
     case TFRT_SELFTEST_SQRT: r = sqrt(x); break;
     case TFRT_SELFTEST_RSQRT: r = 1.0 / sqrt(x); break;          // l2_normalize3's scale
     case TFRT_SELFTEST_MULADD: r = advance(x, y, y); break;       // x + y*y, two roundings
+    case TFRT_SELFTEST_ADJ_RCP: r = adj_rcp(x); break;            // the reverse sweep's own
+    case TFRT_SELFTEST_ADJ_RSQRT: r = adj_rsqrt(x); break;
     default: r = 0.0;
   }
   out[i] = r;
@@ -528,7 +530,7 @@ int tfrt_snell2d(int64_t n, const double* x_start, const double* y_start, const 
 
 int tfrt_selftest_f64(int op, int64_t n, const double* a, const double* b, double* out,
                       void* stream) {
-  if (n < 0 || op < TFRT_SELFTEST_DIV || op > TFRT_SELFTEST_MULADD) return TFRT_E_BADARG;
+  if (n < 0 || op < TFRT_SELFTEST_DIV || op > TFRT_SELFTEST_ADJ_RSQRT) return TFRT_E_BADARG;
   if (n == 0) return 0;
   if (!a || !out || (!b && (op == TFRT_SELFTEST_DIV || op == TFRT_SELFTEST_MULADD)))
     return TFRT_E_BADARG;

@@ -1309,8 +1309,9 @@ int tfrt_source3d_order(const tfrt_source3d_program* program, int64_t first, int
                         const double* face_verts, int64_t n_faces, const double* axis,
                         int32_t* perm, uint32_t* keys_out, void* workspace,
                         size_t workspace_bytes, void* stream) {
-  if (!program || n_rays < 0 || n_rays >= (1ll << 31) || n_faces < 0 || n_faces >= (1ll << 31) ||
-      first < 0 || first + n_rays > program->n_rays)
+  // (the same validation as tfrt_source3d_generate: k_order_pkey evaluates the program)
+  if (!source_program_ok(program) || n_rays < 0 || n_rays >= (1ll << 31) || n_faces < 0 ||
+      n_faces >= (1ll << 31) || first < 0 || first + n_rays > program->n_rays)
     return TFRT_E_BADARG;
   if (n_rays == 0) return 0;
   if (!perm || !workspace) return TFRT_E_BADARG;

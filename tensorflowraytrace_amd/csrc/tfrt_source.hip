@@ -72,13 +72,6 @@ __global__ void k_epoch_advance(int64_t* p0, int64_t* p1, int64_t* p2, int64_t* 
   if (t < n && p[t] != nullptr) p[t][0] += 1;
 }
 
-static bool points_ok(const tfrt_points_program* pg) {
-  if (!pg || pg->count < 0) return false;
-  if (pg->kind == TFRT_PTS_TABLE) return pg->count == 0 || pg->table != nullptr;
-  if (pg->kind < TFRT_PTS_TABLE || pg->kind > TFRT_PTS_SPHERE_LAMBERT) return false;
-  return pg->epoch != nullptr;
-}
-
 }  // namespace tfrt
 
 using namespace tfrt;
@@ -101,7 +94,7 @@ int tfrt_epoch_advance(int64_t* const* epochs, int32_t n, void* stream) {
 int tfrt_points_generate(const tfrt_points_program* program, const int32_t* index,
                          int64_t first, int64_t n, double* points, int32_t point_columns, double* aux0, double* aux1,
                          void* stream) {
-  if (!points_ok(program) || n < 0 || (point_columns != 2 && point_columns != 3))
+  if (!points_program_ok(program) || n < 0 || (point_columns != 2 && point_columns != 3))
     return TFRT_E_BADARG;
   if (first < 0 || (index == nullptr && first + n > program->count)) return TFRT_E_BADARG;
   if (n == 0) return 0;
@@ -114,14 +107,8 @@ int tfrt_points_generate(const tfrt_points_program* program, const int32_t* inde
 int tfrt_source3d_generate(const tfrt_source3d_program* program, const int32_t* index,
                            int64_t first, int64_t n, int32_t state_dtype, void* rays, int64_t stride, double* fields,
                            int64_t field_stride, void* stream) {
-  if (!program || n < 0 || program->kind < TFRT_SRC_APERTURE || program->kind > TFRT_SRC_ANGULAR)
-    return TFRT_E_BADARG;
-  if (!points_ok(&program->b)) return TFRT_E_BADARG;
-  if (program->kind != TFRT_SRC_POINT && !points_ok(&program->a)) return TFRT_E_BADARG;
+  if (n < 0 || !source_program_ok(program)) return TFRT_E_BADARG;
   if (first < 0 || (index == nullptr && first + n > program->n_rays)) return TFRT_E_BADARG;
-  const int64_t ca = program->kind == TFRT_SRC_POINT ? 1 : program->a.count, cb = program->b.count;
-  if ((ca != 1 && ca != program->n_rays) || (cb != 1 && cb != program->n_rays))
-    return TFRT_E_BADARG;   // (undense: every input has one sample or one per ray)
   if ((rays != nullptr && stride < n) || (fields != nullptr && field_stride < n))
     return TFRT_E_BADARG;
   if (n == 0) return 0;

@@ -108,8 +108,16 @@ class _DeviceRandom:
     _kind = None          # _lib.PTS_*
 
     def _device_mode(self):
-        return (_device_random and config.get_device().type == "cuda"
-                and len(self.__dict__.get("_transformations", ())) <= 1)
+        # (a program bakes the transformation's scale / rotation / translation and the
+        # distribution's parameters in as numbers: when one of them requires grad the torch
+        # formulas run instead, so that autograd still reaches it)
+        tr = self.__dict__.get("_transformations", ())
+        baked = [getattr(t, name, None) for t in tr for name in ("scale", "rotation", "translation")]
+        baked.extend(self.__dict__.get(name) for name in
+                     ("radius", "theta_start", "theta_end", "angular_size", "x_size", "y_size"))
+        if any(isinstance(t, torch.Tensor) and t.requires_grad for t in baked):
+            return False
+        return (_device_random and config.get_device().type == "cuda" and len(tr) <= 1)
 
     def _device_update(self):
         from . import _lib

@@ -39,6 +39,7 @@ PI = math.pi
 _GEO3 = ("x_start", "y_start", "z_start", "x_end", "y_end", "z_end")
 _GEO2 = ("x_start", "y_start", "x_end", "y_end")
 _CLASSES = ("active", "finished", "stopped", "dead")
+_RESTORE_CHUNK = 4096      # csrc/tfrt_order.hip SCAN_CHUNK: (pass, 32-ray word) pairs per scan chunk
 
 
 class ReadOnlySet:
@@ -1019,7 +1020,13 @@ class OpticalEngine:
 
     def _run(self, rays, max_passes, flags, predicted=None):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
-        block, scene, fv = self._trace_inputs(rays)
+        # (tfrt_restore_order, which hands an ordered trace's ray sets back in the reference's
+        # order, holds one scan chunk per RESTORE_CHUNK (pass, 32-ray word) pairs in 96 KB of LDS
+        # and 1024 passes at most: a longer or larger trace runs in natural order, as it always did)
+        n_rays = rays.n_rays if hasattr(rays, "n_rays") else rays[_GEO3[0]].shape[0]
+        restorable = (max_passes <= 1024 and
+                      ((n_rays + 31) // 32) * max(int(max_passes), 1) <= 24576 * _RESTORE_CHUNK)
+        block, scene, fv = self._trace_inputs(rays, coherent_ok=restorable)
         if self.dimension == 3:
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
                               self.dead_ray_length, flags, predicted_counts=predicted,

@@ -260,15 +260,20 @@ class FusedStep:
         else:
             # coherent order: the trace runs over src[perm] (its ray ids are positions in that
             # order), so the goal rows go along; the ray sets are restored when somebody asks
-            gkey = (id(erf), eng._order_cache[0], id(perm))
+            # (keyed by the goal TABLE, not by the geometry the order was made from: a goal may
+            # read any source field, and erf.table() is itself cached by the versions of all of
+            # them -- a field changed in place re-evaluates it and, through the key, re-gathers)
+            rowwise = bool(erf.rowwise and callable(erf.goal) and hasattr(src, "permuted"))
+            base = None if rowwise else erf.table(src)
+            gkey = (id(erf), src.cache_key if rowwise else id(base), id(perm), rowwise)
             cached = getattr(self, "_goal_perm", None)
             if cached is None or cached[0] != gkey:
-                if erf.rowwise and callable(erf.goal) and hasattr(src, "permuted"):
+                if rowwise:
                     # made in the trace's order, left in the layout the callable returns
                     rows, by_ray = erf.table(src.permuted(perm), by_ray=True), True
                 else:
-                    rows, by_ray = ops.gather_rows(erf.table(src), perm), False
-                cached = self._goal_perm = (gkey, rows, perm, by_ray)
+                    rows, by_ray = ops.gather_rows(base, perm), False
+                cached = self._goal_perm = (gkey, rows, perm, by_ray, base)   # (holds `base`: its id stays its own)
             goal, goal_by_ray = cached[1], cached[3]
         P, flags = int(opt.trace_depth), eng._flags() | _lib.COMPILE_FINISHED
         dt = ops._DT[block.dtype]

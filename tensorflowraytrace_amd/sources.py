@@ -295,10 +295,18 @@ class SourceBase(RecursivelyUpdatable, ABC):
         if (getattr(self, "_dimension", None) != 3 or self.dense or not dist._device_random
                 or config.get_device().type != "cuda"):
             return None
+        # (a program bakes center, central_angle, the wavelengths and table inputs in as numbers:
+        # a source with one of them requiring grad keeps the differentiable torch path)
+        baked = [self.__dict__.get("_center"), self.__dict__.get("_central_angle"),
+                 self.__dict__.get("_wavelengths")]
+        if any(isinstance(t, torch.Tensor) and t.requires_grad for t in baked):
+            return None
         spec = self._device_inputs()
         if spec is None:
             return None
         kind, a, b, extra = spec
+        if any(isinstance(d, torch.Tensor) and d.requires_grad for d in (a, b)):
+            return None
         live = [d for d in (a, b) if isinstance(d, dist._DeviceRandom)
                 and d.__dict__.get("_device_active")]
         if not live:

@@ -103,6 +103,22 @@ def test_bad_arguments_are_rejected_before_any_launch(lib):
     assert lib.tfrt_ray_order(None, 0, -1, 0, None, 0, None, None, None, None, 0, None) == -1
     assert lib.tfrt_ray_order_workspace_bytes(1_000_000) > 0
     assert lib.tfrt_source3d_order(None, 0, 10, None, 0, None, None, None, None, 0, None) == -1
+    # a program tfrt_source3d_generate refuses is refused by tfrt_source3d_order too (same check):
+    # unknown kind, a random distribution without an epoch counter, a table without storage, an
+    # input that has neither one sample nor one per ray
+    def program(kind=_lib.SRC_APERTURE, a_kind=_lib.PTS_CIRCLE, a_count=10, epoch=ptr, table=None):
+        sp = _lib.Source3DProgram()
+        sp.kind, sp.n_rays = kind, 10
+        for pg, knd, cnt in ((sp.a, a_kind, a_count), (sp.b, _lib.PTS_CIRCLE, 10)):
+            pg.kind, pg.count, pg.epoch, pg.table = knd, cnt, epoch, table
+        return sp
+
+    for bad in (program(kind=7), program(epoch=None), program(a_kind=_lib.PTS_TABLE),
+                program(a_kind=9), program(a_count=3)):
+        args = (ctypes.byref(bad), 0, 10, None, 0, None, ptr, None, ptr, 1 << 16, None)
+        assert lib.tfrt_source3d_order(*args) == -1
+        assert lib.tfrt_source3d_generate(ctypes.byref(bad), None, 0, 10, 0, ptr, 10, None, 0,
+                                          None) == -1
     assert lib.tfrt_epoch_advance(None, 9, None) == -1
 
 

@@ -313,3 +313,37 @@ def test_fused_step_over_a_redrawn_source_equals_the_generic_natural_order_step(
     fin = eng.finished_rays
     ids = eng.last_trace["finished_id"].long()
     assert torch.equal(fin["object_coords"], source["object_coords"][ids])
+
+
+def test_a_source_with_a_differentiable_center_keeps_the_torch_path():
+    """A device program bakes center / central_angle / the transformation in as numbers: when one of
+    them requires grad the source must stay on the differentiable torch path, or d error / d center
+    would silently be zero (the reference's tape reaches them: tfrt/sources.py:464-1095 are plain
+    tensor ops)."""
+    import tfrt.sources as sources
+    d = _dist()
+    d.seed(5)
+    n = 5000
+    center = torch.tensor([1.0, -2.0, 0.5], dtype=torch.float64, device=DEV, requires_grad=True)
+    ps = sources.PointSource(3, center, (1.0, 1.0, 0.2), d.RandomUniformSphere(0.3, n), [500.0],
+                             dense=False)
+    ps.update()
+    assert not isinstance(ps._fields, sources.DeviceRaySet)
+    err = (ps["x_end"] ** 2 + ps["y_start"] * 3.0).sum()
+    g, = torch.autograd.grad(err, [center])
+    assert float(g.abs().min()) > 0.0 or float(g.abs().max()) > 0.0
+    assert abs(float(g[1]) - 3.0 * n) < 1e-6 * n            # d (3 sum y_start) / d center_y
+    # the same source without a gradient request is made on the device
+    ps2 = sources.PointSource(3, center.detach(), (1.0, 1.0, 0.2), d.RandomUniformSphere(0.3, n),
+                              [500.0], dense=False)
+    ps2.update()
+    assert isinstance(ps2._fields, sources.DeviceRaySet)
+    # a transformation that requires grad keeps its distribution on the torch path too
+    shift = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64, device=DEV, requires_grad=True)
+    pts = d.RandomUniformCircle(n, 0.5)
+    d.BasePointTransformation(pts, translation=shift)
+    pts.update()
+    pts.update()
+    assert not pts.__dict__.get("_device_active")
+    gs, = torch.autograd.grad(pts.points.sum(), [shift])
+    assert torch.allclose(gs, torch.full_like(gs, float(n)))

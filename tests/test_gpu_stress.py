@@ -214,3 +214,39 @@ def test_device_float64_primitives_are_correctly_rounded(op, name):
     bad = np.nonzero(got != want)[0]
     ulp = np.abs(got[bad].view(np.int64) - want[bad].view(np.int64)).max() if bad.size else 0
     assert bad.size == 0, f"{name}: {bad.size} of {n} results differ (max {ulp} ulp)"
+
+
+@pytest.mark.parametrize("op,name", [(4, "adj_rcp"), (5, "adj_rsqrt")])
+def test_reverse_sweep_reciprocals_against_ieee(op, name):
+    """The DEVICE branch of trace_math.h's adj_rcp / adj_rsqrt (hardware estimate + two Newton steps;
+    tests/host_math only sees the host branch, which is the plain IEEE operation): against numpy on
+    1M operands over 160 binades, denormal results and operands included.  They are not correctly
+    rounded by design (the reverse sweep's tolerance is 1e-8): the bound is 2 ulp, and the special
+    values must come out as IEEE gives them wherever the sweep can meet them."""
+    from tensorflowraytrace_amd import _lib, ops
+    rng = np.random.default_rng(40 + op)
+    n = 1_000_000
+    a = rng.uniform(1.0, 2.0, n) * 2.0 ** rng.integers(-80, 80, n)
+    if op == 4:
+        a *= rng.choice([-1.0, 1.0], n)
+    # the ends of the range: large operands (results denormal) and tiny ones
+    a[:1000] = rng.uniform(1.0, 2.0, 1000) * 2.0 ** rng.integers(990, 1023, 1000)
+    a[1000:2000] = rng.uniform(1.0, 2.0, 1000) * 2.0 ** rng.integers(-1022, -990, 1000)
+    want = 1.0 / a if op == 4 else 1.0 / np.sqrt(a)
+    ta = torch.tensor(a, device=DEV)
+    out = torch.empty_like(ta)
+    _lib.check(_lib.lib().tfrt_selftest_f64(op, n, ops._p(ta), None, ops._p(out), ops._stream(ta)),
+               "tfrt_selftest_f64")
+    got = out.cpu().numpy()
+    normal = np.abs(want) >= 2.0 ** -1022
+    ulp = np.abs(got[normal].view(np.int64) - want[normal].view(np.int64))
+    assert ulp.max() <= 2, f"{name}: {int((ulp > 2).sum())} results off by more than 2 ulp (max {ulp.max()})"
+    assert (ulp == 0).mean() > 0.9
+    # denormal results: absolute error below two denormal steps
+    assert np.abs(got[~normal] - want[~normal]).max(initial=0.0) <= 2 * 4.9406564584124654e-324 * 2 ** 1
+    # special operands
+    sp = torch.tensor([np.inf, 4.0, 1.0], device=DEV)
+    o2 = torch.empty_like(sp)
+    _lib.check(_lib.lib().tfrt_selftest_f64(op, 3, ops._p(sp), None, ops._p(o2), ops._stream(sp)),
+               "tfrt_selftest_f64")
+    assert o2.cpu().tolist()[1:] == ([0.25, 1.0] if op == 4 else [0.5, 1.0])
