@@ -275,7 +275,15 @@ def main(argv=None):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed_leg(global_rays, trace_mode, step_mode, dtype, profile=False, random_rays=False,
+    def timed_leg(*a, **kw):
+        # (several ranks: a leg that does not finish -- a collective captured on one rank and not
+        # on another hangs, it does not raise -- ends this process with status 124 and the
+        # launcher with it, instead of blocking the node)
+        with tdist.Watchdog(float(os.environ.get("TFRT_BENCH_LEG_TIMEOUT", 300)),
+                            "a bench leg (warm-up, graph capture, timed steps)"):
+            return _timed_leg(*a, **kw)
+
+    def _timed_leg(global_rays, trace_mode, step_mode, dtype, profile=False, random_rays=False,
                   coherent="auto", exact_steps=False):
         """Build the scene with `global_rays` source rays (each rank traces its contiguous
         shard), run warmup steps, then time optimiser steps between barriers: EXACTLY --steps of
@@ -313,13 +321,14 @@ def main(argv=None):
             if fs is not None:
                 tests_local = int(fs.tests_total.item()) - tests0
             tests_total = float(tests_local)
+            per_rank = [dt]
             if world > 1:
                 stats = torch.tensor([dt, float(tests_local)], dtype=torch.float64, device="cuda")
-                tmax = stats[:1].clone()
-                torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-                tsum = stats[1:].clone()
-                torch.distributed.all_reduce(tsum, op=torch.distributed.ReduceOp.SUM)
-                dt, tests_total = float(tmax.item()), float(tsum.item())
+                every = [torch.zeros_like(stats) for _ in range(world)]
+                torch.distributed.all_gather(every, stats)
+                per_rank = [float(e[0].item()) for e in every]
+                dt, tests_total = max(per_rank), float(sum(e[1].item() for e in every))
+            run.per_rank_s = per_rank
             return dt, tests_total
 
         def enough_steps():
@@ -337,6 +346,7 @@ def main(argv=None):
         if profile:
             lib.tfrt_profile_enable(1)
         dt, tests_total = run(steps)
+        per_rank_ms = [t / steps * 1e3 for t in run.per_rank_s]
         kernel_ms = []
         if profile:
             import ctypes
@@ -365,6 +375,7 @@ def main(argv=None):
             if rc == 0:
                 executed = [int(v) for v in ex.tolist()]
         out = dict(dt=dt, steps=steps, tests=tests_total, kernel_ms=kernel_ms, steady=steady,
+                   per_rank_ms=per_rank_ms,
                    counts=eng.last_trace["counts"], M=int(system._merged_face_verts.shape[0]),
                    mode=eng._trace_mode(system),
                    visiting=getattr(eng, "_order_cache", None) is not None,
@@ -387,7 +398,7 @@ def main(argv=None):
         leg = timed_leg(other_rays, args.trace_mode, args.step_mode, args.dtype)
         side["weak_scaling" if not per_rank else "strong_scaling"] = {
             "global_rays": other_rays, "ms_per_step": leg["dt"] / leg["steps"] * 1e3,
-            "tests_per_s": leg["tests"] / leg["dt"]}
+            "per_rank_ms": leg["per_rank_ms"], "tests_per_s": leg["tests"] / leg["dt"]}
     # per-launch time of the dominant kernel, HIP events on the launch stream: needs eagerly
     # launched kernels (events cannot sit inside a replayed graph), so the same step is run
     # `steps` more times as the eager fused sequence -- same kernels, same launches, same data
@@ -545,6 +556,7 @@ def main(argv=None):
         "steps": main_leg["steps"],
         "warmup": args.warmup,
         "ms_per_step": dt / main_leg["steps"] * 1e3,
+        "per_rank_ms": main_leg["per_rank_ms"],
         "timed_region_s": dt,
         "higher_is_better": True,
         "scaling": args.scaling,

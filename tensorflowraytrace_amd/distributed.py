@@ -11,10 +11,18 @@ collective).  Because the gradient of a vector error is the gradient of its sum
 constraints then run identically on every rank, so parameters stay bit-identical without a
 broadcast.
 """
+import datetime
 import os
+import sys
+import threading
 
 import torch
 import torch.distributed as dist
+
+# Seconds a collective (and the rendezvous) may take before the process group gives up
+# (TFRT_DIST_TIMEOUT).  The exchange of this path is one ~50 KB all-reduce per step: a rank that
+# waits two minutes for it is not slow, its peers are gone or a captured collective never ran.
+DEFAULT_TIMEOUT_S = 120.0
 
 
 def is_distributed():
@@ -45,8 +53,47 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local % torch.cuda.device_count())
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rk, world_size=world)
+        timeout = float(os.environ.get("TFRT_DIST_TIMEOUT", DEFAULT_TIMEOUT_S))
+        if backend == "nccl":
+            # (RCCL: a collective that times out aborts the process instead of blocking for ever)
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        dist.init_process_group(backend=backend, rank=rk, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout))
     return rk, world, local
+
+
+class Watchdog:
+    """Bounded wait around a multi-rank phase: ``with Watchdog(seconds, "what"):`` ends the
+    PROCESS with status 124 when the block has not finished in time.  A collective that was captured
+    into a HIP graph on one rank and not on another (or whose peer died) does not raise, it hangs
+    inside the runtime where no Python exception can reach it -- and a launcher then waits for
+    ever.  ``os._exit`` from a timer thread always gets out; nothing is re-executed (a process
+    that has touched the GPU must not exec), the launcher sees the status and ends the other
+    ranks.  ``seconds <= 0`` or a single process: no timer."""
+
+    def __init__(self, seconds, what, only_distributed=True):
+        self.seconds, self.what = float(seconds), what
+        self._timer = None
+        self._on = self.seconds > 0 and (is_distributed() or not only_distributed)
+
+    def _expire(self):
+        try:
+            print(f"[tfrt] rank {rank()}: {self.what} did not finish within {self.seconds:.0f} s "
+                  f"(a hung collective?) -- exiting with status 124", file=sys.stderr, flush=True)
+        finally:
+            os._exit(124)
+
+    def __enter__(self):
+        if self._on:
+            self._timer = threading.Timer(self.seconds, self._expire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
 
 
 def shard_bounds(n, rk=None, world=None):

@@ -45,13 +45,21 @@ _RESTORE_CHUNK = 4096      # csrc/tfrt_order.hip SCAN_CHUNK: (pass, 32-ray word)
 class ReadOnlySet:
     """Read-only view of a field dict (engine.py:27-46)."""
 
-    def __init__(self, fields):
+    def __init__(self, fields, empty=None):
         self._fields = fields
+        # A class that a trace left without rays is an empty dict in the reference (no key at all,
+        # engine.py:1379-1403 amalgamates nothing).  `empty` (field -> zero-length tensor) keeps
+        # that -- the set is falsy, lists no keys -- but lets an error function written as
+        # ``stack([fin["y_end"], ...])`` run on it: with the rays sharded over ranks a rank whose
+        # shard finishes nothing must still take part in the step (its term is an empty sum).
+        self._empty = empty or {}
 
     def __getitem__(self, key):
         try:
             return self._fields[key]
         except KeyError as e:
+            if not self._fields and key in self._empty:
+                return self._empty[key]
             raise KeyError(f"key {key} not in the signature of this set.") from e
 
     def __bool__(self):
@@ -840,7 +848,21 @@ class OpticalEngine:
 
     def _set(self, cls):
         self._resolve_pending()
-        return ReadOnlySet(amalgamate(self._history[cls]))
+        fields = amalgamate(self._history[cls])
+        empty = None
+        src = getattr(self, "_trace_src", None)
+        if not fields and src is not None and bool(src):
+            # (zero-length stand-ins of what the class would hold: see ReadOnlySet)
+            geo = _GEO3 if self.dimension == 3 else _GEO2
+            keys = set(geo) | (set(src.keys()) & self.simple_ray_inheritance)
+            empty = {}
+            for k in keys:
+                try:
+                    v = src[k]
+                except KeyError:
+                    continue
+                empty[k] = v[:0]
+        return ReadOnlySet(fields, empty)
 
     active_rays = property(lambda self: self._set("active"))
     finished_rays = property(lambda self: self._set("finished"))

@@ -128,7 +128,7 @@ def test_quaternion_helpers():
     np.testing.assert_allclose(v.numpy(), [[0, 0, 1]], atol=1e-15)
 
 
-def _lens_api(n_rays=300, k=2):
+def _lens_api(n_rays=300, k=2, end_radius=0.8, target_size=100):
     import tfrt.boundaries as boundaries
     import tfrt.distributions as distributions
     import tfrt.engine as engine
@@ -138,7 +138,7 @@ def _lens_api(n_rays=300, k=2):
     import tfrt.sources as sources
     a = distributions.StaticUniformCircle(n_rays, 0.2)
     distributions.BasePointTransformation(a, translation=(-10, 0, 0))
-    b = distributions.StaticUniformCircle(n_rays, 0.8)
+    b = distributions.StaticUniformCircle(n_rays, end_radius)
     distributions.BasePointTransformation(b)
     source = sources.AperatureSource(3, a, b, [575.0], dense=False,
                                      extra_fields={"object_coords": ("start_point", a, "points")})
@@ -152,7 +152,7 @@ def _lens_api(n_rays=300, k=2):
         [True, False], initial_parameters=[-0.15 * (1 - r2), 0.15 * (1 - r2)],
         material_list=[{"mat_in": 1, "mat_out": 0}] * 2)
     target = boundaries.ManualTriangleBoundary(
-        mesh=mt.plane(center=(10, 0, 0), direction=(1, 0, 0), i_size=100, j_size=100))
+        mesh=mt.plane(center=(10, 0, 0), direction=(1, 0, 0), i_size=target_size, j_size=target_size))
     system = engine.OpticalSystem3D()
     system.optical = lens.surfaces
     system.targets = [target]
