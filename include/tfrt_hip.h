@@ -292,6 +292,14 @@ typedef struct tfrt_scene3d {
    * folded reverse sweep (tfrt_trace3d_backward_goal) needs neither and counts the finished rays
    * and the tests itself; tfrt_trace3d_compact then fills `counts` together with the sets. */
   int32_t in_place;
+  /* With in_place, optional: (n_rays) i32, ray_slot[r] = the column of src_rays that holds the
+   * CALLER's ray r -- the rays were handed over in another order than the caller's own, e.g. the
+   * coherent order of tfrt_ray_order (ray_slot is that permutation's inverse).  The ray sets are
+   * then compacted in the caller's numbering: every class lists, pass after pass, its rays by
+   * ascending r with ray_id = r, exactly what a trace of the rays in the caller's order returns
+   * (tfrt/engine.py:2069-2111, 1379-1403), and class gradients are read in that order by the
+   * reverse sweep -- no tfrt_restore_order afterwards.  NULL: the order of src_rays. */
+  const int32_t* ray_slot;
 } tfrt_scene3d;
 
 /* One class of output rays (finished / active history / stopped / dead), compacted stably in
@@ -342,15 +350,23 @@ int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
  * error flag is set when a capacity is exceeded).  Also records every tape entry's output row,
  * which tfrt_trace3d_backward / _backward_goal need to read class gradients (grad_finished, ...):
  * call it (or give forward its outputs) before a reverse sweep that is handed any.  Same
- * src_rays / n_rays / max_passes / state_dtype / flags / dead_ray_length as the forward call.
+ * src_rays / n_rays / max_passes / state_dtype / flags / dead_ray_length as the forward call;
+ * ray_slot as tfrt_scene3d.ray_slot (NULL: the sets in the order of src_rays).
  * Replaces the ray-set properties of tfrt/engine.py:1379-1403 for a trace whose sets are cut
  * lazily. */
 int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_rays,
                          double dead_ray_length, int32_t max_passes, int32_t state_dtype,
                          uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
                          tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
-                         int32_t* unfinished_id, int32_t* counts, int64_t n_faces, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         int32_t* unfinished_id, int32_t* counts, int64_t n_faces,
+                         const int32_t* ray_slot, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* 1 when tfrt_trace3d_forward takes the in-place route for this scene, ray count and pass count
+ * (tfrt_scene3d.in_place is honoured), 0 when it runs the per-pass launch sequence, < 0 on bad
+ * arguments.  A caller that hands over ray_slot needs to know which of the two orders its ray
+ * sets come back in. */
+int tfrt_trace3d_in_place(const tfrt_scene3d* scene, int64_t n_rays, int32_t max_passes);
 
 /* Work an in-place trace actually executed (measurement; no reference counterpart -- the reference
  * executes every pair, tfrt/engine.py:1103-1166): executed[0] = (ray, face) pairs that reached the

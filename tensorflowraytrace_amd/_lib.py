@@ -32,7 +32,7 @@ class Scene3D(ctypes.Structure):
         ("face_grad_mask", c_vp), ("cluster_order", c_vp), ("n_table_uniform", c_i32),
         ("deterministic", c_i32), ("coherent_rays", c_i32), ("coherent_only", c_i32),
         ("grad_n_in", c_vp), ("grad_n_out", c_vp), ("clear_buffer", c_vp), ("clear_count", c_i64),
-        ("in_place", c_i32),
+        ("in_place", c_i32), ("ray_slot", c_vp),
     ]
 
 
@@ -136,7 +136,9 @@ SIGNATURES = {
         _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_trace3d_compact": (c_i32, [
         c_vp, c_i64, c_i64, c_f64, c_i32, c_i32, c_u32,
-        _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
+        _P(RayOut), _P(RayOut), _P(RayOut), _P(RayOut), c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz,
+        c_vp]),
+    "tfrt_trace3d_in_place": (c_i32, [_P(Scene3D), c_i64, c_i32]),
     "tfrt_trace3d_executed": (c_i32, [c_i64, c_i64, c_i32, c_i32, c_vp, c_sz, c_vp, c_vp]),
     "tfrt_trace3d_backward": (c_i32, [
         c_vp, c_i64, c_i64, _P(Scene3D), c_f64, c_f64, c_i32, c_i32,

@@ -2785,6 +2785,32 @@ __global__ __launch_bounds__(BLOCK) void k_inplace_work(const uint32_t* __restri
   }
 }
 
+// Per-wavefront class counts of an in-place trace in the CALLER's ray numbering
+// (tfrt_scene3d.ray_slot: the rays were handed over in another order, e.g. a coherent one): 64
+// consecutive rays of the caller per wavefront, every lane walks its ray's class bytes through
+// slot_of.  The scan and the gather then work in that numbering, and the ray sets come out as a
+// trace of the caller's own order would list them -- the per-pass boolean_mask order of
+// engine.py:2069-2111 -- without ever being listed in the order of the trace.
+__global__ __launch_bounds__(64) void k_inplace_count(const uint8_t* __restrict__ rec_cls, int64_t n,
+                                                      int N, int P, const int32_t* __restrict__ slot_of,
+                                                      uint32_t* __restrict__ wcount, int wstride) {
+  const int lane = threadIdx.x, qwave = blockIdx.x;
+  const int r = qwave * 64 + lane;
+  bool alive = r < N;
+  const int64_t i = alive ? slot_of[r] : 0;
+  int p = 0;
+  for (; p < P; ++p) {
+    if (__ballot(alive) == 0ull) break;
+    const int cls = alive ? ((int)rec_cls[(size_t)p * n + i] & 3) : -1;
+    uint32_t word = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) word |= (uint32_t)__popcll(__ballot(cls == c)) << (8 * c);
+    if (lane == 0) wcount[(size_t)p * wstride + qwave] = word;
+    if (cls != CLS_ACTIVE) alive = false;
+  }
+  for (int pp = p + lane; pp < P; pp += 64) wcount[(size_t)pp * wstride + qwave] = 0u;
+}
+
 // The ray sets of an in-place trace in the reference's order: a wavefront's lanes walk their
 // rays' records, rank themselves inside their class (ballots) behind their wavefront's base, and
 // write the rows k_react3d would have written at the same slots -- recomputed from the tape, which
@@ -2804,6 +2830,10 @@ struct GatherArgs {
   int64_t n;
   const int4* wbase;     // [p * wstride + wavefront]
   int32_t wstride;
+  // the caller's ray r sits at slot_of[r] of the trace (tfrt_scene3d.ray_slot); null: r itself.
+  // With it the lanes walk the rays in the CALLER's numbering: the sets come out in the caller's
+  // order with the caller's ids, and wbase / counts are those of that numbering (k_inplace_count)
+  const int32_t* slot_of;
   const int32_t* counts;
   uint32_t flags;
   double dead_len;
@@ -2818,7 +2848,8 @@ __global__ __launch_bounds__(64) void k_inplace_gather(GatherArgs<T> a) {
   const int lane = threadIdx.x, qwave = blockIdx.x;
   const int q = qwave * a.bundle + lane;
   const bool has = lane < a.bundle && q < a.N;
-  const int64_t i = has ? q : 0;
+  const int rid = has ? q : 0;                                       // the ray as the caller numbers it
+  const int64_t i = a.slot_of != nullptr ? a.slot_of[rid] : rid;     // ... and where the trace kept it
   bool alive = has, ok = true;
   int p = 0;
   for (; p < a.P; ++p) {
@@ -2846,17 +2877,17 @@ __global__ __launch_bounds__(64) void k_inplace_gather(GatherArgs<T> a) {
           double e2[3] = {e[0], e[1], e[2]};
           if (a.dead_len != 0.0)
             for (int k = 0; k < 3; ++k) e2[k] = advance_between(s[k], a.dead_len, e[k]);
-          ok = emit<T>(a.dead, gslot, s, e2, (int)i, -1) && ok;
+          ok = emit<T>(a.dead, gslot, s, e2, rid, -1) && ok;
         }
       } else {
         double h[3];
         hit_point(s, e, a.rec_t[at], h);
         if (cls == CLS_FINISHED) {
-          if (a.flags & TFRT_COMPILE_FINISHED) ok = emit<T>(a.fin, gslot, s, h, (int)i, tri) && ok;
+          if (a.flags & TFRT_COMPILE_FINISHED) ok = emit<T>(a.fin, gslot, s, h, rid, tri) && ok;
         } else if (cls == CLS_STOPPED) {
-          if (a.flags & TFRT_COMPILE_STOPPED) ok = emit<T>(a.stp, gslot, s, h, (int)i, tri) && ok;
+          if (a.flags & TFRT_COMPILE_STOPPED) ok = emit<T>(a.stp, gslot, s, h, rid, tri) && ok;
         } else if (a.flags & TFRT_COMPILE_ACTIVE) {
-          ok = emit<T>(a.act, gslot, s, h, (int)i, tri) && ok;
+          ok = emit<T>(a.act, gslot, s, h, rid, tri) && ok;
         }
       }
       if (cls != CLS_ACTIVE) alive = false;
@@ -2871,7 +2902,7 @@ __global__ __launch_bounds__(64) void k_inplace_gather(GatherArgs<T> a) {
       const T* rin = a.rays_ws + (size_t)(a.P - 1) * 6 * a.n;
 #pragma unroll
       for (int k = 0; k < 6; ++k) a.unfinished[(int64_t)k * a.N + slot] = rin[k * a.n + i];
-      if (a.unfinished_id != nullptr) a.unfinished_id[slot] = (int32_t)i;
+      if (a.unfinished_id != nullptr) a.unfinished_id[slot] = rid;
     }
   }
 }
@@ -3682,7 +3713,8 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   L.left_list = take((n + 63) / 64 * sizeof(int32_t));
   // in-place traces (tfrt_scene3d.in_place): per pass and wavefront (of 32 rays at least) the packed
   // class counts and the bases k_inplace_scan makes of them
-  L.wcount = take((size_t)((P > 0 ? P : 1) + 2) * inplace_wstride(n) * sizeof(uint32_t));
+  // (P rows of the trace's own counts, two work rows, P rows of counts in the caller's numbering)
+  L.wcount = take((size_t)(2 * (P > 0 ? P : 1) + 2) * inplace_wstride(n) * sizeof(uint32_t));
   L.wbase = take((size_t)(P > 0 ? P : 1) * inplace_wstride(n) * sizeof(int4));
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
@@ -3829,7 +3861,7 @@ static bool inplace_trace(const tfrt_scene3d* sc, int64_t N, int64_t M, int P) {
 
 template <typename T>
 static int inplace_gather_t(const void* src_rays, int64_t src_stride, int64_t N, int64_t M,
-                            double dead_len, int P, uint32_t flags, const tfrt_ray_out* fin, const tfrt_ray_out* act,
+                            const int32_t* ray_slot, double dead_len, int P, uint32_t flags, const tfrt_ray_out* fin, const tfrt_ray_out* act,
                             const tfrt_ray_out* stp, const tfrt_ray_out* dead, void* unfinished,
                             int32_t* unfinished_id, int32_t* counts, char* ws, const Layout3& lay,
                             hipStream_t st) {
@@ -3860,9 +3892,20 @@ static int inplace_gather_t(const void* src_rays, int64_t src_stride, int64_t N,
   a.unfinished = static_cast<T*>(unfinished);
   a.unfinished_id = unfinished_id;
   a.err = counts + (size_t)P * TFRT_COUNTS_PER_PASS + 6;
+  a.slot_of = ray_slot;
+  const uint32_t* wcount = reinterpret_cast<const uint32_t*>(ws + lay.wcount);
+  if (ray_slot != nullptr) {
+    // the caller's numbering: wavefronts of 64 of ITS consecutive rays, counted from the tape
+    // (their rows: behind the trace's own count rows and the two work rows)
+    a.bundle = 64;
+    a.nwaves = cdiv(N, 64);
+    uint32_t* wnat = reinterpret_cast<uint32_t*>(ws + lay.wcount) + (size_t)(P + 2) * a.wstride;
+    hipLaunchKernelGGL(k_inplace_count, dim3(a.nwaves), dim3(64), 0, st, a.rec_cls, a.n, (int)N, P,
+                       ray_slot, wnat, a.wstride);
+    wcount = wnat;
+  }
   // the counts (per pass and class, bases, totals, tests) and every wavefront's bases, then the rows
-  hipLaunchKernelGGL(k_inplace_scan, dim3(P), dim3(1024), 0, st,
-                     reinterpret_cast<const uint32_t*>(ws + lay.wcount), a.nwaves, a.wstride, P,
+  hipLaunchKernelGGL(k_inplace_scan, dim3(P), dim3(1024), 0, st, wcount, a.nwaves, a.wstride, P,
                      (int)N, (int)M, reinterpret_cast<int4*>(ws + lay.wbase), counts);
   hipLaunchKernelGGL((k_inplace_gather<T>), dim3(a.nwaves), dim3(64), 0, st, a);
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
@@ -3990,8 +4033,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     const bool want_rows = (fin && fin->rays) || (act && act->rays) || (stp && stp->rays) ||
                            (dead && dead->rays) || unfinished != nullptr;
     if (want_rows)
-      return inplace_gather_t<T>(src_rays, src_stride, N, M, dead_len, P, flags, fin, act, stp, dead,
-                                 unfinished, unfinished_id, counts, ws, lay, st);
+      return inplace_gather_t<T>(src_rays, src_stride, N, M, sc->ray_slot, dead_len, P, flags, fin,
+                                 act, stp, dead, unfinished, unfinished_id, counts, ws, lay, st);
     return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
   }
   const int chunks_used = ac.order == nullptr ? pl.chunks : pl.g_chunks;
@@ -4284,6 +4327,11 @@ int tfrt_trace3d_forward(const void* src_rays, int64_t src_stride, int64_t n_ray
   return TFRT_E_UNSUPPORTED;
 }
 
+int tfrt_trace3d_in_place(const tfrt_scene3d* scene, int64_t n_rays, int32_t max_passes) {
+  if (!scene_ok(scene) || n_rays < 0 || max_passes < 0) return TFRT_E_BADARG;
+  return inplace_trace(scene, n_rays, scene->n_faces, max_passes) ? 1 : 0;
+}
+
 int tfrt_trace3d_executed(int64_t n_rays, int64_t n_faces, int32_t max_passes, int32_t state_dtype,
                           const void* workspace, size_t workspace_bytes, int64_t* executed,
                           void* stream) {
@@ -4304,8 +4352,9 @@ int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_ray
                          double dead_ray_length, int32_t max_passes, int32_t state_dtype,
                          uint32_t flags, tfrt_ray_out* finished, tfrt_ray_out* active,
                          tfrt_ray_out* stopped, tfrt_ray_out* dead, void* unfinished,
-                         int32_t* unfinished_id, int32_t* counts, int64_t n_faces, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+                         int32_t* unfinished_id, int32_t* counts, int64_t n_faces,
+                         const int32_t* ray_slot, void* workspace, size_t workspace_bytes,
+                         void* stream) {
   if (n_rays < 64 || n_rays >= (1ll << 31) - 4096 || max_passes < 1 || !counts || !workspace ||
       !src_rays || src_stride < n_rays || n_faces < 0)
     return TFRT_E_BADARG;
@@ -4315,15 +4364,15 @@ int tfrt_trace3d_compact(const void* src_rays, int64_t src_stride, int64_t n_ray
   hipStream_t st = static_cast<hipStream_t>(stream);
   char* ws = static_cast<char*>(workspace);
   if (state_dtype == TFRT_F32)
-    return inplace_gather_t<float>(src_rays, src_stride, n_rays, n_faces, dead_ray_length, max_passes, flags,
+    return inplace_gather_t<float>(src_rays, src_stride, n_rays, n_faces, ray_slot, dead_ray_length, max_passes, flags,
                                    finished, active, stopped, dead, unfinished, unfinished_id,
                                    counts, ws, lay, st);
   if (state_dtype == TFRT_F64)
-    return inplace_gather_t<double>(src_rays, src_stride, n_rays, n_faces, dead_ray_length, max_passes,
+    return inplace_gather_t<double>(src_rays, src_stride, n_rays, n_faces, ray_slot, dead_ray_length, max_passes,
                                     flags, finished, active, stopped, dead, unfinished,
                                     unfinished_id, counts, ws, lay, st);
   if (state_dtype == TFRT_F16)
-    return inplace_gather_t<_Float16>(src_rays, src_stride, n_rays, n_faces, dead_ray_length, max_passes,
+    return inplace_gather_t<_Float16>(src_rays, src_stride, n_rays, n_faces, ray_slot, dead_ray_length, max_passes,
                                       flags, finished, active, stopped, dead, unfinished,
                                       unfinished_id, counts, ws, lay, st);
   return TFRT_E_UNSUPPORTED;

@@ -1018,6 +1018,18 @@ class OpticalEngine:
                              (block, ident))
         return perm
 
+    def _order_inverse(self):
+        """The inverse of the current trace's order (tfrt_scene3d.ray_slot), kept with the order it
+        was made from (``_order_cache`` is replaced whenever the order is made again)."""
+        perm = self._trace_perm
+        if perm is None:
+            return None
+        oc = getattr(self, "_order_cache", None)
+        kept = getattr(self, "_order_inv", None)
+        if kept is None or kept[0] is not oc or kept[1] is not perm:
+            kept = self._order_inv = (oc, perm, ops.inverse_order(perm))
+        return kept[2]
+
     def _permuted_table(self, n_table, perm):
         if n_table is None:
             return None
@@ -1052,7 +1064,7 @@ class OpticalEngine:
         if self.dimension == 3:
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
                               self.dead_ray_length, flags, predicted_counts=predicted,
-                              perm=self._trace_perm)
+                              perm=self._trace_perm, ray_slot=self._order_inverse())
             self._note_left_over(out.get("left_over", 0), max_passes)
             return out
         return ops.trace2d(block, scene, max_passes, self.new_ray_length,

@@ -412,6 +412,8 @@ class FusedStep:
                 self._tap_checks += 1
         self._publish_lazily(st, src, P, flags, perm, (block, float(eng.dead_ray_length or 0.0))
                              if inplace else None)
+        # (publish() inverts `perm` when it runs: a replayed graph re-orders a re-drawn source into
+        # the same tensor behind Python's back)
         return grads, st["err"]
 
     def _publish_lazily(self, st, src, P, flags, perm=None, inplace=None):
@@ -425,14 +427,17 @@ class FusedStep:
             if inplace is not None:
                 # the trace ran in place and compacted nothing: the ray sets are gathered from its
                 # tape now, into the reference's (per-pass, stable) order of the traced rays
+                # (with a coherent order: in the SOURCE's order, through the inverse of the order)
                 block, dead_len = inplace
                 o = st["outs"]
                 check(_lib.lib().tfrt_trace3d_compact(
                     ops._p(block), block.shape[1], st["N"], dead_len, P, st["dt"], flags,
                     ctypes.byref(o["finished"]), ctypes.byref(o["active"]),
                     ctypes.byref(o["stopped"]), ctypes.byref(o["dead"]), None, None,
-                    ops._p(st["counts"]), st["M"], ops._p(st["ws"]), st["wsb"],
-                    ops._stream(block)), "tfrt_trace3d_compact")
+                    ops._p(st["counts"]), st["M"],
+                    None if perm is None else ops._p(ops.inverse_order(perm)), ops._p(st["ws"]),
+                    st["wsb"], ops._stream(block)), "tfrt_trace3d_compact")
+                return ops._finish_trace(dict(full), dict(aux), P, None)
             out = ops._finish_trace(dict(full), dict(aux), P, None)
             return out if perm is None else ops.restore_order(out, perm)
         eng._pending_trace = publish

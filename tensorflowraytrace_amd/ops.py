@@ -732,19 +732,30 @@ class _Trace3D(torch.autograd.Function):
         unf_id = ints.take(capN)
         sc = scene.struct(face_verts)
         outs = [_ray_out(*o) for o in (fin, act, stp, dead)]
-        check(L.tfrt_trace3d_forward(
-            _p(src), src.shape[1], N, ctypes.byref(sc), float(opts["new_ray_length"]),
-            float(opts["dead_ray_length"] or 0.0), P, dt, flags,
-            ctypes.byref(outs[0]), ctypes.byref(outs[1]), ctypes.byref(outs[2]),
-            ctypes.byref(outs[3]), _p(unf), _p(unf_id), _p(counts), _p(ws), wsb, _stream(src)),
-            "tfrt_trace3d_forward")
+        perm = opts.get("perm")
+        # an in-place trace over permuted rays compacts its ray sets in the CALLER's order itself
+        # (tfrt_scene3d.ray_slot = the inverse of `perm`): nothing to restore afterwards
+        own_order = bool(perm is not None and N
+                         and L.tfrt_trace3d_in_place(ctypes.byref(sc), N, P) == 1)
+        if own_order:
+            inv = opts.get("ray_slot")
+            inv = inverse_order(perm) if inv is None else inv
+            sc.ray_slot = inv.data_ptr()
+        try:
+            check(L.tfrt_trace3d_forward(
+                _p(src), src.shape[1], N, ctypes.byref(sc), float(opts["new_ray_length"]),
+                float(opts["dead_ray_length"] or 0.0), P, dt, flags,
+                ctypes.byref(outs[0]), ctypes.byref(outs[1]), ctypes.byref(outs[2]),
+                ctypes.byref(outs[3]), _p(unf), _p(unf_id), _p(counts), _p(ws), wsb, _stream(src)),
+                "tfrt_trace3d_forward")
+        finally:
+            sc.ray_slot = None          # (the struct is cached on the scene)
         tape = TraceTape()
         tape.src, tape.face_verts, tape.scene, tape.opts = src, face_verts, scene, dict(opts)
         tape.ws, tape.wsb, tape.counts, tape.dt = ws, wsb, counts, dt
         tape.caps = [o[0].shape[1] if o[0] is not None else 0 for o in (fin, act, stp, dead)]
         tape.dest = None
-        perm = opts.get("perm")
-        if perm is not None and N:
+        if perm is not None and N and not own_order:
             # `src` is a permuted source (src = natural[:, perm], e.g. perm = ray_order(natural)):
             # hand every class back in the reference's order, ids in the natural numbering; the
             # reverse sweep takes the gradients back through `dest`
@@ -929,7 +940,8 @@ def _finish_trace(full, aux, P, predicted_counts):
 
 
 def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
-            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED, predicted_counts=None, perm=None):
+            flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED, predicted_counts=None, perm=None,
+            ray_slot=None):
     """Run the whole 3-D trace.  ``src`` is a (6,N) ray block (f32 or f64) on the GPU.
 
     Returns a dict: for each class c in finished/active/stopped/dead (when compiled) the ray
@@ -942,11 +954,13 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     ``perm`` (int32, N): ``src`` is ``natural[:, perm]`` -- a source handed over in a coherent
     order (``ray_order`` / ``permute_rays``; set ``scene.coherent_rays``).  Every output then comes
     back as the trace of ``natural`` itself gives it: ids in the natural numbering, every class in
-    the reference's order (restored on the device inside the autograd node, gradients included).
+    the reference's order (restored on the device inside the autograd node, gradients included;
+    an in-place trace -- ``scene.in_place`` -- compacts them in that order directly, through
+    ``ray_slot`` = ``inverse_order(perm)``, computed here when not handed in).
     """
     opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
                 dead_ray_length=dead_ray_length, flags=flags,
-                zero_init=predicted_counts is not None, perm=perm)
+                zero_init=predicted_counts is not None, perm=perm, ray_slot=ray_slot)
     grad_n = lambda t: t if (isinstance(t, torch.Tensor) and t.requires_grad) else None
     outs = _Trace3D.apply(src, face_verts, grad_n(scene.n_in_arg), grad_n(scene.n_out_arg),
                           scene, opts)
@@ -1021,6 +1035,16 @@ def ray_order(rays, face_verts=None, axis=None, return_keys=False, out=None):
                                0 if fv is None else fv.shape[0], ax, _p(perm), _p(keys), _p(ws),
                                wsb, _stream(rays)), "tfrt_ray_order")
     return (perm, keys) if return_keys else perm
+
+
+def inverse_order(perm):
+    """``inv`` with ``inv[perm[j]] = j`` (int32): where the caller's ray r sits in a block that was
+    permuted with ``perm`` -- tfrt_scene3d.ray_slot.  (Not cached here: an order tensor is
+    re-written in place by tfrt_ray_order / tfrt_source3d_order without a version bump; the
+    engine keeps the inverse next to the order it belongs to.)"""
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = torch.arange(perm.numel(), dtype=perm.dtype, device=perm.device)
+    return inv
 
 
 def permute_rays(rays, index, out=None):

@@ -163,7 +163,7 @@ def test_compact_entry_fills_the_sets_a_forward_call_without_outputs_left_out():
     unf, unf_id = torch.empty((6, N), dtype=torch.float32, device=DEV), torch.empty(N, dtype=torch.int32, device=DEV)
     _lib.check(L.tfrt_trace3d_compact(ops._p(rays), N, N, 0.0, P, _lib.F32, _flags(),
                                       *[ctypes.byref(o) for o in outs], ops._p(unf), ops._p(unf_id),
-                                      ops._p(counts), M, ops._p(ws), wsb, stream), "compact")
+                                      ops._p(counts), M, None, ops._p(ws), wsb, stream), "compact")
     host = counts.cpu().numpy()
     assert np.array_equal(host[:P * 8].reshape(P, 8), ref["counts"])
     assert host[P * 8 + 6] == 0                                           # no capacity error
@@ -207,3 +207,33 @@ def test_fused_step_in_place_equals_the_per_pass_fused_step():
     assert a[4] == b[4] > 0 and a[5] == b[5] > 0     # error terms, ray-face tests of all steps
     for f in a[2]:
         np.testing.assert_allclose(a[2][f].cpu().numpy(), b[2][f].cpu().numpy(), rtol=0, atol=1e-6, err_msg=f)
+
+
+@pytest.mark.parametrize("n_rays,dtype,passes", [(5000, torch.float32, 4), (70001, torch.float64, 3),
+                                                 (200000, torch.float32, 3)])
+def test_in_place_trace_hands_the_sets_back_in_the_callers_order(n_rays, dtype, passes):
+    """trace3d(permuted rays, perm=order) with scene.in_place: the ray sets come back in the order
+    of the UNPERMUTED source (ids in its numbering, every class pass after pass by ascending id --
+    engine.py:2069-2111) straight from the compaction (tfrt_scene3d.ray_slot), equal to the
+    natural-order trace bit for bit; gradients w.r.t. faces equal the per-pass path's."""
+    from tensorflowraytrace_amd import ops
+    scene = scene_util.lens_scene(n_rays, k_front=7, k_back=5)
+    src, fv0, sc, _ = _gpu_scene(scene, dtype, cluster="group")
+    order = ops.ray_order(src)
+    rays = src[:, order.long()].contiguous()
+    plain = ops.Scene3DArgs(fv0.detach(), sc.catagory, mat_in=sc.mat_in, mat_out=sc.mat_out,
+                            n_table=sc.n_table, cluster_order=ops.cluster_order(fv0.detach()))
+    ref = ops.trace3d(src, fv0.detach(), plain, max_passes=passes, flags=_flags())
+    grads = {}
+    for in_place in (True, False):
+        fv = fv0.detach().clone().requires_grad_(True)
+        out = ops.trace3d(rays, fv, _lens_args(sc, fv.detach(), order, in_place), max_passes=passes,
+                          flags=_flags(), perm=order)
+        _same(out, ref, ("own order", in_place, n_rays, dtype))
+        w = torch.linspace(0.5, 1.5, out["finished"].shape[1], device=DEV, dtype=torch.float64)
+        err = (w * (out["finished"][4].double() ** 2 + out["finished"][5].double() ** 2)).sum()
+        err = err + (out["active"][3].double() * out["active"][0].double()).sum() * 1e-3
+        grads[in_place], = torch.autograd.grad(err, [fv])
+    scale = float(grads[False].abs().max())
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    assert float((grads[True] - grads[False]).abs().max()) <= tol * scale
