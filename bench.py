@@ -117,6 +117,17 @@ def make_error_function():
     return optimizer.GoalError(("y_end", "z_end"), goal, rowwise=True)
 
 
+def make_rowwise_error_function():
+    """The same error as arbitrary torch code, stated row by row (optimizer.RowwiseError): the
+    optimiser evaluates it on fixed-shape tensors inside the step's launch graph."""
+    import tfrt.optimizer as optimizer
+
+    def fn(rays):
+        out = torch.stack([rays["y_end"], rays["z_end"]], dim=1).double()
+        return (out + rays["object_coords"][:, 1:]) ** 2
+    return optimizer.RowwiseError(fn)
+
+
 def cpu_baseline(seconds_budget=20.0):
     """The reference algorithm restated (oracle: dense (M,N) float64 torch ops, forward +
     autograd) on the host cores, on a bounded sample of the same scene: consecutive 256-ray chunks
@@ -296,10 +307,12 @@ def main(argv=None):
         eng, system, params = build_scene(global_rays, args.k_front, args.k_back, ray_dtype,
                                           accelerate=trace_mode, random_rays=random_rays,
                                           coherent=coherent)
+        rowwise = step_mode == "rowwise"
         opt = optimizer.SGD_Optimizer(
-            eng, params, make_error_function(), trace_depth=3, learning_rate=1e-6, grad_clip=1e-3,
+            eng, params, make_rowwise_error_function() if rowwise else make_error_function(),
+            trace_depth=3, learning_rate=1e-6, grad_clip=1e-3,
             fused=False if step_mode == "generic" else "auto",
-            graph="auto" if step_mode == "graph" else False,
+            graph="auto" if step_mode in ("graph", "rowwise") else False,
             speculative=step_mode == "generic")   # (the bench's error function is pure)
         opt.suppress_warnings = True
         for _ in range(args.warmup):
@@ -642,6 +655,15 @@ def main(argv=None):
                                     "note": "same error function as arbitrary torch code (rays "
                                             "ordered on the device, every ray set handed back in "
                                             "the reference's order)"}
+            leg = timed_leg(args.rays, args.trace_mode, "rowwise", args.dtype)
+            legs["rowwise_step"] = {"ms_per_step": leg["dt"] / leg["steps"] * 1e3,
+                                    "tests_per_s": leg["tests"] / leg["dt"],
+                                    "graph_replays": leg["graph_replays"], "in_place": leg["in_place"],
+                                    "note": "the same error function as arbitrary ROW-WISE torch code "
+                                            "(optimizer.RowwiseError): evaluated on fixed-shape "
+                                            "tensors -- every ray's column + a mask -- inside the "
+                                            "step's launch graph, its autograd included; no ray "
+                                            "count is read back"}
             # the reference's own optimisation workload: the source is re-drawn at every step
             # (dev/hexalens.py:36-48 RandomUniformCircle, optimizer.py:217 update() per step)
             leg = timed_leg(args.rays, args.trace_mode, args.step_mode, args.dtype,

@@ -290,7 +290,15 @@ typedef struct tfrt_scene3d {
    * conditions above do not hold.
    * `counts`: a forward call that is given no room for ray sets does not run the scan either -- a
    * folded reverse sweep (tfrt_trace3d_backward_goal) needs neither and counts the finished rays
-   * and the tests itself; tfrt_trace3d_compact then fills `counts` together with the sets. */
+   * and the tests itself; tfrt_trace3d_compact then fills `counts` together with the sets.
+   * 2: as 1, and the FINISHED rays are handed out where they are -- `finished` (capacity >= n_rays,
+   * the only class given) receives ray r's finished row (start, hit point on the target) at
+   * column r, finished->face[r] = the target face hit or -1 when ray r did not finish (its column
+   * then holds the source ray: finite stand-in values that carry no gradient), finished->ray_id[r]
+   * = the number of passes ray r entered; nothing is compacted, `counts` is not written.  For
+   * error functions that work row by row on fixed-shape tensors (no ray count to read back:
+   * tfrt/optimizer.py:216-220 with a mask instead of a boolean_mask); tfrt_trace3d_backward then
+   * takes grad_finished in the same layout (capacity >= n_rays, no other class gradient). */
   int32_t in_place;
   /* With in_place, optional: (n_rays) i32, ray_slot[r] = the column of src_rays that holds the
    * CALLER's ray r -- the rays were handed over in another order than the caller's own, e.g. the

@@ -24,7 +24,7 @@ with torch.no_grad():
 pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(20): step()

@@ -2556,6 +2556,11 @@ struct InplaceArgs {
   const int32_t* mat_out;
   int64_t n_table_stride;
   double L;
+  // tfrt_scene3d.in_place == 2: every ray's finished row at the ray's own column (see there)
+  T* fin_rows;           // 6 x fin_cap, or null
+  int64_t fin_cap;
+  int32_t* fin_face;     // face of the target hit, -1: the ray did not finish
+  int32_t* fin_passes;   // passes the ray entered
 };
 
 #ifdef TFRT_INPLACE_WAVES   // (tuning builds: scratch/build_variants.py)
@@ -2634,6 +2639,29 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
         skip = bi;
       } else {
         active = false;
+        if (a.fin_rows != nullptr) {
+          // this ray's row of the in-place finished block: the row a compaction would store
+          // (start, hit point, rounded to the state type), or -- the ray stopped / died -- the
+          // source ray itself, a finite stand-in that no gradient is ever read for
+          const bool fin = cls == CLS_FINISHED;
+          double h[3] = {0.0, 0.0, 0.0};
+          if (fin) {
+            double s[3], e[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              s[k] = static_cast<double>(W.rtab[k][lane]);
+              e[k] = static_cast<double>(W.rtab[3 + k][lane]);
+            }
+            hit_point(s, e, t, h);
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            a.fin_rows[k * a.fin_cap + i] = fin ? static_cast<T>(W.rtab[k][lane]) : a.src[k * a.src_stride + i];
+            a.fin_rows[(3 + k) * a.fin_cap + i] = fin ? static_cast<T>(h[k]) : a.src[(3 + k) * a.src_stride + i];
+          }
+          a.fin_face[i] = fin ? bi : -1;
+          a.fin_passes[i] = p + 1;
+        }
       }
       a.rec_cls[at] = (uint8_t)tape;
     }
@@ -2642,6 +2670,12 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
     for (int c = 0; c < 4; ++c) word |= (uint32_t)__popcll(__ballot(cls == c)) << (8 * c);
     if (lane == 0) a.wcount[(size_t)p * a.wstride + qwave] = word;
     TFRT_TICK(11);
+  }
+  if (a.fin_rows != nullptr && active) {   // still active after the last pass: not finished either
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.fin_rows[k * a.fin_cap + i] = a.src[k * a.src_stride + i];
+    a.fin_face[i] = -1;
+    a.fin_passes[i] = a.P;
   }
   // (passes this wavefront never reached: no rays)
   for (int pp = p + lane; pp < a.P; pp += 64) a.wcount[(size_t)pp * a.wstride + qwave] = 0u;
@@ -3452,7 +3486,7 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
     for (int p = 0; p < P; ++p) {
       const size_t at = (size_t)p * a.n + j;
       const int tape = a.rec_cls[at], tri = a.rec_tri[at];
-      const int slot = a.inplace == 2 ? j : a.rec_slot[at];
+      const int slot = a.inplace >= 2 ? j : a.rec_slot[at];
       if (a.chain_in_lds) chain[p * 64 + lane] = make_int4(j, tape, slot, tri);
       last = p;
       if ((tape & 3) != CLS_ACTIVE || p == P - 1) break;
@@ -3476,7 +3510,7 @@ __global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4)))
         rec = chain[p * 64 + lane];
       } else {  // (an in-place tape of more passes than the LDS columns hold: the ray stays at i0)
         const size_t at = (size_t)p * a.n + i0;
-        rec = make_int4(i0, a.rec_cls[at], a.inplace == 2 ? i0 : a.rec_slot[at], a.rec_tri[at]);
+        rec = make_int4(i0, a.rec_cls[at], a.inplace >= 2 ? i0 : a.rec_slot[at], a.rec_tri[at]);
       }
       const int j = rec.x, tape = rec.y, slot = rec.z;
       const size_t off = (size_t)p * a.n;
@@ -4022,6 +4056,20 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     a.mat_out = sc->mat_out;
     a.n_table_stride = sc->n_table_stride;
     a.L = L;
+    a.fin_rows = nullptr;
+    a.fin_cap = 0;
+    a.fin_face = a.fin_passes = nullptr;
+    const bool rows_in_place = sc->in_place == 2;
+    if (rows_in_place) {
+      // the finished rows at the rays' own columns: nothing is compacted, nothing else is written
+      if (!fin || !fin->rays || !fin->face || !fin->ray_id || fin->capacity < N ||
+          (act && act->rays) || (stp && stp->rays) || (dead && dead->rays) || unfinished != nullptr)
+        return TFRT_E_BADARG;
+      a.fin_rows = static_cast<T*>(fin->rays);
+      a.fin_cap = fin->capacity;
+      a.fin_face = fin->face;
+      a.fin_passes = fin->ray_id;
+    }
     const BeamScene bs = {ac.susphere, ac.clsphere, ac.csphere, ac.crec, sc->face_verts, c0,
                           ac.n_clusters, cdiv(ac.n_clusters, SUPER), sc->intersect_epsilion,
                           sc->size_epsilion, sc->ray_start_epsilion};
@@ -4030,8 +4078,9 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
       hipLaunchKernelGGL((k_trace_inplace<T>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
     }
     // (no room for ray sets: no scan either -- tfrt_trace3d_compact makes counts and sets later)
-    const bool want_rows = (fin && fin->rays) || (act && act->rays) || (stp && stp->rays) ||
-                           (dead && dead->rays) || unfinished != nullptr;
+    const bool want_rows = !rows_in_place &&
+                           ((fin && fin->rays) || (act && act->rays) || (stp && stp->rays) ||
+                            (dead && dead->rays) || unfinished != nullptr);
     if (want_rows)
       return inplace_gather_t<T>(src_rays, src_stride, N, M, sc->ray_slot, dead_len, P, flags, fin,
                                  act, stp, dead, unfinished, unfinished_id, counts, ws, lay, st);
@@ -4208,7 +4257,13 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
     a.g_fverts = g_fverts;
     // (in-place tape: class gradients are read through rec_slot, which k_inplace_gather fills;
     // a sweep that is handed none but the built-in goal's never reads it)
-    a.inplace = !inplace ? 0 : ((g_fin || g_act || g_stp || g_dead || goal == nullptr) ? 1 : 2);
+    // 3 (tfrt_scene3d.in_place == 2): the finished rows' gradient sits at the rays' own columns,
+    // no other class carries one -- like 2, rec_slot is never read
+    if (inplace && sc->in_place == 2 && (g_act || g_stp || g_dead || goal != nullptr || cap_fin < N))
+      return TFRT_E_BADARG;
+    a.inplace = !inplace ? 0
+                : (sc->in_place == 2 ? 3
+                   : ((g_fin || g_act || g_stp || g_dead || goal == nullptr) ? 1 : 2));
     a.chain_in_lds = P <= CHAIN_MAXP ? 1 : 0;
     a.fin_rays = nullptr;
     a.fin_cap = 0;

@@ -46,6 +46,11 @@ _CLASS_FLAGS = (("finished", _lib.COMPILE_FINISHED), ("active", _lib.COMPILE_ACT
                 ("stopped", _lib.COMPILE_STOPPED), ("dead", _lib.COMPILE_DEAD))
 
 
+class _NotInPlace(RuntimeError):
+    """The fixed-shape path of a RowwiseError needs an in-place trace; this step takes the generic
+    path instead."""
+
+
 class GoalError:
     """``error = squared_difference(stack([finished[f] for f in fields], axis=1), goal)``.
 
@@ -116,6 +121,51 @@ class GoalError:
         return (out - table[:, ids].t()) ** 2
 
 
+class RowwiseError:
+    """An error function of the FINISHED rays that works row by row:
+    ``error = fn(rays)`` with ``rays[field]`` the fields of the finished rays (geometry and every
+    inherited source field, tfrt/engine.py:2242-2281) and the result one row of error terms per
+    ray, shape (n,) or (n, k) -- row i a function of row i of the fields alone.  That is what the
+    reference's optimisation scripts compute under their tape (dev/hexalens.py:144-168 is one
+    instance; any element-wise torch code qualifies, a mean over the rays does not).
+
+    It is an ordinary ``error_function(engine)``; stating the row-wise contract lets the optimiser
+    evaluate ``fn`` on fixed-shape tensors -- every source ray's column, a mask for the rays that
+    finished (tfrt_scene3d.in_place == 2) -- so that the step reads no ray count back and its
+    launches, ``fn``'s own torch kernels and their autograd included, are captured in one HIP graph
+    like a ``GoalError``'s (fused_step.FusedStep).  Columns of rays that did not finish hold finite
+    stand-in values (the source ray); their error terms are masked out of the sum and their
+    gradients are never read."""
+
+    def __init__(self, fn):
+        if not callable(fn):
+            raise ValueError("RowwiseError: fn must be callable")
+        self.fn = fn
+        self.rows = []          # (no built-in goal kernel)
+
+    def __call__(self, engine):
+        return self.fn(engine.finished_rays)
+
+
+class _RowFields:
+    """Field mapping handed to a RowwiseError on the fixed-shape path: geometry = the rows of the
+    in-place finished block, everything else = the source's own fields in the trace's order."""
+
+    def __init__(self, geo, inherited):
+        self._geo, self._inh = geo, inherited
+
+    def __getitem__(self, key):
+        if key in self._geo:
+            return self._geo[key]
+        return self._inh(key)
+
+    def keys(self):
+        return list(self._geo.keys())
+
+    def __bool__(self):
+        return True
+
+
 class _HyperTable:
     """(n_parameters, 3) float64 {scale, clip, sgd_learning_rate} on the device, refreshed through
     a ring of pinned host buffers only when a value changes."""
@@ -178,7 +228,9 @@ class FusedStep:
     @staticmethod
     def eligible(optimizer, args, kwargs):
         eng = optimizer.engine
-        if not isinstance(optimizer.error_function, GoalError) or args or kwargs:
+        if not isinstance(optimizer.error_function, (GoalError, RowwiseError)) or args or kwargs:
+            return False
+        if isinstance(optimizer.error_function, RowwiseError) and not FusedStep.rowwise_ready(eng):
             return False
         if eng.dimension != 3 or not bool(eng.optical_system):
             return False
@@ -190,6 +242,15 @@ class FusedStep:
             return False
         return all(isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float64
                    and p.is_contiguous() for p in optimizer.parameters)
+
+    @staticmethod
+    def rowwise_ready(eng):
+        """A RowwiseError runs on the fixed-shape path once the engine traces this source in place
+        (its rays are ordered and an earlier trace -- of the generic path -- left no wavefront
+        over); until then, and whenever that stops holding, the step takes the generic path."""
+        return (eng.in_place is not False and eng.coherent is not False and not eng.deterministic
+                and getattr(eng, "_visit_all_key", None) is not None
+                and not getattr(eng, "_rowwise_off", False))
 
     # -------------------------------------------------------------------------- buffers
     def _buffers(self, block, fv, P, flags, dt):
@@ -254,6 +315,8 @@ class FusedStep:
         erf = opt.error_function
         block, scene, fv = eng._trace_inputs(src)
         perm = eng._trace_perm
+        if isinstance(erf, RowwiseError):
+            return self._enqueue_rowwise(erf, src, block, scene, fv, perm, tap_log)
         goal_by_ray = False       # (N, fields) rows instead of (fields, N) columns
         if perm is None:
             goal = erf.table(src)
@@ -363,6 +426,18 @@ class FusedStep:
                     ops._p(st["g_fin"]), st["capN"], None, 0, None, 0, None, 0, ops._p(st["g_fv"]),
                     None, ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream),
                     "tfrt_trace3d_backward")
+            grads = self._parameter_gradients(fv, st, tap_log)
+        self._publish_lazily(st, src, P, flags, perm, (block, float(eng.dead_ray_length or 0.0))
+                             if inplace else None)
+        # (publish() inverts `perm` when it runs: a replayed graph re-orders a re-drawn source into
+        # the same tensor behind Python's back)
+        return grads, st["err"]
+
+    def _parameter_gradients(self, fv, st, tap_log):
+        """d error / d parameters from d error / d faces (st["g_fv"]) through update()'s graph."""
+        opt = self.opt
+        grads = [None] * len(opt.parameters)
+        if True:
             # Inside a graph capture: differentiate w.r.t. the aliases update() read the parameters
             # through (see boundaries.tap), never w.r.t. the leaves.  Outside a capture the leaf is
             # differentiated too -- its gradient is the total whatever route update() took -- and
@@ -410,10 +485,91 @@ class FusedStep:
                 grads[i] = g
             if not capturing:
                 self._tap_checks += 1
-        self._publish_lazily(st, src, P, flags, perm, (block, float(eng.dead_ray_length or 0.0))
-                             if inplace else None)
-        # (publish() inverts `perm` when it runs: a replayed graph re-orders a re-drawn source into
-        # the same tensor behind Python's back)
+        return grads
+
+    def _enqueue_rowwise(self, erf, src, block, scene, fv, perm, tap_log):
+        """update (done) -> in-place trace with the finished rows at the rays' own columns ->
+        ``erf.fn`` on fixed-shape tensors + its autograd (torch) -> reverse sweep -> parameter
+        gradients.  No ray count is read; everything is capturable."""
+        opt, eng = self.opt, self.opt.engine
+        P, flags = int(opt.trace_depth), eng._flags() | _lib.COMPILE_FINISHED
+        dt = ops._DT[block.dtype]
+        fvc = fv.detach()
+        if fvc.dtype != torch.float64 or not fvc.is_contiguous():
+            raise RuntimeError("FusedStep: merged faces must be contiguous float64")
+        st = self._buffers(block, fvc, P, flags, dt)
+        N, M, dev = st["N"], st["M"], block.device
+        L = _lib.lib()
+        stream = ops._stream(block)
+        sc = scene.struct(fvc)
+        if not (scene.in_place and sc.coherent_rays
+                and L.tfrt_trace3d_in_place(ctypes.byref(sc), N, P) == 1):
+            eng._rowwise_off = True      # (this source is not traced in place: generic path)
+            raise _NotInPlace()
+        if "rows" not in st:
+            st["rows"] = torch.zeros((6, st["capN"]), dtype=block.dtype, device=dev)
+            st["row_face"] = torch.full((st["capN"],), -1, dtype=torch.int32, device=dev)
+            st["row_passes"] = torch.zeros(st["capN"], dtype=torch.int32, device=dev)
+            st["row_out"] = ops._ray_out(st["rows"], st["row_passes"], st["row_face"])
+        need_back = bool(fv.requires_grad and M > 0)
+        self.folded_backward, self.in_place = False, True
+        sc.in_place = 2
+        if need_back:
+            sc.clear_buffer, sc.clear_count = st["g_fv"].data_ptr(), st["g_fv"].numel()
+        no = st["no_outs"]
+        try:
+            check(L.tfrt_trace3d_forward(
+                ops._p(block), block.shape[1], N, ctypes.byref(sc), float(eng.new_ray_length),
+                float(eng.dead_ray_length or 0.0), P, dt, flags, ctypes.byref(st["row_out"]),
+                ctypes.byref(no["active"]), ctypes.byref(no["stopped"]), ctypes.byref(no["dead"]),
+                None, None, ops._p(st["counts"]), ops._p(st["ws"]), st["wsb"], stream),
+                "tfrt_trace3d_forward")
+            # the user's error function, row by row on every source ray's column
+            leaf = st["rows"].detach().requires_grad_(True)
+            geo = {name: leaf[k] for k, name in enumerate(_GEO3)}
+            if perm is None:
+                inherited = lambda key: src[key]                       # noqa: E731
+            else:
+                cache = st.setdefault("inherited", {})
+
+                def inherited(key, cache=cache):
+                    v = src[key]
+                    hit = cache.get(key)
+                    if hit is None or hit[0] is not v or hit[1] is not perm or hit[2] != v._version:
+                        hit = cache[key] = (v, perm, v._version, v.index_select(0, perm.long()))
+                    return hit[3]
+            e = erf.fn(_RowFields(geo, inherited))
+            if e.dim() == 1:
+                e = e.reshape(-1, 1)
+            if e.shape[0] != N:
+                raise RuntimeError(f"RowwiseError: fn returned {tuple(e.shape)}, expected one row "
+                                   f"per ray ({N})")
+            mask = st["row_face"][:N] >= 0
+            err_sum = torch.where(mask.unsqueeze(1), e.double(), torch.zeros((), dtype=torch.float64,
+                                                                           device=dev)).sum()
+            terms = mask.sum().double() * e.shape[1]
+            with torch.no_grad():
+                st["err"][0] = err_sum.detach()
+                st["err"][1] = terms
+                st["err"][2] = torch.where(terms > 0, err_sum.detach() / torch.clamp(terms, min=1.0),
+                                           torch.full_like(terms, float("nan")))
+                self.tests_total += st["row_passes"][:N].sum() * M
+            grads = [None] * len(opt.parameters)
+            if need_back and err_sum.requires_grad:
+                with torch.autograd.set_multithreading_enabled(False):
+                    g_rows, = torch.autograd.grad(err_sum, [leaf])
+                g64 = g_rows.to(torch.float64).contiguous()
+                check(L.tfrt_trace3d_backward(
+                    ops._p(block), block.shape[1], N, ctypes.byref(sc), float(eng.new_ray_length),
+                    float(eng.dead_ray_length or 0.0), P, dt, ops._p(g64), g64.shape[1], None, 0,
+                    None, 0, None, 0, ops._p(st["g_fv"]), None, ops._p(st["counts"]),
+                    ops._p(st["ws"]), st["wsb"], stream), "tfrt_trace3d_backward")
+                grads = self._parameter_gradients(fv, st, tap_log)
+        finally:
+            sc.in_place = 1 if scene.in_place else 0      # (the struct is cached by the scene)
+            sc.clear_buffer, sc.clear_count = None, 0
+        self._goal_pending = None
+        self._publish_lazily(st, src, P, flags, perm, (block, float(eng.dead_ray_length or 0.0)))
         return grads, st["err"]
 
     def _publish_lazily(self, st, src, P, flags, perm=None, inplace=None):
@@ -573,7 +729,8 @@ class FusedStep:
         return (tuple(id(a) for a in accumulators), tuple(p.data_ptr() for p in opt.parameters),
                 src_id, int(opt.trace_depth),
                 eng._flags(), eng.new_ray_length, eng.dead_ray_length, eng._trace_mode(),
-                id(opt.error_function), id(opt.error_function.goal), opt.error_function.fields,
+                id(opt.error_function), id(getattr(opt.error_function, "goal", None)),
+                getattr(opt.error_function, "fields", None),
                 tdist.world_size(), eng.optical_system.scene_signature(), bool(eng.deterministic),
                 id((getattr(eng, "_order_cache", None) or (None, None, None))[2]),
                 getattr(eng, "_visit_all_key", None) is not None, eng.in_place)

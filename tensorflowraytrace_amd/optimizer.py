@@ -21,7 +21,7 @@ import torch
 
 from . import distributed as tdist
 from . import ops
-from .fused_step import FusedStep, GoalError  # noqa: F401  (GoalError is public API)
+from .fused_step import FusedStep, GoalError, RowwiseError, _NotInPlace  # noqa: F401  (GoalError, RowwiseError: public API)
 
 
 class DeferredScalar:
@@ -353,7 +353,13 @@ class SGD_Optimizer:
             prev = self._pending_error() if self._pending_error is not None else None
             if prev is not None and prev._value is None and prev._tensor is not None:
                 prev._tensor = prev._tensor.clone()
-            err3 = self._fused_step.step(accumulators, lr_scale)   # {sum, n_terms, mean}, device
+            try:
+                err3 = self._fused_step.step(accumulators, lr_scale)   # {sum, n_terms, mean}, device
+            except _NotInPlace:
+                # (a RowwiseError whose source is not traced in place after all: the generic path,
+                # from now on -- FusedStep.rowwise_ready is off for this engine)
+                return self.single_step(accumulators, *args, lr_scale=lr_scale, momentum=momentum,
+                                        verbose=verbose, **kwargs)
             self.iterations += 1
             self.last_error_terms = err3[1]
             err = DeferredScalar(err3[2])
