@@ -2563,12 +2563,15 @@ struct InplaceArgs {
   int32_t* fin_passes;   // passes the ray entered
 };
 
-#ifdef TFRT_INPLACE_WAVES   // (tuning builds: scratch/build_variants.py)
-#define TFRT_INPLACE_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_INPLACE_WAVES, TFRT_INPLACE_WAVES)))
-#else
-#define TFRT_INPLACE_ATTR
+// (four wavefronts per SIMD: left to itself the compiler takes 162 registers -- three wavefronts --
+// once the finished rows are written too, and three are 10 % slower than four, 0.270 against
+// 0.247 ms per step; five only fit with scratch spills and gain nothing)
+#ifndef TFRT_INPLACE_WAVES   // (tuning builds set it: scratch/build_variants.py)
+#define TFRT_INPLACE_WAVES 4
 #endif
-template <typename T>
+#define TFRT_INPLACE_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_INPLACE_WAVES, TFRT_INPLACE_WAVES)))
+// ROWS: tfrt_scene3d.in_place == 2 (the finished rows at the rays' own columns)
+template <typename T, bool ROWS>
 __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceArgs<T> a, BeamScene g) {
   using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
   const int lane = threadIdx.x, qwave = blockIdx.x;
@@ -2639,7 +2642,7 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
         skip = bi;
       } else {
         active = false;
-        if (a.fin_rows != nullptr) {
+        if (ROWS) {
           // this ray's row of the in-place finished block: the row a compaction would store
           // (start, hit point, rounded to the state type), or -- the ray stopped / died -- the
           // source ray itself, a finite stand-in that no gradient is ever read for
@@ -2671,7 +2674,7 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
     if (lane == 0) a.wcount[(size_t)p * a.wstride + qwave] = word;
     TFRT_TICK(11);
   }
-  if (a.fin_rows != nullptr && active) {   // still active after the last pass: not finished either
+  if (ROWS && active) {   // still active after the last pass: not finished either
 #pragma unroll
     for (int k = 0; k < 6; ++k) a.fin_rows[k * a.fin_cap + i] = a.src[k * a.src_stride + i];
     a.fin_face[i] = -1;
@@ -4075,7 +4078,10 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                           sc->size_epsilion, sc->ray_start_epsilion};
     {
       ProfScope prof(TFRT_PROF_INTERSECT, st);
-      hipLaunchKernelGGL((k_trace_inplace<T>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
+      if (rows_in_place)
+        hipLaunchKernelGGL((k_trace_inplace<T, true>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
+      else
+        hipLaunchKernelGGL((k_trace_inplace<T, false>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
     }
     // (no room for ray sets: no scan either -- tfrt_trace3d_compact makes counts and sets later)
     const bool want_rows = !rows_in_place &&

@@ -33,6 +33,7 @@ processes the collective splits it in two graphs (RCCL is called eagerly between
 the same numbers, which is what the parity tests compare.
 """
 import ctypes
+import gc
 
 import numpy as np
 import torch
@@ -818,6 +819,13 @@ class FusedStep:
         # the step itself is done; capturing is an optimisation of the following ones: anything in
         # update() that a capture does not allow (a host->device copy, a blocking read) turns it
         # off for this optimizer and the steps go on eagerly
+        # No cyclic garbage collection while a stream captures: the collector may run at any
+        # allocation, and an unreachable cycle that holds a CUDAGraph or an event of an earlier
+        # optimiser (e.g. the previous FusedStep <-> SGD_Optimizer pair) is then destroyed inside
+        # the capture -- the HIP runtime refuses the destroy call and the process aborts.
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         try:
             torch.cuda.synchronize(dev)
             # (the device is idle: one read tells whether the visiting-order trace of the step just
@@ -859,5 +867,8 @@ class FusedStep:
             self.capture_error = e
             self._graphs = None
             torch.cuda.synchronize(dev)
+        finally:
+            if gc_was_on:
+                gc.enable()
         self._republish()
         return err_now

@@ -88,7 +88,7 @@ def test_rowwise_error_equals_the_goal_error_kernel_for_the_same_error():
     assert opt_r._fused_step.graph_replays >= 1 and opt_r._fused_step.in_place
     np.testing.assert_allclose(errs_r, errs_g, rtol=2e-6)
     for a, b in zip(lens_r.parameters, lens.parameters):
-        assert float((a - b).abs().max()) <= 1e-7 * max(1.0, float(b.abs().max()))
+        assert float((a - b).detach().abs().max()) <= 1e-7 * max(1.0, float(b.detach().abs().max()))
 
 
 def test_rowwise_error_without_an_in_place_trace_takes_the_generic_path():
