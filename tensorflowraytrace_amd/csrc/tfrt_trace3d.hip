@@ -445,13 +445,43 @@ __device__ __forceinline__ void super_spheres_block(
 // derives the frame origin itself -- the mean of P0 over 64 evenly spaced faces, one wave, the
 // same arithmetic in every block, rounded to float32 like k_center's -- and block 0 publishes it
 // for the kernels that follow and clears the trace's counters.
+// What k_trace_inplace needs once per pass, behind the beam walk (the reaction and the tape): kept
+// in device memory -- the set-up launch writes it -- and re-read by scalar loads when a pass gets
+// there.  As by-value kernel arguments these twenty pointers and sizes stayed in scalar registers
+// across the whole walk; the compiler spilled them to lanes of a vector register and reloaded
+// them sixteen at a time, ~80 v_readlane per pass.
+struct InplaceTape {
+  void* rays_ws;         // child of pass p (input of pass p + 1) at (p * 6 + k) * n + ray
+  int32_t* rec_tri;      // [p * n + ray]
+  double* rec_t;
+  uint8_t* rec_cls;
+  int64_t n;
+  uint32_t* wcount;      // [p * wstride + wavefront]: four class counts, one byte each
+  int64_t wstride;       // rows P and P + 1: the wavefront's executed work (beam_pass `work`)
+  const int32_t* catagory;
+  const double* fnorm;   // FaceTables
+  const double* feta;    // ... or null: the indices depend on the ray (n_table, one column per ray)
+  const double* n_table;
+  const int32_t* mat_in;
+  const int32_t* mat_out;
+  int64_t n_table_stride;
+  double L;
+  // tfrt_scene3d.in_place == 2: every ray's finished row at the ray's own column (see there)
+  void* fin_rows;        // 6 x fin_cap, or null
+  int64_t fin_cap;
+  int32_t* fin_face;     // face of the target hit, -1: the ray did not finish
+  int32_t* fin_passes;   // passes the ray entered
+};
+
 __global__ __launch_bounds__(BLOCK) void k_hierarchy_spheres(
     const double* __restrict__ fverts, int M, const int32_t* __restrict__ order,
     double* __restrict__ c0_out, double size_eps, int n_clusters, int n_super,
     float4* __restrict__ csphere, int32_t* __restrict__ cface, float4* __restrict__ clsphere,
     float4* __restrict__ crec, float4* __restrict__ susphere, int32_t* nrays0, int n,
     int32_t* tail8, unsigned int* scan_ticket, int32_t* __restrict__ hist0, int hist_len,
-    FaceTables ft, double* __restrict__ clear_buf, int64_t clear_n) {
+    FaceTables ft, double* __restrict__ clear_buf, int64_t clear_n, InplaceTape tape,
+    InplaceTape* __restrict__ tape_out) {
+  if (tape_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *tape_out = tape;
   // (coherent-ray traces: the class histogram the first pass's intersect kernels add into)
   for (int k = blockIdx.x * BLOCK + threadIdx.x; k < hist_len; k += gridDim.x * BLOCK) hist0[k] = 0;
   // (tfrt_scene3d.clear_buffer: the block a reverse sweep will accumulate into)
@@ -2541,38 +2571,21 @@ struct InplaceArgs {
   const T* src;          // source rays (inputs of pass 1)
   int64_t src_stride;
   int32_t N, P, bundle, nwaves;
-  T* rays_ws;            // child of pass p (input of pass p + 1) at (p * 6 + k) * n + ray
-  int32_t* rec_tri;      // [p * n + ray]
-  double* rec_t;
-  uint8_t* rec_cls;
-  int64_t n;
-  uint32_t* wcount;      // [p * wstride + wavefront]: four class counts, one byte each
-  int32_t wstride;       // rows P and P + 1: the wavefront's executed work (beam_pass `work`)
-  const int32_t* catagory;
-  const double* fnorm;   // FaceTables
-  const double* feta;    // ... or null: the indices depend on the ray (n_table, one column per ray)
-  const double* n_table;
-  const int32_t* mat_in;
-  const int32_t* mat_out;
-  int64_t n_table_stride;
-  double L;
-  // tfrt_scene3d.in_place == 2: every ray's finished row at the ray's own column (see there)
-  T* fin_rows;           // 6 x fin_cap, or null
-  int64_t fin_cap;
-  int32_t* fin_face;     // face of the target hit, -1: the ray did not finish
-  int32_t* fin_passes;   // passes the ray entered
+  const InplaceTape* tape;   // (device memory: see InplaceTape)
 };
 
-// (four wavefronts per SIMD: left to itself the compiler takes 162 registers -- three wavefronts --
-// once the finished rows are written too, and three are 10 % slower than four, 0.270 against
-// 0.247 ms per step; five only fit with scratch spills and gain nothing)
+// Wavefronts per SIMD: five for the plain kernel (96 registers, no scratch; with the 8 KB of LDS a
+// wavefront takes, five is also what a CU's LDS holds), 0.244 against 0.250 ms per step with four.
+// The kernel that also writes the finished rows needs 119 registers: four (pinned -- left to itself
+// the compiler took 162, three wavefronts, and the step 0.270 ms).  float64 state: the LDS (9.7 KB
+// per wavefront) admits four either way.
 #ifndef TFRT_INPLACE_WAVES   // (tuning builds set it: scratch/build_variants.py)
-#define TFRT_INPLACE_WAVES 4
+#define TFRT_INPLACE_WAVES 5
 #endif
 #define TFRT_INPLACE_ATTR __attribute__((amdgpu_waves_per_eu(TFRT_INPLACE_WAVES, TFRT_INPLACE_WAVES)))
 // ROWS: tfrt_scene3d.in_place == 2 (the finished rows at the rays' own columns)
 template <typename T, bool ROWS>
-__global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceArgs<T> a, BeamScene g) {
+__device__ __forceinline__ void trace_inplace(const InplaceArgs<T>& a, const BeamScene& g) {
   using RT = std::conditional_t<sizeof(T) <= 4, float, double>;
   const int lane = threadIdx.x, qwave = blockIdx.x;
   const int q = qwave * a.bundle + lane;
@@ -2593,14 +2606,19 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
                      work);
     wave_fence();
     TFRT_TICK_INIT;
+    // (the pointer is made opaque here, pass by pass: the loads below stay below the walk
+    // instead of being hoisted in front of the loop and kept in registers across it)
+    const InplaceTape* tp = a.tape;
+    __asm__ volatile("" : "+s"(tp));
+    const InplaceTape& tq = *tp;
     int cls = -1;
     if (active) {
       const int bi = W.best_i[lane];
       const double t = dkey_inv(W.best_k[lane]);
-      cls = (bi < 0) ? CLS_DEAD : cat_to_cls(a.catagory[bi]);
-      const size_t at = (size_t)p * a.n + i;
-      a.rec_tri[at] = bi;
-      a.rec_t[at] = t;
+      cls = (bi < 0) ? CLS_DEAD : cat_to_cls(tq.catagory[bi]);
+      const size_t at = (size_t)p * tq.n + i;
+      tq.rec_tri[at] = bi;
+      tq.rec_t[at] = t;
       int tape = cls;
       if (cls == CLS_ACTIVE) {
         // k_react3d's reaction: project the end onto the hit, refract / reflect (float64 Snell)
@@ -2612,30 +2630,30 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
         }
         hit_point(s, e, t, h);
         double un[3], n1, n2, n_in;
-        const double* fp = a.fnorm + 3 * (int64_t)bi;
+        const double* fp = tq.fnorm + 3 * (int64_t)bi;
 #pragma unroll
         for (int k = 0; k < 3; ++k) un[k] = fp[k];
-        if (a.feta != nullptr) {
-          const double* fe = a.feta + 4 * (int64_t)bi;
+        if (tq.feta != nullptr) {
+          const double* fe = tq.feta + 4 * (int64_t)bi;
           n1 = fe[0];
           n2 = fe[1];
           n_in = fe[2];
         } else {
           // (feta is only absent in "index" mode with one table column per source ray)
-          n_in = a.n_table[(int64_t)a.mat_in[bi] * a.n_table_stride + i];
-          const double n_out = a.n_table[(int64_t)a.mat_out[bi] * a.n_table_stride + i];
+          n_in = tq.n_table[(int64_t)tq.mat_in[bi] * tq.n_table_stride + i];
+          const double n_out = tq.n_table[(int64_t)tq.mat_out[bi] * tq.n_table_stride + i];
           snell_ratios(n_in, n_out, &n1, &n2);
         }
         const Snell3 f = snell3d_core(s, h, un, n1, n2, n_in == 0.0);
         tape |= (f.nu > 0.0 ? TAPE_INTERNAL : 0) | (f.reflect ? TAPE_REFLECT : 0);
         // the child, rounded to the state type where the per-pass path stores it; it stays here
-        T* out = a.rays_ws + (size_t)p * 6 * a.n;
+        T* out = static_cast<T*>(tq.rays_ws) + (size_t)p * 6 * tq.n;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const T hs = static_cast<T>(h[k]);
-          const T es = static_cast<T>(advance(h[k], a.L, f.w[k]));
-          out[k * a.n + i] = hs;
-          out[(3 + k) * a.n + i] = es;
+          const T es = static_cast<T>(advance(h[k], tq.L, f.w[k]));
+          out[k * tq.n + i] = hs;
+          out[(3 + k) * tq.n + i] = es;
           W.rtab[k][lane] = static_cast<RT>(hs);
           W.rtab[3 + k][lane] = static_cast<RT>(es);
         }
@@ -2647,6 +2665,7 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
           // (start, hit point, rounded to the state type), or -- the ray stopped / died -- the
           // source ray itself, a finite stand-in that no gradient is ever read for
           const bool fin = cls == CLS_FINISHED;
+          T* fin_rows = static_cast<T*>(tq.fin_rows);
           double h[3] = {0.0, 0.0, 0.0};
           if (fin) {
             double s[3], e[3];
@@ -2659,31 +2678,43 @@ __global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceA
           }
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            a.fin_rows[k * a.fin_cap + i] = fin ? static_cast<T>(W.rtab[k][lane]) : a.src[k * a.src_stride + i];
-            a.fin_rows[(3 + k) * a.fin_cap + i] = fin ? static_cast<T>(h[k]) : a.src[(3 + k) * a.src_stride + i];
+            fin_rows[k * tq.fin_cap + i] = fin ? static_cast<T>(W.rtab[k][lane]) : a.src[k * a.src_stride + i];
+            fin_rows[(3 + k) * tq.fin_cap + i] = fin ? static_cast<T>(h[k]) : a.src[(3 + k) * a.src_stride + i];
           }
-          a.fin_face[i] = fin ? bi : -1;
-          a.fin_passes[i] = p + 1;
+          tq.fin_face[i] = fin ? bi : -1;
+          tq.fin_passes[i] = p + 1;
         }
       }
-      a.rec_cls[at] = (uint8_t)tape;
+      tq.rec_cls[at] = (uint8_t)tape;
     }
     uint32_t word = 0u;
 #pragma unroll
     for (int c = 0; c < 4; ++c) word |= (uint32_t)__popcll(__ballot(cls == c)) << (8 * c);
-    if (lane == 0) a.wcount[(size_t)p * a.wstride + qwave] = word;
+    if (lane == 0) tq.wcount[(size_t)p * tq.wstride + qwave] = word;
     TFRT_TICK(11);
   }
+  const InplaceTape& te = *a.tape;
   if (ROWS && active) {   // still active after the last pass: not finished either
+    T* fin_rows = static_cast<T*>(te.fin_rows);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a.fin_rows[k * a.fin_cap + i] = a.src[k * a.src_stride + i];
-    a.fin_face[i] = -1;
-    a.fin_passes[i] = a.P;
+    for (int k = 0; k < 6; ++k) fin_rows[k * te.fin_cap + i] = a.src[k * a.src_stride + i];
+    te.fin_face[i] = -1;
+    te.fin_passes[i] = a.P;
   }
   // (passes this wavefront never reached: no rays)
-  for (int pp = p + lane; pp < a.P; pp += 64) a.wcount[(size_t)pp * a.wstride + qwave] = 0u;
-  if (lane < 2) a.wcount[(size_t)(a.P + lane) * a.wstride + qwave] = work[lane];
+  for (int pp = p + lane; pp < a.P; pp += 64) te.wcount[(size_t)pp * te.wstride + qwave] = 0u;
+  if (lane < 2) te.wcount[(size_t)(a.P + lane) * te.wstride + qwave] = work[lane];
   TFRT_WAVE_END(qwave);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) TFRT_INPLACE_ATTR void k_trace_inplace(InplaceArgs<T> a, BeamScene g) {
+  trace_inplace<T, false>(a, g);
+}
+template <typename T>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_trace_inplace_rows(
+    InplaceArgs<T> a, BeamScene g) {
+  trace_inplace<T, true>(a, g);
 }
 
 // The counts of an in-place trace: workgroup p sums the class counts of the passes before its own
@@ -3709,7 +3740,7 @@ static Plan3 make_plan(int64_t N, int64_t M) {
 struct Layout3 {
   size_t c0, sphere, nrays, blockcnt, blockoff, rowtot, rowbase, ticket, part_t, part_i, prep;
   size_t csphere, cface, clsphere, susphere, crec, fnorm, feta, hist_a, hist_b, left_list, wcount,
-      wbase;
+      wbase, tape_args;
   size_t rays, rayid, lasttri, rec_tri, rec_slot, rec_t, rec_cls, gbuf, stash_g, stash_face, fix_acc,
       fix_flag, fix_max, total;
 };
@@ -3753,6 +3784,7 @@ static Layout3 make_layout(int64_t N, int64_t M, int P, int dtype, const Plan3& 
   // (P rows of the trace's own counts, two work rows, P rows of counts in the caller's numbering)
   L.wcount = take((size_t)(2 * (P > 0 ? P : 1) + 2) * inplace_wstride(n) * sizeof(uint32_t));
   L.wbase = take((size_t)(P > 0 ? P : 1) * inplace_wstride(n) * sizeof(int4));
+  L.tape_args = take(sizeof(InplaceTape));
   L.rays = take((size_t)P * 6 * n * esz);        // inputs of pass 1..P
   L.rayid = take((size_t)P * n * sizeof(int32_t));
   L.lasttri = take((size_t)P * n * sizeof(int32_t));
@@ -4016,6 +4048,35 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     pl.g_chunk_clusters = (ac.n_clusters + 7) / 8 * 8;
   }
   const bool inplace = inplace_trace(sc, N, M, P);
+  const bool rows_in_place = inplace && sc->in_place == 2;
+  InplaceTape tape = {};
+  if (inplace) {
+    tape.rays_ws = rays_ws;
+    tape.rec_tri = rec_tri;
+    tape.rec_t = rec_t;
+    tape.rec_cls = rec_cls;
+    tape.n = (int64_t)n;
+    tape.wcount = reinterpret_cast<uint32_t*>(ws + lay.wcount);
+    tape.wstride = (int64_t)inplace_wstride(N);
+    tape.catagory = sc->catagory;
+    tape.fnorm = ft.fnorm;
+    tape.feta = ft.feta;
+    tape.n_table = sc->n_table;
+    tape.mat_in = sc->mat_in;
+    tape.mat_out = sc->mat_out;
+    tape.n_table_stride = sc->n_table_stride;
+    tape.L = L;
+    if (rows_in_place) {
+      // the finished rows at the rays' own columns: nothing is compacted, nothing else is written
+      if (!fin || !fin->rays || !fin->face || !fin->ray_id || fin->capacity < N ||
+          (act && act->rays) || (stp && stp->rays) || (dead && dead->rays) || unfinished != nullptr)
+        return TFRT_E_BADARG;
+      tape.fin_rows = fin->rays;
+      tape.fin_cap = fin->capacity;
+      tape.fin_face = fin->face;
+      tape.fin_passes = fin->ray_id;
+    }
+  }
   if (M > 0) {
     if (ac.order != nullptr) {  // (the hierarchy kernel also does k_center's work)
       const int cl_blocks = cdiv((int64_t)ac.n_clusters * CLUSTER, BLOCK);
@@ -4025,7 +4086,8 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
                          n_super, ac.csphere, ac.cface, ac.clsphere, ac.crec, ac.susphere, nrays,
                          (int)N, tail, ticket, hist_ab[0],
                          (coherent && !inplace) ? pl.nblk * 4 + 1 : 0, ft,
-                         sc->clear_buffer, sc->clear_buffer ? sc->clear_count : 0);
+                         sc->clear_buffer, sc->clear_buffer ? sc->clear_count : 0, tape,
+                         inplace ? reinterpret_cast<InplaceTape*>(ws + lay.tape_args) : nullptr);
     } else {
       hipLaunchKernelGGL(k_center, dim3(1), dim3(BLOCK), 0, st, sc->face_verts, M, c0, nrays,
                          (int)N, tail, ticket);
@@ -4044,44 +4106,16 @@ static int trace3d_forward_t(const void* src_rays, int64_t src_stride, int64_t N
     a.P = P;
     a.bundle = inplace_bundle(N);
     a.nwaves = cdiv(N, a.bundle);
-    a.rays_ws = rays_ws;
-    a.rec_tri = rec_tri;
-    a.rec_t = rec_t;
-    a.rec_cls = rec_cls;
-    a.n = (int64_t)n;
-    a.wcount = reinterpret_cast<uint32_t*>(ws + lay.wcount);
-    a.wstride = (int32_t)inplace_wstride(N);
-    a.catagory = sc->catagory;
-    a.fnorm = ft.fnorm;
-    a.feta = ft.feta;
-    a.n_table = sc->n_table;
-    a.mat_in = sc->mat_in;
-    a.mat_out = sc->mat_out;
-    a.n_table_stride = sc->n_table_stride;
-    a.L = L;
-    a.fin_rows = nullptr;
-    a.fin_cap = 0;
-    a.fin_face = a.fin_passes = nullptr;
-    const bool rows_in_place = sc->in_place == 2;
-    if (rows_in_place) {
-      // the finished rows at the rays' own columns: nothing is compacted, nothing else is written
-      if (!fin || !fin->rays || !fin->face || !fin->ray_id || fin->capacity < N ||
-          (act && act->rays) || (stp && stp->rays) || (dead && dead->rays) || unfinished != nullptr)
-        return TFRT_E_BADARG;
-      a.fin_rows = static_cast<T*>(fin->rays);
-      a.fin_cap = fin->capacity;
-      a.fin_face = fin->face;
-      a.fin_passes = fin->ray_id;
-    }
+    a.tape = reinterpret_cast<const InplaceTape*>(ws + lay.tape_args);
     const BeamScene bs = {ac.susphere, ac.clsphere, ac.csphere, ac.crec, sc->face_verts, c0,
                           ac.n_clusters, cdiv(ac.n_clusters, SUPER), sc->intersect_epsilion,
                           sc->size_epsilion, sc->ray_start_epsilion};
     {
       ProfScope prof(TFRT_PROF_INTERSECT, st);
       if (rows_in_place)
-        hipLaunchKernelGGL((k_trace_inplace<T, true>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
+        hipLaunchKernelGGL((k_trace_inplace_rows<T>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
       else
-        hipLaunchKernelGGL((k_trace_inplace<T, false>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
+        hipLaunchKernelGGL((k_trace_inplace<T>), dim3(a.nwaves), dim3(64), 0, st, a, bs);
     }
     // (no room for ray sets: no scan either -- tfrt_trace3d_compact makes counts and sets later)
     const bool want_rows = !rows_in_place &&
