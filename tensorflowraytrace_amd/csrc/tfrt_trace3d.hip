@@ -3391,8 +3391,9 @@ __device__ __forceinline__ int backward_core(
       }
       double gn[2];
       const bool want_n = has_child && sc.grad_n_in != nullptr && sc.n_table == nullptr;
-      adjoint3d(s, e, P, t_rec, has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP, gn,
-                ((tape & TAPE_INTERNAL) ? 1 : 0) | ((tape & TAPE_REFLECT) ? 2 : 0), want_n);
+      const int branch = ((tape & TAPE_INTERNAL) ? 1 : 0) | ((tape & TAPE_REFLECT) ? 2 : 0);
+      adjoint3d(s, e, P, t_rec, has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP, gn, branch,
+                want_n);
       if (want_n) {  // "value" mode: d error / d (per-face refractive indices)
         if (gn[0] != 0.0) unsafeAtomicAdd(sc.grad_n_in + tri, gn[0]);
         if (gn[1] != 0.0) unsafeAtomicAdd(sc.grad_n_out + tri, gn[1]);
@@ -3492,8 +3493,12 @@ struct ChainArgs {
   int32_t chain_in_lds;    // the chain's records wait in LDS (P <= CHAIN_MAXP), else re-read (in place only)
 };
 
+#ifndef TFRT_CHAIN_WAVES   // (tuning builds set it: scratch/build_variants.py)
+#define TFRT_CHAIN_WAVES 4
+#endif
 template <typename T, int BW, bool GOAL>
-__global__ __launch_bounds__(64 * BW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_backward_chain(
+__global__ __launch_bounds__(64 * BW)
+__attribute__((amdgpu_waves_per_eu(TFRT_CHAIN_WAVES, TFRT_CHAIN_WAVES))) void k_backward_chain(
     ChainArgs<T> a, tfrt_scene3d sc) {
   // the reference's squared_difference and reduce_sum are separate ops: no contraction
 #pragma clang fp contract(off)
