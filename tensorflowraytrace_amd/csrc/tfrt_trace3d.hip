@@ -2598,6 +2598,9 @@ __device__ __forceinline__ void trace_inplace(const InplaceArgs<T>& a, const Bea
   bool active = has;
   int skip = -1;
   int p = 0;
+  static_assert(sizeof(InplaceTape) % 4 == 0 && sizeof(InplaceTape) / 4 <= 64, "one word per lane");
+  const uint32_t tape_words =
+      reinterpret_cast<const uint32_t*>(a.tape)[lane < (int)(sizeof(InplaceTape) / 4) ? lane : 0];
   TFRT_WAVE_BEGIN;
   unsigned work[2] = {0u, 0u};
   for (; p < a.P; ++p) {
@@ -2606,11 +2609,21 @@ __device__ __forceinline__ void trace_inplace(const InplaceArgs<T>& a, const Bea
                      work);
     wave_fence();
     TFRT_TICK_INIT;
-    // (the pointer is made opaque here, pass by pass: the loads below stay below the walk
-    // instead of being hoisted in front of the loop and kept in registers across it)
-    const InplaceTape* tp = a.tape;
-    __asm__ volatile("" : "+s"(tp));
-    const InplaceTape& tq = *tp;
+    // (the struct waits in ONE vector register, a word per lane, and is unpacked here, pass by
+    // pass: the register is made opaque first, so that the unpacking stays below the walk instead
+    // of being hoisted in front of the loop -- forty scalar registers kept across it.  Scalar
+    // loads at this point were the other way to keep them out of the walk, and stalled every
+    // wavefront for a memory round trip per pass)
+    uint32_t tw = tape_words;
+    __asm__ volatile("" : "+v"(tw));
+    InplaceTape tq;
+    {
+      uint32_t w[sizeof(InplaceTape) / 4];
+#pragma unroll
+      for (int k = 0; k < (int)(sizeof(InplaceTape) / 4); ++k)
+        w[k] = (uint32_t)__builtin_amdgcn_readlane((int)tw, k);
+      __builtin_memcpy(&tq, w, sizeof(InplaceTape));
+    }
     int cls = -1;
     if (active) {
       const int bi = W.best_i[lane];
@@ -2693,7 +2706,14 @@ __device__ __forceinline__ void trace_inplace(const InplaceArgs<T>& a, const Bea
     if (lane == 0) tq.wcount[(size_t)p * tq.wstride + qwave] = word;
     TFRT_TICK(11);
   }
-  const InplaceTape& te = *a.tape;
+  InplaceTape te;
+  {
+    uint32_t w[sizeof(InplaceTape) / 4];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(InplaceTape) / 4); ++k)
+      w[k] = (uint32_t)__builtin_amdgcn_readlane((int)tape_words, k);
+    __builtin_memcpy(&te, w, sizeof(InplaceTape));
+  }
   if (ROWS && active) {   // still active after the last pass: not finished either
     T* fin_rows = static_cast<T*>(te.fin_rows);
 #pragma unroll
