@@ -8,7 +8,7 @@ src = open(os.path.join(os.path.dirname(__file__), "perf_cfg5a.py")).read().spli
 exec(src)
 eng, system = build(torch.float32)
 h = ctypes.CDLL(_lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 32)()
 names = ["-", "(ray,super) pairs", "queued clusters", "member hits", "past screen", "-"]
 prev = np.zeros(8)
 for P in range(1, 7):
