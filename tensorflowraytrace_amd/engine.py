@@ -671,6 +671,10 @@ class OpticalEngine:
         # verify_trace() (SGD_Optimizer does this; a wrong guess only costs a re-evaluation of
         # the error function).  Off by default: ray_trace() then returns exact sets.
         self.speculative_counts = False
+        # ray_trace() of a source that is traced in place returns once the trace is enqueued and
+        # cuts the ray sets when they are first asked for (exact sets, no speculation; False:
+        # always wait for the counts inside ray_trace())
+        self.lazy_ray_sets = True
         self._predicted = None
         self._pending_trace = None
         self._last_trace = None
@@ -1052,7 +1056,7 @@ class OpticalEngine:
             if int(left_over) > 0.05 * waves:
                 self._incoherent_key = key
 
-    def _run(self, rays, max_passes, flags, predicted=None):
+    def _run(self, rays, max_passes, flags, predicted=None, lazy_ok=False):
         """One fused trace of ``max_passes`` passes over the ray set ``rays`` (field dict)."""
         # (tfrt_restore_order, which hands an ordered trace's ray sets back in the reference's
         # order, holds one scan chunk per RESTORE_CHUNK (pass, 32-ray word) pairs in 96 KB of LDS
@@ -1062,10 +1066,16 @@ class OpticalEngine:
                       ((n_rays + 31) // 32) * max(int(max_passes), 1) <= 24576 * _RESTORE_CHUNK)
         block, scene, fv = self._trace_inputs(rays, coherent_ok=restorable)
         if self.dimension == 3:
+            # A source that is traced in place has shown that it leaves no wavefront over: nothing
+            # of this trace needs to be known on the host before the next one is enqueued, so the
+            # ray sets are cut (one host read of the counts) when somebody first asks for them --
+            # the device works on this trace while the host prepares the next update()
+            lazy = bool(lazy_ok and scene.in_place and predicted is None)
             out = ops.trace3d(block, fv, scene, max_passes, self.new_ray_length,
                               self.dead_ray_length, flags, predicted_counts=predicted,
-                              perm=self._trace_perm, ray_slot=self._order_inverse())
-            self._note_left_over(out.get("left_over", 0), max_passes)
+                              perm=self._trace_perm, ray_slot=self._order_inverse(), lazy=lazy)
+            if not lazy:
+                self._note_left_over(out.get("left_over", 0), max_passes)
             return out
         return ops.trace2d(block, scene, max_passes, self.new_ray_length,
                            self.dead_ray_length, flags, predicted_counts=predicted)
@@ -1118,8 +1128,12 @@ class OpticalEngine:
                int(max_iterations), self._flags())
         if self.speculative_counts and self._predicted is not None and self._predicted[0] == sig:
             predicted = self._predicted[1]
-        out = self._run(src, int(max_iterations), self._flags(), predicted)
+        out = self._run(src, int(max_iterations), self._flags(), predicted,
+                        lazy_ok=self.lazy_ray_sets and not self.speculative_counts)
         self._trace_sig, self._trace_src = sig, src
+        if "finish" in out:
+            self._pending_trace = out["finish"]       # (cut on first use: _resolve_pending)
+            return
         self._publish(out)
         if "pending" not in out:
             self._predicted = (sig, out["raw_counts"])

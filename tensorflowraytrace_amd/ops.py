@@ -941,7 +941,7 @@ def _finish_trace(full, aux, P, predicted_counts):
 
 def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
             flags=_lib.COMPILE_ACTIVE | _lib.COMPILE_FINISHED, predicted_counts=None, perm=None,
-            ray_slot=None):
+            ray_slot=None, lazy=False):
     """Run the whole 3-D trace.  ``src`` is a (6,N) ray block (f32 or f64) on the GPU.
 
     Returns a dict: for each class c in finished/active/stopped/dead (when compiled) the ray
@@ -957,6 +957,8 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     the reference's order (restored on the device inside the autograd node, gradients included;
     an in-place trace -- ``scene.in_place`` -- compacts them in that order directly, through
     ``ray_slot`` = ``inverse_order(perm)``, computed here when not handed in).
+
+    ``lazy``: do not wait for the counts; returns ``{"finish": callable}`` instead.
     """
     opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
                 dead_ray_length=dead_ray_length, flags=flags,
@@ -969,6 +971,11 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     full = dict(zip(_CLASS_NAMES, blocks))
     for name, r in rows.items():
         aux[name + "_rows"] = r
+    if lazy:
+        # nothing is read back here: the caller cuts the sets (one host read of the counts) when
+        # somebody asks for them -- ``out["finish"]()`` returns the dict this function returns
+        P = int(max_passes)
+        return {"finish": lambda: _finish_trace(full, aux, P, None)}
     return _finish_trace(full, aux, int(max_passes), predicted_counts)
 
 
