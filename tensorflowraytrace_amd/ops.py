@@ -737,19 +737,40 @@ class _Trace3D(torch.autograd.Function):
         # (tfrt_scene3d.ray_slot = the inverse of `perm`): nothing to restore afterwards
         own_order = bool(perm is not None and N
                          and L.tfrt_trace3d_in_place(ctypes.byref(sc), N, P) == 1)
+        inv = None
         if own_order:
             inv = opts.get("ray_slot")
             inv = inverse_order(perm) if inv is None else inv
             sc.ray_slot = inv.data_ptr()
+        # lazy (trace3d(lazy=True)) over an in-place trace: the forward call is given no room for
+        # ray sets -- set-up launch + ONE trace launch --, and the sets are compacted from the tape
+        # (tfrt_trace3d_compact into the very tensors returned here) when the caller cuts them
+        in_place_now = bool(N and (own_order or (
+            perm is None and L.tfrt_trace3d_in_place(ctypes.byref(sc), N, P) == 1)))
+        defer = bool(opts.get("lazy") and in_place_now)
+        none = [_ray_out(None, None, None) for _ in range(4)] if defer else None
+        fo = none if defer else outs
         try:
             check(L.tfrt_trace3d_forward(
                 _p(src), src.shape[1], N, ctypes.byref(sc), float(opts["new_ray_length"]),
                 float(opts["dead_ray_length"] or 0.0), P, dt, flags,
-                ctypes.byref(outs[0]), ctypes.byref(outs[1]), ctypes.byref(outs[2]),
-                ctypes.byref(outs[3]), _p(unf), _p(unf_id), _p(counts), _p(ws), wsb, _stream(src)),
+                ctypes.byref(fo[0]), ctypes.byref(fo[1]), ctypes.byref(fo[2]),
+                ctypes.byref(fo[3]), None if defer else _p(unf), None if defer else _p(unf_id),
+                _p(counts), _p(ws), wsb, _stream(src)),
                 "tfrt_trace3d_forward")
         finally:
             sc.ray_slot = None          # (the struct is cached on the scene)
+        if defer:
+            M = face_verts.shape[0]
+            dead_len = float(opts["dead_ray_length"] or 0.0)
+
+            def compact(src=src, outs=outs, unf=unf, unf_id=unf_id, counts=counts, ws=ws, inv=inv):
+                check(L.tfrt_trace3d_compact(
+                    _p(src), src.shape[1], N, dead_len, P, dt, flags, ctypes.byref(outs[0]),
+                    ctypes.byref(outs[1]), ctypes.byref(outs[2]), ctypes.byref(outs[3]), _p(unf),
+                    _p(unf_id), _p(counts), M, _p(inv), _p(ws), wsb, _stream(src)),
+                    "tfrt_trace3d_compact")
+            opts["_compact"] = compact
         tape = TraceTape()
         tape.src, tape.face_verts, tape.scene, tape.opts = src, face_verts, scene, dict(opts)
         tape.ws, tape.wsb, tape.counts, tape.dt = ws, wsb, counts, dt
@@ -962,11 +983,12 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
     """
     opts = dict(max_passes=max_passes, new_ray_length=new_ray_length,
                 dead_ray_length=dead_ray_length, flags=flags,
-                zero_init=predicted_counts is not None, perm=perm, ray_slot=ray_slot)
+                zero_init=predicted_counts is not None, perm=perm, ray_slot=ray_slot, lazy=lazy)
     grad_n = lambda t: t if (isinstance(t, torch.Tensor) and t.requires_grad) else None
     outs = _Trace3D.apply(src, face_verts, grad_n(scene.n_in_arg), grad_n(scene.n_out_arg),
                           scene, opts)
     aux = opts.pop("_aux")
+    compact = opts.pop("_compact", None)
     blocks, rows = _split_rows(outs, [aux[name + "_id"] is not None for name in _CLASS_NAMES], 6)
     full = dict(zip(_CLASS_NAMES, blocks))
     for name, r in rows.items():
@@ -975,7 +997,12 @@ def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_len
         # nothing is read back here: the caller cuts the sets (one host read of the counts) when
         # somebody asks for them -- ``out["finish"]()`` returns the dict this function returns
         P = int(max_passes)
-        return {"finish": lambda: _finish_trace(full, aux, P, None)}
+
+        def finish():
+            if compact is not None:     # (an in-place trace that has not compacted its sets yet)
+                compact()
+            return _finish_trace(full, aux, P, None)
+        return {"finish": finish}
     return _finish_trace(full, aux, int(max_passes), predicted_counts)
 
 

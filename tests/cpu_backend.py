@@ -22,7 +22,7 @@ def build_faces(vertices, faces, update_mask=None):
 
 
 def trace3d(src, face_verts, scene, max_passes, new_ray_length=1.0, dead_ray_length=None,
-            flags=3, predicted_counts=None, perm=None, ray_slot=None):
+            flags=3, predicted_counts=None, perm=None, ray_slot=None, lazy=False):
     assert perm is None          # (a coherent order is a device matter: CPU blocks are never sorted)
     n = src.shape[1]
     fv = face_verts.double()
