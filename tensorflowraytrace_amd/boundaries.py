@@ -595,6 +595,11 @@ class TriangleBoundaryBase(BoundaryBase):
             ks |= set(_TRI_COLS) | {"norm"}
         return ks
 
+    def __contains__(self, key):
+        # (without building the key set: the system's merge asks this a dozen times per update)
+        return key in self._fields or (
+            (key in _TRI_COLS or key == "norm") and self._face_verts is not None)
+
     def __getitem__(self, key):
         if key in self._fields:
             return self._fields[key]
