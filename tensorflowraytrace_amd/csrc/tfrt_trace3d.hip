@@ -1197,9 +1197,20 @@ __device__ __forceinline__ void group_walk(
       const int v = lane < nb ? (int)rlist[wave][lane] : 0;
       const int cl0 = (v >> 8) * SUPER, sl = v & 255;
       double l1s[3] = {0.0, 0.0, 0.0};
+      // ... and how far along its line this pair's ray has a hit already (inf: none).  A cluster
+      // whose sphere lies wholly beyond that cannot hold the nearest hit, nor a tie with it: rays
+      // that run along a long wall (a light guide: 48 clusters queued per ray and pass, against 5
+      // on a lens) lose most of their queue here once the first batches have been decided.
+      float reach = INFINITY;
       if (last_tri != nullptr && eps_start >= 0.0) {  // (wave-uniform: only the behind test needs it)
         double l1e[3];
         ray_of(sl, l1s, l1e);
+        const double bu = dkey_inv(best_k[wave][sl]);
+        if (bu < 1.0e300) {
+          const double dx = l1e[0] - l1s[0], dy = l1e[1] - l1s[1], dz = l1e[2] - l1s[2];
+          // (rounded up generously: 1e-4 relative dwarfs the float32 rounding of everything here)
+          reach = (float)(bu * sqrt(dx * dx + dy * dy + dz * dz)) * 1.0001f;
+        }
       }
       if (lane < nb) {
         const float4 fa = prep_ab[wave][2 * sl], fb = prep_ab[wave][2 * sl + 1];
@@ -1214,8 +1225,11 @@ __device__ __forceinline__ void group_walk(
                     uz = fa.x * fb.y - fa.y * fb.x;
         const float sx = rel_c0(l1s[0], cx, cxf), sy = rel_c0(l1s[1], cy, cyf),
                     sz = rel_c0(l1s[2], cz, czf);
-        const float t_off = fmaf(-sx, ux, fmaf(-sy, uy, -sz * uz)) +
-                            (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
+        const float t_err = (32.f * 5.9604644775390625e-08f) * (fabsf(sx) + fabsf(sy) + fabsf(sz));
+        const float t_off = fmaf(-sx, ux, fmaf(-sy, uy, -sz * uz)) + t_err;
+        // (a LOWER bound of a centre's coordinate along the ray is tq - 2 t_err; |u| = 1 to 1e-6:
+        // inside reach's 1e-4)
+        const float far0 = reach + 2.f * t_err;
         // (first pass of a trace -- no ray starts on a face yet: sources normally sit outside
         // the scene, nothing lies behind them and the test would only cost; wave-uniform)
         // (and only while hits must lie ahead of the start: ray_start_epsilion >= 0)
@@ -1227,7 +1241,9 @@ __device__ __forceinline__ void group_walk(
             const float pb = fmaf(sp.x, fb.x, fmaf(sp.y, fb.y, fmaf(sp.z, fb.z, fb.w)));
             const float tq = fmaf(sp.x, ux, fmaf(sp.y, uy, fmaf(sp.z, uz, t_off)));
             const bool behind = tq < 0.f && tq * tq > sp.w;
-            hits |= ((fmaf(pa, pa, pb * pb) <= sp.w && !behind) ? 1u : 0u) << c;
+            const float over = tq - far0;      // (reach = inf: -inf, never beyond; NaN: never)
+            const bool beyond = over > 0.f && over * over > sp.w;
+            hits |= ((fmaf(pa, pa, pb * pb) <= sp.w && !behind && !beyond) ? 1u : 0u) << c;
           }
         } else {
 #pragma unroll
