@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFRT_VERSION 106 /* 0.1.0 */
+#define TFRT_VERSION 107 /* 0.1.0 */
 
 #define TFRT_F32 0
 #define TFRT_F64 1
@@ -790,6 +790,19 @@ int tfrt_source3d_order(const tfrt_source3d_program* program, int64_t first, int
                         const double* face_verts, int64_t n_faces, const double* axis,
                         int32_t* index, uint32_t* keys_out, void* workspace,
                         size_t workspace_bytes, void* stream);
+
+/* The same order up to ties, made faster, for a source that is re-drawn before every optimiser step
+ * (distributions.py:1586-1598: the order is made again every step): most significant digit first --
+ * ONE stable scatter by the key's high digit, then every bucket of it is sorted by the low digit in
+ * LDS (one workgroup per bucket) -- five launches instead of the two-pass sort's eight.  Rays with
+ * the SAME key (the same cell of the key grid: about one ray per cell) land in an order that may vary
+ * from run to run.  A trace's results do not depend on the order of its rays (tfrt_scene3d.ray_slot
+ * numbers them as the caller does); only the rounding of sums over rays does, as with any atomic
+ * accumulation.  Not for deterministic runs.  Same arguments and workspace as tfrt_source3d_order. */
+int tfrt_source3d_order_cells(const tfrt_source3d_program* program, int64_t first, int64_t n_rays,
+                              const double* face_verts, int64_t n_faces, const double* axis,
+                              int32_t* index, uint32_t* keys_out, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* epochs[k][0] += 1 for k < n (n <= 8 distinct device counters, host array of pointers): one
  * launch for all the distributions a source draws from. */

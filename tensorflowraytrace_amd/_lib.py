@@ -11,7 +11,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFRT_LIB_PATH") or os.path.join(HERE, "libtfrt_hip.so")
 
-ABI_VERSION = 106          # TFRT_VERSION of include/tfrt_hip.h this module's signatures are written for
+ABI_VERSION = 107          # TFRT_VERSION of include/tfrt_hip.h this module's signatures are written for
 F32, F64, F16 = 0, 1, 2
 OPTICAL, STOP, TARGET = 0, 1, 2
 CLS_ACTIVE, CLS_FINISHED, CLS_STOPPED, CLS_DEAD = 0, 1, 2, 3
@@ -188,6 +188,8 @@ SIGNATURES = {
                                    c_vp, c_vp, c_vp, c_sz, c_vp]),
     "tfrt_source3d_order": (c_i32, [_P(Source3DProgram), c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
                                     c_vp, c_sz, c_vp]),
+    "tfrt_source3d_order_cells": (c_i32, [_P(Source3DProgram), c_i64, c_i64, c_vp, c_i64, c_vp, c_vp,
+                                          c_vp, c_vp, c_sz, c_vp]),
     "tfrt_epoch_advance": (c_i32, [c_vp, c_i32, c_vp]),
     "tfrt_points_generate": (c_i32, [_P(PointsProgram), c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp,
                                      c_vp]),

@@ -374,12 +374,14 @@ __global__ __launch_bounds__(BLOCK) void k_order_key(const float2* __restrict__ 
   for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
 }
 
+
 // Program sources: rays -> coordinates -> keys in ONE launch, float32 evaluation.  Every workgroup
 // makes the frame itself from the same 256 sample rays (the same arithmetic in every workgroup:
 // block_frame) and takes the extents of the key grid from those samples, widened by 1/16 -- a ray
 // outside them lands in an edge cell --, so nothing has to pass over all rays before the keys are
-// made.  Also leaves the histogram of the low digits per sort tile.
-template <int ITEMS>
+// made.  Also leaves the histogram of the low digits per sort tile -- of the HIGH digits when HIGH
+// (tfrt_source3d_order_cells: the scatter by the high digit comes first, see k_bucket_sort).
+template <int ITEMS, bool HIGH>
 __global__ __launch_bounds__(BLOCK) void k_order_pkey(const ProgramRays src, int n,
                                                       const double* __restrict__ fverts, int M,
                                                       double ax0, double ax1, double ax2,
@@ -446,12 +448,13 @@ __global__ __launch_bounds__(BLOCK) void k_order_pkey(const ProgramRays src, int
         key = hilbert_index((unsigned)fx, (unsigned)fy, bits);
       }
       keys[i] = key;
-      atomicAdd(&h_lds[key & (unsigned)(bins - 1)], 1u);
+      atomicAdd(&h_lds[(HIGH ? key >> bits : key) & (unsigned)(bins - 1)], 1u);
     }
   }
   __syncthreads();
   for (int d = tid; d < bins; d += BLOCK) hist[(int64_t)blockIdx.x * bins + d] = h_lds[d];
 }
+
 
 // ------------------------------------------------------------------------------ radix sort
 //
@@ -729,6 +732,74 @@ __global__ __launch_bounds__(BLOCK) void k_sort_scatter(
 }
 
 // ------------------------------------------------------------------------------ permutations
+
+// Second half of the most-significant-digit-first sort (tfrt_source3d_order_cells): workgroup d
+// takes the bucket of high digit d -- consecutive pairs after the stable scatter by that digit --
+// and places its items by their low digit: a histogram in LDS, its scan, one atomic counter per
+// digit.  Any bucket size (a source whose rays all fall in one bucket is sorted by one workgroup:
+// slow, still right); items with the same key land in an order that may vary from run to run.
+__global__ __launch_bounds__(BLOCK) void k_bucket_sort(const uint2* __restrict__ pairs, int bits,
+                                                       const unsigned* __restrict__ dtotal,
+                                                       int32_t* __restrict__ perm) {
+  extern __shared__ unsigned lds[];   // low-digit counters [bins] | first places of the buckets [bins]
+  __shared__ unsigned wsum[WAVES];
+  const int bins = 1 << bits, tid = threadIdx.x;
+  unsigned* cnt = lds;
+  unsigned* pre = lds + bins;
+  lds_exclusive_from(dtotal, bins, pre, wsum);
+  const unsigned start = pre[blockIdx.x], len = dtotal[blockIdx.x];
+  if (len == 0u) return;   // (block-uniform)
+  for (int k = tid; k < bins; k += BLOCK) cnt[k] = 0u;
+  __syncthreads();
+  const unsigned mask = (unsigned)(bins - 1);
+  // (a bucket normally holds n / bins items, a thousand at a million rays: a thread's first KEEP
+  // items stay in registers between the two loops, their loads all in flight together)
+  constexpr int KEEP = 8;
+  uint2 mine[KEEP];
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    const unsigned i = tid + q * BLOCK;
+    mine[q] = i < len ? pairs[start + i] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q)
+    if (tid + q * BLOCK < len) atomicAdd(&cnt[mine[q].x & mask], 1u);
+  for (unsigned i = tid + KEEP * BLOCK; i < len; i += BLOCK)
+    atomicAdd(&cnt[pairs[start + i].x & mask], 1u);
+  __syncthreads();
+  {  // exclusive scan of the counters, in place (a thread's own run of consecutive digits)
+    const int per = (bins + BLOCK - 1) / BLOCK;
+    const int lo = tid * per;
+    unsigned sum = 0;
+    for (int q = 0; q < per; ++q) {
+      const int i = lo + q;
+      if (i < bins) {
+        const unsigned t = cnt[i];
+        cnt[i] = sum;
+        sum += t;
+      }
+    }
+    unsigned total;
+    const unsigned base = block_exclusive(sum, wsum, &total);
+    for (int q = 0; q < per; ++q) {
+      const int i = lo + q;
+      if (i < bins) cnt[i] += base;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < KEEP; ++q) {
+    if (tid + q * BLOCK < len) {
+      const unsigned pos = atomicAdd(&cnt[mine[q].x & mask], 1u);
+      perm[start + pos] = (int32_t)mine[q].y;
+    }
+  }
+  for (unsigned i = tid + KEEP * BLOCK; i < len; i += BLOCK) {
+    const uint2 p = pairs[start + i];
+    const unsigned pos = atomicAdd(&cnt[p.x & mask], 1u);
+    perm[start + pos] = (int32_t)p.y;
+  }
+}
 
 template <int BYTES>
 struct Vec;
@@ -1160,7 +1231,7 @@ static int sort_keys(const OrderLayout& L, char* ws, int n, unsigned* keys, int3
 template <typename R>
 static int ray_order_t(const R& src, int64_t N, const double* fverts, int64_t M,
                        const double* axis, int32_t* perm, uint32_t* keys_out, char* ws,
-                       const OrderLayout& L, hipStream_t st) {
+                       const OrderLayout& L, hipStream_t st, bool cells = false) {
   const int n = (int)N;
   unsigned* mm = reinterpret_cast<unsigned*>(ws + L.head);
   OrderFrame* frame = reinterpret_cast<OrderFrame*>(ws + L.head + MM_SLOTS * 16);
@@ -1176,11 +1247,41 @@ static int ray_order_t(const R& src, int64_t N, const double* fverts, int64_t M,
   }
   const size_t hl = ((size_t)1 << L.bits) * sizeof(unsigned);
   int rc = 0;
+  if constexpr (R::HAS_F32) {
+    if (cells) {
+      // most significant digit first: one stable scatter by the high digit (its histogram comes
+      // with the keys), then every bucket of it is sorted by the low digit in LDS
+      uint2* pairs = reinterpret_cast<uint2*>(ws + L.pairs);
+      unsigned* seg = reinterpret_cast<unsigned*>(ws + L.seg);
+      unsigned* dtotal = reinterpret_cast<unsigned*>(ws + L.dtotal);
+      const int bins = 1 << L.bits;
+      const size_t lds = scatter_lds_bytes(L.bits, L.items);
+      if (lds > 160 * 1024) return TFRT_E_UNSUPPORTED;
+      const dim3 cgrid(cdiv(bins, BLOCK), L.nseg);
+#define TFRT_ORDER_MSD(I)                                                                          \
+  {                                                                                                \
+    hipLaunchKernelGGL((k_order_pkey<I, true>), dim3(L.nblk), dim3(BLOCK), hl, st, src, n, fverts, \
+                       (int)M, a0, a1, a2, axis ? 1 : 0, L.bits, keys, hist, L.nblk);              \
+    hipLaunchKernelGGL(k_colscan_rows, cgrid, dim3(BLOCK), 0, st, hist, L.nblk, bins, seg);        \
+    hipLaunchKernelGGL(k_colscan_segs, dim3(cgrid.x), dim3(BLOCK), 0, st, seg, L.nseg, bins,       \
+                       dtotal);                                                                    \
+    hipLaunchKernelGGL((k_sort_scatter<I, true, false>), dim3(L.nblk), dim3(BLOCK), lds, st, keys, \
+                       static_cast<const uint2*>(nullptr), n, L.bits, L.bits, hist, seg, dtotal,   \
+                       pairs, static_cast<int32_t*>(nullptr));                                     \
+  }
+      if (L.items == 4) TFRT_ORDER_MSD(4)
+      else TFRT_ORDER_MSD(8)
+#undef TFRT_ORDER_MSD
+      hipLaunchKernelGGL(k_bucket_sort, dim3(bins), dim3(BLOCK), 2 * bins * sizeof(unsigned), st,
+                         pairs, L.bits, dtotal, perm);
+      return 0;
+    }
+  }
 #define TFRT_ORDER_ITEMS(I)                                                                       \
   {                                                                                               \
     if constexpr (R::HAS_F32)   /* a program's rays: frame, extents and keys in one launch */     \
-      hipLaunchKernelGGL((k_order_pkey<I>), dim3(L.nblk), dim3(BLOCK), hl, st, src, n, fverts,    \
-                         (int)M, a0, a1, a2, axis ? 1 : 0, L.bits, keys, hist, L.nblk);           \
+      hipLaunchKernelGGL((k_order_pkey<I, false>), dim3(L.nblk), dim3(BLOCK), hl, st, src, n,     \
+                         fverts, (int)M, a0, a1, a2, axis ? 1 : 0, L.bits, keys, hist, L.nblk);    \
     else                                                                                          \
       hipLaunchKernelGGL((k_order_key<I>), dim3(L.nblk), dim3(BLOCK), hl, st, xy, n, mm, L.bits,  \
                          keys, hist, L.nblk);                                                     \
@@ -1305,10 +1406,10 @@ int tfrt_ray_order(const void* rays, int64_t stride, int64_t n_rays, int32_t sta
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
 }
 
-int tfrt_source3d_order(const tfrt_source3d_program* program, int64_t first, int64_t n_rays,
-                        const double* face_verts, int64_t n_faces, const double* axis,
-                        int32_t* perm, uint32_t* keys_out, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+static int source3d_order(const tfrt_source3d_program* program, int64_t first, int64_t n_rays,
+                          const double* face_verts, int64_t n_faces, const double* axis,
+                          int32_t* perm, uint32_t* keys_out, void* workspace,
+                          size_t workspace_bytes, void* stream, bool cells) {
   // (the same validation as tfrt_source3d_generate: k_order_pkey evaluates the program)
   if (!source_program_ok(program) || n_rays < 0 || n_rays >= (1ll << 31) || n_faces < 0 ||
       n_faces >= (1ll << 31) || first < 0 || first + n_rays > program->n_rays)
@@ -1321,9 +1422,26 @@ int tfrt_source3d_order(const tfrt_source3d_program* program, int64_t first, int
   src.sp = *program;
   src.first = first;
   const int rc = ray_order_t(src, n_rays, face_verts, n_faces, axis, perm, keys_out,
-                             static_cast<char*>(workspace), L, static_cast<hipStream_t>(stream));
+                             static_cast<char*>(workspace), L, static_cast<hipStream_t>(stream),
+                             cells);
   if (rc != 0) return rc;
   return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
+}
+
+int tfrt_source3d_order(const tfrt_source3d_program* program, int64_t first, int64_t n_rays,
+                        const double* face_verts, int64_t n_faces, const double* axis,
+                        int32_t* perm, uint32_t* keys_out, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  return source3d_order(program, first, n_rays, face_verts, n_faces, axis, perm, keys_out,
+                        workspace, workspace_bytes, stream, false);
+}
+
+int tfrt_source3d_order_cells(const tfrt_source3d_program* program, int64_t first, int64_t n_rays,
+                              const double* face_verts, int64_t n_faces, const double* axis,
+                              int32_t* perm, uint32_t* keys_out, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  return source3d_order(program, first, n_rays, face_verts, n_faces, axis, perm, keys_out,
+                        workspace, workspace_bytes, stream, true);
 }
 
 size_t tfrt_permute_rays_workspace_bytes(int64_t n_rays, int32_t state_dtype) {

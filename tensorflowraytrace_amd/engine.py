@@ -1013,7 +1013,10 @@ class OpticalEngine:
             perm = None
             if cached is not None and cached[5][1] == ident and cached[1].numel() == n:
                 perm = cached[1]
-            perm = rays.order(fv, out=perm)
+            # (re-made every step: the faster sort, ties in any order, unless the run must repeat
+            # bit for bit -- the order is invisible in the results, only sums over rays round
+            # differently)
+            perm = rays.order(fv, out=perm, stable=bool(self.deterministic))
             block_p = rays.permuted(perm).ray_block(dt)
         else:
             perm = ops.ray_order(block, fv)

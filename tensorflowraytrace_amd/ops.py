@@ -1190,9 +1190,12 @@ def restore_order(out, perm):
     return new
 
 
-def source3d_order(program, n, first=0, face_verts=None, axis=None, out=None, device=None):
+def source3d_order(program, n, first=0, face_verts=None, axis=None, out=None, device=None,
+                   stable=True):
     """``ray_order`` of rays ``first .. first + n`` of a source program (tfrt_source3d_order): the
-    rays are never written in source order."""
+    rays are never written in source order.  ``stable=False``: the same order up to ties, most
+    significant digit first (tfrt_source3d_order_cells) -- fewer launches; rays with the same key may
+    land in an order that varies from run to run."""
     n = int(n)
     dev = device if device is not None else (out.device if out is not None else face_verts.device)
     perm = out if out is not None else torch.empty(n, dtype=torch.int32, device=dev)
@@ -1205,9 +1208,9 @@ def source3d_order(program, n, first=0, face_verts=None, axis=None, out=None, de
         wsb = L.tfrt_ray_order_workspace_bytes(n)
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
         ax = None if axis is None else (ctypes.c_double * 3)(*[float(v) for v in axis])
-        check(L.tfrt_source3d_order(ctypes.byref(program), int(first), n, _p(fv),
-                                    0 if fv is None else fv.shape[0], ax, _p(perm), None, _p(ws),
-                                    wsb, _stream(perm)), "tfrt_source3d_order")
+        fn = L.tfrt_source3d_order if stable else L.tfrt_source3d_order_cells
+        check(fn(ctypes.byref(program), int(first), n, _p(fv), 0 if fv is None else fv.shape[0], ax,
+                 _p(perm), None, _p(ws), wsb, _stream(perm)), "tfrt_source3d_order")
     return perm
 
 

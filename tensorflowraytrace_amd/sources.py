@@ -133,13 +133,14 @@ class DeviceRaySet:
             return part
         return part.index_select(0, self._index.long())
 
-    def order(self, face_verts=None, out=None):
-        """A coherent order of the set's rays (ops.ray_order) straight from the program."""
+    def order(self, face_verts=None, out=None, stable=True):
+        """A coherent order of the set's rays (ops.ray_order) straight from the program
+        (``stable=False``: ops.source3d_order's faster sort, ties in any order)."""
         from . import ops
         src = self._src
         axis = src.axis_hint() if hasattr(src, "axis_hint") else None
         return ops.source3d_order(src._dev_program[1], self._n, self._first, face_verts, axis,
-                                  out=out, device=src._dev_device)
+                                  out=out, device=src._dev_device, stable=stable)
 
     def ray_block(self, dtype):
         """(6, n) block of the ray-state dtype: a persistent buffer, filled once per update."""

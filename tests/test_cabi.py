@@ -51,7 +51,7 @@ def test_version_and_strerror(lib):
     from tensorflowraytrace_amd import _lib
     header = open(os.path.join(os.path.dirname(__file__), "..", "include", "tfrt_hip.h")).read()
     declared = int(re.search(r"#define TFRT_VERSION (\d+)", header).group(1))
-    assert lib.tfrt_version() == declared == _lib.ABI_VERSION == 106
+    assert lib.tfrt_version() == declared == _lib.ABI_VERSION == 107
     assert lib.tfrt_strerror(0) == b"ok"
     for code in (-1, -2, -3, -4, -99):
         assert len(lib.tfrt_strerror(code)) > 0
