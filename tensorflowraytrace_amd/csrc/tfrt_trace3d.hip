@@ -3341,7 +3341,7 @@ __global__ __launch_bounds__(BLOCK) void k_fixed_finish(int64_t m9,
 // Reverse of one ray slot of one pass, in registers: `child` holds the gradient w.r.t. the slot's
 // child ray (start, end) when it has one; gs / ge receive the gradient w.r.t. the slot's input
 // ray.  Returns the face whose gradient gP must be accumulated (-1: none).
-template <typename T>
+template <typename T, bool GN = true>   // GN: the caller may want d error / d (per-face indices)
 __device__ __forceinline__ int backward_core(
     int i, int tape, int slot, const T* __restrict__ rays_in, int64_t stride_in,
     const int32_t* __restrict__ ray_id_in, const int32_t* __restrict__ rec_tri,
@@ -3426,7 +3426,7 @@ __device__ __forceinline__ int backward_core(
         load_face(has_child);
       }
       double gn[2];
-      const bool want_n = has_child && sc.grad_n_in != nullptr && sc.n_table == nullptr;
+      const bool want_n = GN && has_child && sc.grad_n_in != nullptr && sc.n_table == nullptr;
       const int branch = ((tape & TAPE_INTERNAL) ? 1 : 0) | ((tape & TAPE_REFLECT) ? 2 : 0);
       adjoint3d(s, e, P, t_rec, has_child, n_in, n_out, L, g_s, g_h, g_ce, gs, ge, gP, gn, branch,
                 want_n);
@@ -3532,7 +3532,9 @@ struct ChainArgs {
 #ifndef TFRT_CHAIN_WAVES   // (tuning builds set it: scratch/build_variants.py)
 #define TFRT_CHAIN_WAVES 4
 #endif
-template <typename T, int BW, bool GOAL>
+// GN = false: no gradient with respect to the per-face indices is asked for (tfrt_scene3d.grad_n_in
+// null -- the usual case; the adjoint's index terms and the two atomics are not compiled in)
+template <typename T, int BW, bool GOAL, bool GN>
 __global__ __launch_bounds__(64 * BW)
 __attribute__((amdgpu_waves_per_eu(TFRT_CHAIN_WAVES, TFRT_CHAIN_WAVES))) void k_backward_chain(
     ChainArgs<T> a, tfrt_scene3d sc) {
@@ -3632,9 +3634,9 @@ __attribute__((amdgpu_waves_per_eu(TFRT_CHAIN_WAVES, TFRT_CHAIN_WAVES))) void k_
         }
       }
       double gs[3], ge[3];
-      tri = backward_core<T>(j, tape, slot, rin, sin, idin, a.rec_tri + off, a.rec_t + off,
-                             a.counts + (size_t)p * TFRT_COUNTS_PER_PASS, sc, a.L, a.dead_len,
-                             p < P - 1, child, GOAL ? seed : nullptr, a.g_fin, a.cap_fin, a.g_act,
+      tri = backward_core<T, GN>(j, tape, slot, rin, sin, idin, a.rec_tri + off, a.rec_t + off,
+                                 a.counts + (size_t)p * TFRT_COUNTS_PER_PASS, sc, a.L, a.dead_len,
+                                 p < P - 1, child, GOAL ? seed : nullptr, a.g_fin, a.cap_fin, a.g_act,
                              a.cap_act, a.g_stp, a.cap_stp, a.g_dead, a.cap_dead, gs, ge, gP,
                              rec.w, a.feta, a.inplace != 0);
       for (int k = 0; k < 3; ++k) {
@@ -4370,12 +4372,18 @@ static int trace3d_backward_t(const void* src_rays, int64_t src_stride, int64_t 
       a.goal_ray_stride = goal->goal_ray_stride;
       a.partial = goal->partial;
       a.partial_cnt = goal->partial_cnt;
-      if (N > 0)
-        hipLaunchKernelGGL((k_backward_chain<T, 1, true>), dim3(cdiv(N, 64)), dim3(64), chain_lds,
-                           st, a, *sc);
+      if (N > 0 && sc->grad_n_in != nullptr)
+        hipLaunchKernelGGL((k_backward_chain<T, 1, true, true>), dim3(cdiv(N, 64)), dim3(64),
+                           chain_lds, st, a, *sc);
+      else if (N > 0)
+        hipLaunchKernelGGL((k_backward_chain<T, 1, true, false>), dim3(cdiv(N, 64)), dim3(64),
+                           chain_lds, st, a, *sc);
+    } else if (N > 0 && sc->grad_n_in != nullptr) {
+      hipLaunchKernelGGL((k_backward_chain<T, 1, false, true>), dim3(cdiv(N, 64)), dim3(64),
+                         chain_lds, st, a, *sc);
     } else if (N > 0) {
-      hipLaunchKernelGGL((k_backward_chain<T, 1, false>), dim3(cdiv(N, 64)), dim3(64), chain_lds,
-                         st, a, *sc);
+      hipLaunchKernelGGL((k_backward_chain<T, 1, false, false>), dim3(cdiv(N, 64)), dim3(64),
+                         chain_lds, st, a, *sc);
     }
     return hipGetLastError() == hipSuccess ? 0 : TFRT_E_LAUNCH;
   }
