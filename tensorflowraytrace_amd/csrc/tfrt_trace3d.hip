@@ -2970,28 +2970,32 @@ __global__ __launch_bounds__(64) void k_inplace_gather(GatherArgs<T> a) {
       const int4 wb = a.wbase[(size_t)p * a.wstride + qwave];
       const int in_pass = (cls == 0 ? wb.x : (cls == 1 ? wb.y : (cls == 2 ? wb.z : wb.w))) + rank;
       const int64_t gslot = (int64_t)a.counts[(size_t)p * TFRT_COUNTS_PER_PASS + 4 + cls] + in_pass;
-      a.rec_slot[at] = (int32_t)gslot;
-      const T* rin = p == 0 ? a.src : a.rays_ws + (size_t)(p - 1) * 6 * a.n;
-      const int64_t sin = p == 0 ? a.src_stride : a.n;
-      double s[3], e[3];
-      load_ray3(rin, sin, i, s, e);
-      const int tri = a.rec_tri[at];
-      if (cls == CLS_DEAD) {
-        if (a.flags & TFRT_COMPILE_DEAD) {
+      // Only a record whose class is compiled is read at all -- and only such a record can carry a
+      // gradient, so only it needs its row in rec_slot.  With the caller's numbering every access to
+      // the tape here is a scattered one (the lanes' rays lie anywhere in the trace's order): the
+      // records of rays that merely went on to the next pass, two thirds of them, cost nine of those
+      // each while active rays were not asked for.
+      const uint32_t want = cls == CLS_DEAD       ? TFRT_COMPILE_DEAD
+                            : cls == CLS_FINISHED ? TFRT_COMPILE_FINISHED
+                            : cls == CLS_STOPPED  ? TFRT_COMPILE_STOPPED
+                                                  : TFRT_COMPILE_ACTIVE;
+      if (a.flags & want) {
+        a.rec_slot[at] = (int32_t)gslot;
+        const T* rin = p == 0 ? a.src : a.rays_ws + (size_t)(p - 1) * 6 * a.n;
+        const int64_t sin = p == 0 ? a.src_stride : a.n;
+        double s[3], e[3];
+        load_ray3(rin, sin, i, s, e);
+        if (cls == CLS_DEAD) {
           double e2[3] = {e[0], e[1], e[2]};
           if (a.dead_len != 0.0)
             for (int k = 0; k < 3; ++k) e2[k] = advance_between(s[k], a.dead_len, e[k]);
           ok = emit<T>(a.dead, gslot, s, e2, rid, -1) && ok;
-        }
-      } else {
-        double h[3];
-        hit_point(s, e, a.rec_t[at], h);
-        if (cls == CLS_FINISHED) {
-          if (a.flags & TFRT_COMPILE_FINISHED) ok = emit<T>(a.fin, gslot, s, h, rid, tri) && ok;
-        } else if (cls == CLS_STOPPED) {
-          if (a.flags & TFRT_COMPILE_STOPPED) ok = emit<T>(a.stp, gslot, s, h, rid, tri) && ok;
-        } else if (a.flags & TFRT_COMPILE_ACTIVE) {
-          ok = emit<T>(a.act, gslot, s, h, rid, tri) && ok;
+        } else {
+          const int tri = a.rec_tri[at];
+          double h[3];
+          hit_point(s, e, a.rec_t[at], h);
+          const tfrt_ray_out& o = cls == CLS_FINISHED ? a.fin : (cls == CLS_STOPPED ? a.stp : a.act);
+          ok = emit<T>(o, gslot, s, h, rid, tri) && ok;
         }
       }
       if (cls != CLS_ACTIVE) alive = false;
