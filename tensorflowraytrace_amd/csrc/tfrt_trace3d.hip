@@ -2624,6 +2624,20 @@ __device__ __forceinline__ void trace_inplace(const InplaceArgs<T>& a, const Bea
     beam_pass<T, RT>(W, g, lane, a.bundle, active, skip, p == 0, /*coherent_only=*/1, TFRT_WI_ARG,
                      work);
     wave_fence();
+#ifdef TFRT_BURN   // (tuning experiment: extra independent float32 FMAs per pass -- does the launch notice?)
+    {
+      float x0 = (float)lane, x1 = x0 + 1.f, x2 = x0 + 2.f, x3 = x0 + 3.f;
+#pragma unroll
+      for (int k = 0; k < TFRT_BURN; ++k) {
+        x0 = fmaf(x0, 1.0001f, 0.5f);
+        x1 = fmaf(x1, 1.0001f, 0.5f);
+        x2 = fmaf(x2, 1.0001f, 0.5f);
+        x3 = fmaf(x3, 1.0001f, 0.5f);
+        __asm__ volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+      }
+      if (x0 + x1 + x2 + x3 == 12345.678f) W.best_i[lane] = -2;
+    }
+#endif
     TFRT_TICK_INIT;
     // (the struct waits in ONE vector register, a word per lane, and is unpacked here, pass by
     // pass: the register is made opaque first, so that the unpacking stays below the walk instead
